@@ -1,0 +1,130 @@
+/*
+ * cpecan_oracle.h -- CPU restatement of cPecan's banded pair-HMM posterior DP.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may build, load or call it.  The shipped path
+ * (cpecan-signal_amd/) never links against or falls back to anything in oracle/.
+ *
+ * Each function names the reference file:line whose arithmetic (operation order,
+ * float-suffixed literals, NULL-neighbour handling) it restates.  The reference cannot be
+ * built here (it needs sonLib, which is absent; writing a stand-in is not allowed), so the
+ * restatement is pinned by the reference's own test vectors -- see tests/test_oracle_*.py.
+ */
+#ifndef CPECAN_ORACLE_H_
+#define CPECAN_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NUM_KMERS 4096
+#define ORC_KMER_LEN 6
+#define ORC_MODEL_PARAMS 5
+#define ORC_PROB_1 10000000 /* PAIR_ALIGNMENT_PROB_1, inc/pairwiseAligner.h:26 */
+
+/* model kinds */
+#define ORC_SM3_STRAWMAN 0 /* stateMachine3_cellCalculate + strawMan emissions */
+#define ORC_SM5_SYMBOL 1   /* stateMachine5_cellCalculate + symbol emissions   */
+
+/* sm3 transition slots (log space), order of struct _StateMachine3 inc/stateMachine.h:179-187 */
+enum {
+    ORC_T3_MATCH_CONTINUE = 0, ORC_T3_MATCH_FROM_GAP_X, ORC_T3_MATCH_FROM_GAP_Y,
+    ORC_T3_GAP_OPEN_X, ORC_T3_GAP_OPEN_Y, ORC_T3_GAP_EXTEND_X, ORC_T3_GAP_EXTEND_Y,
+    ORC_T3_GAP_SWITCH_TO_X, ORC_T3_GAP_SWITCH_TO_Y, ORC_T3_COUNT
+};
+
+typedef struct {
+    int32_t kind;          /* ORC_SM3_STRAWMAN | ORC_SM5_SYMBOL */
+    int32_t stateNumber;   /* 3 | 5 */
+    double t[17];          /* transitions: sm3 uses ORC_T3_*, sm5 uses struct order of _StateMachine5 */
+    const double *match;   /* sm3: [1+4096*5] EMISSION_MATCH_PROBS; sm5: [16] */
+    const double *gapX;    /* sm3: [4096] EMISSION_GAP_X_PROBS;    sm5: [4]  */
+    const double *gapY;    /* sm3: [1+4096*5] EMISSION_GAP_Y_PROBS; sm5: [4]  */
+} orc_model;
+
+typedef struct {
+    double threshold;
+    int64_t minDiagsBetweenTraceBack;
+    int64_t traceBackDiagonals;
+    int64_t diagonalExpansion;
+    int64_t splitMatrixBiggerThanThis;
+} orc_params;
+
+/* sufficient statistics of the strawMan signal HMM (ContinuousPairHmm, impl/continuousHmm.c:90) */
+typedef struct {
+    double transitions[9]; /* [from*3+to] */
+    double kmerGap[ORC_NUM_KMERS];
+    double likelihood;
+} orc_expectations;
+
+/* result container (growable) */
+typedef struct {
+    int64_t n, cap;
+    int64_t *triples;  /* n * 3: (posterior*1e7 floored, x, y) */
+    double *logp;      /* n: (F+B)-total exponent that produced each triple (oracle extra) */
+    int64_t nTotals, capTotals;
+    int64_t *totalsXay;   /* diagonal at which totalProbability was refreshed (global order) */
+    double *totals;       /* its value */
+    int64_t cells;        /* sum of band widths over all processed sub-alignments */
+} orc_result;
+
+void orc_defaults_sm3_nanopore(orc_model *m);   /* impl/stateMachine.c:1278-1289 */
+void orc_defaults_sm5(orc_model *m, double *match16, double *gap4x, double *gap4y); /* :60-82,:920-937 */
+void orc_params_default(orc_params *p);         /* impl/pairwiseAligner.c:1428-1441 */
+
+double orc_logAdd(double x, double y);           /* impl/pairwiseAligner.c:238-255 */
+int64_t orc_kmer_index(const char *kmer);        /* impl/stateMachine.c:104-139 (6 chars read) */
+double orc_logGaussPdf(double x, double mu, double sigma);            /* :333-343 */
+double orc_strawman_match(const double *model, int64_t kmerIndex, const double *event); /* :595-629 */
+double orc_kmer_gap(const double *gapX, int64_t kmerIndex);           /* :175-187 */
+void orc_scale_model(double *match, double scale, double shift, double var, double scale_sd,
+                     double var_sd); /* :631-651 */
+
+/* band_construct, impl/pairwiseAligner.c:132-184.  anchors = nAnchors (x,y) pairs.
+ * xmyL/xmyR must hold lX+lY+1 entries.  Returns 0, or -1 for an invalid diagonal. */
+int orc_band(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY, int64_t expansion,
+             int64_t *xmyL, int64_t *xmyR);
+
+/* getSplitPoints, impl/pairwiseAligner.c:1289-1340.  out holds 4-tuples; returns count. */
+int64_t orc_split_points(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY,
+                         int64_t maxMatrixSize, int raggedLeft, int raggedRight, int64_t *out,
+                         int64_t outCap);
+
+orc_result *orc_result_new(void);
+void orc_result_free(orc_result *r);
+
+/*
+ * getAlignedPairsUsingAnchors (impl/pairwiseAligner.c:1456) with
+ * diagonalCalculationPosteriorMatchProbs.  x = char string (sm3: lX k-mers => lX+5 chars;
+ * sm5: lX bases), y = events double[3*lY] (sm3) or char string (sm5).
+ * If hmm != NULL runs getExpectationsUsingAnchors (:1571) with
+ * diagonalCalculation_Expectations instead and emits no triples.
+ */
+int orc_aligned_pairs_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y,
+                                    int64_t lY, const int64_t *anchors, int64_t nAnchors,
+                                    const orc_params *p, int raggedLeft, int raggedRight,
+                                    orc_expectations *hmm, orc_result *out);
+
+/* getAlignedPairsWithoutBanding, impl/pairwiseAligner.c:1512-1569 */
+int orc_aligned_pairs_without_banding(const orc_model *m, const char *x, int64_t lX, const void *y,
+                                      int64_t lY, const orc_params *p, int raggedLeft,
+                                      int raggedRight, orc_result *out);
+
+/*
+ * Debug/verification variant of one getPosteriorProbsWithBanding call (:870): additionally copies
+ * every forward diagonal and every backward diagonal (as it stands when its posteriors are taken)
+ * into dumpF/dumpB, laid out [sum of widths of earlier diagonals + cell][state].
+ */
+int orc_banded_dump(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
+                    const int64_t *anchors, int64_t nAnchors, const orc_params *p, int raggedLeft,
+                    int raggedRight, double *dumpF, double *dumpB, orc_result *out);
+
+/* continuousPairHmm_normalize, impl/continuousHmm.c:174-204 */
+void orc_expectations_normalize(orc_expectations *e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

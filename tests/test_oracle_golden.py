@@ -1,0 +1,152 @@
+"""Pins the CPU oracle (oracle/cpecan_oracle.c) to the reference's own known answers.
+
+Every expected value below is a golden vector held by the reference's CuTest suites
+(tests/pairwiseAlignerTest.c, tests/signalPairwiseTest.c) or a data file they use
+(models/template_median68pA.model, tests/test_npReads/*), copied as data into tests/golden/.
+The reference itself cannot be built here (sonLib is absent), so these are what pin the oracle.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import pyoracle as o
+
+
+def test_bands_golden():
+    # tests/pairwiseAlignerTest.c:74-99 (test_bands): anchors, lX=6, lY=5, expansion=2
+    L, R = o.band([(1, 0), (2, 1), (3, 3)], 6, 5, 2)
+    expect = [(0, 0), (-1, 1), (-2, 2), (-1, 3), (-2, 4), (-1, 3), (-2, 4), (-3, 3), (-2, 2),
+              (-1, 3), (0, 2), (1, 1)]
+    assert list(zip(L.tolist(), R.tolist())) == expect
+
+
+def test_split_points_golden():
+    # tests/pairwiseAlignerTest.c:596-665 (test_getSplitPoints)
+    ms = 2000 * 2000
+    assert o.split_points([], 3000, 1000, ms, 0, 0).tolist() == [[0, 0, 3000, 1000]]
+    lX, lY = 20000, 25000
+    assert o.split_points([], lX, lY, ms, 1, 1).tolist() == []
+    assert o.split_points([], lX, lY, ms, 1, 0).tolist() == [[18000, 23000, lX, lY]]
+    assert o.split_points([], lX, lY, ms, 0, 1).tolist() == [[0, 0, 2000, 2000]]
+    assert o.split_points([], lX, lY, ms, 0, 0).tolist() == [[0, 0, 2000, 2000],
+                                                             [18000, 23000, lX, lY]]
+    anchors = [(2000, 2000), (4002, 4001), (5000, 5000), (8000, 6000), (9000, 9000),
+               (10000, 14000), (15000, 15000), (16000, 16000)]
+    assert o.split_points(anchors, lX, lY, ms, 0, 0).tolist() == [
+        [0, 0, 3001, 3001], [3002, 3001, 9500, 11001], [9501, 12000, 12001, 14500],
+        [13000, 14501, 18000, 18001], [18001, 23000, 20000, 25000]]
+
+
+def test_logadd_property():
+    # tests/pairwiseAlignerTest.c:139-149 (test_logAdd): |exp(logAdd(log i, log j)) - (i+j)| < 1e-3
+    rng = np.random.default_rng(1)
+    L = o.lib()
+    for i, j in rng.random((20000, 2)):
+        got = math.exp(L.orc_logAdd(math.log(i), math.log(j)))
+        assert abs(got - (i + j)) < 1e-3
+    ninf = float("-inf")
+    assert L.orc_logAdd(ninf, -3.0) == -3.0 and L.orc_logAdd(-3.0, ninf) == -3.0
+    assert L.orc_logAdd(ninf, ninf) == ninf
+    assert L.orc_logAdd(0.0, -7.5) == 0.0  # gap >= 7.5 returns the larger operand exactly
+
+
+def test_logadd_not_below_max():
+    # property the kernels' exact sequential fold relies on: logAdd(x,y) >= max(x,y)
+    L = o.lib()
+    d = np.linspace(0, 7.5, 200001)[:-1]
+    for dd in d[::97]:
+        assert L.orc_logAdd(0.0, -dd) >= 0.0
+
+
+def test_kmer_index():
+    L = o.lib()
+    assert L.orc_kmer_index(b"AAAAAA") == 0
+    assert L.orc_kmer_index(b"AAAAAC") == 1
+    assert L.orc_kmer_index(b"TTTTTT") == 4095
+    assert L.orc_kmer_index(b"CAAAAA") == 1024
+    assert L.orc_kmer_index(b"ACGTNA") > 4096
+    assert L.orc_kmer_index(b"nAAAAA") > 4096
+
+
+def test_gauss_pdf_known_answers(template_model):
+    # tests/signalPairwiseTest.c:27-34,116-134: log N(x; mu, sigma) against the brute-force pdf
+    match = template_model[0]
+    L = o.lib()
+    x, mu, sd = 62.784241, match[1], match[2]
+    control = (1 / math.sqrt(2 * math.pi)) * (1 / sd) * math.exp(-0.5 * ((x - mu) / sd) ** 2)
+    assert abs(L.orc_logGaussPdf(x, mu, sd) - math.log(control)) < 1e-3
+    assert abs(math.exp(L.orc_logGaussPdf(0.0, 0.0, 1.0)) - 1 / math.sqrt(2 * math.pi)) < 1e-3
+    assert L.orc_logGaussPdf(1.0, 0.0, 0.0) == float("-inf")  # sigma == 0 -> LOG_ZERO
+
+
+def test_scale_model(template_model, zymo_read):
+    # tests/signalPairwiseTest.c:1007-1040 (test_scaleModel), exact equality
+    match = template_model[0]
+    scale, shift, var, scale_sd, var_sd = zymo_read["template_params"]
+    m = match.copy()
+    o.lib().orc_scale_model(m.ctypes.data, scale, shift, var, scale_sd, var_sd)
+    k = np.arange(1, 1 + 4096 * 5, 5)
+    assert np.array_equal(m[k], match[k] * scale + shift)
+    assert np.array_equal(m[k + 1], match[k + 1] * var)
+    assert np.array_equal(m[k + 2], match[k + 2] * scale_sd)
+    assert np.array_equal(m[k + 4], match[k + 4] * var_sd)
+    expect = np.array([math.sqrt(math.pow(a, 3.0) / b) for a, b in zip(m[k + 2], m[k + 4])])
+    assert np.array_equal(m[k + 3], expect)
+
+
+def test_strawman_toy_pairs(template_model):
+    # tests/signalPairwiseTest.c:580-685: "ACGATACGGACAT" vs 7 events, exactly 8 pairs >= 0.2
+    match, _, gapy = template_model
+    m = o.Sm3Model(match, gapy)
+    sX = "ACGATACGGACAT"
+    sY = [58.743435, 0.887833, 0.0571, 53.604965, 0.816836, 0.0571, 58.432015, 0.735143, 0.0571,
+          63.684352, 0.795437, 0.0571, 58.921430, 0.812959, 0.0571, 59.895882, 0.740952, 0.0571,
+          61.684303, 0.722332, 0.0571]
+    r = o.aligned_pairs_without_banding(m, sX, len(sX) - 5, sY, o.default_params(threshold=0.2))
+    pairs = sorted((int(x), int(y)) for _, x, y in r["triples"])
+    assert pairs == [(0, 0), (1, 1), (2, 2), (3, 3), (4, 3), (5, 4), (6, 5), (7, 6)]
+
+
+def test_five_state_toy_pairs():
+    # tests/pairwiseAlignerTest.c:278-373: "AGCG" vs "AGTTCG", exactly 4 pairs >= 0.2
+    r = o.aligned_pairs_without_banding(o.Sm5Model(), "AGCG", 4, "AGTTCG",
+                                        o.default_params(threshold=0.2))
+    pairs = sorted((int(x), int(y)) for _, x, y in r["triples"])
+    assert pairs == [(0, 0), (1, 1), (2, 4), (3, 5)]
+
+
+def test_real_read_unbanded_986(template_model, zymo_read):
+    # tests/signalPairwiseTest.c:1166-1173: strawMan, Zymo template read (799 events) vs 897-nt
+    # reference, getAlignedPairsWithoutBanding, threshold 0.01 -> exactly 986 aligned pairs.
+    match, _, gapy = template_model
+    m = o.Sm3Model(match, gapy).scaled(*zymo_read["template_params"])
+    ref = zymo_read["reference"]
+    r = o.aligned_pairs_without_banding(m, ref, len(ref) - 5, zymo_read["template_events"],
+                                        o.default_params())
+    tri = r["triples"]
+    assert len(tri) == 986
+    assert len({(int(x), int(y)) for _, x, y in tri}) == 986
+    assert tri[:, 0].min() > 0 and tri[:, 0].max() <= 10000000
+
+
+def test_banded_matches_unbanded_on_real_read(template_model, zymo_read):
+    # The reference's banded count on this read (987, signalPairwiseTest.c:1163) needs lastz anchors,
+    # which cannot be regenerated here.  What can be pinned: with a band that covers the whole
+    # matrix and a single traceback window the banded driver must reproduce the un-banded result
+    # (:1166-1173) except for the per-10-diagonal refresh of totalProbability (quirk Q2).
+    match, _, gapy = template_model
+    m = o.Sm3Model(match, gapy).scaled(*zymo_read["template_params"])
+    ref = zymo_read["reference"]
+    lX = len(ref) - 5
+    ev = zymo_read["template_events"]
+    full = o.aligned_pairs_without_banding(m, ref, lX, ev, o.default_params())
+    p = o.default_params(minDiagsBetweenTraceBack=100000, diagonalExpansion=4000)
+    banded = o.aligned_pairs_using_anchors(m, ref, lX, ev, [], p)
+    F = {(int(x), int(y)): int(q) for q, x, y in full["triples"]}
+    B = {(int(x), int(y)): int(q) for q, x, y in banded["triples"]}
+    assert set(F) <= set(B) and len(B) - len(F) <= 2
+    assert max(abs(F[k] - B[k]) for k in F) < 50000
+    assert len(banded["totals"]) == (lX + 799 + 9) // 10
+    assert np.ptp(banded["totals"]) < 0.01
+    assert banded["cells"] == full["cells"] == (lX + 1) * 800
