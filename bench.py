@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- banded pair-HMM forward/backward/posterior throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step is one pass of the hot path (forward, checkpointed backward, posterior decode) over one
+synthetic batch per GPU: BASELINE.json configs[2], 1024 reads x (10k events x 5k k-mers), band
+(diagonalExpansion) 100, per-read scaled pore models.  Inputs are resident in HBM before the timed
+region.  Reads shard across ranks with no data-path collective (weak scaling: every GPU gets its
+own 1024 reads).  Rank 0 prints ONE JSON line.
+
+value      = in-band cells (each counted once) of all ranks / max-over-ranks wall time, Gcells/s
+roofline   = algorithmic bytes (48 B per cell: one fp64 write + one re-read of 3 states,
+             SURVEY.md section 8d) / average kernel duration measured with HIP events on the
+             library's own stream, against the 8 TB/s HBM peak
+cpu_baseline = the CPU oracle (a port of the reference's algorithm; the reference itself cannot be
+             built here) timed on rank 0 over the first reads of the same batch, one thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=1024)
+    ap.add_argument("--events", type=int, default=10000)
+    ap.add_argument("--kmers", type=int, default=5000)
+    ap.add_argument("--band", type=int, default=100)
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 systolic")
+    ap.add_argument("--cpu-reads", type=int, default=20, help="reads timed on the CPU oracle (0: skip)")
+    ap.add_argument("--check", type=int, default=2, help="reads compared with the oracle after the run")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import synth
+    from cpecan_load import binding
+    cp = binding()
+
+    # ---- inputs: this rank's reads, uploaded before the timed region -------------------------
+    t0 = time.time()
+    config_id = 3 + 100 * rank  # distinct read seeds per rank
+    batch = synth.make_batch(config_id, args.reads, args.kmers, args.events, anchor_every=50)
+    t_gen = time.time() - t0
+    ctx = cp.Context(local_rank)
+    t0 = time.time()
+    ctx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in batch["models"]])
+    t_models = time.time() - t0
+    bp = cp.BandParams(0.01, 1000, 40, args.band)
+    items = np.zeros(len(batch["items"]), cp.ITEM_DTYPE)
+    for i, it in enumerate(batch["items"]):
+        items[i] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"],
+                    it["n_anchors"], it["model"], 1, 1, 0)  # ragged ends, as vanillaAlign.c:203
+    t0 = time.time()
+    b = cp.Batch(ctx, items, batch["x_chars"], batch["events"], batch["anchors"], bp,
+                 cp.MODE_POSTERIOR, args.kernel, 0)
+    t_upload = time.time() - t0
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        b.run()
+        b.sync()
+    sync_all()
+    kernel_ms = []
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        b.run()
+        b.sync()
+        kernel_ms.append(b.elapsed_ms()[1])
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    npairs, ntot, ncells = b.counts()
+    cells = int(ncells.sum())
+    if world > 1:
+        ct = torch.tensor([cells], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        total_cells = int(ct.item())
+    else:
+        total_cells = cells
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    gcells = total_cells * args.steps / elapsed / 1e9
+    reads_per_s = args.reads * world * args.steps / elapsed
+    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    bytes_per_cell = 48.0
+    achieved = cells * bytes_per_cell / avg_kernel_s / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "kernel_ms": round(1e3 * avg_kernel_s, 3), "bytes_per_cell": bytes_per_cell,
+                "frac_of_measured_copy_6290": round(achieved / 6290.0, 5)}
+
+    # ---- parity spot check + CPU baseline (oracle = checker / baseline only) -------------------
+    check = {"reads": 0}
+    cpu = None
+    if args.check > 0 or args.cpu_reads > 0:
+        from harness import assert_same_pairs, run_oracle_item
+        n_cpu = max(args.check, args.cpu_reads)
+        t_cpu, cpu_cells = 0.0, 0
+        for i in range(min(n_cpu, args.reads)):
+            t0 = time.perf_counter()
+            ref = run_oracle_item(batch, i, bp, (1, 1))
+            t_cpu += time.perf_counter() - t0
+            cpu_cells += ref["cells"]
+            if i < args.check:
+                tri, lp = b.pairs(i, npairs[i])
+                xay, tot = b.totals(i, ntot[i])
+                assert_same_pairs(dict(triples=tri, logp=lp), ref)
+                assert np.array_equal(tot, ref["totals"])
+                check["reads"] += 1
+        if args.cpu_reads > 0:
+            cpu = {"value": round(cpu_cells / t_cpu / 1e9, 6), "unit": "Gcells/s", "cores": 1,
+                   "kind": "port", "seconds": round(t_cpu, 2),
+                   "sample": "first %d reads of the same batch, one thread, oracle/cpecan_oracle.c"
+                             % min(n_cpu, args.reads)}
+
+    out = {
+        "metric": "banded fwd-bwd Gcells/s", "value": round(gcells, 4), "unit": "Gcells/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "reads_per_s": round(reads_per_s, 1),
+        "config": {"workload": "BASELINE configs[2]: %d reads/GPU x (%d events x %d k-mers), "
+                               "diagonalExpansion %d, 3-state strawMan signal HMM, per-read scaled "
+                               "models, posterior decode" % (args.reads, args.events, args.kmers, args.band),
+                   "cells_per_gpu": cells, "pairs_per_gpu": int(npairs.sum()),
+                   "kernel": {0: "auto", 1: "general", 2: "systolic"}[args.kernel],
+                   "parallelism": "reads sharded over %d GPU(s), no collective" % world},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "parity_check": check,
+        "host_prep_s": {"generate": round(t_gen, 2), "derive_models": round(t_models, 2),
+                        "upload_and_band": round(t_upload, 2)},
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

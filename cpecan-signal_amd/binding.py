@@ -1,0 +1,267 @@
+"""ctypes view of the C-ABI in include/cpecan_hip.h (libcpecan_hip.so), for tests and bench.py.
+
+This file adds no computation: every call goes straight through the C-ABI.  It never imports the
+oracle and has no CPU fallback -- without a GPU, Context() raises CpecanError(CPECAN_ENODEVICE).
+The directory name contains a hyphen, so load this module by path:
+
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("cpecan_binding", ".../cpecan-signal_amd/binding.py")
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpecan_hip.so")
+
+OK, ENODEVICE, EINVAL, EHIP, EOVERFLOW, EBAND = 0, -1, -2, -3, -4, -5
+MODE_POSTERIOR, MODE_EXPECTATIONS = 0, 1
+KERNEL_AUTO, KERNEL_GENERAL, KERNEL_SYSTOLIC = 0, 1, 2
+FLAG_DEBUG_DUMP = 1
+FLAG_UNBANDED = 2
+NUM_KMERS = 4096
+MODEL_TABLE_LEN = 1 + NUM_KMERS * 5
+EXPECTATION_LEN = 9 + NUM_KMERS + 1
+
+# every symbol include/cpecan_hip.h declares
+EXPORTS = [
+    "cpecan_hip_device_count", "cpecan_hip_ctx_create", "cpecan_hip_ctx_destroy",
+    "cpecan_hip_last_error", "cpecan_hip_version", "cpecan_hip_models_create",
+    "cpecan_hip_models_clear", "cpecan_band_construct", "cpecan_split_points",
+    "cpecan_hip_batch_create", "cpecan_hip_batch_run", "cpecan_hip_batch_sync",
+    "cpecan_hip_batch_elapsed_ms", "cpecan_hip_batch_counts", "cpecan_hip_batch_fetch_pairs",
+    "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
+    "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
+    "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream",
+]
+
+
+class CpecanError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("cpecan_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Sm3ModelDesc(C.Structure):
+    _fields_ = [("transitions", C.c_double * 9), ("match_probs", C.c_void_p),
+                ("gap_x_probs", C.c_void_p), ("gap_y_probs", C.c_void_p)]
+
+
+class Item(C.Structure):
+    _fields_ = [("x_offset", C.c_int64), ("lX", C.c_int64), ("y_offset", C.c_int64),
+                ("lY", C.c_int64), ("anchor_offset", C.c_int64), ("n_anchors", C.c_int64),
+                ("model_id", C.c_int32), ("ragged_left", C.c_int32), ("ragged_right", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class BandParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("minDiagsBetweenTraceBack", C.c_int64),
+                ("traceBackDiagonals", C.c_int64), ("diagonalExpansion", C.c_int64)]
+
+
+ITEM_DTYPE = np.dtype([("x_offset", "<i8"), ("lX", "<i8"), ("y_offset", "<i8"), ("lY", "<i8"),
+                       ("anchor_offset", "<i8"), ("n_anchors", "<i8"), ("model_id", "<i4"),
+                       ("ragged_left", "<i4"), ("ragged_right", "<i4"), ("reserved", "<i4")])
+assert ITEM_DTYPE.itemsize == C.sizeof(Item)
+
+NANOPORE_TRANSITIONS = (  # stateMachine3_setTransitionsToNanoporeDefaults, stateMachine.c:1278
+    -0.23552123624314988, -0.21880828092192281, -0.013406326748077823, -1.6269694202638481,
+    -4.3187242127300092, -1.6269694202638481, -4.3187242127239411, float("-inf"), float("-inf"))
+
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s", "libcpecan_hip.so"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise CpecanError(ENODEVICE, "libcpecan_hip.so is not built (run __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.cpecan_hip_last_error.restype = C.c_char_p
+        L.cpecan_hip_version.restype = C.c_char_p
+        L.cpecan_split_points.restype = C.c_int64
+        L.cpecan_split_points.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_int, C.c_int, C.c_void_p, C.c_int64]
+        L.cpecan_band_construct.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                            C.c_void_p, C.c_void_p]
+        L.cpecan_hip_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.cpecan_hip_ctx_destroy.argtypes = [C.c_void_p]
+        L.cpecan_hip_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.cpecan_hip_models_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cpecan_hip_models_clear.argtypes = [C.c_void_p]
+        L.cpecan_hip_batch_create.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.c_int32, C.c_int32,
+            C.POINTER(C.c_void_p)]
+        for name in ("run", "sync", "destroy"):
+            getattr(L, "cpecan_hip_batch_" + name).argtypes = [C.c_void_p]
+        L.cpecan_hip_batch_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.cpecan_hip_batch_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cpecan_hip_batch_fetch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+        L.cpecan_hip_batch_fetch_totals.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+        L.cpecan_hip_batch_expectations_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p),
+                                                               C.POINTER(C.c_int64)]
+        L.cpecan_hip_batch_fetch_expectations.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.cpecan_hip_batch_debug_cells.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != OK:
+        raise CpecanError(rc, lib().cpecan_hip_last_error().decode())
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = lib().cpecan_hip_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+def band_construct(anchors, lX, lY, expansion):
+    a = np.ascontiguousarray(anchors, dtype=np.int64).reshape(-1, 2)
+    L = np.zeros(lX + lY + 1, np.int32)
+    R = np.zeros(lX + lY + 1, np.int32)
+    _check(lib().cpecan_band_construct(_ptr(a), a.shape[0], lX, lY, expansion, _ptr(L), _ptr(R)))
+    return L, R
+
+
+def split_points(anchors, lX, lY, max_matrix, ragged_left, ragged_right):
+    a = np.ascontiguousarray(anchors, dtype=np.int64).reshape(-1, 2)
+    out = np.zeros((a.shape[0] + 2, 4), np.int64)
+    n = lib().cpecan_split_points(_ptr(a), a.shape[0], lX, lY, max_matrix, int(ragged_left),
+                                  int(ragged_right), _ptr(out), out.shape[0])
+    return out[:n]
+
+
+class Context:
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(lib().cpecan_hip_ctx_create(device, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            lib().cpecan_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stream(self):
+        s = C.c_void_p()
+        _check(lib().cpecan_hip_ctx_stream(self.h, C.byref(s)))
+        return s.value
+
+    def models_create(self, models, threads=0):
+        """models: list of (transitions[9], match[20481], gap_x[4096], gap_y[20481]) -> ids"""
+        n = len(models)
+        descs = (Sm3ModelDesc * n)()
+        keep = []
+        for i, (t, match, gx, gy) in enumerate(models):
+            match = np.ascontiguousarray(match, dtype=np.float64)
+            gx = np.ascontiguousarray(gx, dtype=np.float64)
+            gy = np.ascontiguousarray(gy, dtype=np.float64)
+            assert match.size == MODEL_TABLE_LEN and gy.size == MODEL_TABLE_LEN and gx.size == NUM_KMERS
+            keep += [match, gx, gy]
+            for j in range(9):
+                descs[i].transitions[j] = t[j]
+            descs[i].match_probs = match.ctypes.data
+            descs[i].gap_x_probs = gx.ctypes.data
+            descs[i].gap_y_probs = gy.ctypes.data
+        ids = np.zeros(n, np.int32)
+        _check(lib().cpecan_hip_models_create(self.h, C.cast(descs, C.c_void_p), n, threads, _ptr(ids)))
+        return ids
+
+    def models_clear(self):
+        _check(lib().cpecan_hip_models_clear(self.h))
+
+
+class Batch:
+    """cpecan_batch: items is a numpy array of ITEM_DTYPE."""
+
+    def __init__(self, ctx, items, x_chars, events, anchors, params, mode=MODE_POSTERIOR,
+                 kernel=KERNEL_AUTO, flags=0):
+        self.ctx = ctx
+        items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
+        xb = np.frombuffer(x_chars.encode() if isinstance(x_chars, str) else bytes(x_chars), np.uint8)
+        ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+        an = np.ascontiguousarray(anchors, dtype=np.int64).reshape(-1, 2)
+        h = C.c_void_p()
+        _check(lib().cpecan_hip_batch_create(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
+                                             _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
+                                             C.byref(params), mode, kernel, flags, C.byref(h)))
+        self.h = h
+        self.n = items.shape[0]
+
+    def run(self):
+        _check(lib().cpecan_hip_batch_run(self.h))
+
+    def sync(self):
+        _check(lib().cpecan_hip_batch_sync(self.h))
+
+    def elapsed_ms(self):
+        a, k = C.c_float(), C.c_float()
+        _check(lib().cpecan_hip_batch_elapsed_ms(self.h, C.byref(a), C.byref(k)))
+        return a.value, k.value
+
+    def counts(self):
+        p = np.zeros(self.n, np.int64)
+        t = np.zeros(self.n, np.int64)
+        c = np.zeros(self.n, np.int64)
+        _check(lib().cpecan_hip_batch_counts(self.h, _ptr(p), _ptr(t), _ptr(c)))
+        return p, t, c
+
+    def pairs(self, item, n):
+        tri = np.zeros((max(int(n), 1), 3), np.int64)
+        lp = np.zeros(max(int(n), 1), np.float64)
+        _check(lib().cpecan_hip_batch_fetch_pairs(self.h, item, _ptr(tri), _ptr(lp), tri.shape[0]))
+        return tri[:n], lp[:n]
+
+    def totals(self, item, n):
+        xay = np.zeros(max(int(n), 1), np.int64)
+        tot = np.zeros(max(int(n), 1), np.float64)
+        _check(lib().cpecan_hip_batch_fetch_totals(self.h, item, _ptr(xay), _ptr(tot), xay.size))
+        return xay[:n], tot[:n]
+
+    def expectations(self, model_id):
+        out = np.zeros(EXPECTATION_LEN)
+        _check(lib().cpecan_hip_batch_fetch_expectations(self.h, int(model_id), _ptr(out)))
+        return out
+
+    def expectations_device_ptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        _check(lib().cpecan_hip_batch_expectations_device_ptr(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def debug_cells(self, item, n_cells):
+        F = np.zeros((n_cells, 3))
+        B = np.zeros((n_cells, 3))
+        _check(lib().cpecan_hip_batch_debug_cells(self.h, item, _ptr(F), _ptr(B), n_cells))
+        return F, B
+
+    def close(self):
+        if self.h:
+            lib().cpecan_hip_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,579 @@
+/*
+ * cpecan_hip.hip -- the C-ABI of include/cpecan_hip.h: contexts, model upload, batches.
+ *
+ * Host side of the thin layer between the reference-shaped C host code and the gfx950 kernels.
+ * Nothing here computes DP cells: when no GPU is usable every compute entry point fails with
+ * CPECAN_ENODEVICE (there is deliberately no CPU fallback).
+ */
+#include "cpecan_hip.h"
+
+#include "cpecan_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+extern "C" __global__ void cpecan_k_general(const DevItem *, DevParams, const int *, const int *,
+                                            const long long *, const unsigned short *,
+                                            const double *, const double *, double *, double *,
+                                            long long *, double *, long long *, long long *,
+                                            double *, long long *, double *, double *);
+extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned short *);
+
+extern "C" int cpecan_systolic_max_width(void);
+extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, long long nItems,
+                                      DevParams P, const long long *anchors,
+                                      const unsigned short *kidx, const double *events,
+                                      const double *models, double *Fring, long long ringDoubles,
+                                      int *workCounter, long long *pairs, double *pairLogp,
+                                      long long *nPairs, long long *totXay, double *totVal,
+                                      long long *nTot, long long *nCells, double *expect,
+                                      int nWorkers);
+extern "C" long long cpecan_systolic_ring_doubles(const DevParams *P);
+extern "C" int cpecan_systolic_workers(int device, long long nItems);
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(CPECAN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                 \
+    } while (0)
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **) &p, count * sizeof(T));
+    }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+} // namespace
+
+struct cpecan_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<double> models; /* nModels * CP_MODEL_STRIDE */
+    std::vector<double> hostModels;
+    int nModels = 0;
+};
+
+struct cpecan_batch {
+    cpecan_ctx *ctx = nullptr;
+    int64_t nItems = 0;
+    int mode = 0, kernel = 0, flags = 0;
+    DevParams P{};
+    std::vector<DevItem> hItems;
+    DevBuf<DevItem> items;
+    DevBuf<int> bandL, bandR;
+    DevBuf<long long> cellPrefix;
+    DevBuf<char> chars;
+    DevBuf<unsigned short> kidx;
+    DevBuf<double> events;
+    DevBuf<long long> anchors;
+    DevBuf<double> Fstore, Bstore, dbgB;
+    DevBuf<long long> pairs;
+    DevBuf<double> pairLogp;
+    DevBuf<long long> nPairs, totXay, nTot, nCells;
+    DevBuf<double> totVal;
+    DevBuf<double> expect;
+    DevBuf<int> workCounter;
+    long long ringDoubles = 0;
+    int nWorkers = 0;
+    int nModels = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    std::vector<long long> hNPairs, hNTot, hNCells;
+    bool countsValid = false, ran = false;
+};
+
+extern "C" {
+
+const char *cpecan_hip_last_error(void) { return g_err.c_str(); }
+const char *cpecan_hip_version(void) { return "cpecan-signal_amd 0.1 (gfx950)"; }
+
+int cpecan_hip_device_count(int *count) {
+    if (!count) return fail(CPECAN_EINVAL, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(CPECAN_ENODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    *count = n;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_ctx_create(int device, cpecan_ctx **out) {
+    if (!out) return fail(CPECAN_EINVAL, "ctx is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(CPECAN_ENODEVICE, "no HIP device is available; this library has no CPU path");
+    if (device < 0 || device >= n) return fail(CPECAN_EINVAL, "device %d out of range (%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    cpecan_ctx *c = new (std::nothrow) cpecan_ctx();
+    if (!c) return fail(CPECAN_EINVAL, "out of host memory");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(CPECAN_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_ctx_destroy(cpecan_ctx *c) {
+    if (!c) return CPECAN_OK;
+    (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_ctx_stream(cpecan_ctx *c, void **stream) {
+    if (!c || !stream) return fail(CPECAN_EINVAL, "NULL argument");
+    *stream = (void *) c->stream;
+    return CPECAN_OK;
+}
+
+/* One derived row per k-mer.  K = log_inv_sqrt_2pi - log(sigma) is the part of
+ * emissions_signal_logGaussPdf (impl/stateMachine.c:333-343) that does not depend on the event;
+ * evaluated here with the host libm exactly as the reference's per-cell code would. */
+static void derive_rows(const cpecan_sm3_model *m, double *dst) {
+    const double c = -0.91893853320467267;
+    for (int i = 0; i < 9; i++) dst[i] = m->transitions[i];
+    for (int i = 9; i < CP_MODEL_HEADER; i++) dst[i] = 0.0;
+    double *rows = dst + CP_MODEL_HEADER;
+    for (int k = 0; k <= CPECAN_NUM_KMERS; k++) {
+        double *r = rows + (size_t) k * CP_ROW;
+        if (k == CPECAN_NUM_KMERS) { /* "not a k-mer": model reads 0.0, gap prob LOG_ZERO (:185,:223) */
+            for (int j = 0; j < CP_ROW; j++) r[j] = 0.0;
+            r[CP_K1] = r[CP_K2] = r[CP_YK1] = r[CP_YK2] = -INFINITY;
+            r[CP_GAPX] = -INFINITY;
+            continue;
+        }
+        const double *a = m->match_probs + 1 + (size_t) k * CPECAN_MODEL_PARAMS;
+        const double *b = m->gap_y_probs + 1 + (size_t) k * CPECAN_MODEL_PARAMS;
+        const double sd[4] = { a[1], a[3], b[1], b[3] };
+        const double mu[4] = { a[0], a[2], b[0], b[2] };
+        for (int g = 0; g < 4; g++) {
+            double *q = r + 4 * g;
+            q[0] = mu[g];
+            q[1] = sd[g];
+            q[2] = sd[g] == 0.0 ? 0.0 : 1.0 / sd[g];
+            q[3] = sd[g] == 0.0 ? -INFINITY : c - log(sd[g]);
+        }
+        r[CP_GAPX] = m->gap_x_probs[k];
+        r[17] = 0.0;
+    }
+}
+
+int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int32_t n,
+                             int32_t threads, int32_t *ids) {
+    if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++)
+        if (!models[i].match_probs || !models[i].gap_x_probs || !models[i].gap_y_probs)
+            return fail(CPECAN_EINVAL, "model %d has a NULL table", i);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t old = c->hostModels.size();
+    c->hostModels.resize(old + (size_t) n * CP_MODEL_STRIDE);
+    int nt = threads > 0 ? threads : (int) std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, (int) n));
+    std::vector<std::thread> pool;
+    for (int w = 0; w < nt; w++)
+        pool.emplace_back([&, w]() {
+            for (int i = w; i < n; i += nt)
+                derive_rows(&models[i], c->hostModels.data() + old + (size_t) i * CP_MODEL_STRIDE);
+        });
+    for (auto &t : pool) t.join();
+    for (int i = 0; i < n; i++) ids[i] = c->nModels + i;
+    c->nModels += n;
+    hipError_t e = c->models.alloc(c->hostModels.size());
+    if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(c->models.p, c->hostModels.data(), c->hostModels.size() * sizeof(double),
+                      hipMemcpyHostToDevice));
+    return CPECAN_OK;
+}
+
+int cpecan_hip_models_clear(cpecan_ctx *c) {
+    if (!c) return fail(CPECAN_EINVAL, "ctx is NULL");
+    (void) hipSetDevice(c->device);
+    c->models.release();
+    c->hostModels.clear();
+    c->nModels = 0;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_destroy(cpecan_batch *b) {
+    if (!b) return CPECAN_OK;
+    (void) hipSetDevice(b->ctx->device);
+    if (b->ev0) (void) hipEventDestroy(b->ev0);
+    if (b->ev1) (void) hipEventDestroy(b->ev1);
+    if (b->ev2) (void) hipEventDestroy(b->ev2);
+    delete b;
+    return CPECAN_OK;
+}
+
+#define B_TRY(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            int rc_ = fail(CPECAN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                              \
+            cpecan_hip_batch_destroy(b);                                                     \
+            return rc_;                                                                      \
+        }                                                                                    \
+    } while (0)
+
+int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
+                            const char *xChars, int64_t nX, const double *events, int64_t nEvents,
+                            const int64_t *anchors, int64_t nAnchorPairs,
+                            const cpecan_band_params *params, int32_t mode, int32_t kernel,
+                            int32_t flags, cpecan_batch **out) {
+    if (!c || !items || nItems <= 0 || !xChars || !events || !params || !out)
+        return fail(CPECAN_EINVAL, "bad argument");
+    if (nAnchorPairs > 0 && !anchors) return fail(CPECAN_EINVAL, "anchors is NULL");
+    if (mode != CPECAN_MODE_POSTERIOR && mode != CPECAN_MODE_EXPECTATIONS)
+        return fail(CPECAN_EINVAL, "unknown mode %d", mode);
+    if (params->diagonalExpansion < 0 || (params->diagonalExpansion & 1) ||
+        params->traceBackDiagonals < 1 || params->minDiagsBetweenTraceBack < 2 ||
+        params->traceBackDiagonals + 1 >= params->minDiagsBetweenTraceBack)
+        return fail(CPECAN_EINVAL, "banding parameters violate the prerequisites of "
+                                   "getPosteriorProbsWithBanding (pairwiseAligner.c:880-884)");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool unbanded = (flags & CPECAN_FLAG_UNBANDED) != 0;
+    if (unbanded && (mode != CPECAN_MODE_POSTERIOR || kernel == CPECAN_KERNEL_SYSTOLIC))
+        return fail(CPECAN_EINVAL, "un-banded alignment: posterior mode on the general kernel only");
+
+    /* per-item validation + band tables (host integer work) */
+    std::vector<DevItem> hItems((size_t) nItems);
+    std::vector<int> hL, hR;
+    std::vector<long long> hPre;
+    long long cellTotal = 0, pairTotal = 0, totTotal = 0, bwsTotal = 0;
+    int globalMaxWidth = 0;
+    for (int64_t i = 0; i < nItems; i++) {
+        const cpecan_item &s = items[i];
+        if (s.lX < 0 || s.lY < 0 || s.x_offset < 0 || s.y_offset < 0 || s.n_anchors < 0 ||
+            s.anchor_offset < 0 || s.x_offset + s.lX + (s.lX > 0 ? 5 : 0) > nX ||
+            s.y_offset + s.lY > nEvents || s.anchor_offset + s.n_anchors > nAnchorPairs)
+            return fail(CPECAN_EINVAL, "item %lld points outside the supplied buffers", (long long) i);
+        if (s.model_id < 0 || s.model_id >= c->nModels)
+            return fail(CPECAN_EINVAL, "item %lld: unknown model id %d", (long long) i, s.model_id);
+        if (s.lX + s.lY >= (1ll << 30)) return fail(CPECAN_EINVAL, "item %lld too long", (long long) i);
+        DevItem &d = hItems[(size_t) i];
+        d.lX = s.lX; d.lY = s.lY; d.xOff = s.x_offset; d.yOff = s.y_offset;
+        d.anchorOff = s.anchor_offset; d.nAnchors = s.n_anchors;
+        d.model = s.model_id; d.raggedL = s.ragged_left ? 1 : 0; d.raggedR = s.ragged_right ? 1 : 0;
+        const long long nDiag = s.lX + s.lY + 1;
+        d.diagBase = (long long) hL.size();
+        hL.resize(hL.size() + (size_t) nDiag);
+        hR.resize(hR.size() + (size_t) nDiag);
+        hPre.resize(hPre.size() + (size_t) nDiag);
+        /* getAlignedPairsWithoutBanding builds its band from no anchors, expansion 2 (:1532) */
+        int rc = cpecan_band_construct(unbanded || !anchors ? nullptr : anchors + 2 * s.anchor_offset,
+                                       unbanded ? 0 : s.n_anchors, s.lX, s.lY,
+                                       unbanded ? 2 : params->diagonalExpansion,
+                                       hL.data() + d.diagBase, hR.data() + d.diagBase);
+        if (rc != CPECAN_OK)
+            return fail(rc, "item %lld: anchors do not describe a valid band", (long long) i);
+        long long cells = 0;
+        int maxW = 0;
+        for (long long k = 0; k < nDiag; k++) {
+            hPre[(size_t) (d.diagBase + k)] = cells;
+            int w = ((hR[(size_t) (d.diagBase + k)] - hL[(size_t) (d.diagBase + k)]) >> 1) + 1;
+            cells += w;
+            maxW = std::max(maxW, w);
+        }
+        d.nCells = cells;
+        d.maxWidth = maxW;
+        globalMaxWidth = std::max(globalMaxWidth, maxW);
+        d.cellBase = cellTotal;
+        cellTotal += cells;
+        d.pairBase = pairTotal;
+        d.pairCap = 4 * (s.lX + s.lY) + 64;
+        pairTotal += d.pairCap;
+        d.totBase = totTotal;
+        d.totCap = (nDiag + 9) / 10 + nDiag / std::max<long long>(1, params->minDiagsBetweenTraceBack -
+                                                                     params->traceBackDiagonals - 1) + 4;
+        totTotal += d.totCap;
+        d.bwsBase = bwsTotal;
+        bwsTotal += 3ll * maxW * 3;
+    }
+
+    cpecan_batch *b = new (std::nothrow) cpecan_batch();
+    if (!b) return fail(CPECAN_EINVAL, "out of host memory");
+    b->ctx = c;
+    b->nItems = nItems;
+    b->mode = mode;
+    b->flags = flags;
+    b->nModels = c->nModels;
+    b->P.threshold = params->threshold;
+    b->P.minDiags = params->minDiagsBetweenTraceBack;
+    b->P.tbDiags = params->traceBackDiagonals;
+    b->P.expansion = params->diagonalExpansion;
+    b->P.mode = mode;
+    b->P.debug = (flags & CPECAN_FLAG_DEBUG_DUMP) ? 1 : 0;
+    b->P.unbanded = unbanded ? 1 : 0;
+
+    int useKernel = kernel;
+    if (useKernel == CPECAN_KERNEL_AUTO)
+        useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && !b->P.debug && !unbanded)
+                        ? CPECAN_KERNEL_SYSTOLIC : CPECAN_KERNEL_GENERAL;
+    if (useKernel == CPECAN_KERNEL_SYSTOLIC && globalMaxWidth > cpecan_systolic_max_width()) {
+        delete b;
+        return fail(CPECAN_EINVAL, "band is %d cells wide; the systolic kernel handles at most %d",
+                    globalMaxWidth, cpecan_systolic_max_width());
+    }
+    if (useKernel == CPECAN_KERNEL_SYSTOLIC && b->P.debug) {
+        delete b;
+        return fail(CPECAN_EINVAL, "cell dumps are only available from the general kernel");
+    }
+    b->kernel = useKernel;
+    b->hItems = hItems;
+
+    B_TRY(b->items.alloc((size_t) nItems));
+    B_TRY(hipMemcpy(b->items.p, hItems.data(), (size_t) nItems * sizeof(DevItem), hipMemcpyHostToDevice));
+    B_TRY(b->chars.alloc((size_t) nX + 8));
+    B_TRY(hipMemset(b->chars.p, 0, (size_t) nX + 8));
+    B_TRY(hipMemcpy(b->chars.p, xChars, (size_t) nX, hipMemcpyHostToDevice));
+    B_TRY(b->kidx.alloc((size_t) nX + 8));
+    B_TRY(b->events.alloc((size_t) 3 * nEvents + 8));
+    B_TRY(hipMemcpy(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+    B_TRY(b->anchors.alloc((size_t) 2 * nAnchorPairs + 2));
+    if (nAnchorPairs > 0)
+        B_TRY(hipMemcpy(b->anchors.p, anchors, (size_t) 2 * nAnchorPairs * sizeof(long long),
+                        hipMemcpyHostToDevice));
+    B_TRY(b->pairs.alloc((size_t) pairTotal * 3));
+    B_TRY(b->pairLogp.alloc((size_t) pairTotal));
+    B_TRY(b->nPairs.alloc((size_t) nItems));
+    B_TRY(b->nTot.alloc((size_t) nItems));
+    B_TRY(b->nCells.alloc((size_t) nItems));
+    B_TRY(b->totXay.alloc((size_t) totTotal));
+    B_TRY(b->totVal.alloc((size_t) totTotal));
+    B_TRY(b->expect.alloc((size_t) b->nModels * CPECAN_EXPECTATION_LEN));
+    B_TRY(hipMemset(b->expect.p, 0, b->expect.n * sizeof(double)));
+    b->hNCells.resize((size_t) nItems);
+    for (int64_t i = 0; i < nItems; i++) b->hNCells[(size_t) i] = hItems[(size_t) i].nCells;
+
+    if (useKernel == CPECAN_KERNEL_GENERAL) {
+        B_TRY(b->bandL.alloc(hL.size()));
+        B_TRY(b->bandR.alloc(hR.size()));
+        B_TRY(b->cellPrefix.alloc(hPre.size()));
+        B_TRY(hipMemcpy(b->bandL.p, hL.data(), hL.size() * sizeof(int), hipMemcpyHostToDevice));
+        B_TRY(hipMemcpy(b->bandR.p, hR.data(), hR.size() * sizeof(int), hipMemcpyHostToDevice));
+        B_TRY(hipMemcpy(b->cellPrefix.p, hPre.data(), hPre.size() * sizeof(long long), hipMemcpyHostToDevice));
+        B_TRY(b->Fstore.alloc((size_t) cellTotal * 3));
+        B_TRY(b->Bstore.alloc((size_t) bwsTotal));
+        if (b->P.debug) {
+            B_TRY(b->dbgB.alloc((size_t) cellTotal * 3));
+            B_TRY(hipMemset(b->dbgB.p, 0xff, (size_t) cellTotal * 3 * sizeof(double)));
+        }
+    } else {
+        b->nWorkers = cpecan_systolic_workers(c->device, nItems);
+        b->ringDoubles = cpecan_systolic_ring_doubles(&b->P);
+        B_TRY(b->Fstore.alloc((size_t) b->nWorkers * (size_t) b->ringDoubles));
+        B_TRY(b->workCounter.alloc(4));
+    }
+    B_TRY(hipEventCreate(&b->ev0));
+    B_TRY(hipEventCreate(&b->ev1));
+    B_TRY(hipEventCreate(&b->ev2));
+
+    /* k-mer indices are part of input preparation (done once, like H2D) */
+    {
+        long long n = (long long) nX;
+        int threads = 256;
+        int blocks = (int) ((n + threads - 1) / threads);
+        if (blocks > 0)
+            hipLaunchKernelGGL(cpecan_k_kmer_index, dim3(blocks), dim3(threads), 0, c->stream,
+                               (const char *) b->chars.p, n, b->kidx.p);
+        B_TRY(hipGetLastError());
+        B_TRY(hipStreamSynchronize(c->stream));
+    }
+    *out = b;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_run(cpecan_batch *b) {
+    if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
+    cpecan_ctx *c = b->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    b->countsValid = false;
+    HIP_TRY(hipEventRecord(b->ev0, c->stream));
+    if (b->mode == CPECAN_MODE_EXPECTATIONS)
+        HIP_TRY(hipMemsetAsync(b->expect.p, 0, b->expect.n * sizeof(double), c->stream));
+    HIP_TRY(hipEventRecord(b->ev1, c->stream));
+    if (b->kernel == CPECAN_KERNEL_GENERAL) {
+        hipLaunchKernelGGL(cpecan_k_general, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
+                           (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
+                           (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
+                           (const unsigned short *) b->kidx.p, (const double *) b->events.p,
+                           (const double *) c->models.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
+                           b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
+                           b->dbgB.p, b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemsetAsync(b->workCounter.p, 0, 4 * sizeof(int), c->stream));
+        int rc = cpecan_systolic_launch(c->stream, b->items.p, b->nItems, b->P, b->anchors.p,
+                                        b->kidx.p, b->events.p, c->models.p, b->Fstore.p,
+                                        b->ringDoubles, b->workCounter.p, b->pairs.p, b->pairLogp.p,
+                                        b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
+                                        b->nCells.p,
+                                        b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr,
+                                        b->nWorkers);
+        if (rc != 0) return fail(CPECAN_EHIP, "systolic kernel launch failed: %s",
+                                 hipGetErrorString(hipGetLastError()));
+    }
+    HIP_TRY(hipEventRecord(b->ev2, c->stream));
+    b->ran = true;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_sync(cpecan_batch *b) {
+    if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_elapsed_ms(cpecan_batch *b, float *msTotal, float *msKernel) {
+    if (!b || !b->ran) return fail(CPECAN_EINVAL, "batch has not run");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipEventSynchronize(b->ev2));
+    float a = 0, k = 0;
+    HIP_TRY(hipEventElapsedTime(&a, b->ev0, b->ev2));
+    HIP_TRY(hipEventElapsedTime(&k, b->ev1, b->ev2));
+    if (msTotal) *msTotal = a;
+    if (msKernel) *msKernel = k;
+    return CPECAN_OK;
+}
+
+static int ensure_counts(cpecan_batch *b) {
+    if (!b->ran) return fail(CPECAN_EINVAL, "batch has not run");
+    if (b->countsValid) return CPECAN_OK;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    b->hNPairs.resize((size_t) b->nItems);
+    b->hNTot.resize((size_t) b->nItems);
+    HIP_TRY(hipMemcpy(b->hNPairs.data(), b->nPairs.p, (size_t) b->nItems * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(b->hNTot.data(), b->nTot.p, (size_t) b->nItems * sizeof(long long), hipMemcpyDeviceToHost));
+    b->countsValid = true;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_counts(cpecan_batch *b, int64_t *nPairs, int64_t *nTotals, int64_t *nCells) {
+    if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
+    int rc = ensure_counts(b);
+    if (rc) return rc;
+    for (int64_t i = 0; i < b->nItems; i++) {
+        if (nPairs) nPairs[i] = b->hNPairs[(size_t) i];
+        if (nTotals) nTotals[i] = b->hNTot[(size_t) i];
+        if (nCells) nCells[i] = b->hNCells[(size_t) i];
+    }
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_fetch_pairs(cpecan_batch *b, int64_t item, int64_t *triples, double *logp,
+                                 int64_t cap) {
+    if (!b || item < 0 || item >= b->nItems || !triples) return fail(CPECAN_EINVAL, "bad argument");
+    int rc = ensure_counts(b);
+    if (rc) return rc;
+    const DevItem &d = b->hItems[(size_t) item];
+    long long n = b->hNPairs[(size_t) item];
+    if (n > d.pairCap)
+        return fail(CPECAN_EOVERFLOW, "item %lld produced %lld pairs, device capacity %lld",
+                    (long long) item, n, d.pairCap);
+    if (n > cap) return fail(CPECAN_EOVERFLOW, "need room for %lld triples", n);
+    if (n == 0) return CPECAN_OK;
+    HIP_TRY(hipMemcpy(triples, b->pairs.p + d.pairBase * 3, (size_t) n * 3 * sizeof(long long),
+                      hipMemcpyDeviceToHost));
+    if (logp)
+        HIP_TRY(hipMemcpy(logp, b->pairLogp.p + d.pairBase, (size_t) n * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_fetch_totals(cpecan_batch *b, int64_t item, int64_t *xay, double *total,
+                                  int64_t cap) {
+    if (!b || item < 0 || item >= b->nItems) return fail(CPECAN_EINVAL, "bad argument");
+    int rc = ensure_counts(b);
+    if (rc) return rc;
+    const DevItem &d = b->hItems[(size_t) item];
+    long long n = b->hNTot[(size_t) item];
+    if (n > d.totCap) return fail(CPECAN_EOVERFLOW, "totals overflow (%lld > %lld)", n, d.totCap);
+    if (n > cap) return fail(CPECAN_EOVERFLOW, "need room for %lld totals", n);
+    if (n == 0) return CPECAN_OK;
+    if (xay)
+        HIP_TRY(hipMemcpy(xay, b->totXay.p + d.totBase, (size_t) n * sizeof(long long), hipMemcpyDeviceToHost));
+    if (total)
+        HIP_TRY(hipMemcpy(total, b->totVal.p + d.totBase, (size_t) n * sizeof(double), hipMemcpyDeviceToHost));
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_expectations_device_ptr(cpecan_batch *b, void **devPtr, int64_t *nDoubles) {
+    if (!b || !devPtr) return fail(CPECAN_EINVAL, "bad argument");
+    *devPtr = (void *) b->expect.p;
+    if (nDoubles) *nDoubles = (int64_t) b->expect.n;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_fetch_expectations(cpecan_batch *b, int32_t modelId, double *out) {
+    if (!b || !out || modelId < 0 || modelId >= b->nModels) return fail(CPECAN_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(hipMemcpy(out, b->expect.p + (size_t) modelId * CPECAN_EXPECTATION_LEN,
+                      CPECAN_EXPECTATION_LEN * sizeof(double), hipMemcpyDeviceToHost));
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_debug_cells(cpecan_batch *b, int64_t item, double *forward, double *backward,
+                                 int64_t nCells) {
+    if (!b || item < 0 || item >= b->nItems) return fail(CPECAN_EINVAL, "bad argument");
+    if (!b->P.debug || b->kernel != CPECAN_KERNEL_GENERAL)
+        return fail(CPECAN_EINVAL, "batch was not created with CPECAN_FLAG_DEBUG_DUMP");
+    const DevItem &d = b->hItems[(size_t) item];
+    if (nCells < d.nCells) return fail(CPECAN_EOVERFLOW, "need room for %lld cells", d.nCells);
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    if (forward)
+        HIP_TRY(hipMemcpy(forward, b->Fstore.p + d.cellBase * 3, (size_t) d.nCells * 3 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    if (backward)
+        HIP_TRY(hipMemcpy(backward, b->dbgB.p + d.cellBase * 3, (size_t) d.nCells * 3 * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    return CPECAN_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,151 @@
+/*
+ * cpecan_hip.h -- C-ABI of the MI355X (gfx950) implementation of cPecan's banded pair-HMM
+ * forward / backward / posterior DP over nanopore events x reference k-mers.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, no HIP or C++ types in any signature.
+ * This is the boundary the reference's C code would link against for this path; each entry point
+ * names the reference interface it replaces.  All functions return CPECAN_OK (0) or a negative
+ * CPECAN_E* code; cpecan_hip_last_error() gives the message of the calling thread's last failure.
+ * There is no CPU fallback: without a usable GPU every compute entry point fails with
+ * CPECAN_ENODEVICE.
+ */
+#ifndef CPECAN_HIP_H_
+#define CPECAN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPECAN_OK 0
+#define CPECAN_ENODEVICE (-1)  /* no HIP device / runtime error at start-up          */
+#define CPECAN_EINVAL (-2)     /* bad argument                                       */
+#define CPECAN_EHIP (-3)       /* a HIP call failed (message in last_error)          */
+#define CPECAN_EOVERFLOW (-4)  /* an output capacity was too small                   */
+#define CPECAN_EBAND (-5)      /* anchors describe an invalid band (diagonal_construct throw) */
+
+#define CPECAN_NUM_KMERS 4096
+#define CPECAN_KMER_LENGTH 6
+#define CPECAN_MODEL_PARAMS 5
+#define CPECAN_MODEL_TABLE_LEN (1 + CPECAN_NUM_KMERS * CPECAN_MODEL_PARAMS)
+#define CPECAN_PAIR_ALIGNMENT_PROB_1 10000000 /* inc/pairwiseAligner.h:26 */
+
+typedef struct cpecan_ctx cpecan_ctx;     /* one per (host thread, GPU): device, stream, models */
+typedef struct cpecan_batch cpecan_batch; /* a set of independent alignments resident in HBM    */
+
+/* ---- start-up ------------------------------------------------------------------------------ */
+int cpecan_hip_device_count(int *count);
+int cpecan_hip_ctx_create(int device, cpecan_ctx **ctx);
+int cpecan_hip_ctx_destroy(cpecan_ctx *ctx);
+const char *cpecan_hip_last_error(void);
+const char *cpecan_hip_version(void);
+
+/* ---- model ---------------------------------------------------------------------------------
+ * Replaces the StateMachine3 the reference builds with getStrawManStateMachine3()
+ * (impl/stateMachine.c:1725) and rescales per read with emissions_signal_scaleModel() (:631):
+ * transitions in the order of struct _StateMachine3 (inc/stateMachine.h:179-187), emission tables
+ * in the reference's own layout (EMISSION_MATCH_PROBS / EMISSION_GAP_Y_PROBS = 1+4096*5 doubles,
+ * EMISSION_GAP_X_PROBS = 4096 doubles).  The tables are read once, on the host, to derive the
+ * device table (log sigma etc. use the host libm, as the reference's per-cell log() does). */
+typedef struct {
+    double transitions[9]; /* MATCH_CONTINUE, MATCH_FROM_GAP_X, MATCH_FROM_GAP_Y, GAP_OPEN_X,
+                              GAP_OPEN_Y, GAP_EXTEND_X, GAP_EXTEND_Y, GAP_SWITCH_TO_X, GAP_SWITCH_TO_Y */
+    const double *match_probs; /* [CPECAN_MODEL_TABLE_LEN] */
+    const double *gap_x_probs; /* [CPECAN_NUM_KMERS]       */
+    const double *gap_y_probs; /* [CPECAN_MODEL_TABLE_LEN] */
+} cpecan_sm3_model;
+
+/* Derives and uploads n models (host work is spread over `threads` OS threads, <=0: all cores);
+ * ids[i] receives the handle of models[i]. */
+int cpecan_hip_models_create(cpecan_ctx *ctx, const cpecan_sm3_model *models, int32_t n,
+                             int32_t threads, int32_t *ids);
+int cpecan_hip_models_clear(cpecan_ctx *ctx);
+
+/* ---- band / split geometry (host integer code, exported because the reference exports it) ----
+ * cpecan_band_construct: band_construct (impl/pairwiseAligner.c:132); xmyL/xmyR hold lX+lY+1 entries.
+ * cpecan_split_points: getSplitPoints (:1313); out holds up to cap 4-tuples; returns the count. */
+int cpecan_band_construct(const int64_t *anchors, int64_t n_anchors, int64_t lX, int64_t lY,
+                          int64_t expansion, int32_t *xmyL, int32_t *xmyR);
+int64_t cpecan_split_points(const int64_t *anchors, int64_t n_anchors, int64_t lX, int64_t lY,
+                            int64_t max_matrix_size, int ragged_left, int ragged_right,
+                            int64_t *out, int64_t cap);
+
+/* ---- batch ---------------------------------------------------------------------------------
+ * One work item = one getPosteriorProbsWithBanding() call (impl/pairwiseAligner.c:870): a k-mer
+ * sequence X of lX elements (lX+5 nucleotides starting at x_chars[x_offset]), an event sequence Y
+ * of lY elements (events[3*(y_offset+i)] = mean, noise, duration -- the reference's layout),
+ * anchors relative to the item, ragged-end flags and a model.  Sub-alignments produced by
+ * getSplitPoints are separate items that point into the same buffers. */
+typedef struct {
+    int64_t x_offset, lX;
+    int64_t y_offset, lY;
+    int64_t anchor_offset, n_anchors; /* into anchors[] as (x,y) pairs */
+    int32_t model_id;
+    int32_t ragged_left, ragged_right;
+    int32_t reserved;
+} cpecan_item;
+
+/* the PairwiseAlignmentParameters fields this path reads (inc/pairwiseAligner.h:80-91) */
+typedef struct {
+    double threshold;
+    int64_t minDiagsBetweenTraceBack;
+    int64_t traceBackDiagonals;
+    int64_t diagonalExpansion;
+} cpecan_band_params;
+
+#define CPECAN_MODE_POSTERIOR 0    /* diagonalCalculationPosteriorMatchProbs (:756) */
+#define CPECAN_MODE_EXPECTATIONS 1 /* diagonalCalculation_Expectations (:841)       */
+
+#define CPECAN_KERNEL_AUTO 0
+#define CPECAN_KERNEL_GENERAL 1  /* any band width; diagonals live in HBM            */
+#define CPECAN_KERNEL_SYSTOLIC 2 /* band <= 192 k-mers wide; register-resident wavefront */
+
+#define CPECAN_FLAG_DEBUG_DUMP 1 /* keep forward/backward cells for cpecan_hip_batch_debug_cells */
+#define CPECAN_FLAG_UNBANDED 2   /* getAlignedPairsWithoutBanding (:1512): full matrix, one traceback from
+                                    the last diagonal, one totalProbability taken there; anchors and
+                                    diagonalExpansion are ignored (general kernel only) */
+
+/* Copies the inputs to HBM and builds per-item band tables.  All host pointers may be released
+ * after the call returns. */
+int cpecan_hip_batch_create(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
+                            const char *x_chars, int64_t n_x_chars, const double *events,
+                            int64_t n_events, const int64_t *anchors, int64_t n_anchor_pairs,
+                            const cpecan_band_params *params, int32_t mode, int32_t kernel,
+                            int32_t flags, cpecan_batch **batch);
+/* Runs the DP for every item (asynchronous on the context's stream). */
+int cpecan_hip_batch_run(cpecan_batch *batch);
+int cpecan_hip_batch_sync(cpecan_batch *batch);
+/* HIP-event time of the last run's kernels, in ms (after sync). */
+int cpecan_hip_batch_elapsed_ms(cpecan_batch *batch, float *ms_total, float *ms_dp_kernel);
+/* Per-item result sizes: aligned pairs, refreshes of totalProbability, in-band cells. */
+int cpecan_hip_batch_counts(cpecan_batch *batch, int64_t *n_pairs, int64_t *n_totals,
+                            int64_t *n_cells);
+/* Aligned pairs of one item as (floor(p*1e7), x, y) int64 triples in the order the reference's
+ * diagonalPosteriorProbFn emits them (windows forward, diagonals descending, x-y ascending);
+ * logp (may be NULL) receives (F+B)-total for each. */
+int cpecan_hip_batch_fetch_pairs(cpecan_batch *batch, int64_t item, int64_t *triples, double *logp,
+                                 int64_t cap);
+/* totalProbability refreshes of one item: the diagonal and the value, in the order computed. */
+int cpecan_hip_batch_fetch_totals(cpecan_batch *batch, int64_t item, int64_t *xay, double *total,
+                                  int64_t cap);
+/* Expectations (mode EXPECTATIONS): per model id, 9 transitions [from*3+to] + 4096 k-mer gap bins
+ * + likelihood = 4106 doubles, summed over the items of the batch that use that model. The device
+ * buffer pointer is exposed so that a caller can all-reduce it in place (RCCL) before fetching. */
+#define CPECAN_EXPECTATION_LEN (9 + CPECAN_NUM_KMERS + 1)
+int cpecan_hip_batch_expectations_device_ptr(cpecan_batch *batch, void **dev_ptr, int64_t *n_doubles);
+int cpecan_hip_batch_fetch_expectations(cpecan_batch *batch, int32_t model_id, double *out);
+/* Debug: forward cells and backward cells (as they stand when posteriors are taken) of an item,
+ * [cell][state] with cells ordered by diagonal then x-y; needs CPECAN_FLAG_DEBUG_DUMP. */
+int cpecan_hip_batch_debug_cells(cpecan_batch *batch, int64_t item, double *forward,
+                                 double *backward, int64_t n_cells);
+int cpecan_hip_batch_destroy(cpecan_batch *batch);
+
+/* Stream of the context as an opaque pointer (a hipStream_t) for callers that need to order
+ * their own work (e.g. an RCCL all-reduce of the expectations) after the batch kernels. */
+int cpecan_hip_ctx_stream(cpecan_ctx *ctx, void **stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,39 @@
+"""The C-ABI library loads, exports every symbol include/cpecan_hip.h declares, and refuses to
+compute without a GPU (there is no CPU fallback in the product)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from cpecan_load import binding, ROOT
+
+cp = binding()
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "cpecan_hip.h")).read()
+    declared = set(re.findall(r"\b(cpecan_[a-z_]+)\s*\(", header))
+    assert declared == set(cp.EXPORTS), declared ^ set(cp.EXPORTS)
+    lib = ctypes.CDLL(cp.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+
+
+def test_no_oracle_in_product():
+    # the shipped path must not reach into oracle/: no reference to it in product sources or binding
+    prod = os.path.join(ROOT, "cpecan-signal_amd")
+    for dirpath, _, files in os.walk(prod):
+        for f in files:
+            if f.endswith((".hip", ".h", ".c", ".cpp", ".py")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "liborc" not in text and "pyoracle" not in text and "cpecan_oracle" not in text, f
+
+
+def test_fails_loudly_without_gpu():
+    if cp.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(cp.CpecanError) as ei:
+        cp.Context(0)
+    assert ei.value.code == cp.ENODEVICE
+    assert "no CPU path" in str(ei.value)
