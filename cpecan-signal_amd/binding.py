@@ -34,7 +34,7 @@ EXPORTS = [
     "cpecan_hip_batch_elapsed_ms", "cpecan_hip_batch_counts", "cpecan_hip_batch_fetch_pairs",
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
-    "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream",
+    "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         L.cpecan_hip_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.cpecan_hip_models_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.cpecan_hip_models_clear.argtypes = [C.c_void_p]
+        L.cpecan_hip_selftest_division.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]
         L.cpecan_hip_batch_create.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
             C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.c_int32, C.c_int32,
@@ -190,6 +191,11 @@ class Context:
 
     def models_clear(self):
         _check(lib().cpecan_hip_models_clear(self.h))
+
+    def selftest_division(self, n, seed=1):
+        bad = C.c_int64(-1)
+        _check(lib().cpecan_hip_selftest_division(self.h, n, seed, C.byref(bad)))
+        return bad.value
 
 
 class Batch:

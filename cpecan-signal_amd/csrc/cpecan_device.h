@@ -65,6 +65,7 @@ struct DevParams {
     double threshold;
     long long minDiags, tbDiags, expansion;
     int mode, debug, unbanded, pad;
+    double logThrSlack; /* log(threshold) minus a safety margin: cells below it skip exp() */
 };
 
 /* lookup(): impl/pairwiseAligner.c:238-249 -- four cubics, float literals */

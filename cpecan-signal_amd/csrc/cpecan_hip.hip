@@ -29,16 +29,19 @@ extern "C" __global__ void cpecan_k_general(const DevItem *, DevParams, const in
 extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned short *);
 
 extern "C" int cpecan_systolic_max_width(void);
-extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, long long nItems,
-                                      DevParams P, const long long *anchors,
+extern "C" int cpecan_systolic_rows(void);
+extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned long long seed,
+                                       unsigned long long *bad);
+extern "C" int cpecan_systolic_occupancy(int *workgroupsPerCU);
+extern "C" int cpecan_systolic_launch(hipStream_t stream, int nWorkgroups, const DevItem *items,
+                                      long long nItems, DevParams P, const long long *anchors,
+                                      const double *track, const long long *trackBase,
                                       const unsigned short *kidx, const double *events,
                                       const double *models, double *Fring, long long ringDoubles,
-                                      int *workCounter, long long *pairs, double *pairLogp,
-                                      long long *nPairs, long long *totXay, double *totVal,
-                                      long long *nTot, long long *nCells, double *expect,
-                                      int nWorkers);
-extern "C" long long cpecan_systolic_ring_doubles(const DevParams *P);
-extern "C" int cpecan_systolic_workers(int device, long long nItems);
+                                      int ringD, int *workCounter, long long *pairs,
+                                      double *pairLogp, long long *nPairs, long long *totXay,
+                                      double *totVal, long long *nTot, long long *nCells,
+                                      int maxLX, int buildTrack);
 
 namespace {
 
@@ -109,7 +112,10 @@ struct cpecan_batch {
     DevBuf<double> totVal;
     DevBuf<double> expect;
     DevBuf<int> workCounter;
+    DevBuf<double> track;
+    DevBuf<long long> trackBase;
     long long ringDoubles = 0;
+    int ringD = 0, maxLX = 0;
     int nWorkers = 0;
     int nModels = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -227,6 +233,21 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
     return CPECAN_OK;
 }
 
+int cpecan_hip_selftest_division(cpecan_ctx *c, int64_t n, uint64_t seed, int64_t *mismatches) {
+    if (!c || n <= 0 || !mismatches) return fail(CPECAN_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<unsigned long long> bad;
+    HIP_TRY(bad.alloc(1));
+    HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), c->stream));
+    if (cpecan_systolic_divtest(c->stream, n, seed, bad.p) != 0)
+        return fail(CPECAN_EHIP, "division self-test launch failed");
+    unsigned long long h = 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(&h, bad.p, sizeof h, hipMemcpyDeviceToHost));
+    *mismatches = (int64_t) h;
+    return CPECAN_OK;
+}
+
 int cpecan_hip_models_clear(cpecan_ctx *c) {
     if (!c) return fail(CPECAN_EINVAL, "ctx is NULL");
     (void) hipSetDevice(c->device);
@@ -282,8 +303,10 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     std::vector<DevItem> hItems((size_t) nItems);
     std::vector<int> hL, hR;
     std::vector<long long> hPre;
-    long long cellTotal = 0, pairTotal = 0, totTotal = 0, bwsTotal = 0;
-    int globalMaxWidth = 0;
+    long long cellTotal = 0, pairTotal = 0, totTotal = 0, bwsTotal = 0, trackTotal = 0;
+    int globalMaxWidth = 0, maxSpan = 1, maxLX = 0;
+    bool systolicOk = true; /* band edges move by at most one k-mer per diagonal */
+    std::vector<long long> hTrackBase((size_t) nItems);
     for (int64_t i = 0; i < nItems; i++) {
         const cpecan_item &s = items[i];
         if (s.lX < 0 || s.lY < 0 || s.x_offset < 0 || s.y_offset < 0 || s.n_anchors < 0 ||
@@ -319,6 +342,28 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
         }
         d.nCells = cells;
         d.maxWidth = maxW;
+        {   /* traceback schedule of getPosteriorProbsWithBanding (:917-918): longest span of forward
+             * diagonals that must be resident at once, and the edge-step property the systolic
+             * kernel relies on */
+            const int *Lp = hL.data() + d.diagBase, *Rp = hR.data() + d.diagBase;
+            long long tracedBackTo = 0;
+            for (long long k = 1; k < nDiag; k++) {
+                const int xmn = (int) ((k + Lp[k]) / 2), xmx = (int) ((k + Rp[k]) / 2);
+                const int pmn = (int) ((k - 1 + Lp[k - 1]) / 2), pmx = (int) ((k - 1 + Rp[k - 1]) / 2);
+                if (xmn < pmn || xmn > pmn + 1 || xmx < pmx || xmx > pmx + 1) systolicOk = false;
+                const bool atEnd = k == nDiag - 1;
+                const int w = ((Rp[k] - Lp[k]) >> 1) + 1;
+                const bool tb = k >= tracedBackTo + params->minDiagsBetweenTraceBack &&
+                                w <= params->diagonalExpansion * 2 + 1;
+                if (atEnd || tb) {
+                    maxSpan = std::max<long long>(maxSpan, k - tracedBackTo + 1);
+                    tracedBackTo = k - (params->traceBackDiagonals + 1);
+                }
+            }
+        }
+        hTrackBase[(size_t) i] = trackTotal;
+        trackTotal += s.lX + 1;
+        maxLX = std::max<int>(maxLX, (int) s.lX);
         globalMaxWidth = std::max(globalMaxWidth, maxW);
         d.cellBase = cellTotal;
         cellTotal += cells;
@@ -347,19 +392,22 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     b->P.mode = mode;
     b->P.debug = (flags & CPECAN_FLAG_DEBUG_DUMP) ? 1 : 0;
     b->P.unbanded = unbanded ? 1 : 0;
+    b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
     int useKernel = kernel;
     if (useKernel == CPECAN_KERNEL_AUTO)
-        useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && !b->P.debug && !unbanded)
+        useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && systolicOk && !b->P.debug &&
+                     !unbanded && mode == CPECAN_MODE_POSTERIOR)
                         ? CPECAN_KERNEL_SYSTOLIC : CPECAN_KERNEL_GENERAL;
-    if (useKernel == CPECAN_KERNEL_SYSTOLIC && globalMaxWidth > cpecan_systolic_max_width()) {
+    if (useKernel == CPECAN_KERNEL_SYSTOLIC &&
+        (globalMaxWidth > cpecan_systolic_max_width() || !systolicOk)) {
         delete b;
-        return fail(CPECAN_EINVAL, "band is %d cells wide; the systolic kernel handles at most %d",
-                    globalMaxWidth, cpecan_systolic_max_width());
+        return fail(CPECAN_EINVAL, "band is %d cells wide (systolic kernel: at most %d, edges moving "
+                    "one k-mer per diagonal)", globalMaxWidth, cpecan_systolic_max_width());
     }
-    if (useKernel == CPECAN_KERNEL_SYSTOLIC && b->P.debug) {
+    if (useKernel == CPECAN_KERNEL_SYSTOLIC && (b->P.debug || mode != CPECAN_MODE_POSTERIOR)) {
         delete b;
-        return fail(CPECAN_EINVAL, "cell dumps are only available from the general kernel");
+        return fail(CPECAN_EINVAL, "cell dumps and expectations are only available from the general kernel");
     }
     b->kernel = useKernel;
     b->hItems = hItems;
@@ -402,10 +450,20 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
             B_TRY(hipMemset(b->dbgB.p, 0xff, (size_t) cellTotal * 3 * sizeof(double)));
         }
     } else {
-        b->nWorkers = cpecan_systolic_workers(c->device, nItems);
-        b->ringDoubles = cpecan_systolic_ring_doubles(&b->P);
+        /* persistent workgroups: as many as stay resident, never more than there are items */
+        int perCU = 0, cus = 0;
+        if (cpecan_systolic_occupancy(&perCU) != 0 || perCU < 1) perCU = 1;
+        B_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+        b->nWorkers = (int) std::min<long long>(nItems, (long long) perCU * cus);
+        b->ringD = maxSpan + 4;
+        b->ringDoubles = (long long) b->ringD * cpecan_systolic_rows() * 3 * 64;
+        b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) b->nWorkers * (size_t) b->ringDoubles));
         B_TRY(b->workCounter.alloc(4));
+        B_TRY(b->track.alloc((size_t) trackTotal * CP_ROW));
+        B_TRY(b->trackBase.alloc((size_t) nItems));
+        B_TRY(hipMemcpy(b->trackBase.p, hTrackBase.data(), (size_t) nItems * sizeof(long long),
+                        hipMemcpyHostToDevice));
     }
     B_TRY(hipEventCreate(&b->ev0));
     B_TRY(hipEventCreate(&b->ev1));
@@ -446,13 +504,14 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(hipMemsetAsync(b->workCounter.p, 0, 4 * sizeof(int), c->stream));
-        int rc = cpecan_systolic_launch(c->stream, b->items.p, b->nItems, b->P, b->anchors.p,
-                                        b->kidx.p, b->events.p, c->models.p, b->Fstore.p,
-                                        b->ringDoubles, b->workCounter.p, b->pairs.p, b->pairLogp.p,
+        /* the per-item track of emission constants is rebuilt every run: it is a function of the
+         * inputs (k-mers x model), so it belongs inside the timed region */
+        int rc = cpecan_systolic_launch(c->stream, b->nWorkers, b->items.p, b->nItems, b->P,
+                                        b->anchors.p, b->track.p, b->trackBase.p, b->kidx.p,
+                                        b->events.p, c->models.p, b->Fstore.p, b->ringDoubles,
+                                        b->ringD, b->workCounter.p, b->pairs.p, b->pairLogp.p,
                                         b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
-                                        b->nCells.p,
-                                        b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr,
-                                        b->nWorkers);
+                                        b->nCells.p, b->maxLX, 1);
         if (rc != 0) return fail(CPECAN_EHIP, "systolic kernel launch failed: %s",
                                  hipGetErrorString(hipGetLastError()));
     }

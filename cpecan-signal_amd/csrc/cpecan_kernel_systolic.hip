@@ -1,10 +1,758 @@
-/* placeholder until the register-systolic kernel lands: reports width 0 so AUTO picks the general kernel */
+/*
+ * cpecan_kernel_systolic.hip -- the throughput kernel: banded forward / backward / posterior DP
+ * with the anti-diagonal wavefront of the recurrence held in registers.
+ *
+ * Mapping (designed for CDNA4's 64-lane waves, not translated from anything):
+ *   - one 256-thread workgroup per alignment; lanes own reference k-mers, not DP cells: slot
+ *     s = x mod 256 is lane s % 64 of wave s / 64 (bands up to 256 k-mers wide).  A k-mer's 17
+ *     emission constants stay in its lane's VGPRs while x is inside the band, so the inner loop
+ *     loads nothing per cell.
+ *   - one loop iteration = one anti-diagonal.  Forward: a cell needs (x-1,y) and (x-1,y-1) from the
+ *     lane below (one DPP wave-rotate per value) and (x,y-1) from itself; only lane 0 of a wave
+ *     takes its neighbour from the wave below through 40 bytes of LDS (one barrier per diagonal).
+ *     The event a lane scores also moves up one lane per diagonal, so events travel with the cells;
+ *     only the event that enters the band is fetched, from a 64-event register chunk that is
+ *     refilled two chunks ahead.
+ *   - backward is the mirror image (messages travel down one lane); it is a gather, with the
+ *     reference's scatter order of accumulation kept per state (see cpecan_kernel_general.hip).
+ *   - forward cells go to HBM once ([diagonal][wave][state][lane]: 512-byte coalesced stores) into
+ *     a per-workgroup ring holding one traceback window, and are read once by the backward sweep:
+ *     2 x 3 x 8 = 48 bytes per cell, the kernel's algorithmic HBM traffic.
+ *   - a wave whose 64 slots hold no in-band cell on a diagonal skips the arithmetic.
+ *   - band geometry is recomputed from the anchors in scalar registers; per-diagonal band tables
+ *     never exist in memory.
+ *   - workgroups are persistent: each pulls the next alignment from an atomic counter (the host
+ *     orders items longest-first), so ragged batches balance over the chip.
+ * MFMA is not used: the recurrence is a scan with an approximate log-add, not a contraction.
+ *
+ * Numerics: identical to the general kernel and the CPU oracle, bit for bit.  The only algebraic
+ * change is the division (x - mu) / sigma, done as a Markstein-corrected multiply by the
+ * host-rounded reciprocal (two fused multiply-adds), which returns the correctly rounded quotient
+ * (tests/test_systolic_gpu.py checks it against IEEE division on 10^8 operands).
+ */
 #include "cpecan_device.h"
-extern "C" int cpecan_systolic_max_width(void) { return 0; }
-extern "C" long long cpecan_systolic_ring_doubles(const DevParams *) { return 0; }
-extern "C" int cpecan_systolic_workers(int, long long) { return 0; }
-extern "C" int cpecan_systolic_launch(hipStream_t, const DevItem *, long long, DevParams,
-                                      const long long *, const unsigned short *, const double *,
-                                      const double *, double *, long long, int *, long long *,
-                                      double *, long long *, long long *, double *, long long *,
-                                      long long *, double *, int) { return -1; }
+
+#define SY_R 4
+#define SY_P (64 * SY_R)
+#define SY_NPRM 17
+
+namespace {
+
+struct Shared {
+    double xch[2][SY_R][8];  /* boundary-lane values, double-buffered by diagonal parity */
+    double vbuf[SY_P];       /* totalProbability terms of the current diagonal, by slot  */
+    double wbuf[SY_P];
+    unsigned long long vmask[SY_R], wmask[SY_R];
+    double total;
+    int cnt[2][SY_R][2];     /* aligned-pair counts per wave, double-buffered */
+    int item;
+};
+
+/* lane i <- lane i-1 (lane 0 <- lane 63) */
+__device__ __forceinline__ double ror1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x13C, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x13C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+/* lane i <- lane i+1 (lane 63 <- lane 0) */
+__device__ __forceinline__ double rol1(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast(double v, int srcLane) { /* srcLane wave-uniform */
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+/* logAdd (impl/pairwiseAligner.c:238-255), branch-free: same value in every case -- hi/lo are the
+ * operands as the reference's two branches order them, the "smaller operand is -inf" and ">= 7.5"
+ * exits both yield hi, and (-inf) - (-inf) = NaN fails d < 7.5 exactly like those exits. */
+__device__ __forceinline__ double ladd(double x, double y) {
+    const bool lt = x < y;
+    const double hi = lt ? y : x, lo = lt ? x : y;
+    const double d = hi - lo;
+    const bool p1 = d <= 1.00f, p2 = d <= 2.50f, p3 = d <= 4.50f;
+    const double c3 = p1 ? (double) -0.009350833524763f : p2 ? (double) -0.014532321752540f
+                    : p3 ? (double) -0.004605031767994f : (double) -0.000458661602210f;
+    const double c2 = p1 ? (double) 0.130659527668286f : p2 ? (double) 0.139942324101744f
+                    : p3 ? (double) 0.063427417320019f : (double) 0.009695946122598f;
+    const double c1 = p1 ? (double) 0.498799810682272f : p2 ? (double) 0.495635523139337f
+                    : p3 ? (double) 0.695956496475118f : (double) 0.930734667215156f;
+    const double c0 = p1 ? (double) 0.693203116424741f : p2 ? (double) 0.692140569840976f
+                    : p3 ? (double) 0.514272634594009f : (double) 0.168037164329057f;
+    const double r = ((c3 * d + c2) * d + c1) * d + c0 + lo;
+    return d < 7.5 ? r : hi;
+}
+
+/* log N(x; mu, sd) = K + (-0.5*a*a), a = (x-mu)/sd (impl/stateMachine.c:333-343); the quotient is
+ * q + fma(-q, sd, t) * rsd with q = t*rsd, rsd = RN(1/sd): Markstein's correction step, which
+ * rounds to the same double as the division.  sd == 0 rows carry rsd = 0, K = -inf => -inf. */
+__device__ __forceinline__ double lgauss(double x, double mu, double sd, double rsd, double K) {
+    const double t = x - mu;
+    const double q = t * rsd;
+    const double rem = __fma_rn(-q, sd, t);
+    const double a = __fma_rn(rem, rsd, q);
+    return K + (-0.5 * a * a);
+}
+
+struct Band {
+    const long long *an;
+    int nA, lX, lY, e2; /* e2 = diagonalExpansion / 2 */
+    int ai, pxay, nxay, xLo, xHi, yLo, yHi;
+
+    __device__ __forceinline__ static int clampi(int z, int hi) { return z < 0 ? 0 : (z > hi ? hi : z); }
+    /* rectangle between anchor a-1 and anchor a (a == nA: up to the end point): the closed form of
+     * band_construct, impl/pairwiseAligner.c:132-184 (see cpecan_geometry.c) */
+    __device__ __forceinline__ void load(int a) {
+        int px = 0, py = 0, nx = lX, ny = lY;
+        if (a > 0) { px = (int) an[2 * (a - 1)] + 1; py = (int) an[2 * (a - 1) + 1] + 1; }
+        if (a < nA) { nx = (int) an[2 * a] + 1; ny = (int) an[2 * a + 1] + 1; }
+        ai = uni(a);
+        pxay = uni(px + py);
+        nxay = uni(nx + ny);
+        xLo = uni(clampi(px - e2, lX));
+        yLo = uni(clampi(py - e2, lY));
+        xHi = uni(clampi(nx + e2, lX));
+        yHi = uni(clampi(ny + e2, lY));
+    }
+    __device__ __forceinline__ void range(int d, int &xmin, int &xmax) {
+        if (d <= 0) { xmin = 0; xmax = 0; return; }
+        while (d > nxay && ai < nA) load(ai + 1);
+        while (d <= pxay && ai > 0) load(ai - 1);
+        int a = d - yHi, b = d - yLo;
+        xmin = a > xLo ? a : xLo;
+        xmax = b < xHi ? b : xHi;
+    }
+};
+
+/* does wave w hold an in-band slot: waves (xmin>>6) .. (xmax>>6), modulo R */
+__device__ __forceinline__ bool row_active(int w, int xmin, int xmax) {
+    int first = xmin >> 6, n = (xmax >> 6) - first;
+    return ((w - first) & (SY_R - 1)) <= n;
+}
+
+/* 64 consecutive events (mean, noise) held one per lane, plus the neighbouring 64 prefetched */
+struct EvChunk {
+    double am, an, bm, bn;
+    int base; /* event index held by lane 0 of chunk a */
+    const double *ev;
+    int lY;
+
+    __device__ __forceinline__ void fetch(int b, double &m, double &n, int lane) {
+        int i = b + lane;
+        bool ok = i >= 0 && i < lY;
+        m = ok ? ev[3 * (long long) i] : 0.0;
+        n = ok ? ev[3 * (long long) i + 1] : 0.0;
+    }
+    __device__ __forceinline__ void init_up(int first, int lane) {
+        base = uni(first);
+        fetch(base, am, an, lane);
+        fetch(base + 64, bm, bn, lane);
+    }
+    __device__ __forceinline__ void init_down(int first, int lane) {
+        base = uni(first - 63);
+        fetch(base, am, an, lane);
+        fetch(base - 64, bm, bn, lane);
+    }
+    /* event e (wave-uniform; non-decreasing over calls in steady state).  e < 0 is NULLEVENT
+     * (:261): its emissions only ever meet -inf cells, a finite stand-in keeps NaN out */
+    __device__ __forceinline__ void get_up(int e, double &m, double &n, int lane) {
+        if (e < 0) { m = 0.0; n = 0.0; return; }
+        if (e < base || e >= base + 64) {
+            if (e >= base + 64 && e < base + 128) {
+                am = bm; an = bn; base = uni(base + 64); fetch(base + 64, bm, bn, lane);
+            } else {
+                init_up(e, lane);
+            }
+        }
+        m = bcast(am, e - base);
+        n = bcast(an, e - base);
+    }
+    __device__ __forceinline__ void get_down(int e, double &m, double &n, int lane) {
+        if (e < 0) { m = 0.0; n = 0.0; return; }
+        if (e < base || e >= base + 64) {
+            if (e < base && e >= base - 64) {
+                am = bm; an = bn; base = uni(base - 64); fetch(base - 64, bm, bn, lane);
+            } else {
+                init_down(e, lane);
+            }
+        }
+        m = bcast(am, e - base);
+        n = bcast(an, e - base);
+    }
+};
+
+struct ItemOut {
+    long long *pairs;
+    double *logp;
+    long long pairCap;
+    long long *totXay;
+    double *totVal;
+    long long totCap;
+    long long nPairs, nTot;
+};
+
+__device__ __forceinline__ void load_params(double (&dst)[SY_NPRM], const double *__restrict__ track, int x) {
+    const double *p = track + (long long) x * CP_ROW;
+#pragma unroll
+    for (int j = 0; j < SY_NPRM; j++) dst[j] = p[j];
+}
+
+/* aligned pairs found on a diagonal, written one barrier later when every wave's count is known */
+struct Pending {
+    bool any, hit, segB;
+    int r0, par, prefix;
+    long long p;
+    int x, y;
+    double e;
+};
+
+__device__ __forceinline__ void flush_pending(Pending &pd, Shared &sh, ItemOut &out, int wave) {
+    if (!pd.any) return;
+    int sumA = 0, before = 0;
+    const int rel = (wave - pd.r0) & (SY_R - 1);
+#pragma unroll
+    for (int k = 0; k < SY_R; k++) {
+        const int c = sh.cnt[pd.par][(pd.r0 + k) & (SY_R - 1)][0];
+        if (k < rel) before += c;
+        sumA += c;
+    }
+    const int cB = sh.cnt[pd.par][pd.r0][1];
+    if (pd.hit) {
+        const long long idx = out.nPairs + (pd.segB ? sumA : before) + pd.prefix;
+        if (idx < out.pairCap) {
+            long long *o = out.pairs + idx * 3;
+            o[0] = pd.p;
+            o[1] = pd.x - 1;
+            o[2] = pd.y - 1;
+            out.logp[idx] = pd.e;
+        }
+    }
+    out.nPairs += sumA + cB;
+    pd.any = false;
+}
+
+/* One alignment on one workgroup of SY_R waves. */
+__device__ void run_item(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
+                         const double *__restrict__ track, const double *__restrict__ events,
+                         const double *__restrict__ model, double *ring, int ringD, ItemOut &out,
+                         long long &cellCount, Shared &sh) {
+    const int lane = threadIdx.x & 63;
+    const int wave = uni(threadIdx.x >> 6);
+    const int waveBelow = (wave + SY_R - 1) & (SY_R - 1), waveAbove = (wave + 1) & (SY_R - 1);
+    const int lX = (int) it.lX, lY = (int) it.lY, D = lX + lY;
+    const double *__restrict__ ev = events + 3 * it.yOff;
+
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) T[i] = model[i];
+
+    Band band;
+    band.an = anchors + 2 * it.anchorOff;
+    band.nA = (int) it.nAnchors;
+    band.lX = lX;
+    band.lY = lY;
+    band.e2 = (int) (P.expansion / 2);
+    band.load(0);
+
+    /* ---- per-slot state (this lane's k-mer) ---- */
+    int xs = wave * 64 + lane;
+    double prm[SY_NPRM];
+    double Fm = CP_NEG_INF, Fx = CP_NEG_INF, Fy = CP_NEG_INF; /* forward cell, current diagonal  */
+    double Lm = CP_NEG_INF, Lx = CP_NEG_INF, Ly = CP_NEG_INF; /* slot-1's cell, previous diagonal */
+    double em = 0.0, en = 0.0;                                /* event scored on this diagonal    */
+    double st[SY_NPRM];                                       /* next k-mer to enter (prefetched) */
+#pragma unroll
+    for (int j = 0; j < SY_NPRM; j++) prm[j] = 0.0;
+
+    /* diagonal 0: the single cell (0,0) holds the start vector (:897-898, stateMachine.c:1168-1177) */
+    load_params(st, track, 0);
+    if (wave == 0 && lane == 0) {
+        Fm = it.raggedL ? CP_NEG_INF : 0.0;
+        Fx = it.raggedL ? 0.0 : CP_NEG_INF;
+        Fy = Fx;
+#pragma unroll
+        for (int j = 0; j < SY_NPRM; j++) prm[j] = st[j];
+    }
+    int xin = 1; /* k-mers below xin have been installed */
+    load_params(st, track, xin <= lX ? xin : lX);
+
+    auto ring_ptr = [&](int d, int w, int s) -> double * {
+        return ring + ((((long long) (d % ringD)) * SY_R + w) * 3 + s) * 64;
+    };
+    if (wave == 0) {
+        ring_ptr(0, 0, 0)[lane] = Fm;
+        ring_ptr(0, 0, 1)[lane] = Fx;
+        ring_ptr(0, 0, 2)[lane] = Fy;
+    }
+    if (lane == 63) {
+        double *x = sh.xch[0][wave];
+        x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
+    }
+    cellCount += 1;
+
+    EvChunk fwdEv;
+    fwdEv.ev = ev;
+    fwdEv.lY = lY;
+    fwdEv.init_up(0, lane);
+
+    int xminP = 0;
+    int tracedBackTo = 0;
+
+    for (int d = 1; d <= D; d++) {
+        int xmin, xmax;
+        band.range(d, xmin, xmax);
+        cellCount += xmax - xmin + 1;
+
+        /* ---------------- forward step ---------------- */
+        __syncthreads();
+        double rm = ror1(Fm), rx = ror1(Fx), ry = ror1(Fy), rem_ = ror1(em), ren_ = ror1(en);
+        if (lane == 0) {
+            const double *x = sh.xch[(d - 1) & 1][waveBelow];
+            rm = x[0]; rx = x[1]; ry = x[2]; rem_ = x[3]; ren_ = x[4];
+        }
+        if (xs < xmin) xs += SY_P;
+        const bool valid = xs <= xmax;
+        em = rem_;
+        en = ren_;
+        while (xin <= xmax) { /* install the entering k-mer's constants (at most one per step) */
+            if (((xin >> 6) & (SY_R - 1)) == wave && lane == (xin & 63)) {
+#pragma unroll
+                for (int j = 0; j < SY_NPRM; j++) prm[j] = st[j];
+            }
+            xin++;
+            load_params(st, track, xin <= lX ? xin : lX);
+        }
+        if (xmin == xminP) { /* the top cell's event is new to the band */
+            double nm, nn;
+            fwdEv.get_up(d - xmin - 1, nm, nn, lane);
+            if (((xmin >> 6) & (SY_R - 1)) == wave && lane == (xmin & 63)) { em = nm; en = nn; }
+        }
+        double nmv = CP_NEG_INF, nxv = CP_NEG_INF, nyv = CP_NEG_INF;
+        if (row_active(wave, xmin, xmax)) {
+            const double px = prm[CP_GAPX];
+            const double pm = lgauss(em, prm[CP_MU], prm[CP_SD], prm[CP_RSD], prm[CP_K1])
+                            + lgauss(en, prm[CP_NMU], prm[CP_NSD], prm[CP_RNSD], prm[CP_K2]);
+            const double py = lgauss(em, prm[CP_YMU], prm[CP_YSD], prm[CP_RYSD], prm[CP_YK1])
+                            + lgauss(en, prm[CP_YNMU], prm[CP_YNSD], prm[CP_RYNSD], prm[CP_YK2]);
+            /* cell_calculateForward: to[t] = logAdd(to[t], from[f] + (eP + tP)) (:365-376) in the
+             * order of stateMachine3_cellCalculate (stateMachine.c:1314-1333) */
+            double gx = rm + (px + T[T_GAP_OPEN_X]);
+            gx = ladd(gx, rx + (px + T[T_GAP_EXTEND_X]));
+            gx = ladd(gx, ry + (px + T[T_GAP_SWITCH_TO_X]));
+            double mm = Lm + (pm + T[T_MATCH_CONTINUE]);
+            mm = ladd(mm, Lx + (pm + T[T_MATCH_FROM_GAP_X]));
+            mm = ladd(mm, Ly + (pm + T[T_MATCH_FROM_GAP_Y]));
+            double gy = Fm + (py + T[T_GAP_OPEN_Y]);
+            gy = ladd(gy, Fy + (py + T[T_GAP_EXTEND_Y]));
+            nmv = valid ? mm : CP_NEG_INF;
+            nxv = valid ? gx : CP_NEG_INF;
+            nyv = valid ? gy : CP_NEG_INF;
+            ring_ptr(d, wave, 0)[lane] = nmv;
+            ring_ptr(d, wave, 1)[lane] = nxv;
+            ring_ptr(d, wave, 2)[lane] = nyv;
+        }
+        Lm = rm; Lx = rx; Ly = ry;
+        Fm = nmv; Fx = nxv; Fy = nyv;
+        if (lane == 63) {
+            double *x = sh.xch[d & 1][wave];
+            x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
+        }
+        xminP = xmin;
+
+        const bool atEnd = d == D;
+        const bool tb = d >= tracedBackTo + P.minDiags && (xmax - xmin + 1) <= P.expansion * 2 + 1;
+        if (!(atEnd || tb)) continue;
+
+        /* ---------------- traceback window (:921-992) ---------------- */
+        const int dTop = d;
+        const int tracedBackFrom = dTop - (atEnd ? 0 : (int) P.tbDiags + 1);
+        if (xs > xmax) xs -= SY_P; /* backward representative: xmax-P < x <= xmax */
+        bool tvalid = xs >= xmin;  /* slot in band on diagonal t */
+        double Bm, Bx, By;                          /* backward cell on diagonal t                    */
+        double Hm = CP_NEG_INF, Hx = CP_NEG_INF, Hy = CP_NEG_INF; /* middle-block msgs from t+2 (moved) */
+        double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1     */
+        double Um = CP_NEG_INF, Uy = CP_NEG_INF;                  /* upper-block msgs from t+1 (same slot) */
+        double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1      */
+        double pmPrev = 0.0, BmPrev = CP_NEG_INF;                 /* match emission / backward match of t+1 */
+        bool validPrev = false;
+        {
+            double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
+            if (atEnd && it.raggedR) {
+                e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
+                e1 = T[T_GAP_EXTEND_X];
+                e2 = T[T_GAP_EXTEND_Y];
+            } else {
+                e0 = T[T_MATCH_CONTINUE];
+                e1 = T[T_MATCH_FROM_GAP_X];
+                e2 = T[T_MATCH_FROM_GAP_Y];
+            }
+            Bm = tvalid ? e0 : CP_NEG_INF;
+            Bx = tvalid ? e1 : CP_NEG_INF;
+            By = tvalid ? e2 : CP_NEG_INF;
+        }
+        double bem = em, ben = en;
+        int xinB = xmin - 1; /* k-mers above xinB are installed */
+        load_params(st, track, xinB >= 0 ? xinB : 0);
+        EvChunk bwdEv;
+        bwdEv.ev = ev;
+        bwdEv.lY = lY;
+        bwdEv.init_down(dTop - xmax - 1, lane);
+
+        Pending pd;
+        pd.any = false;
+        double total = CP_NEG_INF;
+        int calcs = 0;
+        int bxmin = xmin, bxmax = xmax; /* band of diagonal t   */
+        int nxmin = xmin, nxmax = xmax; /* band of diagonal t+1 */
+        for (int t = dTop; t > tracedBackTo; t--) {
+            if (t < dTop) {
+                nxmin = bxmin; nxmax = bxmax;
+                band.range(t, bxmin, bxmax);
+                __syncthreads();
+                double gm = rol1(Gm), gx_ = rol1(Gx), gy_ = rol1(Gy);
+                double hm = rol1(Mm), hx = rol1(Mx), hy = rol1(My);
+                double sem = rol1(bem), sen = rol1(ben);
+                if (lane == 63) {
+                    const double *x = sh.xch[(t + 1) & 1][waveAbove];
+                    gm = x[0]; gx_ = x[1]; gy_ = x[2]; hm = x[3]; hx = x[4]; hy = x[5];
+                    sem = x[6]; sen = x[7];
+                }
+                flush_pending(pd, sh, out, wave);
+                if (xs > bxmax) xs -= SY_P;
+                const bool bvalid = xs >= bxmin;
+                bem = sem;
+                ben = sen;
+                while (xinB >= bxmin) {
+                    if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) {
+#pragma unroll
+                        for (int j = 0; j < SY_NPRM; j++) prm[j] = st[j];
+                    }
+                    xinB--;
+                    load_params(st, track, xinB >= 0 ? xinB : 0);
+                }
+                if (bxmax == nxmax) { /* the bottom cell's event is new to the band */
+                    double nm, nn;
+                    bwdEv.get_down(t - bxmax - 1, nm, nn, lane);
+                    if (((bxmax >> 6) & (SY_R - 1)) == wave && lane == (bxmax & 63)) { bem = nm; ben = nn; }
+                }
+                BmPrev = Bm;
+                validPrev = tvalid;
+                tvalid = bvalid;
+                double bm = CP_NEG_INF, bx = CP_NEG_INF, by = CP_NEG_INF;
+                if (row_active(wave, bxmin, bxmax)) {
+                    /* gather form of cell_calculateBackward: (t+2) middle block, then (t+1, smaller
+                     * x-y) upper block, then (t+1, larger x-y) lower block */
+                    bm = ladd(ladd(Hm, Um), gm);
+                    bx = ladd(Hx, gx_);
+                    by = ladd(ladd(Hy, Uy), gy_);
+                    bm = bvalid ? bm : CP_NEG_INF;
+                    bx = bvalid ? bx : CP_NEG_INF;
+                    by = bvalid ? by : CP_NEG_INF;
+                }
+                Bm = bm; Bx = bx; By = by;
+                Hm = hm; Hx = hx; Hy = hy;
+            }
+            /* messages this diagonal sends to t-1 and t-2 */
+            double pmCur = 0.0;
+            const bool active = row_active(wave, bxmin, bxmax);
+            Mm = Mx = My = Um = Uy = Gm = Gx = Gy = CP_NEG_INF;
+            if (active) {
+                const double px = prm[CP_GAPX];
+                const double pm = lgauss(bem, prm[CP_MU], prm[CP_SD], prm[CP_RSD], prm[CP_K1])
+                                + lgauss(ben, prm[CP_NMU], prm[CP_NSD], prm[CP_RNSD], prm[CP_K2]);
+                const double py = lgauss(bem, prm[CP_YMU], prm[CP_YSD], prm[CP_RYSD], prm[CP_YK1])
+                                + lgauss(ben, prm[CP_YNMU], prm[CP_YNSD], prm[CP_RYNSD], prm[CP_YK2]);
+                pmCur = pm;
+                Mm = Bm + (pm + T[T_MATCH_CONTINUE]);
+                Mx = Bm + (pm + T[T_MATCH_FROM_GAP_X]);
+                My = Bm + (pm + T[T_MATCH_FROM_GAP_Y]);
+                Um = By + (py + T[T_GAP_OPEN_Y]);
+                Uy = By + (py + T[T_GAP_EXTEND_Y]);
+                Gm = Bx + (px + T[T_GAP_OPEN_X]);
+                Gx = Bx + (px + T[T_GAP_EXTEND_X]);
+                Gy = Bx + (px + T[T_GAP_SWITCH_TO_X]);
+            }
+            if (lane == 0) {
+                double *x = sh.xch[t & 1][wave];
+                x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My; x[6] = bem; x[7] = ben;
+            }
+
+            if (t <= tracedBackFrom) {
+                const double fM = active ? ring_ptr(t, wave, 0)[lane] : CP_NEG_INF;
+                const int r0 = (bxmin >> 6) & (SY_R - 1), l0 = bxmin & 63;
+                if (calcs++ % 10 == 0) {
+                    /* diagonalCalculationTotalProbability :736-754 */
+                    double v = CP_NEG_INF, w_ = CP_NEG_INF;
+                    if (active) {
+                        const double fx = ring_ptr(t, wave, 1)[lane], fy = ring_ptr(t, wave, 2)[lane];
+                        v = fM + Bm; /* cell_dotProduct :391-397 */
+                        v = ladd(v, fx + Bx);
+                        v = ladd(v, fy + By);
+                    }
+                    const bool second = t + 1 <= dTop;
+                    if (second) {
+                        /* matches stepping over t: forward[t-1] --match--> cells of t+1, dotted with
+                         * backward[t+1]; only the match state of that clone is ever above -inf */
+                        int pxmin, pxmax;
+                        band.range(t - 1, pxmin, pxmax);
+                        const int sw = lane == 0 ? waveBelow : wave; /* slot-1 lives there */
+                        const int sl = (lane + 63) & 63;
+                        double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
+                        if (row_active(sw, pxmin, pxmax)) {
+                            s0 = ring_ptr(t - 1, sw, 0)[sl];
+                            s1 = ring_ptr(t - 1, sw, 1)[sl];
+                            s2 = ring_ptr(t - 1, sw, 2)[sl];
+                        }
+                        band.range(t, pxmin, pxmax); /* leave the cursor on t */
+                        double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
+                        mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]));
+                        mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]));
+                        w_ = mm + BmPrev;
+                    }
+                    sh.vbuf[wave * 64 + lane] = v;
+                    sh.wbuf[wave * 64 + lane] = w_;
+                    const unsigned long long vm = __ballot(tvalid), wm = __ballot(validPrev);
+                    if (lane == 0) { sh.vmask[wave] = vm; sh.wmask[wave] = wm; }
+                    __syncthreads();
+                    if (wave == 0) {
+                        double acc = CP_NEG_INF;
+                        for (int k = 0; k <= SY_R; k++) {
+                            const int r = (r0 + k) & (SY_R - 1);
+                            const bool inSeg = k == 0 ? lane >= l0 : (k == SY_R ? lane < l0 : true);
+                            const bool ok = ((sh.vmask[r] >> lane) & 1ull) && inSeg;
+                            acc = cp_wave_seq_fold(acc, sh.vbuf[r * 64 + lane], ok);
+                        }
+                        if (second) {
+                            const int q0 = (nxmin >> 6) & (SY_R - 1), m0 = nxmin & 63;
+                            double acc2 = CP_NEG_INF;
+                            for (int k = 0; k <= SY_R; k++) {
+                                const int r = (q0 + k) & (SY_R - 1);
+                                const bool inSeg = k == 0 ? lane >= m0 : (k == SY_R ? lane < m0 : true);
+                                const bool ok = ((sh.wmask[r] >> lane) & 1ull) && inSeg;
+                                acc2 = cp_wave_seq_fold(acc2, sh.wbuf[r * 64 + lane], ok);
+                            }
+                            acc = cp_logAdd(acc, acc2);
+                        }
+                        if (lane == 0) {
+                            sh.total = acc;
+                            if (out.nTot < out.totCap) {
+                                out.totXay[out.nTot] = t;
+                                out.totVal[out.nTot] = acc;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    total = sh.total;
+                    out.nTot++;
+                }
+                /* diagonalCalculationPosteriorMatchProbs :756-795; pairs are written after the next
+                 * barrier, when every wave's count for this diagonal is visible */
+                {
+                    const int y = t - xs;
+                    bool hit = false;
+                    double e = 0.0, p = 0.0;
+                    if (active && tvalid && xs > 0 && y > 0) {
+                        e = (fM + Bm) - total;
+                        if (e >= P.logThrSlack) {
+                            p = exp(e);
+                            hit = p >= P.threshold;
+                        }
+                    }
+                    const bool isR0 = wave == r0;
+                    const bool segB = isR0 && lane < l0;
+                    const unsigned long long hm_ = __ballot(hit);
+                    const unsigned long long mB = isR0 ? ((1ull << l0) - 1ull) : 0ull;
+                    const unsigned long long hitsA = hm_ & ~mB, hitsB = hm_ & mB;
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (p > 1.0) p = 1.0;
+                    pd.any = true;
+                    pd.hit = hit;
+                    pd.segB = segB;
+                    pd.r0 = r0;
+                    pd.par = t & 1;
+                    pd.prefix = segB ? __popcll(hitsB & below) : __popcll(hitsA & below);
+                    pd.p = (long long) floor(p * 10000000.0);
+                    pd.x = xs;
+                    pd.y = y;
+                    pd.e = e;
+                    if (lane == 0) {
+                        sh.cnt[t & 1][wave][0] = __popcll(hitsA);
+                        sh.cnt[t & 1][wave][1] = __popcll(hitsB);
+                    }
+                }
+            }
+            pmPrev = pmCur;
+        }
+        __syncthreads();
+        flush_pending(pd, sh, out, wave);
+        tracedBackTo = tracedBackFrom;
+        if (atEnd) break;
+
+        /* ---------------- resume the forward sweep at dTop ---------------- */
+        band.range(dTop, xmin, xmax);
+        while (xs < xmin) xs += SY_P; /* the sweep down left slots on lower k-mers; move back up */
+        {
+            const bool v = xs <= xmax;
+            if (v) load_params(prm, track, xs);
+            const bool a = row_active(wave, xmin, xmax);
+            Fm = a ? ring_ptr(dTop, wave, 0)[lane] : CP_NEG_INF;
+            Fx = a ? ring_ptr(dTop, wave, 1)[lane] : CP_NEG_INF;
+            Fy = a ? ring_ptr(dTop, wave, 2)[lane] : CP_NEG_INF;
+            int qmin, qmax;
+            band.range(dTop - 1, qmin, qmax);
+            const int sw = lane == 0 ? waveBelow : wave;
+            const int sl = (lane + 63) & 63;
+            const bool a1 = row_active(sw, qmin, qmax);
+            Lm = a1 ? ring_ptr(dTop - 1, sw, 0)[sl] : CP_NEG_INF;
+            Lx = a1 ? ring_ptr(dTop - 1, sw, 1)[sl] : CP_NEG_INF;
+            Ly = a1 ? ring_ptr(dTop - 1, sw, 2)[sl] : CP_NEG_INF;
+            band.range(dTop, xmin, xmax);
+            const int ei = dTop - xs - 1;
+            const bool okE = v && ei >= 0 && ei < lY;
+            em = okE ? ev[3 * (long long) ei] : 0.0;
+            en = okE ? ev[3 * (long long) ei + 1] : 0.0;
+        }
+        if (lane == 63) {
+            double *x = sh.xch[dTop & 1][wave];
+            x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
+        }
+        xin = xmax + 1;
+        load_params(st, track, xin <= lX ? xin : lX);
+        xminP = xmin;
+    }
+}
+
+} // namespace
+
+extern "C" __global__ __launch_bounds__(256) void cpecan_k_systolic(
+    const DevItem *__restrict__ items, long long nItems, DevParams P,
+    const long long *__restrict__ anchors, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ events,
+    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD,
+    int *workCounter, long long *pairs, double *pairLogp, long long *nPairs, long long *totXay,
+    double *totVal, long long *nTot, long long *nCells) {
+    __shared__ Shared sh;
+    double *ring = Fring + (long long) blockIdx.x * ringDoubles;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh.item = atomicAdd(workCounter, 1);
+        __syncthreads();
+        const int idx = __builtin_amdgcn_readfirstlane(sh.item);
+        if (idx >= nItems) break;
+        const DevItem it = items[idx];
+        ItemOut out;
+        out.pairs = pairs + it.pairBase * 3;
+        out.logp = pairLogp + it.pairBase;
+        out.pairCap = it.pairCap;
+        out.totXay = totXay + it.totBase;
+        out.totVal = totVal + it.totBase;
+        out.totCap = it.totCap;
+        out.nPairs = 0;
+        out.nTot = 0;
+        long long cells = 0;
+        if (it.lX + it.lY > 0)
+            run_item(it, P, anchors, track + trackBase[idx] * CP_ROW, events,
+                     models + (long long) it.model * CP_MODEL_STRIDE, ring, ringD, out, cells, sh);
+        if (threadIdx.x == 0) {
+            nPairs[idx] = out.nPairs;
+            nTot[idx] = out.nTot;
+            nCells[idx] = cells;
+        }
+    }
+}
+
+/* per-item track of emission constants: row x (0..lX) = model row of the k-mer that matrix column x
+ * scores (column 0 = the "not a k-mer" sentinel, sequence_getKmer index -1, :314-318) */
+extern "C" __global__ void cpecan_k_track(const DevItem *__restrict__ items, long long nItems,
+                                          const long long *__restrict__ trackBase,
+                                          const unsigned short *__restrict__ kidx,
+                                          const double *__restrict__ models, double *track) {
+    const long long item = blockIdx.y;
+    if (item >= nItems) return;
+    const DevItem it = items[item];
+    const double *rows = models + (long long) it.model * CP_MODEL_STRIDE + CP_MODEL_HEADER;
+    const long long n = (it.lX + 1) * CP_ROW;
+    double *dst = track + trackBase[item] * CP_ROW;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long) gridDim.x * blockDim.x) {
+        const long long x = i / CP_ROW;
+        const int j = (int) (i - x * CP_ROW);
+        const int k = x == 0 ? 4096 : (int) kidx[it.xOff + x - 1];
+        dst[i] = rows[(long long) k * CP_ROW + j];
+    }
+}
+
+/* division self-test (see cpecan_hip_selftest_division) */
+extern "C" __global__ void cpecan_k_divtest(long long n, unsigned long long seed, unsigned long long *bad) {
+    long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long local = 0;
+    for (; i < n; i += (long long) gridDim.x * blockDim.x) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long) (i + 1);
+        double u[3];
+        for (int k = 0; k < 3; k++) { /* splitmix64 */
+            z += 0x9E3779B97F4A7C15ull;
+            unsigned long long r = z;
+            r = (r ^ (r >> 30)) * 0xBF58476D1CE4E5B9ull;
+            r = (r ^ (r >> 27)) * 0x94D049BB133111EBull;
+            r ^= r >> 31;
+            u[k] = (double) (r >> 11) * (1.0 / 9007199254740992.0);
+        }
+        const bool noise = (i & 1) != 0;
+        const double x = noise ? 0.001 + 4.0 * u[0] : 30.0 + 70.0 * u[0];
+        const double mu = noise ? 0.3 + 2.0 * u[1] : 40.0 + 45.0 * u[1];
+        const double sd = noise ? 0.05 + 1.5 * u[2] : 0.3 + 4.0 * u[2];
+        const double rsd = 1.0 / sd;
+        const double t = x - mu;
+        const double q = t * rsd;
+        const double rem = __fma_rn(-q, sd, t);
+        const double a = __fma_rn(rem, rsd, q);
+        const double ref = t / sd;
+        if (!(a == ref)) local++;
+    }
+    if (local) atomicAdd(bad, local);
+}
+
+extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned long long seed,
+                                       unsigned long long *bad) {
+    hipLaunchKernelGGL(cpecan_k_divtest, dim3(1024), dim3(256), 0, stream, n, seed, bad);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int cpecan_systolic_max_width(void) { return SY_P; }
+extern "C" int cpecan_systolic_rows(void) { return SY_R; }
+
+extern "C" int cpecan_systolic_launch(hipStream_t stream, int nWorkgroups, const DevItem *items,
+                                      long long nItems, DevParams P, const long long *anchors,
+                                      const double *track, const long long *trackBase,
+                                      const unsigned short *kidx, const double *events,
+                                      const double *models, double *Fring, long long ringDoubles,
+                                      int ringD, int *workCounter, long long *pairs,
+                                      double *pairLogp, long long *nPairs, long long *totXay,
+                                      double *totVal, long long *nTot, long long *nCells,
+                                      int maxLX, int buildTrack) {
+    if (buildTrack) {
+        int bx = (int) ((((long long) maxLX + 1) * CP_ROW + 255) / 256);
+        if (bx > 64) bx = 64;
+        hipLaunchKernelGGL(cpecan_k_track, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items,
+                           nItems, trackBase, kidx, models, (double *) track);
+        if (hipGetLastError() != hipSuccess) return -1;
+    }
+    hipLaunchKernelGGL(cpecan_k_systolic, dim3(nWorkgroups), dim3(256), 0, stream, items, nItems, P,
+                       anchors, track, trackBase, events, models, Fring, ringDoubles, ringD,
+                       workCounter, pairs, pairLogp, nPairs, totXay, totVal, nTot, nCells);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+extern "C" int cpecan_systolic_occupancy(int *workgroupsPerCU) {
+    int n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpecan_k_systolic, 256, 0);
+    if (e != hipSuccess) return -1;
+    *workgroupsPerCU = n;
+    return 0;
+}

@@ -141,6 +141,12 @@ int cpecan_hip_batch_debug_cells(cpecan_batch *batch, int64_t item, double *forw
                                  double *backward, int64_t n_cells);
 int cpecan_hip_batch_destroy(cpecan_batch *batch);
 
+/* Self-test of the systolic kernel's division: evaluates (x - mu) / sigma for n pseudo-random operand
+ * triples (event-like x, model-like mu and sigma, derived from seed) both as an IEEE division and as
+ * the Markstein-corrected multiply by RN(1/sigma) the kernel uses; *mismatches receives the number
+ * of operands where the two doubles differ (expected: 0). */
+int cpecan_hip_selftest_division(cpecan_ctx *ctx, int64_t n, uint64_t seed, int64_t *mismatches);
+
 /* Stream of the context as an opaque pointer (a hipStream_t) for callers that need to order
  * their own work (e.g. an RCCL all-reduce of the expectations) after the batch kernels. */
 int cpecan_hip_ctx_stream(cpecan_ctx *ctx, void **stream);

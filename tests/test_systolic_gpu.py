@@ -1,0 +1,82 @@
+"""GPU parity of the systolic (register-wavefront) kernel against the oracle, through the C-ABI.
+
+Same bar as the general kernel: posterior exponents and totalProbability values bit-identical to the
+oracle's doubles, aligned pairs in the reference's emission order, integer posteriors within 1."""
+import numpy as np
+import pytest
+
+import synth
+from harness import assert_same_pairs, band_params, cp, run_gpu, run_oracle_item
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = cp.Context(0)
+    yield c
+    c.close()
+
+
+def test_division_by_reciprocal_is_exact(ctx):
+    # the kernel's (x-mu)/sigma: Markstein-corrected multiply == IEEE division on 1e8 operands
+    assert ctx.selftest_division(100_000_000, seed=7) == 0
+
+
+CASES = [
+    dict(n=4, lX=120, lY=250, e=20, md=60, tb=10, every=25, ragged=(0, 0)),
+    dict(n=4, lX=300, lY=610, e=40, md=100, tb=40, every=50, ragged=(1, 1)),
+    dict(n=3, lX=700, lY=1400, e=100, md=300, tb=40, every=50, ragged=(1, 1)),
+    dict(n=3, lX=257, lY=400, e=100, md=150, tb=40, every=50, ragged=(1, 0)),
+    dict(n=3, lX=90, lY=200, e=0, md=30, tb=5, every=10, ragged=(0, 1)),
+    dict(n=2, lX=520, lY=500, e=60, md=120, tb=20, every=40, ragged=(0, 0)),   # more k-mers than events
+    dict(n=2, lX=64, lY=64, e=200, md=1000, tb=40, every=1000, ragged=(1, 1)),  # unanchored, full matrix
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_systolic_matches_oracle(ctx, case):
+    batch = synth.make_batch(21, case["n"], case["lX"], case["lY"], anchor_every=case["every"])
+    bp = band_params(0.01, case["md"], case["tb"], case["e"])
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=case["ragged"])
+    for i in range(case["n"]):
+        ref = run_oracle_item(batch, i, bp, case["ragged"])
+        assert res[i]["cells"] == ref["cells"]
+        assert np.array_equal(res[i]["totals_xay"], ref["totals_xay"])
+        assert np.array_equal(res[i]["totals"], ref["totals"])
+        assert_same_pairs(res[i], ref)
+
+
+def test_systolic_ragged_batch_and_degenerate_items(ctx):
+    batch = synth.make_batch(22, 12, 200, 400, anchor_every=40, length_sigma=0.6)
+    base = batch["items"][0]
+    batch["items"] += [dict(base, lX=0, n_anchors=0), dict(base, lY=0, n_anchors=0),
+                       dict(base, lX=0, lY=0, n_anchors=0), dict(base, lX=1, lY=1, n_anchors=0)]
+    bp = band_params(0.01, 100, 20, 60)
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=(1, 1))
+    for i in range(len(batch["items"])):
+        ref = run_oracle_item(batch, i, bp, (1, 1))
+        assert np.array_equal(res[i]["totals"], ref["totals"]), i
+        assert_same_pairs(res[i], ref)
+
+
+def test_systolic_equals_general_kernel(ctx):
+    batch = synth.make_batch(23, 6, 400, 800, anchor_every=50)
+    bp = band_params(0.01, 200, 40, 100)
+    a, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=(1, 1))
+    g, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_GENERAL, ragged=(1, 1))
+    for x, y in zip(a, g):
+        assert np.array_equal(x["triples"], y["triples"])
+        assert np.array_equal(x["logp"], y["logp"])
+        assert np.array_equal(x["totals"], y["totals"])
+
+
+def test_too_wide_band_is_refused_by_systolic_and_routed_by_auto(ctx):
+    batch = synth.make_batch(24, 1, 400, 800, anchor_every=400)  # sparse anchors: band > 256
+    bp = band_params(0.01, 200, 40, 300)
+    with pytest.raises(cp.CpecanError) as ei:
+        run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC)
+    assert ei.value.code == cp.EINVAL
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_AUTO)
+    ref = run_oracle_item(batch, 0, bp)
+    assert_same_pairs(res[0], ref)
