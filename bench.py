@@ -163,7 +163,7 @@ def main():
                                "diagonalExpansion %d, 3-state strawMan signal HMM, per-read scaled "
                                "models, posterior decode" % (args.reads, args.events, args.kmers, args.band),
                    "cells_per_gpu": cells, "pairs_per_gpu": int(npairs.sum()),
-                   "kernel": {0: "auto", 1: "general", 2: "systolic"}[args.kernel],
+                   "kernel": b.info(),
                    "parallelism": "reads sharded over %d GPU(s), no collective" % world},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -34,7 +34,7 @@ EXPORTS = [
     "cpecan_hip_batch_elapsed_ms", "cpecan_hip_batch_counts", "cpecan_hip_batch_fetch_pairs",
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
-    "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division",
+    "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info",
 ]
 
 
@@ -104,6 +104,7 @@ def lib():
         for name in ("run", "sync", "destroy"):
             getattr(L, "cpecan_hip_batch_" + name).argtypes = [C.c_void_p]
         L.cpecan_hip_batch_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.cpecan_hip_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.cpecan_hip_batch_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cpecan_hip_batch_fetch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
         L.cpecan_hip_batch_fetch_totals.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
@@ -225,6 +226,12 @@ class Batch:
         a, k = C.c_float(), C.c_float()
         _check(lib().cpecan_hip_batch_elapsed_ms(self.h, C.byref(a), C.byref(k)))
         return a.value, k.value
+
+    def info(self):
+        k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().cpecan_hip_batch_info(self.h, C.byref(k), C.byref(w), C.byref(m)))
+        return dict(kernel={1: "general", 2: "systolic"}.get(k.value, str(k.value)), workgroups=w.value,
+                    max_band_width=m.value)
 
     def counts(self):
         p = np.zeros(self.n, np.int64)

@@ -116,7 +116,7 @@ struct cpecan_batch {
     DevBuf<long long> trackBase;
     long long ringDoubles = 0;
     int ringD = 0, maxLX = 0;
-    int nWorkers = 0;
+    int nWorkers = 0, maxWidth = 0;
     int nModels = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     std::vector<long long> hNPairs, hNTot, hNCells;
@@ -410,6 +410,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
         return fail(CPECAN_EINVAL, "cell dumps and expectations are only available from the general kernel");
     }
     b->kernel = useKernel;
+    b->maxWidth = globalMaxWidth;
     b->hItems = hItems;
 
     B_TRY(b->items.alloc((size_t) nItems));
@@ -517,6 +518,14 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
     }
     HIP_TRY(hipEventRecord(b->ev2, c->stream));
     b->ran = true;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_info(cpecan_batch *b, int32_t *kernel, int32_t *workgroups, int32_t *maxWidth) {
+    if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
+    if (kernel) *kernel = b->kernel;
+    if (workgroups) *workgroups = b->kernel == CPECAN_KERNEL_GENERAL ? (int32_t) b->nItems : b->nWorkers;
+    if (maxWidth) *maxWidth = b->maxWidth;
     return CPECAN_OK;
 }
 

@@ -69,6 +69,13 @@ __device__ __forceinline__ double bcast(double v, int srcLane) { /* srcLane wave
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain every global
+ * store of the forward ring (s_waitcnt vmcnt(0)) on each anti-diagonal; nothing the waves exchange
+ * inside an alignment goes through global memory, so only lgkmcnt has to reach zero. */
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 /* logAdd (impl/pairwiseAligner.c:238-255), branch-free: same value in every case -- hi/lo are the
  * operands as the reference's two branches order them, the "smaller operand is -inf" and ">= 7.5"
  * exits both yield hi, and (-inf) - (-inf) = NaN fails d < 7.5 exactly like those exits. */
@@ -202,6 +209,18 @@ __device__ __forceinline__ void load_params(double (&dst)[SY_NPRM], const double
 #pragma unroll
     for (int j = 0; j < SY_NPRM; j++) dst[j] = p[j];
 }
+/* staging of the next k-mer to enter the band: ONE coalesced 144-byte load per wave, lane j keeps
+ * constant j; the lane that owns the k-mer's slot takes them with readlanes a few diagonals later */
+__device__ __forceinline__ double stage_row(const double *__restrict__ track, int x, int lane) {
+    return track[(long long) x * CP_ROW + (lane < CP_ROW ? lane : 0)];
+}
+__device__ __forceinline__ void install_row(double (&prm)[SY_NPRM], double staged, bool mine) {
+#pragma unroll
+    for (int j = 0; j < SY_NPRM; j++) {
+        const double v = bcast(staged, j);
+        prm[j] = mine ? v : prm[j];
+    }
+}
 
 /* aligned pairs found on a diagonal, written one barrier later when every wave's count is known */
 struct Pending {
@@ -266,21 +285,20 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
     double Fm = CP_NEG_INF, Fx = CP_NEG_INF, Fy = CP_NEG_INF; /* forward cell, current diagonal  */
     double Lm = CP_NEG_INF, Lx = CP_NEG_INF, Ly = CP_NEG_INF; /* slot-1's cell, previous diagonal */
     double em = 0.0, en = 0.0;                                /* event scored on this diagonal    */
-    double st[SY_NPRM];                                       /* next k-mer to enter (prefetched) */
+    double st;                                                /* constants of the next k-mer to enter */
 #pragma unroll
     for (int j = 0; j < SY_NPRM; j++) prm[j] = 0.0;
 
     /* diagonal 0: the single cell (0,0) holds the start vector (:897-898, stateMachine.c:1168-1177) */
-    load_params(st, track, 0);
+    st = stage_row(track, 0, lane);
+    install_row(prm, st, wave == 0 && lane == 0);
     if (wave == 0 && lane == 0) {
         Fm = it.raggedL ? CP_NEG_INF : 0.0;
         Fx = it.raggedL ? 0.0 : CP_NEG_INF;
         Fy = Fx;
-#pragma unroll
-        for (int j = 0; j < SY_NPRM; j++) prm[j] = st[j];
     }
     int xin = 1; /* k-mers below xin have been installed */
-    load_params(st, track, xin <= lX ? xin : lX);
+    st = stage_row(track, xin <= lX ? xin : lX, lane);
 
     auto ring_ptr = [&](int d, int w, int s) -> double * {
         return ring + ((((long long) (d % ringD)) * SY_R + w) * 3 + s) * 64;
@@ -310,7 +328,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
         cellCount += xmax - xmin + 1;
 
         /* ---------------- forward step ---------------- */
-        __syncthreads();
+        lds_barrier();
         double rm = ror1(Fm), rx = ror1(Fx), ry = ror1(Fy), rem_ = ror1(em), ren_ = ror1(en);
         if (lane == 0) {
             const double *x = sh.xch[(d - 1) & 1][waveBelow];
@@ -321,12 +339,9 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
         em = rem_;
         en = ren_;
         while (xin <= xmax) { /* install the entering k-mer's constants (at most one per step) */
-            if (((xin >> 6) & (SY_R - 1)) == wave && lane == (xin & 63)) {
-#pragma unroll
-                for (int j = 0; j < SY_NPRM; j++) prm[j] = st[j];
-            }
+            install_row(prm, st, ((xin >> 6) & (SY_R - 1)) == wave && lane == (xin & 63));
             xin++;
-            load_params(st, track, xin <= lX ? xin : lX);
+            st = stage_row(track, xin <= lX ? xin : lX, lane);
         }
         if (xmin == xminP) { /* the top cell's event is new to the band */
             double nm, nn;
@@ -398,7 +413,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
         }
         double bem = em, ben = en;
         int xinB = xmin - 1; /* k-mers above xinB are installed */
-        load_params(st, track, xinB >= 0 ? xinB : 0);
+        st = stage_row(track, xinB >= 0 ? xinB : 0, lane);
         EvChunk bwdEv;
         bwdEv.ev = ev;
         bwdEv.lY = lY;
@@ -406,6 +421,9 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
 
         Pending pd;
         pd.any = false;
+        /* forward match cells are fetched one diagonal ahead of their use */
+        double fMnext = (dTop <= tracedBackFrom && row_active(wave, xmin, xmax))
+                            ? ring_ptr(dTop, wave, 0)[lane] : CP_NEG_INF;
         double total = CP_NEG_INF;
         int calcs = 0;
         int bxmin = xmin, bxmax = xmax; /* band of diagonal t   */
@@ -414,7 +432,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
             if (t < dTop) {
                 nxmin = bxmin; nxmax = bxmax;
                 band.range(t, bxmin, bxmax);
-                __syncthreads();
+                lds_barrier();
                 double gm = rol1(Gm), gx_ = rol1(Gx), gy_ = rol1(Gy);
                 double hm = rol1(Mm), hx = rol1(Mx), hy = rol1(My);
                 double sem = rol1(bem), sen = rol1(ben);
@@ -429,12 +447,9 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
                 bem = sem;
                 ben = sen;
                 while (xinB >= bxmin) {
-                    if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) {
-#pragma unroll
-                        for (int j = 0; j < SY_NPRM; j++) prm[j] = st[j];
-                    }
+                    install_row(prm, st, ((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63));
                     xinB--;
-                    load_params(st, track, xinB >= 0 ? xinB : 0);
+                    st = stage_row(track, xinB >= 0 ? xinB : 0, lane);
                 }
                 if (bxmax == nxmax) { /* the bottom cell's event is new to the band */
                     double nm, nn;
@@ -483,8 +498,15 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
                 x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My; x[6] = bem; x[7] = ben;
             }
 
+            const double fM = fMnext;
+            {
+                int pxmin, pxmax;
+                band.range(t - 1, pxmin, pxmax);
+                fMnext = (t - 1 <= tracedBackFrom && t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax))
+                             ? ring_ptr(t - 1, wave, 0)[lane] : CP_NEG_INF;
+                band.range(t, pxmin, pxmax); /* leave the cursor on t */
+            }
             if (t <= tracedBackFrom) {
-                const double fM = active ? ring_ptr(t, wave, 0)[lane] : CP_NEG_INF;
                 const int r0 = (bxmin >> 6) & (SY_R - 1), l0 = bxmin & 63;
                 if (calcs++ % 10 == 0) {
                     /* diagonalCalculationTotalProbability :736-754 */
@@ -519,7 +541,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
                     sh.wbuf[wave * 64 + lane] = w_;
                     const unsigned long long vm = __ballot(tvalid), wm = __ballot(validPrev);
                     if (lane == 0) { sh.vmask[wave] = vm; sh.wmask[wave] = wm; }
-                    __syncthreads();
+                    lds_barrier();
                     if (wave == 0) {
                         double acc = CP_NEG_INF;
                         for (int k = 0; k <= SY_R; k++) {
@@ -547,7 +569,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
                             }
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();
                     total = sh.total;
                     out.nTot++;
                 }
@@ -589,7 +611,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
             }
             pmPrev = pmCur;
         }
-        __syncthreads();
+        lds_barrier();
         flush_pending(pd, sh, out, wave);
         tracedBackTo = tracedBackFrom;
         if (atEnd) break;
@@ -623,7 +645,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
             x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
         }
         xin = xmax + 1;
-        load_params(st, track, xin <= lX ? xin : lX);
+        st = stage_row(track, xin <= lX ? xin : lX, lane);
         xminP = xmin;
     }
 }

@@ -118,6 +118,9 @@ int cpecan_hip_batch_run(cpecan_batch *batch);
 int cpecan_hip_batch_sync(cpecan_batch *batch);
 /* HIP-event time of the last run's kernels, in ms (after sync). */
 int cpecan_hip_batch_elapsed_ms(cpecan_batch *batch, float *ms_total, float *ms_dp_kernel);
+/* Which kernel the batch uses (CPECAN_KERNEL_GENERAL / _SYSTOLIC after AUTO is resolved), how many
+ * workgroups it launches and the widest band (cells) among its items. */
+int cpecan_hip_batch_info(cpecan_batch *batch, int32_t *kernel, int32_t *workgroups, int32_t *max_width);
 /* Per-item result sizes: aligned pairs, refreshes of totalProbability, in-band cells. */
 int cpecan_hip_batch_counts(cpecan_batch *batch, int64_t *n_pairs, int64_t *n_totals,
                             int64_t *n_cells);

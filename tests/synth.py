@@ -83,9 +83,12 @@ def make_read(rng, match, lX, lY, anchor_every=50, jitter=2):
     first_ev = np.concatenate([[0], np.cumsum(counts)[:-1]])
     anchors = []
     px, py = -1, -1
-    for x in range(anchor_every // 2, lX, anchor_every):
-        if counts[x] == 0:
-            continue
+    for x0 in range(anchor_every // 2, lX, anchor_every):
+        x = x0
+        while x < lX and counts[x] == 0:  # the anchor sits on the true path: next k-mer that emitted
+            x += 1
+        if x >= lX:
+            break
         y = int(first_ev[x]) + int(rng.integers(-jitter, jitter + 1))
         y = min(max(y, 0), lY - 1)
         if x > px and y > py:
