@@ -30,6 +30,7 @@ extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned
 
 extern "C" int cpecan_systolic_max_width(void);
 extern "C" int cpecan_systolic_rows(void);
+extern "C" int cpecan_systolic_ring_row_doubles(void);
 extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned long long seed,
                                        unsigned long long *bad);
 extern "C" int cpecan_systolic_occupancy(int *workgroupsPerCU);
@@ -456,8 +457,9 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
         if (cpecan_systolic_occupancy(&perCU) != 0 || perCU < 1) perCU = 1;
         B_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
         b->nWorkers = (int) std::min<long long>(nItems, (long long) perCU * cus);
-        b->ringD = maxSpan + 4;
-        b->ringDoubles = (long long) b->ringD * cpecan_systolic_rows() * 3 * 64;
+        b->ringD = 64;
+        while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernel masks with ringD-1 */
+        b->ringDoubles = (long long) b->ringD * cpecan_systolic_ring_row_doubles();
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) b->nWorkers * (size_t) b->ringDoubles));
         B_TRY(b->workCounter.alloc(4));

@@ -35,10 +35,12 @@
 #define SY_R 4
 #define SY_P (64 * SY_R)
 #define SY_NPRM 17
+#define SY_RING_VALUES 5 /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
 
 namespace {
 
 struct Shared {
+    double coef[16];         /* lookup() cubics, [piece][c3,c2,c1,c0]: one ds_read_b128 pair per logAdd */
     double xch[2][SY_R][8];  /* boundary-lane values, double-buffered by diagonal parity */
     double vbuf[SY_P];       /* totalProbability terms of the current diagonal, by slot  */
     double wbuf[SY_P];
@@ -76,24 +78,25 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-/* logAdd (impl/pairwiseAligner.c:238-255), branch-free: same value in every case -- hi/lo are the
- * operands as the reference's two branches order them, the "smaller operand is -inf" and ">= 7.5"
- * exits both yield hi, and (-inf) - (-inf) = NaN fails d < 7.5 exactly like those exits. */
-__device__ __forceinline__ double ladd(double x, double y) {
-    const bool lt = x < y;
-    const double hi = lt ? y : x, lo = lt ? x : y;
+/* logAdd (impl/pairwiseAligner.c:238-255), branch-free and bit-identical: hi/lo are the operands
+ * as the reference's two branches order them; its "smaller operand is -inf" and ">= 7.5" exits both
+ * yield hi, and (-inf) - (-inf) = NaN fails d < 7.5 exactly like those exits.  The cubic's four
+ * float-literal coefficients come from a 128-byte LDS table indexed by the piece (<=1, <=2.5,
+ * <=4.5, else): two ds_read_b128 instead of a 24-select chain. */
+__device__ __forceinline__ double ladd(double x, double y, const double *coef) {
+    const double hi = __builtin_fmax(x, y), lo = __builtin_fmin(x, y);
     const double d = hi - lo;
-    const bool p1 = d <= 1.00f, p2 = d <= 2.50f, p3 = d <= 4.50f;
-    const double c3 = p1 ? (double) -0.009350833524763f : p2 ? (double) -0.014532321752540f
-                    : p3 ? (double) -0.004605031767994f : (double) -0.000458661602210f;
-    const double c2 = p1 ? (double) 0.130659527668286f : p2 ? (double) 0.139942324101744f
-                    : p3 ? (double) 0.063427417320019f : (double) 0.009695946122598f;
-    const double c1 = p1 ? (double) 0.498799810682272f : p2 ? (double) 0.495635523139337f
-                    : p3 ? (double) 0.695956496475118f : (double) 0.930734667215156f;
-    const double c0 = p1 ? (double) 0.693203116424741f : p2 ? (double) 0.692140569840976f
-                    : p3 ? (double) 0.514272634594009f : (double) 0.168037164329057f;
-    const double r = ((c3 * d + c2) * d + c1) * d + c0 + lo;
+    const int idx = (d > 1.00f ? 4 : 0) + (d > 2.50f ? 4 : 0) + (d > 4.50f ? 4 : 0);
+    const double *c = coef + idx;
+    const double r = ((c[0] * d + c[1]) * d + c[2]) * d + c[3] + lo;
     return d < 7.5 ? r : hi;
+}
+__device__ __forceinline__ void init_coef(double *coef) {
+    const float t[16] = { -0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
+                          -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
+                          -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
+                          -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f };
+    if (threadIdx.x < 16) coef[threadIdx.x] = (double) t[threadIdx.x];
 }
 
 /* log N(x; mu, sd) = K + (-0.5*a*a), a = (x-mu)/sd (impl/stateMachine.c:333-343); the quotient is
@@ -256,6 +259,19 @@ __device__ __forceinline__ void flush_pending(Pending &pd, Shared &sh, ItemOut &
     pd.any = false;
 }
 
+/* lane i <- lane i-1 of src, lane 0 <- old (DPP wave_shr:1 leaves lanes without a source untouched) */
+__device__ __forceinline__ double shr1(double old, double src) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x138, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+/* lane i <- lane i+1 of src, lane 63 <- old */
+__device__ __forceinline__ double shl1(double old, double src) {
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), 0x130, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 /* One alignment on one workgroup of SY_R waves. */
 __device__ void run_item(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
                          const double *__restrict__ track, const double *__restrict__ events,
@@ -266,6 +282,10 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
     const int waveBelow = (wave + SY_R - 1) & (SY_R - 1), waveAbove = (wave + 1) & (SY_R - 1);
     const int lX = (int) it.lX, lY = (int) it.lY, D = lX + lY;
     const double *__restrict__ ev = events + 3 * it.yOff;
+    const double *cf = sh.coef;
+    /* a -inf gapY->gapX transition (the nanopore default, stateMachine.c:1287) contributes
+     * logAdd(acc, -inf) == acc: skip that term (wave-uniform) */
+    const bool hasSwitchX = model[T_GAP_SWITCH_TO_X] > CP_NEG_INF;
 
     double T[9];
 #pragma unroll
@@ -278,6 +298,18 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
     band.lY = lY;
     band.e2 = (int) (P.expansion / 2);
     band.load(0);
+
+    /* ring of forward diagonals: [diagonal & (ringD-1)][wave][Fm,Fx,Fy,pm,py][lane] */
+    double *const rw = ring + wave * (SY_RING_VALUES * 64) + lane;
+    const int ringMask = ringD - 1;
+    auto rp = [&](int d, int s) -> double * {
+        return rw + (long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + s * 64;
+    };
+    /* same, for the slot below this lane's (lane 0: lane 63 of the wave below) */
+    double *const rwb = ring + (lane == 0 ? waveBelow : wave) * (SY_RING_VALUES * 64) + ((lane + 63) & 63);
+    auto rpb = [&](int d, int s) -> double * {
+        return rwb + (long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + s * 64;
+    };
 
     /* ---- per-slot state (this lane's k-mer) ---- */
     int xs = wave * 64 + lane;
@@ -299,14 +331,12 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
     }
     int xin = 1; /* k-mers below xin have been installed */
     st = stage_row(track, xin <= lX ? xin : lX, lane);
-
-    auto ring_ptr = [&](int d, int w, int s) -> double * {
-        return ring + ((((long long) (d % ringD)) * SY_R + w) * 3 + s) * 64;
-    };
     if (wave == 0) {
-        ring_ptr(0, 0, 0)[lane] = Fm;
-        ring_ptr(0, 0, 1)[lane] = Fx;
-        ring_ptr(0, 0, 2)[lane] = Fy;
+        *rp(0, 0) = Fm;
+        *rp(0, 1) = Fx;
+        *rp(0, 2) = Fy;
+        *rp(0, 3) = 0.0;
+        *rp(0, 4) = 0.0;
     }
     if (lane == 63) {
         double *x = sh.xch[0][wave];
@@ -329,24 +359,21 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
 
         /* ---------------- forward step ---------------- */
         lds_barrier();
-        double rm = ror1(Fm), rx = ror1(Fx), ry = ror1(Fy), rem_ = ror1(em), ren_ = ror1(en);
-        if (lane == 0) {
-            const double *x = sh.xch[(d - 1) & 1][waveBelow];
-            rm = x[0]; rx = x[1]; ry = x[2]; rem_ = x[3]; ren_ = x[4];
-        }
+        const double *xb = sh.xch[(d - 1) & 1][waveBelow];
+        const double rm = shr1(xb[0], Fm), rx = shr1(xb[1], Fx), ry = shr1(xb[2], Fy);
+        em = shr1(xb[3], em);
+        en = shr1(xb[4], en);
         if (xs < xmin) xs += SY_P;
         const bool valid = xs <= xmax;
-        em = rem_;
-        en = ren_;
-        while (xin <= xmax) { /* install the entering k-mer's constants (at most one per step) */
-            install_row(prm, st, ((xin >> 6) & (SY_R - 1)) == wave && lane == (xin & 63));
+        while (xin <= xmax) { /* the entering k-mer's constants (at most one k-mer per step) */
+            if (((xin >> 6) & (SY_R - 1)) == wave) install_row(prm, st, lane == (xin & 63));
             xin++;
-            st = stage_row(track, xin <= lX ? xin : lX, lane);
+            if (((xin >> 6) & (SY_R - 1)) == wave) st = stage_row(track, xin <= lX ? xin : lX, lane);
         }
-        if (xmin == xminP) { /* the top cell's event is new to the band */
+        if (xmin == xminP && ((xmin >> 6) & (SY_R - 1)) == wave) { /* the top cell's event is new */
             double nm, nn;
             fwdEv.get_up(d - xmin - 1, nm, nn, lane);
-            if (((xmin >> 6) & (SY_R - 1)) == wave && lane == (xmin & 63)) { em = nm; en = nn; }
+            if (lane == (xmin & 63)) { em = nm; en = nn; }
         }
         double nmv = CP_NEG_INF, nxv = CP_NEG_INF, nyv = CP_NEG_INF;
         if (row_active(wave, xmin, xmax)) {
@@ -358,19 +385,21 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
             /* cell_calculateForward: to[t] = logAdd(to[t], from[f] + (eP + tP)) (:365-376) in the
              * order of stateMachine3_cellCalculate (stateMachine.c:1314-1333) */
             double gx = rm + (px + T[T_GAP_OPEN_X]);
-            gx = ladd(gx, rx + (px + T[T_GAP_EXTEND_X]));
-            gx = ladd(gx, ry + (px + T[T_GAP_SWITCH_TO_X]));
+            gx = ladd(gx, rx + (px + T[T_GAP_EXTEND_X]), cf);
+            if (hasSwitchX) gx = ladd(gx, ry + (px + T[T_GAP_SWITCH_TO_X]), cf);
             double mm = Lm + (pm + T[T_MATCH_CONTINUE]);
-            mm = ladd(mm, Lx + (pm + T[T_MATCH_FROM_GAP_X]));
-            mm = ladd(mm, Ly + (pm + T[T_MATCH_FROM_GAP_Y]));
+            mm = ladd(mm, Lx + (pm + T[T_MATCH_FROM_GAP_X]), cf);
+            mm = ladd(mm, Ly + (pm + T[T_MATCH_FROM_GAP_Y]), cf);
             double gy = Fm + (py + T[T_GAP_OPEN_Y]);
-            gy = ladd(gy, Fy + (py + T[T_GAP_EXTEND_Y]));
+            gy = ladd(gy, Fy + (py + T[T_GAP_EXTEND_Y]), cf);
             nmv = valid ? mm : CP_NEG_INF;
             nxv = valid ? gx : CP_NEG_INF;
             nyv = valid ? gy : CP_NEG_INF;
-            ring_ptr(d, wave, 0)[lane] = nmv;
-            ring_ptr(d, wave, 1)[lane] = nxv;
-            ring_ptr(d, wave, 2)[lane] = nyv;
+            *rp(d, 0) = nmv;
+            *rp(d, 1) = nxv;
+            *rp(d, 2) = nyv;
+            *rp(d, 3) = pm; /* the sweep back re-uses the two event-dependent emissions */
+            *rp(d, 4) = py;
         }
         Lm = rm; Lx = rx; Ly = ry;
         Fm = nmv; Fx = nxv; Fy = nyv;
@@ -389,11 +418,11 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
         const int tracedBackFrom = dTop - (atEnd ? 0 : (int) P.tbDiags + 1);
         if (xs > xmax) xs -= SY_P; /* backward representative: xmax-P < x <= xmax */
         bool tvalid = xs >= xmin;  /* slot in band on diagonal t */
-        double Bm, Bx, By;                          /* backward cell on diagonal t                    */
+        double Bm, Bx, By;                                        /* backward cell on diagonal t        */
         double Hm = CP_NEG_INF, Hx = CP_NEG_INF, Hy = CP_NEG_INF; /* middle-block msgs from t+2 (moved) */
-        double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1     */
+        double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1      */
         double Um = CP_NEG_INF, Uy = CP_NEG_INF;                  /* upper-block msgs from t+1 (same slot) */
-        double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1      */
+        double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1       */
         double pmPrev = 0.0, BmPrev = CP_NEG_INF;                 /* match emission / backward match of t+1 */
         bool validPrev = false;
         {
@@ -411,61 +440,64 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
             Bx = tvalid ? e1 : CP_NEG_INF;
             By = tvalid ? e2 : CP_NEG_INF;
         }
-        double bem = em, ben = en;
+        /* the sweep back needs one constant per k-mer, its gap-X emission: held per slot, refreshed
+         * from a 64-k-mer chunk when a k-mer enters at the low edge of the band */
+        double pxReg = prm[CP_GAPX];
         int xinB = xmin - 1; /* k-mers above xinB are installed */
-        st = stage_row(track, xinB >= 0 ? xinB : 0, lane);
-        EvChunk bwdEv;
-        bwdEv.ev = ev;
-        bwdEv.lY = lY;
-        bwdEv.init_down(dTop - xmax - 1, lane);
+        int pxBase = (xinB >= 0 ? xinB : 0) & ~63;
+        double pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
 
         Pending pd;
         pd.any = false;
-        /* forward match cells are fetched one diagonal ahead of their use */
-        double fMnext = (dTop <= tracedBackFrom && row_active(wave, xmin, xmax))
-                            ? ring_ptr(dTop, wave, 0)[lane] : CP_NEG_INF;
-        double total = CP_NEG_INF;
-        int calcs = 0;
         int bxmin = xmin, bxmax = xmax; /* band of diagonal t   */
         int nxmin = xmin, nxmax = xmax; /* band of diagonal t+1 */
+        int pxmin, pxmax;               /* band of diagonal t-1 */
+        band.range(dTop - 1, pxmin, pxmax);
+        /* forward match cell and the two emissions are fetched one diagonal ahead of their use */
+        const bool aTop = row_active(wave, xmin, xmax);
+        double fMc = aTop ? *rp(dTop, 0) : CP_NEG_INF;
+        double pmc = aTop ? *rp(dTop, 3) : 0.0, pyc = aTop ? *rp(dTop, 4) : 0.0;
+        double fMn = CP_NEG_INF, pmn = 0.0, pyn = 0.0;
+        double total = CP_NEG_INF;
+        int calcs = 0;
         for (int t = dTop; t > tracedBackTo; t--) {
+            const bool active = row_active(wave, bxmin, bxmax);
+            const bool activeP = t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax);
+            if (activeP) { /* issue the loads for t-1 now, consume them next iteration */
+                fMn = *rp(t - 1, 0);
+                pmn = *rp(t - 1, 3);
+                pyn = *rp(t - 1, 4);
+            } else {
+                fMn = CP_NEG_INF; pmn = 0.0; pyn = 0.0;
+            }
             if (t < dTop) {
-                nxmin = bxmin; nxmax = bxmax;
-                band.range(t, bxmin, bxmax);
                 lds_barrier();
-                double gm = rol1(Gm), gx_ = rol1(Gx), gy_ = rol1(Gy);
-                double hm = rol1(Mm), hx = rol1(Mx), hy = rol1(My);
-                double sem = rol1(bem), sen = rol1(ben);
-                if (lane == 63) {
-                    const double *x = sh.xch[(t + 1) & 1][waveAbove];
-                    gm = x[0]; gx_ = x[1]; gy_ = x[2]; hm = x[3]; hx = x[4]; hy = x[5];
-                    sem = x[6]; sen = x[7];
-                }
+                const double *xa = sh.xch[(t + 1) & 1][waveAbove];
+                const double gm = shl1(xa[0], Gm), gx_ = shl1(xa[1], Gx), gy_ = shl1(xa[2], Gy);
+                const double hm = shl1(xa[3], Mm), hx = shl1(xa[4], Mx), hy = shl1(xa[5], My);
                 flush_pending(pd, sh, out, wave);
                 if (xs > bxmax) xs -= SY_P;
                 const bool bvalid = xs >= bxmin;
-                bem = sem;
-                ben = sen;
                 while (xinB >= bxmin) {
-                    install_row(prm, st, ((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63));
+                    if (xinB < pxBase) {
+                        pxBase -= 64;
+                        pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
+                    }
+                    const double v = bcast(pxChunk, xinB - pxBase);
+                    if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) pxReg = v;
                     xinB--;
-                    st = stage_row(track, xinB >= 0 ? xinB : 0, lane);
-                }
-                if (bxmax == nxmax) { /* the bottom cell's event is new to the band */
-                    double nm, nn;
-                    bwdEv.get_down(t - bxmax - 1, nm, nn, lane);
-                    if (((bxmax >> 6) & (SY_R - 1)) == wave && lane == (bxmax & 63)) { bem = nm; ben = nn; }
                 }
                 BmPrev = Bm;
                 validPrev = tvalid;
                 tvalid = bvalid;
                 double bm = CP_NEG_INF, bx = CP_NEG_INF, by = CP_NEG_INF;
-                if (row_active(wave, bxmin, bxmax)) {
+                if (active) {
                     /* gather form of cell_calculateBackward: (t+2) middle block, then (t+1, smaller
                      * x-y) upper block, then (t+1, larger x-y) lower block */
-                    bm = ladd(ladd(Hm, Um), gm);
-                    bx = ladd(Hx, gx_);
-                    by = ladd(ladd(Hy, Uy), gy_);
+                    bm = ladd(ladd(Hm, Um, cf), gm, cf);
+                    bx = ladd(Hx, gx_, cf);
+                    by = ladd(Hy, Uy, cf);
+                    if (hasSwitchX) by = ladd(by, gy_, cf);
                     bm = bvalid ? bm : CP_NEG_INF;
                     bx = bvalid ? bx : CP_NEG_INF;
                     by = bvalid ? by : CP_NEG_INF;
@@ -474,67 +506,47 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
                 Hm = hm; Hx = hx; Hy = hy;
             }
             /* messages this diagonal sends to t-1 and t-2 */
-            double pmCur = 0.0;
-            const bool active = row_active(wave, bxmin, bxmax);
             Mm = Mx = My = Um = Uy = Gm = Gx = Gy = CP_NEG_INF;
             if (active) {
-                const double px = prm[CP_GAPX];
-                const double pm = lgauss(bem, prm[CP_MU], prm[CP_SD], prm[CP_RSD], prm[CP_K1])
-                                + lgauss(ben, prm[CP_NMU], prm[CP_NSD], prm[CP_RNSD], prm[CP_K2]);
-                const double py = lgauss(bem, prm[CP_YMU], prm[CP_YSD], prm[CP_RYSD], prm[CP_YK1])
-                                + lgauss(ben, prm[CP_YNMU], prm[CP_YNSD], prm[CP_RYNSD], prm[CP_YK2]);
-                pmCur = pm;
-                Mm = Bm + (pm + T[T_MATCH_CONTINUE]);
-                Mx = Bm + (pm + T[T_MATCH_FROM_GAP_X]);
-                My = Bm + (pm + T[T_MATCH_FROM_GAP_Y]);
-                Um = By + (py + T[T_GAP_OPEN_Y]);
-                Uy = By + (py + T[T_GAP_EXTEND_Y]);
-                Gm = Bx + (px + T[T_GAP_OPEN_X]);
-                Gx = Bx + (px + T[T_GAP_EXTEND_X]);
-                Gy = Bx + (px + T[T_GAP_SWITCH_TO_X]);
+                Mm = Bm + (pmc + T[T_MATCH_CONTINUE]);
+                Mx = Bm + (pmc + T[T_MATCH_FROM_GAP_X]);
+                My = Bm + (pmc + T[T_MATCH_FROM_GAP_Y]);
+                Um = By + (pyc + T[T_GAP_OPEN_Y]);
+                Uy = By + (pyc + T[T_GAP_EXTEND_Y]);
+                Gm = Bx + (pxReg + T[T_GAP_OPEN_X]);
+                Gx = Bx + (pxReg + T[T_GAP_EXTEND_X]);
+                Gy = Bx + (pxReg + T[T_GAP_SWITCH_TO_X]);
             }
             if (lane == 0) {
                 double *x = sh.xch[t & 1][wave];
-                x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My; x[6] = bem; x[7] = ben;
+                x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My;
             }
 
-            const double fM = fMnext;
-            {
-                int pxmin, pxmax;
-                band.range(t - 1, pxmin, pxmax);
-                fMnext = (t - 1 <= tracedBackFrom && t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax))
-                             ? ring_ptr(t - 1, wave, 0)[lane] : CP_NEG_INF;
-                band.range(t, pxmin, pxmax); /* leave the cursor on t */
-            }
             if (t <= tracedBackFrom) {
+                const double fM = fMc;
                 const int r0 = (bxmin >> 6) & (SY_R - 1), l0 = bxmin & 63;
                 if (calcs++ % 10 == 0) {
                     /* diagonalCalculationTotalProbability :736-754 */
                     double v = CP_NEG_INF, w_ = CP_NEG_INF;
                     if (active) {
-                        const double fx = ring_ptr(t, wave, 1)[lane], fy = ring_ptr(t, wave, 2)[lane];
+                        const double fx = *rp(t, 1), fy = *rp(t, 2);
                         v = fM + Bm; /* cell_dotProduct :391-397 */
-                        v = ladd(v, fx + Bx);
-                        v = ladd(v, fy + By);
+                        v = ladd(v, fx + Bx, cf);
+                        v = ladd(v, fy + By, cf);
                     }
                     const bool second = t + 1 <= dTop;
                     if (second) {
                         /* matches stepping over t: forward[t-1] --match--> cells of t+1, dotted with
                          * backward[t+1]; only the match state of that clone is ever above -inf */
-                        int pxmin, pxmax;
-                        band.range(t - 1, pxmin, pxmax);
-                        const int sw = lane == 0 ? waveBelow : wave; /* slot-1 lives there */
-                        const int sl = (lane + 63) & 63;
                         double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
-                        if (row_active(sw, pxmin, pxmax)) {
-                            s0 = ring_ptr(t - 1, sw, 0)[sl];
-                            s1 = ring_ptr(t - 1, sw, 1)[sl];
-                            s2 = ring_ptr(t - 1, sw, 2)[sl];
+                        if (row_active(lane == 0 ? waveBelow : wave, pxmin, pxmax)) {
+                            s0 = *rpb(t - 1, 0);
+                            s1 = *rpb(t - 1, 1);
+                            s2 = *rpb(t - 1, 2);
                         }
-                        band.range(t, pxmin, pxmax); /* leave the cursor on t */
                         double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
-                        mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]));
-                        mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]));
+                        mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);
+                        mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]), cf);
                         w_ = mm + BmPrev;
                     }
                     sh.vbuf[wave * 64 + lane] = v;
@@ -609,7 +621,11 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
                     }
                 }
             }
-            pmPrev = pmCur;
+            pmPrev = pmc;
+            fMc = fMn; pmc = pmn; pyc = pyn;
+            nxmin = bxmin; nxmax = bxmax;
+            bxmin = pxmin; bxmax = pxmax;
+            if (t - 2 > tracedBackTo) band.range(t - 2, pxmin, pxmax);
         }
         lds_barrier();
         flush_pending(pd, sh, out, wave);
@@ -623,17 +639,15 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
             const bool v = xs <= xmax;
             if (v) load_params(prm, track, xs);
             const bool a = row_active(wave, xmin, xmax);
-            Fm = a ? ring_ptr(dTop, wave, 0)[lane] : CP_NEG_INF;
-            Fx = a ? ring_ptr(dTop, wave, 1)[lane] : CP_NEG_INF;
-            Fy = a ? ring_ptr(dTop, wave, 2)[lane] : CP_NEG_INF;
+            Fm = a ? *rp(dTop, 0) : CP_NEG_INF;
+            Fx = a ? *rp(dTop, 1) : CP_NEG_INF;
+            Fy = a ? *rp(dTop, 2) : CP_NEG_INF;
             int qmin, qmax;
             band.range(dTop - 1, qmin, qmax);
-            const int sw = lane == 0 ? waveBelow : wave;
-            const int sl = (lane + 63) & 63;
-            const bool a1 = row_active(sw, qmin, qmax);
-            Lm = a1 ? ring_ptr(dTop - 1, sw, 0)[sl] : CP_NEG_INF;
-            Lx = a1 ? ring_ptr(dTop - 1, sw, 1)[sl] : CP_NEG_INF;
-            Ly = a1 ? ring_ptr(dTop - 1, sw, 2)[sl] : CP_NEG_INF;
+            const bool a1 = row_active(lane == 0 ? waveBelow : wave, qmin, qmax);
+            Lm = a1 ? *rpb(dTop - 1, 0) : CP_NEG_INF;
+            Lx = a1 ? *rpb(dTop - 1, 1) : CP_NEG_INF;
+            Ly = a1 ? *rpb(dTop - 1, 2) : CP_NEG_INF;
             band.range(dTop, xmin, xmax);
             const int ei = dTop - xs - 1;
             const bool okE = v && ei >= 0 && ei < lY;
@@ -646,6 +660,7 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
         }
         xin = xmax + 1;
         st = stage_row(track, xin <= lX ? xin : lX, lane);
+        fwdEv.init_up(dTop - xmin, lane);
         xminP = xmin;
     }
 }
@@ -660,6 +675,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_systolic(
     int *workCounter, long long *pairs, double *pairLogp, long long *nPairs, long long *totXay,
     double *totVal, long long *nTot, long long *nCells) {
     __shared__ Shared sh;
+    init_coef(sh.coef);
     double *ring = Fring + (long long) blockIdx.x * ringDoubles;
     for (;;) {
         __syncthreads();
@@ -748,6 +764,7 @@ extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned
 
 extern "C" int cpecan_systolic_max_width(void) { return SY_P; }
 extern "C" int cpecan_systolic_rows(void) { return SY_R; }
+extern "C" int cpecan_systolic_ring_row_doubles(void) { return SY_R * SY_RING_VALUES * 64; }
 
 extern "C" int cpecan_systolic_launch(hipStream_t stream, int nWorkgroups, const DevItem *items,
                                       long long nItems, DevParams P, const long long *anchors,
