@@ -33,16 +33,15 @@ extern "C" int cpecan_systolic_rows(void);
 extern "C" int cpecan_systolic_ring_row_doubles(void);
 extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned long long seed,
                                        unsigned long long *bad);
-extern "C" int cpecan_systolic_occupancy(int *workgroupsPerCU);
-extern "C" int cpecan_systolic_launch(hipStream_t stream, int nWorkgroups, const DevItem *items,
-                                      long long nItems, DevParams P, const long long *anchors,
-                                      const double *track, const long long *trackBase,
-                                      const unsigned short *kidx, const double *events,
-                                      const double *models, double *Fring, long long ringDoubles,
-                                      int ringD, int *workCounter, long long *pairs,
-                                      double *pairLogp, long long *nPairs, long long *totXay,
-                                      double *totVal, long long *nTot, long long *nCells,
-                                      int maxLX, int buildTrack);
+extern "C" int cpecan_systolic_state_bytes(void);
+extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, long long nItems,
+                                      DevParams P, const long long *anchors, const double *track,
+                                      const long long *trackBase, const unsigned short *kidx,
+                                      const double *events, const double *models, double *Fring,
+                                      long long ringDoubles, int ringD, void *states, int windows,
+                                      long long *pairs, double *pairLogp, long long *nPairs,
+                                      long long *totXay, double *totVal, long long *nTot,
+                                      long long *nCells, int maxLX);
 
 namespace {
 
@@ -113,6 +112,8 @@ struct cpecan_batch {
     DevBuf<double> totVal;
     DevBuf<double> expect;
     DevBuf<int> workCounter;
+    DevBuf<char> syStates;
+    int nWindows = 0;
     DevBuf<double> track;
     DevBuf<long long> trackBase;
     long long ringDoubles = 0;
@@ -305,7 +306,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     std::vector<int> hL, hR;
     std::vector<long long> hPre;
     long long cellTotal = 0, pairTotal = 0, totTotal = 0, bwsTotal = 0, trackTotal = 0;
-    int globalMaxWidth = 0, maxSpan = 1, maxLX = 0;
+    int globalMaxWidth = 0, maxSpan = 1, maxLX = 0, maxWindows = 0;
     bool systolicOk = true; /* band edges move by at most one k-mer per diagonal */
     std::vector<long long> hTrackBase((size_t) nItems);
     for (int64_t i = 0; i < nItems; i++) {
@@ -348,6 +349,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
              * kernel relies on */
             const int *Lp = hL.data() + d.diagBase, *Rp = hR.data() + d.diagBase;
             long long tracedBackTo = 0;
+            int windows = 0;
             for (long long k = 1; k < nDiag; k++) {
                 const int xmn = (int) ((k + Lp[k]) / 2), xmx = (int) ((k + Rp[k]) / 2);
                 const int pmn = (int) ((k - 1 + Lp[k - 1]) / 2), pmx = (int) ((k - 1 + Rp[k - 1]) / 2);
@@ -357,10 +359,12 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
                 const bool tb = k >= tracedBackTo + params->minDiagsBetweenTraceBack &&
                                 w <= params->diagonalExpansion * 2 + 1;
                 if (atEnd || tb) {
+                    windows++;
                     maxSpan = std::max<long long>(maxSpan, k - tracedBackTo + 1);
                     tracedBackTo = k - (params->traceBackDiagonals + 1);
                 }
             }
+            maxWindows = std::max(maxWindows, windows);
         }
         hTrackBase[(size_t) i] = trackTotal;
         trackTotal += s.lX + 1;
@@ -452,17 +456,16 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
             B_TRY(hipMemset(b->dbgB.p, 0xff, (size_t) cellTotal * 3 * sizeof(double)));
         }
     } else {
-        /* persistent workgroups: as many as stay resident, never more than there are items */
-        int perCU = 0, cus = 0;
-        if (cpecan_systolic_occupancy(&perCU) != 0 || perCU < 1) perCU = 1;
-        B_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-        b->nWorkers = (int) std::min<long long>(nItems, (long long) perCU * cus);
+        /* one workgroup per alignment and launch; the ring of forward diagonals lives per alignment
+         * because the forward and backward kernels of a window are separate launches */
+        b->nWorkers = (int) nItems;
+        b->nWindows = maxWindows;
         b->ringD = 64;
-        while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernel masks with ringD-1 */
+        while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernels mask with ringD-1 */
         b->ringDoubles = (long long) b->ringD * cpecan_systolic_ring_row_doubles();
         b->maxLX = maxLX;
-        B_TRY(b->Fstore.alloc((size_t) b->nWorkers * (size_t) b->ringDoubles));
-        B_TRY(b->workCounter.alloc(4));
+        B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
+        B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
         B_TRY(b->track.alloc((size_t) trackTotal * CP_ROW));
         B_TRY(b->trackBase.alloc((size_t) nItems));
         B_TRY(hipMemcpy(b->trackBase.p, hTrackBase.data(), (size_t) nItems * sizeof(long long),
@@ -506,15 +509,14 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            b->dbgB.p, b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
     } else {
-        HIP_TRY(hipMemsetAsync(b->workCounter.p, 0, 4 * sizeof(int), c->stream));
         /* the per-item track of emission constants is rebuilt every run: it is a function of the
          * inputs (k-mers x model), so it belongs inside the timed region */
-        int rc = cpecan_systolic_launch(c->stream, b->nWorkers, b->items.p, b->nItems, b->P,
-                                        b->anchors.p, b->track.p, b->trackBase.p, b->kidx.p,
-                                        b->events.p, c->models.p, b->Fstore.p, b->ringDoubles,
-                                        b->ringD, b->workCounter.p, b->pairs.p, b->pairLogp.p,
+        int rc = cpecan_systolic_launch(c->stream, b->items.p, b->nItems, b->P, b->anchors.p,
+                                        b->track.p, b->trackBase.p, b->kidx.p, b->events.p,
+                                        c->models.p, b->Fstore.p, b->ringDoubles, b->ringD,
+                                        b->syStates.p, b->nWindows, b->pairs.p, b->pairLogp.p,
                                         b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
-                                        b->nCells.p, b->maxLX, 1);
+                                        b->nCells.p, b->maxLX);
         if (rc != 0) return fail(CPECAN_EHIP, "systolic kernel launch failed: %s",
                                  hipGetErrorString(hipGetLastError()));
     }

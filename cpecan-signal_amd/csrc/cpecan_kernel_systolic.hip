@@ -228,36 +228,10 @@ __device__ __forceinline__ void install_row(double (&prm)[SY_NPRM], double stage
 /* aligned pairs found on a diagonal, written one barrier later when every wave's count is known */
 struct Pending {
     bool any, hit, segB;
-    int r0, par, prefix;
-    long long p;
-    int x, y;
+    int r0, par, prefix, t;
+    int p; /* floor(posterior * 1e7) */
     double e;
 };
-
-__device__ __forceinline__ void flush_pending(Pending &pd, Shared &sh, ItemOut &out, int wave) {
-    if (!pd.any) return;
-    int sumA = 0, before = 0;
-    const int rel = (wave - pd.r0) & (SY_R - 1);
-#pragma unroll
-    for (int k = 0; k < SY_R; k++) {
-        const int c = sh.cnt[pd.par][(pd.r0 + k) & (SY_R - 1)][0];
-        if (k < rel) before += c;
-        sumA += c;
-    }
-    const int cB = sh.cnt[pd.par][pd.r0][1];
-    if (pd.hit) {
-        const long long idx = out.nPairs + (pd.segB ? sumA : before) + pd.prefix;
-        if (idx < out.pairCap) {
-            long long *o = out.pairs + idx * 3;
-            o[0] = pd.p;
-            o[1] = pd.x - 1;
-            o[2] = pd.y - 1;
-            out.logp[idx] = pd.e;
-        }
-    }
-    out.nPairs += sumA + cB;
-    pd.any = false;
-}
 
 /* lane i <- lane i-1 of src, lane 0 <- old (DPP wave_shr:1 leaves lanes without a source untouched) */
 __device__ __forceinline__ double shr1(double old, double src) {
@@ -272,94 +246,151 @@ __device__ __forceinline__ double shl1(double old, double src) {
     return __hiloint2double(hi, lo);
 }
 
-/* One alignment on one workgroup of SY_R waves. */
-__device__ void run_item(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
-                         const double *__restrict__ track, const double *__restrict__ events,
-                         const double *__restrict__ model, double *ring, int ringD, ItemOut &out,
-                         long long &cellCount, Shared &sh) {
-    const int lane = threadIdx.x & 63;
-    const int wave = uni(threadIdx.x >> 6);
-    const int waveBelow = (wave + SY_R - 1) & (SY_R - 1), waveAbove = (wave + 1) & (SY_R - 1);
+/* Per-alignment state handed between the forward-window and backward-window kernels. */
+struct SyState {
+    int d;            /* last forward diagonal completed */
+    int tracedBackTo; /* as in getPosteriorProbsWithBanding (:903) */
+    int finished;     /* forward reached the last diagonal */
+    int bandAi;       /* band cursor (anchor rectangle) at diagonal d */
+    int winValid, winTop, winFrom, winTo, winAtEnd; /* traceback window for the backward kernel */
+    int pad;
+    long long nPairs, nTot, cells;
+};
+
+struct Geometry {
+    int lane, wave, waveBelow, waveAbove;
+    double *rw, *rwb; /* ring bases of this lane's slot and of the slot below it */
+    int ringMask;
+    __device__ __forceinline__ double *rp(int d, int s) const {
+        return rw + (long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + s * 64;
+    }
+    __device__ __forceinline__ double *rpb(int d, int s) const {
+        return rwb + (long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + s * 64;
+    }
+};
+
+__device__ __forceinline__ Geometry make_geometry(double *ring, int ringD) {
+    Geometry g;
+    g.lane = threadIdx.x & 63;
+    g.wave = uni(threadIdx.x >> 6);
+    g.waveBelow = (g.wave + SY_R - 1) & (SY_R - 1);
+    g.waveAbove = (g.wave + 1) & (SY_R - 1);
+    /* ring of forward diagonals: [diagonal & (ringD-1)][wave][Fm,Fx,Fy,pm,py][lane] */
+    g.rw = ring + g.wave * (SY_RING_VALUES * 64) + g.lane;
+    g.rwb = ring + (g.lane == 0 ? g.waveBelow : g.wave) * (SY_RING_VALUES * 64) + ((g.lane + 63) & 63);
+    g.ringMask = ringD - 1;
+    return g;
+}
+
+__device__ __forceinline__ void make_band(Band &band, const DevItem &it, const DevParams &P,
+                                          const long long *__restrict__ anchors, int ai) {
+    band.an = anchors + 2 * it.anchorOff;
+    band.nA = (int) it.nAnchors;
+    band.lX = (int) it.lX;
+    band.lY = (int) it.lY;
+    band.e2 = (int) (P.expansion / 2);
+    band.load(ai);
+}
+
+/* Forward sweep of one alignment from its saved diagonal up to (and including) the next traceback
+ * point; describes the window for the backward kernel. */
+__device__ void forward_window(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
+                               const double *__restrict__ track, const double *__restrict__ events,
+                               const double *__restrict__ model, double *ring, int ringD,
+                               SyState *state, Shared &sh) {
+    const Geometry g = make_geometry(ring, ringD);
+    const int lane = g.lane, wave = g.wave;
     const int lX = (int) it.lX, lY = (int) it.lY, D = lX + lY;
     const double *__restrict__ ev = events + 3 * it.yOff;
     const double *cf = sh.coef;
     /* a -inf gapY->gapX transition (the nanopore default, stateMachine.c:1287) contributes
      * logAdd(acc, -inf) == acc: skip that term (wave-uniform) */
     const bool hasSwitchX = model[T_GAP_SWITCH_TO_X] > CP_NEG_INF;
-
     double T[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
 
+    const int d0 = state->d;
+    int tracedBackTo = state->tracedBackTo;
+    long long cells = state->cells;
     Band band;
-    band.an = anchors + 2 * it.anchorOff;
-    band.nA = (int) it.nAnchors;
-    band.lX = lX;
-    band.lY = lY;
-    band.e2 = (int) (P.expansion / 2);
-    band.load(0);
-
-    /* ring of forward diagonals: [diagonal & (ringD-1)][wave][Fm,Fx,Fy,pm,py][lane] */
-    double *const rw = ring + wave * (SY_RING_VALUES * 64) + lane;
-    const int ringMask = ringD - 1;
-    auto rp = [&](int d, int s) -> double * {
-        return rw + (long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + s * 64;
-    };
-    /* same, for the slot below this lane's (lane 0: lane 63 of the wave below) */
-    double *const rwb = ring + (lane == 0 ? waveBelow : wave) * (SY_RING_VALUES * 64) + ((lane + 63) & 63);
-    auto rpb = [&](int d, int s) -> double * {
-        return rwb + (long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + s * 64;
-    };
+    make_band(band, it, P, anchors, state->bandAi);
 
     /* ---- per-slot state (this lane's k-mer) ---- */
-    int xs = wave * 64 + lane;
+    int xs;
     double prm[SY_NPRM];
-    double Fm = CP_NEG_INF, Fx = CP_NEG_INF, Fy = CP_NEG_INF; /* forward cell, current diagonal  */
-    double Lm = CP_NEG_INF, Lx = CP_NEG_INF, Ly = CP_NEG_INF; /* slot-1's cell, previous diagonal */
-    double em = 0.0, en = 0.0;                                /* event scored on this diagonal    */
-    double st;                                                /* constants of the next k-mer to enter */
-#pragma unroll
-    for (int j = 0; j < SY_NPRM; j++) prm[j] = 0.0;
-
-    /* diagonal 0: the single cell (0,0) holds the start vector (:897-898, stateMachine.c:1168-1177) */
-    st = stage_row(track, 0, lane);
-    install_row(prm, st, wave == 0 && lane == 0);
-    if (wave == 0 && lane == 0) {
-        Fm = it.raggedL ? CP_NEG_INF : 0.0;
-        Fx = it.raggedL ? 0.0 : CP_NEG_INF;
-        Fy = Fx;
-    }
-    int xin = 1; /* k-mers below xin have been installed */
-    st = stage_row(track, xin <= lX ? xin : lX, lane);
-    if (wave == 0) {
-        *rp(0, 0) = Fm;
-        *rp(0, 1) = Fx;
-        *rp(0, 2) = Fy;
-        *rp(0, 3) = 0.0;
-        *rp(0, 4) = 0.0;
-    }
-    if (lane == 63) {
-        double *x = sh.xch[0][wave];
-        x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
-    }
-    cellCount += 1;
-
+    double Fm, Fx, Fy; /* forward cell, current diagonal   */
+    double Lm, Lx, Ly; /* slot-1's cell, previous diagonal */
+    double em, en;     /* event scored on this diagonal    */
+    double st;         /* constants of the next k-mer to enter the band */
+    int xin, xminP;
     EvChunk fwdEv;
     fwdEv.ev = ev;
     fwdEv.lY = lY;
-    fwdEv.init_up(0, lane);
 
-    int xminP = 0;
-    int tracedBackTo = 0;
+    if (d0 == 0) {
+        /* diagonal 0: the single cell (0,0) holds the start vector (:897-898, stateMachine.c:1168-1177) */
+        xs = wave * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < SY_NPRM; j++) prm[j] = 0.0;
+        Fm = Fx = Fy = Lm = Lx = Ly = CP_NEG_INF;
+        em = en = 0.0;
+        st = stage_row(track, 0, lane);
+        install_row(prm, st, wave == 0 && lane == 0);
+        if (wave == 0 && lane == 0) {
+            Fm = it.raggedL ? CP_NEG_INF : 0.0;
+            Fx = it.raggedL ? 0.0 : CP_NEG_INF;
+            Fy = Fx;
+        }
+        if (wave == 0) {
+            *g.rp(0, 0) = Fm;
+            *g.rp(0, 1) = Fx;
+            *g.rp(0, 2) = Fy;
+            *g.rp(0, 3) = 0.0;
+            *g.rp(0, 4) = 0.0;
+        }
+        cells += 1;
+        xin = 1;
+        xminP = 0;
+        fwdEv.init_up(0, lane);
+    } else {
+        /* resume at d0: constants of the k-mers in the band, forward cells of d0 and d0-1, events */
+        int xmin, xmax, qmin, qmax;
+        band.range(d0 - 1, qmin, qmax);
+        band.range(d0, xmin, xmax);
+        xs = wave * 64 + lane;
+        xs += ((xmin - xs + SY_P - 1) / SY_P) * SY_P; /* the k-mer >= xmin that lives in this slot */
+        const bool v = xs <= xmax;
+        load_params(prm, track, xs <= lX ? xs : lX);
+        const bool a = row_active(wave, xmin, xmax);
+        Fm = a ? *g.rp(d0, 0) : CP_NEG_INF;
+        Fx = a ? *g.rp(d0, 1) : CP_NEG_INF;
+        Fy = a ? *g.rp(d0, 2) : CP_NEG_INF;
+        const bool a1 = row_active(lane == 0 ? g.waveBelow : wave, qmin, qmax);
+        Lm = a1 ? *g.rpb(d0 - 1, 0) : CP_NEG_INF;
+        Lx = a1 ? *g.rpb(d0 - 1, 1) : CP_NEG_INF;
+        Ly = a1 ? *g.rpb(d0 - 1, 2) : CP_NEG_INF;
+        const int ei = d0 - xs - 1;
+        const bool okE = v && ei >= 0 && ei < lY;
+        em = okE ? ev[3 * (long long) ei] : 0.0;
+        en = okE ? ev[3 * (long long) ei + 1] : 0.0;
+        xin = xmax + 1;
+        xminP = xmin;
+        fwdEv.init_up(d0 - xmin, lane);
+    }
+    st = stage_row(track, xin <= lX ? xin : lX, lane);
+    if (lane == 63) {
+        double *x = sh.xch[d0 & 1][wave];
+        x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
+    }
 
-    for (int d = 1; d <= D; d++) {
+    for (int d = d0 + 1; d <= D; d++) {
         int xmin, xmax;
         band.range(d, xmin, xmax);
-        cellCount += xmax - xmin + 1;
+        cells += xmax - xmin + 1;
 
-        /* ---------------- forward step ---------------- */
         lds_barrier();
-        const double *xb = sh.xch[(d - 1) & 1][waveBelow];
+        const double *xb = sh.xch[(d - 1) & 1][g.waveBelow];
         const double rm = shr1(xb[0], Fm), rx = shr1(xb[1], Fx), ry = shr1(xb[2], Fy);
         em = shr1(xb[3], em);
         en = shr1(xb[4], en);
@@ -395,11 +426,11 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
             nmv = valid ? mm : CP_NEG_INF;
             nxv = valid ? gx : CP_NEG_INF;
             nyv = valid ? gy : CP_NEG_INF;
-            *rp(d, 0) = nmv;
-            *rp(d, 1) = nxv;
-            *rp(d, 2) = nyv;
-            *rp(d, 3) = pm; /* the sweep back re-uses the two event-dependent emissions */
-            *rp(d, 4) = py;
+            *g.rp(d, 0) = nmv;
+            *g.rp(d, 1) = nxv;
+            *g.rp(d, 2) = nyv;
+            *g.rp(d, 3) = pm; /* the sweep back re-uses the two event-dependent emissions */
+            *g.rp(d, 4) = py;
         }
         Lm = rm; Lx = rx; Ly = ry;
         Fm = nmv; Fx = nxv; Fy = nyv;
@@ -411,298 +442,352 @@ __device__ void run_item(const DevItem &it, const DevParams &P, const long long 
 
         const bool atEnd = d == D;
         const bool tb = d >= tracedBackTo + P.minDiags && (xmax - xmin + 1) <= P.expansion * 2 + 1;
-        if (!(atEnd || tb)) continue;
-
-        /* ---------------- traceback window (:921-992) ---------------- */
-        const int dTop = d;
-        const int tracedBackFrom = dTop - (atEnd ? 0 : (int) P.tbDiags + 1);
-        if (xs > xmax) xs -= SY_P; /* backward representative: xmax-P < x <= xmax */
-        bool tvalid = xs >= xmin;  /* slot in band on diagonal t */
-        double Bm, Bx, By;                                        /* backward cell on diagonal t        */
-        double Hm = CP_NEG_INF, Hx = CP_NEG_INF, Hy = CP_NEG_INF; /* middle-block msgs from t+2 (moved) */
-        double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1      */
-        double Um = CP_NEG_INF, Uy = CP_NEG_INF;                  /* upper-block msgs from t+1 (same slot) */
-        double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1       */
-        double pmPrev = 0.0, BmPrev = CP_NEG_INF;                 /* match emission / backward match of t+1 */
-        bool validPrev = false;
-        {
-            double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
-            if (atEnd && it.raggedR) {
-                e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
-                e1 = T[T_GAP_EXTEND_X];
-                e2 = T[T_GAP_EXTEND_Y];
-            } else {
-                e0 = T[T_MATCH_CONTINUE];
-                e1 = T[T_MATCH_FROM_GAP_X];
-                e2 = T[T_MATCH_FROM_GAP_Y];
+        if (atEnd || tb) { /* traceback point (:917-921): hand the window to the backward kernel */
+            if (threadIdx.x == 0) {
+                const int from = d - (atEnd ? 0 : (int) P.tbDiags + 1);
+                state->d = d;
+                state->bandAi = band.ai;
+                state->finished = atEnd ? 1 : 0;
+                state->winValid = 1;
+                state->winTop = d;
+                state->winFrom = from;
+                state->winTo = tracedBackTo;
+                state->winAtEnd = atEnd ? 1 : 0;
+                state->tracedBackTo = from;
+                state->cells = cells;
             }
-            Bm = tvalid ? e0 : CP_NEG_INF;
-            Bx = tvalid ? e1 : CP_NEG_INF;
-            By = tvalid ? e2 : CP_NEG_INF;
+            return;
         }
-        /* the sweep back needs one constant per k-mer, its gap-X emission: held per slot, refreshed
-         * from a 64-k-mer chunk when a k-mer enters at the low edge of the band */
-        double pxReg = prm[CP_GAPX];
-        int xinB = xmin - 1; /* k-mers above xinB are installed */
-        int pxBase = (xinB >= 0 ? xinB : 0) & ~63;
-        double pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
-
-        Pending pd;
-        pd.any = false;
-        int bxmin = xmin, bxmax = xmax; /* band of diagonal t   */
-        int nxmin = xmin, nxmax = xmax; /* band of diagonal t+1 */
-        int pxmin, pxmax;               /* band of diagonal t-1 */
-        band.range(dTop - 1, pxmin, pxmax);
-        /* forward match cell and the two emissions are fetched one diagonal ahead of their use */
-        const bool aTop = row_active(wave, xmin, xmax);
-        double fMc = aTop ? *rp(dTop, 0) : CP_NEG_INF;
-        double pmc = aTop ? *rp(dTop, 3) : 0.0, pyc = aTop ? *rp(dTop, 4) : 0.0;
-        double fMn = CP_NEG_INF, pmn = 0.0, pyn = 0.0;
-        double total = CP_NEG_INF;
-        int calcs = 0;
-        for (int t = dTop; t > tracedBackTo; t--) {
-            const bool active = row_active(wave, bxmin, bxmax);
-            const bool activeP = t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax);
-            if (activeP) { /* issue the loads for t-1 now, consume them next iteration */
-                fMn = *rp(t - 1, 0);
-                pmn = *rp(t - 1, 3);
-                pyn = *rp(t - 1, 4);
-            } else {
-                fMn = CP_NEG_INF; pmn = 0.0; pyn = 0.0;
-            }
-            if (t < dTop) {
-                lds_barrier();
-                const double *xa = sh.xch[(t + 1) & 1][waveAbove];
-                const double gm = shl1(xa[0], Gm), gx_ = shl1(xa[1], Gx), gy_ = shl1(xa[2], Gy);
-                const double hm = shl1(xa[3], Mm), hx = shl1(xa[4], Mx), hy = shl1(xa[5], My);
-                flush_pending(pd, sh, out, wave);
-                if (xs > bxmax) xs -= SY_P;
-                const bool bvalid = xs >= bxmin;
-                while (xinB >= bxmin) {
-                    if (xinB < pxBase) {
-                        pxBase -= 64;
-                        pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
-                    }
-                    const double v = bcast(pxChunk, xinB - pxBase);
-                    if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) pxReg = v;
-                    xinB--;
-                }
-                BmPrev = Bm;
-                validPrev = tvalid;
-                tvalid = bvalid;
-                double bm = CP_NEG_INF, bx = CP_NEG_INF, by = CP_NEG_INF;
-                if (active) {
-                    /* gather form of cell_calculateBackward: (t+2) middle block, then (t+1, smaller
-                     * x-y) upper block, then (t+1, larger x-y) lower block */
-                    bm = ladd(ladd(Hm, Um, cf), gm, cf);
-                    bx = ladd(Hx, gx_, cf);
-                    by = ladd(Hy, Uy, cf);
-                    if (hasSwitchX) by = ladd(by, gy_, cf);
-                    bm = bvalid ? bm : CP_NEG_INF;
-                    bx = bvalid ? bx : CP_NEG_INF;
-                    by = bvalid ? by : CP_NEG_INF;
-                }
-                Bm = bm; Bx = bx; By = by;
-                Hm = hm; Hx = hx; Hy = hy;
-            }
-            /* messages this diagonal sends to t-1 and t-2 */
-            Mm = Mx = My = Um = Uy = Gm = Gx = Gy = CP_NEG_INF;
-            if (active) {
-                Mm = Bm + (pmc + T[T_MATCH_CONTINUE]);
-                Mx = Bm + (pmc + T[T_MATCH_FROM_GAP_X]);
-                My = Bm + (pmc + T[T_MATCH_FROM_GAP_Y]);
-                Um = By + (pyc + T[T_GAP_OPEN_Y]);
-                Uy = By + (pyc + T[T_GAP_EXTEND_Y]);
-                Gm = Bx + (pxReg + T[T_GAP_OPEN_X]);
-                Gx = Bx + (pxReg + T[T_GAP_EXTEND_X]);
-                Gy = Bx + (pxReg + T[T_GAP_SWITCH_TO_X]);
-            }
-            if (lane == 0) {
-                double *x = sh.xch[t & 1][wave];
-                x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My;
-            }
-
-            if (t <= tracedBackFrom) {
-                const double fM = fMc;
-                const int r0 = (bxmin >> 6) & (SY_R - 1), l0 = bxmin & 63;
-                if (calcs++ % 10 == 0) {
-                    /* diagonalCalculationTotalProbability :736-754 */
-                    double v = CP_NEG_INF, w_ = CP_NEG_INF;
-                    if (active) {
-                        const double fx = *rp(t, 1), fy = *rp(t, 2);
-                        v = fM + Bm; /* cell_dotProduct :391-397 */
-                        v = ladd(v, fx + Bx, cf);
-                        v = ladd(v, fy + By, cf);
-                    }
-                    const bool second = t + 1 <= dTop;
-                    if (second) {
-                        /* matches stepping over t: forward[t-1] --match--> cells of t+1, dotted with
-                         * backward[t+1]; only the match state of that clone is ever above -inf */
-                        double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
-                        if (row_active(lane == 0 ? waveBelow : wave, pxmin, pxmax)) {
-                            s0 = *rpb(t - 1, 0);
-                            s1 = *rpb(t - 1, 1);
-                            s2 = *rpb(t - 1, 2);
-                        }
-                        double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
-                        mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);
-                        mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]), cf);
-                        w_ = mm + BmPrev;
-                    }
-                    sh.vbuf[wave * 64 + lane] = v;
-                    sh.wbuf[wave * 64 + lane] = w_;
-                    const unsigned long long vm = __ballot(tvalid), wm = __ballot(validPrev);
-                    if (lane == 0) { sh.vmask[wave] = vm; sh.wmask[wave] = wm; }
-                    lds_barrier();
-                    if (wave == 0) {
-                        double acc = CP_NEG_INF;
-                        for (int k = 0; k <= SY_R; k++) {
-                            const int r = (r0 + k) & (SY_R - 1);
-                            const bool inSeg = k == 0 ? lane >= l0 : (k == SY_R ? lane < l0 : true);
-                            const bool ok = ((sh.vmask[r] >> lane) & 1ull) && inSeg;
-                            acc = cp_wave_seq_fold(acc, sh.vbuf[r * 64 + lane], ok);
-                        }
-                        if (second) {
-                            const int q0 = (nxmin >> 6) & (SY_R - 1), m0 = nxmin & 63;
-                            double acc2 = CP_NEG_INF;
-                            for (int k = 0; k <= SY_R; k++) {
-                                const int r = (q0 + k) & (SY_R - 1);
-                                const bool inSeg = k == 0 ? lane >= m0 : (k == SY_R ? lane < m0 : true);
-                                const bool ok = ((sh.wmask[r] >> lane) & 1ull) && inSeg;
-                                acc2 = cp_wave_seq_fold(acc2, sh.wbuf[r * 64 + lane], ok);
-                            }
-                            acc = cp_logAdd(acc, acc2);
-                        }
-                        if (lane == 0) {
-                            sh.total = acc;
-                            if (out.nTot < out.totCap) {
-                                out.totXay[out.nTot] = t;
-                                out.totVal[out.nTot] = acc;
-                            }
-                        }
-                    }
-                    lds_barrier();
-                    total = sh.total;
-                    out.nTot++;
-                }
-                /* diagonalCalculationPosteriorMatchProbs :756-795; pairs are written after the next
-                 * barrier, when every wave's count for this diagonal is visible */
-                {
-                    const int y = t - xs;
-                    bool hit = false;
-                    double e = 0.0, p = 0.0;
-                    if (active && tvalid && xs > 0 && y > 0) {
-                        e = (fM + Bm) - total;
-                        if (e >= P.logThrSlack) {
-                            p = exp(e);
-                            hit = p >= P.threshold;
-                        }
-                    }
-                    const bool isR0 = wave == r0;
-                    const bool segB = isR0 && lane < l0;
-                    const unsigned long long hm_ = __ballot(hit);
-                    const unsigned long long mB = isR0 ? ((1ull << l0) - 1ull) : 0ull;
-                    const unsigned long long hitsA = hm_ & ~mB, hitsB = hm_ & mB;
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    if (p > 1.0) p = 1.0;
-                    pd.any = true;
-                    pd.hit = hit;
-                    pd.segB = segB;
-                    pd.r0 = r0;
-                    pd.par = t & 1;
-                    pd.prefix = segB ? __popcll(hitsB & below) : __popcll(hitsA & below);
-                    pd.p = (long long) floor(p * 10000000.0);
-                    pd.x = xs;
-                    pd.y = y;
-                    pd.e = e;
-                    if (lane == 0) {
-                        sh.cnt[t & 1][wave][0] = __popcll(hitsA);
-                        sh.cnt[t & 1][wave][1] = __popcll(hitsB);
-                    }
-                }
-            }
-            pmPrev = pmc;
-            fMc = fMn; pmc = pmn; pyc = pyn;
-            nxmin = bxmin; nxmax = bxmax;
-            bxmin = pxmin; bxmax = pxmax;
-            if (t - 2 > tracedBackTo) band.range(t - 2, pxmin, pxmax);
-        }
-        lds_barrier();
-        flush_pending(pd, sh, out, wave);
-        tracedBackTo = tracedBackFrom;
-        if (atEnd) break;
-
-        /* ---------------- resume the forward sweep at dTop ---------------- */
-        band.range(dTop, xmin, xmax);
-        while (xs < xmin) xs += SY_P; /* the sweep down left slots on lower k-mers; move back up */
-        {
-            const bool v = xs <= xmax;
-            if (v) load_params(prm, track, xs);
-            const bool a = row_active(wave, xmin, xmax);
-            Fm = a ? *rp(dTop, 0) : CP_NEG_INF;
-            Fx = a ? *rp(dTop, 1) : CP_NEG_INF;
-            Fy = a ? *rp(dTop, 2) : CP_NEG_INF;
-            int qmin, qmax;
-            band.range(dTop - 1, qmin, qmax);
-            const bool a1 = row_active(lane == 0 ? waveBelow : wave, qmin, qmax);
-            Lm = a1 ? *rpb(dTop - 1, 0) : CP_NEG_INF;
-            Lx = a1 ? *rpb(dTop - 1, 1) : CP_NEG_INF;
-            Ly = a1 ? *rpb(dTop - 1, 2) : CP_NEG_INF;
-            band.range(dTop, xmin, xmax);
-            const int ei = dTop - xs - 1;
-            const bool okE = v && ei >= 0 && ei < lY;
-            em = okE ? ev[3 * (long long) ei] : 0.0;
-            en = okE ? ev[3 * (long long) ei + 1] : 0.0;
-        }
-        if (lane == 63) {
-            double *x = sh.xch[dTop & 1][wave];
-            x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
-        }
-        xin = xmax + 1;
-        st = stage_row(track, xin <= lX ? xin : lX, lane);
-        fwdEv.init_up(dTop - xmin, lane);
-        xminP = xmin;
     }
+}
+
+/* xs: the lane's k-mer on the pending diagonal (flush runs before the slot can be recycled) */
+__device__ __forceinline__ void flush_pending(Pending &pd, Shared &sh, ItemOut &out, int wave, int xs) {
+    if (!pd.any) return;
+    int sumA = 0, before = 0;
+    const int rel = (wave - pd.r0) & (SY_R - 1);
+#pragma unroll
+    for (int k = 0; k < SY_R; k++) {
+        const int c = sh.cnt[pd.par][(pd.r0 + k) & (SY_R - 1)][0];
+        if (k < rel) before += c;
+        sumA += c;
+    }
+    const int cB = sh.cnt[pd.par][pd.r0][1];
+    if (pd.hit) {
+        const long long idx = out.nPairs + (pd.segB ? sumA : before) + pd.prefix;
+        if (idx < out.pairCap) {
+            long long *o = out.pairs + idx * 3;
+            o[0] = pd.p;
+            o[1] = xs - 1;
+            o[2] = pd.t - xs - 1;
+            out.logp[idx] = pd.e;
+        }
+    }
+    out.nPairs += sumA + cB;
+    pd.any = false;
+}
+
+/* Backward sweep + posterior decode of one traceback window (:921-992). */
+__device__ void backward_window(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
+                                const double *__restrict__ track, const double *__restrict__ model,
+                                double *ring, int ringD, SyState *state, ItemOut &out, Shared &sh) {
+    const Geometry g = make_geometry(ring, ringD);
+    const int lane = g.lane, wave = g.wave;
+    const int lX = (int) it.lX;
+    const double *cf = sh.coef;
+    const bool hasSwitchX = model[T_GAP_SWITCH_TO_X] > CP_NEG_INF;
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) T[i] = model[i];
+
+    const int dTop = state->winTop, tracedBackFrom = state->winFrom, tracedBackTo = state->winTo;
+    const bool atEnd = state->winAtEnd != 0;
+    Band band;
+    make_band(band, it, P, anchors, state->bandAi);
+
+    int bxmin, bxmax;               /* band of diagonal t   */
+    band.range(dTop, bxmin, bxmax);
+    int nxmin = bxmin, nxmax = bxmax; /* band of diagonal t+1 */
+    int pxmin, pxmax;               /* band of diagonal t-1 */
+    band.range(dTop - 1, pxmin, pxmax);
+
+    int xs = wave * 64 + lane;      /* backward representative: xmax-P < x <= xmax */
+    xs += ((bxmin - xs + SY_P - 1) / SY_P) * SY_P;
+    if (xs > bxmax) xs -= SY_P;
+    bool tvalid = xs >= bxmin;      /* slot in band on diagonal t */
+    double Bm, Bx, By;                                        /* backward cell on diagonal t        */
+    double Hm = CP_NEG_INF, Hx = CP_NEG_INF, Hy = CP_NEG_INF; /* middle-block msgs from t+2 (moved) */
+    double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1      */
+    double Um = CP_NEG_INF, Uy = CP_NEG_INF;                  /* upper-block msgs from t+1 (same slot) */
+    double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1       */
+    double pmPrev = 0.0, BmPrev = CP_NEG_INF;                 /* match emission / backward match of t+1 */
+    bool validPrev = false;
+    {
+        double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
+        if (atEnd && it.raggedR) {
+            e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
+            e1 = T[T_GAP_EXTEND_X];
+            e2 = T[T_GAP_EXTEND_Y];
+        } else {
+            e0 = T[T_MATCH_CONTINUE];
+            e1 = T[T_MATCH_FROM_GAP_X];
+            e2 = T[T_MATCH_FROM_GAP_Y];
+        }
+        Bm = tvalid ? e0 : CP_NEG_INF;
+        Bx = tvalid ? e1 : CP_NEG_INF;
+        By = tvalid ? e2 : CP_NEG_INF;
+    }
+    /* the sweep back needs one constant per k-mer, its gap-X emission: held per slot, refreshed
+     * from a 64-k-mer chunk when a k-mer enters at the low edge of the band */
+    double pxReg = track[(long long) (tvalid ? xs : 0) * CP_ROW + CP_GAPX];
+    int xinB = bxmin - 1; /* k-mers above xinB are installed */
+    int pxBase = (xinB >= 0 ? xinB : 0) & ~63;
+    double pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
+
+    Pending pd;
+    pd.any = false;
+    /* forward match cell and the two emissions are fetched one diagonal ahead of their use */
+    const bool aTop = row_active(wave, bxmin, bxmax);
+    double fMc = aTop ? *g.rp(dTop, 0) : CP_NEG_INF;
+    double pmc = aTop ? *g.rp(dTop, 3) : 0.0, pyc = aTop ? *g.rp(dTop, 4) : 0.0;
+    double fMn = CP_NEG_INF, pmn = 0.0, pyn = 0.0;
+    double total = CP_NEG_INF;
+    int calcs = 0;
+    for (int t = dTop; t > tracedBackTo; t--) {
+        const bool active = row_active(wave, bxmin, bxmax);
+        const bool activeP = t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax);
+        if (activeP) { /* issue the loads for t-1 now, consume them next iteration */
+            fMn = *g.rp(t - 1, 0);
+            pmn = *g.rp(t - 1, 3);
+            pyn = *g.rp(t - 1, 4);
+        } else {
+            fMn = CP_NEG_INF; pmn = 0.0; pyn = 0.0;
+        }
+        if (t < dTop) {
+            lds_barrier();
+            const double *xa = sh.xch[(t + 1) & 1][g.waveAbove];
+            const double gm = shl1(xa[0], Gm), gx_ = shl1(xa[1], Gx), gy_ = shl1(xa[2], Gy);
+            const double hm = shl1(xa[3], Mm), hx = shl1(xa[4], Mx), hy = shl1(xa[5], My);
+            flush_pending(pd, sh, out, wave, xs);
+            if (xs > bxmax) xs -= SY_P;
+            const bool bvalid = xs >= bxmin;
+            while (xinB >= bxmin) {
+                if (xinB < pxBase) {
+                    pxBase -= 64;
+                    pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
+                }
+                const double v = bcast(pxChunk, xinB - pxBase);
+                if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) pxReg = v;
+                xinB--;
+            }
+            BmPrev = Bm;
+            validPrev = tvalid;
+            tvalid = bvalid;
+            double bm = CP_NEG_INF, bx = CP_NEG_INF, by = CP_NEG_INF;
+            if (active) {
+                /* gather form of cell_calculateBackward: (t+2) middle block, then (t+1, smaller
+                 * x-y) upper block, then (t+1, larger x-y) lower block */
+                bm = ladd(ladd(Hm, Um, cf), gm, cf);
+                bx = ladd(Hx, gx_, cf);
+                by = ladd(Hy, Uy, cf);
+                if (hasSwitchX) by = ladd(by, gy_, cf);
+                bm = bvalid ? bm : CP_NEG_INF;
+                bx = bvalid ? bx : CP_NEG_INF;
+                by = bvalid ? by : CP_NEG_INF;
+            }
+            Bm = bm; Bx = bx; By = by;
+            Hm = hm; Hx = hx; Hy = hy;
+        }
+        /* messages this diagonal sends to t-1 and t-2 */
+        Mm = Mx = My = Um = Uy = Gm = Gx = Gy = CP_NEG_INF;
+        if (active) {
+            Mm = Bm + (pmc + T[T_MATCH_CONTINUE]);
+            Mx = Bm + (pmc + T[T_MATCH_FROM_GAP_X]);
+            My = Bm + (pmc + T[T_MATCH_FROM_GAP_Y]);
+            Um = By + (pyc + T[T_GAP_OPEN_Y]);
+            Uy = By + (pyc + T[T_GAP_EXTEND_Y]);
+            Gm = Bx + (pxReg + T[T_GAP_OPEN_X]);
+            Gx = Bx + (pxReg + T[T_GAP_EXTEND_X]);
+            Gy = Bx + (pxReg + T[T_GAP_SWITCH_TO_X]);
+        }
+        if (lane == 0) {
+            double *x = sh.xch[t & 1][wave];
+            x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My;
+        }
+
+        if (t <= tracedBackFrom) {
+            const double fM = fMc;
+            const int r0 = (bxmin >> 6) & (SY_R - 1), l0 = bxmin & 63;
+            if (calcs++ % 10 == 0) {
+                /* diagonalCalculationTotalProbability :736-754 */
+                double v = CP_NEG_INF, w_ = CP_NEG_INF;
+                if (active) {
+                    const double fx = *g.rp(t, 1), fy = *g.rp(t, 2);
+                    v = fM + Bm; /* cell_dotProduct :391-397 */
+                    v = ladd(v, fx + Bx, cf);
+                    v = ladd(v, fy + By, cf);
+                }
+                const bool second = t + 1 <= dTop;
+                if (second) {
+                    /* matches stepping over t: forward[t-1] --match--> cells of t+1, dotted with
+                     * backward[t+1]; only the match state of that clone is ever above -inf */
+                    double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
+                    if (row_active(lane == 0 ? g.waveBelow : wave, pxmin, pxmax)) {
+                        s0 = *g.rpb(t - 1, 0);
+                        s1 = *g.rpb(t - 1, 1);
+                        s2 = *g.rpb(t - 1, 2);
+                    }
+                    double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
+                    mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);
+                    mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]), cf);
+                    w_ = mm + BmPrev;
+                }
+                sh.vbuf[wave * 64 + lane] = v;
+                sh.wbuf[wave * 64 + lane] = w_;
+                const unsigned long long vm = __ballot(tvalid), wm = __ballot(validPrev);
+                if (lane == 0) { sh.vmask[wave] = vm; sh.wmask[wave] = wm; }
+                lds_barrier();
+                if (wave == 0) {
+                    double acc = CP_NEG_INF;
+                    for (int k = 0; k <= SY_R; k++) {
+                        const int r = (r0 + k) & (SY_R - 1);
+                        const bool inSeg = k == 0 ? lane >= l0 : (k == SY_R ? lane < l0 : true);
+                        const bool ok = ((sh.vmask[r] >> lane) & 1ull) && inSeg;
+                        acc = cp_wave_seq_fold(acc, sh.vbuf[r * 64 + lane], ok);
+                    }
+                    if (second) {
+                        const int q0 = (nxmin >> 6) & (SY_R - 1), m0 = nxmin & 63;
+                        double acc2 = CP_NEG_INF;
+                        for (int k = 0; k <= SY_R; k++) {
+                            const int r = (q0 + k) & (SY_R - 1);
+                            const bool inSeg = k == 0 ? lane >= m0 : (k == SY_R ? lane < m0 : true);
+                            const bool ok = ((sh.wmask[r] >> lane) & 1ull) && inSeg;
+                            acc2 = cp_wave_seq_fold(acc2, sh.wbuf[r * 64 + lane], ok);
+                        }
+                        acc = cp_logAdd(acc, acc2);
+                    }
+                    if (lane == 0) {
+                        sh.total = acc;
+                        if (out.nTot < out.totCap) {
+                            out.totXay[out.nTot] = t;
+                            out.totVal[out.nTot] = acc;
+                        }
+                    }
+                }
+                lds_barrier();
+                total = sh.total;
+                out.nTot++;
+            }
+            /* diagonalCalculationPosteriorMatchProbs :756-795; pairs are written after the next
+             * barrier, when every wave's count for this diagonal is visible */
+            {
+                const int y = t - xs;
+                bool hit = false;
+                double e = 0.0, p = 0.0;
+                if (active && tvalid && xs > 0 && y > 0) {
+                    e = (fM + Bm) - total;
+                    if (e >= P.logThrSlack) {
+                        p = exp(e);
+                        hit = p >= P.threshold;
+                    }
+                }
+                const bool isR0 = wave == r0;
+                const bool segB = isR0 && lane < l0;
+                const unsigned long long hm_ = __ballot(hit);
+                const unsigned long long mB = isR0 ? ((1ull << l0) - 1ull) : 0ull;
+                const unsigned long long hitsA = hm_ & ~mB, hitsB = hm_ & mB;
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (p > 1.0) p = 1.0;
+                pd.any = true;
+                pd.hit = hit;
+                pd.segB = segB;
+                pd.r0 = r0;
+                pd.par = t & 1;
+                pd.prefix = segB ? __popcll(hitsB & below) : __popcll(hitsA & below);
+                pd.p = (int) floor(p * 10000000.0);
+                pd.t = t;
+                pd.e = e;
+                if (lane == 0) {
+                    sh.cnt[t & 1][wave][0] = __popcll(hitsA);
+                    sh.cnt[t & 1][wave][1] = __popcll(hitsB);
+                }
+            }
+        }
+        pmPrev = pmc;
+        fMc = fMn; pmc = pmn; pyc = pyn;
+        nxmin = bxmin; nxmax = bxmax;
+        bxmin = pxmin; bxmax = pxmax;
+        if (t - 2 > tracedBackTo) band.range(t - 2, pxmin, pxmax);
+    }
+    lds_barrier();
+    flush_pending(pd, sh, out, wave, xs);
+    (void) nxmax;
 }
 
 } // namespace
 
-extern "C" __global__ __launch_bounds__(256) void cpecan_k_systolic(
+/* One workgroup per alignment: forward sweep up to its next traceback point. */
+extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const long long *__restrict__ anchors, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
     const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD,
-    int *workCounter, long long *pairs, double *pairLogp, long long *nPairs, long long *totXay,
-    double *totVal, long long *nTot, long long *nCells) {
+    SyState *states) {
     __shared__ Shared sh;
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    SyState *state = states + idx;
+    const DevItem it = items[idx];
+    if (state->finished || it.lX + it.lY == 0) return;
     init_coef(sh.coef);
-    double *ring = Fring + (long long) blockIdx.x * ringDoubles;
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) sh.item = atomicAdd(workCounter, 1);
-        __syncthreads();
-        const int idx = __builtin_amdgcn_readfirstlane(sh.item);
-        if (idx >= nItems) break;
-        const DevItem it = items[idx];
-        ItemOut out;
-        out.pairs = pairs + it.pairBase * 3;
-        out.logp = pairLogp + it.pairBase;
-        out.pairCap = it.pairCap;
-        out.totXay = totXay + it.totBase;
-        out.totVal = totVal + it.totBase;
-        out.totCap = it.totCap;
-        out.nPairs = 0;
-        out.nTot = 0;
-        long long cells = 0;
-        if (it.lX + it.lY > 0)
-            run_item(it, P, anchors, track + trackBase[idx] * CP_ROW, events,
-                     models + (long long) it.model * CP_MODEL_STRIDE, ring, ringD, out, cells, sh);
-        if (threadIdx.x == 0) {
-            nPairs[idx] = out.nPairs;
-            nTot[idx] = out.nTot;
-            nCells[idx] = cells;
-        }
+    __syncthreads();
+    forward_window(it, P, anchors, track + trackBase[idx] * CP_ROW, events,
+                   models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD,
+                   state, sh);
+}
+
+/* One workgroup per alignment: backward sweep + posterior decode of the window just described. */
+extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
+    const DevItem *__restrict__ items, long long nItems, DevParams P,
+    const long long *__restrict__ anchors, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
+    long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
+    long long *totXay, double *totVal) {
+    __shared__ Shared sh;
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    SyState *state = states + idx;
+    if (!state->winValid) return;
+    const DevItem it = items[idx];
+    init_coef(sh.coef);
+    __syncthreads();
+    ItemOut out;
+    out.pairs = pairs + it.pairBase * 3;
+    out.logp = pairLogp + it.pairBase;
+    out.pairCap = it.pairCap;
+    out.totXay = totXay + it.totBase;
+    out.totVal = totVal + it.totBase;
+    out.totCap = it.totCap;
+    out.nPairs = state->nPairs;
+    out.nTot = state->nTot;
+    backward_window(it, P, anchors, track + trackBase[idx] * CP_ROW,
+                    models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD,
+                    state, out, sh);
+    if (threadIdx.x == 0) {
+        state->nPairs = out.nPairs;
+        state->nTot = out.nTot;
+        state->winValid = 0;
     }
+}
+
+/* results of the per-alignment states into the batch's count arrays */
+extern "C" __global__ void cpecan_k_sy_counts(const SyState *states, long long nItems,
+                                              long long *nPairs, long long *nTot, long long *nCells) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nItems) return;
+    nPairs[i] = states[i].nPairs;
+    nTot[i] = states[i].nTot;
+    nCells[i] = states[i].cells;
 }
 
 /* per-item track of emission constants: row x (0..lX) = model row of the k-mer that matrix column x
@@ -766,31 +851,39 @@ extern "C" int cpecan_systolic_max_width(void) { return SY_P; }
 extern "C" int cpecan_systolic_rows(void) { return SY_R; }
 extern "C" int cpecan_systolic_ring_row_doubles(void) { return SY_R * SY_RING_VALUES * 64; }
 
-extern "C" int cpecan_systolic_launch(hipStream_t stream, int nWorkgroups, const DevItem *items,
-                                      long long nItems, DevParams P, const long long *anchors,
-                                      const double *track, const long long *trackBase,
-                                      const unsigned short *kidx, const double *events,
-                                      const double *models, double *Fring, long long ringDoubles,
-                                      int ringD, int *workCounter, long long *pairs,
-                                      double *pairLogp, long long *nPairs, long long *totXay,
-                                      double *totVal, long long *nTot, long long *nCells,
-                                      int maxLX, int buildTrack) {
-    if (buildTrack) {
-        int bx = (int) ((((long long) maxLX + 1) * CP_ROW + 255) / 256);
-        if (bx > 64) bx = 64;
-        hipLaunchKernelGGL(cpecan_k_track, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items,
-                           nItems, trackBase, kidx, models, (double *) track);
-        if (hipGetLastError() != hipSuccess) return -1;
+extern "C" int cpecan_systolic_state_bytes(void) { return (int) sizeof(SyState); }
+
+/* One pass over a batch: track of emission constants, then `windows` rounds of
+ * {forward to the next traceback point, backward + decode of that window} for every alignment. */
+extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, long long nItems,
+                                      DevParams P, const long long *anchors, const double *track,
+                                      const long long *trackBase, const unsigned short *kidx,
+                                      const double *events, const double *models, double *Fring,
+                                      long long ringDoubles, int ringD, void *states, int windows,
+                                      long long *pairs, double *pairLogp, long long *nPairs,
+                                      long long *totXay, double *totVal, long long *nTot,
+                                      long long *nCells, int maxLX) {
+    int bx = (int) ((((long long) maxLX + 1) * CP_ROW + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(cpecan_k_track, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items,
+                       nItems, trackBase, kidx, models, (double *) track);
+    if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(SyState), stream) != hipSuccess) return -1;
+    for (int w = 0; w < windows; w++) {
+        hipLaunchKernelGGL(cpecan_k_sy_forward, dim3((unsigned) nItems), dim3(256), 0, stream, items,
+                           nItems, P, anchors, track, trackBase, events, models, Fring, ringDoubles,
+                           ringD, (SyState *) states);
+        hipLaunchKernelGGL(cpecan_k_sy_backward, dim3((unsigned) nItems), dim3(256), 0, stream, items,
+                           nItems, P, anchors, track, trackBase, models, Fring, ringDoubles, ringD,
+                           (SyState *) states, pairs, pairLogp, totXay, totVal);
     }
-    hipLaunchKernelGGL(cpecan_k_systolic, dim3(nWorkgroups), dim3(256), 0, stream, items, nItems, P,
-                       anchors, track, trackBase, events, models, Fring, ringDoubles, ringD,
-                       workCounter, pairs, pairLogp, nPairs, totXay, totVal, nTot, nCells);
+    hipLaunchKernelGGL(cpecan_k_sy_counts, dim3((unsigned) ((nItems + 255) / 256)), dim3(256), 0, stream,
+                       (const SyState *) states, nItems, nPairs, nTot, nCells);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 extern "C" int cpecan_systolic_occupancy(int *workgroupsPerCU) {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpecan_k_systolic, 256, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpecan_k_sy_backward, 256, 0);
     if (e != hipSuccess) return -1;
     *workgroupsPerCU = n;
     return 0;
