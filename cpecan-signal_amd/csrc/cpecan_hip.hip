@@ -34,6 +34,7 @@ extern "C" int cpecan_systolic_ring_row_doubles(void);
 extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned long long seed,
                                        unsigned long long *bad);
 extern "C" int cpecan_systolic_state_bytes(void);
+extern "C" long long cpecan_systolic_scratch_bytes(int ringD);
 extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, long long nItems,
                                       DevParams P, const long long *anchors, const double *track,
                                       const long long *trackBase, const unsigned short *kidx,
@@ -41,7 +42,8 @@ extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, 
                                       long long ringDoubles, int ringD, void *states, int windows,
                                       long long *pairs, double *pairLogp, long long *nPairs,
                                       long long *totXay, double *totVal, long long *nTot,
-                                      long long *nCells, int maxLX);
+                                      long long *nCells, int maxLX, char *scratch,
+                                      long long scratchBytes);
 
 namespace {
 
@@ -112,7 +114,8 @@ struct cpecan_batch {
     DevBuf<double> totVal;
     DevBuf<double> expect;
     DevBuf<int> workCounter;
-    DevBuf<char> syStates;
+    DevBuf<char> syStates, syScratch;
+    long long scratchBytes = 0;
     int nWindows = 0;
     DevBuf<double> track;
     DevBuf<long long> trackBase;
@@ -466,6 +469,8 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
+        b->scratchBytes = (cpecan_systolic_scratch_bytes(b->ringD) + 63) / 64 * 64;
+        B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
         B_TRY(b->track.alloc((size_t) trackTotal * CP_ROW));
         B_TRY(b->trackBase.alloc((size_t) nItems));
         B_TRY(hipMemcpy(b->trackBase.p, hTrackBase.data(), (size_t) nItems * sizeof(long long),
@@ -516,7 +521,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                         c->models.p, b->Fstore.p, b->ringDoubles, b->ringD,
                                         b->syStates.p, b->nWindows, b->pairs.p, b->pairLogp.p,
                                         b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
-                                        b->nCells.p, b->maxLX);
+                                        b->nCells.p, b->maxLX, b->syScratch.p, b->scratchBytes);
         if (rc != 0) return fail(CPECAN_EHIP, "systolic kernel launch failed: %s",
                                  hipGetErrorString(hipGetLastError()));
     }

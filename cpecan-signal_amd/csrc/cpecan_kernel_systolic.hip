@@ -461,36 +461,36 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
     }
 }
 
-/* xs: the lane's k-mer on the pending diagonal (flush runs before the slot can be recycled) */
-__device__ __forceinline__ void flush_pending(Pending &pd, Shared &sh, ItemOut &out, int wave, int xs) {
-    if (!pd.any) return;
-    int sumA = 0, before = 0;
-    const int rel = (wave - pd.r0) & (SY_R - 1);
-#pragma unroll
-    for (int k = 0; k < SY_R; k++) {
-        const int c = sh.cnt[pd.par][(pd.r0 + k) & (SY_R - 1)][0];
-        if (k < rel) before += c;
-        sumA += c;
-    }
-    const int cB = sh.cnt[pd.par][pd.r0][1];
-    if (pd.hit) {
-        const long long idx = out.nPairs + (pd.segB ? sumA : before) + pd.prefix;
-        if (idx < out.pairCap) {
-            long long *o = out.pairs + idx * 3;
-            o[0] = pd.p;
-            o[1] = xs - 1;
-            o[2] = pd.t - xs - 1;
-            out.logp[idx] = pd.e;
-        }
-    }
-    out.nPairs += sumA + cB;
-    pd.any = false;
+/* value of ring row `s` of diagonal d for matrix column x (any thread may ask for any column) */
+__device__ __forceinline__ double ring_at(const double *ring, int ringMask, int d, int s, int x) {
+    const int slot = x & (SY_P - 1);
+    return ring[(long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + (slot >> 6) * (SY_RING_VALUES * 64)
+                + s * 64 + (slot & 63)];
 }
 
-/* Backward sweep + posterior decode of one traceback window (:921-992). */
+/* per-window bookkeeping kept in HBM scratch (private to the alignment's workgroup) */
+struct WinTotal {
+    int t, xmin, xmax, nxmin, nxmax, second;
+    double total;
+};
+
+/*
+ * Backward sweep + posterior decode of one traceback window (:921-992), in three phases:
+ *  S  the sweep back: one anti-diagonal per iteration, cells and messages in registers.  It leaves
+ *     per cell F.match + B.match (in the ring slot of the match emission, dead by then) and, on the
+ *     diagonals where the reference refreshes totalProbability, the two per-cell terms of that sum
+ *     (HBM scratch);
+ *  T  totalProbability (:736-754) for every refresh of the window at once: the reference's
+ *     order-dependent logAdd fold is inherently serial, so each THREAD folds one diagonal's terms
+ *     privately, in the reference's order -- ~200 independent chains instead of one wave-wide chain
+ *     per refresh inside the sweep;
+ *  D  diagonalCalculationPosteriorMatchProbs (:756-795) for the window: hits are counted per
+ *     diagonal, prefix-summed in emission order (diagonals descending, x-y ascending) and written.
+ */
 __device__ void backward_window(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
                                 const double *__restrict__ track, const double *__restrict__ model,
-                                double *ring, int ringD, SyState *state, ItemOut &out, Shared &sh) {
+                                double *ring, int ringD, SyState *state, ItemOut &out, Shared &sh,
+                                int *cntBuf, WinTotal *wtot, double *vw) {
     const Geometry g = make_geometry(ring, ringD);
     const int lane = g.lane, wave = g.wave;
     const int lX = (int) it.lX;
@@ -502,226 +502,287 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
 
     const int dTop = state->winTop, tracedBackFrom = state->winFrom, tracedBackTo = state->winTo;
     const bool atEnd = state->winAtEnd != 0;
+    const int bandAiTop = state->bandAi;
     Band band;
-    make_band(band, it, P, anchors, state->bandAi);
+    make_band(band, it, P, anchors, bandAiTop);
 
-    int bxmin, bxmax;               /* band of diagonal t   */
-    band.range(dTop, bxmin, bxmax);
-    int nxmin = bxmin, nxmax = bxmax; /* band of diagonal t+1 */
-    int pxmin, pxmax;               /* band of diagonal t-1 */
-    band.range(dTop - 1, pxmin, pxmax);
-
-    int xs = wave * 64 + lane;      /* backward representative: xmax-P < x <= xmax */
-    xs += ((bxmin - xs + SY_P - 1) / SY_P) * SY_P;
-    if (xs > bxmax) xs -= SY_P;
-    bool tvalid = xs >= bxmin;      /* slot in band on diagonal t */
-    double Bm, Bx, By;                                        /* backward cell on diagonal t        */
-    double Hm = CP_NEG_INF, Hx = CP_NEG_INF, Hy = CP_NEG_INF; /* middle-block msgs from t+2 (moved) */
-    double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1      */
-    double Um = CP_NEG_INF, Uy = CP_NEG_INF;                  /* upper-block msgs from t+1 (same slot) */
-    double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1       */
-    double pmPrev = 0.0, BmPrev = CP_NEG_INF;                 /* match emission / backward match of t+1 */
-    bool validPrev = false;
+    /* ------------------------------ phase S: the sweep back ------------------------------ */
     {
-        double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
-        if (atEnd && it.raggedR) {
-            e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
-            e1 = T[T_GAP_EXTEND_X];
-            e2 = T[T_GAP_EXTEND_Y];
-        } else {
-            e0 = T[T_MATCH_CONTINUE];
-            e1 = T[T_MATCH_FROM_GAP_X];
-            e2 = T[T_MATCH_FROM_GAP_Y];
-        }
-        Bm = tvalid ? e0 : CP_NEG_INF;
-        Bx = tvalid ? e1 : CP_NEG_INF;
-        By = tvalid ? e2 : CP_NEG_INF;
-    }
-    /* the sweep back needs one constant per k-mer, its gap-X emission: held per slot, refreshed
-     * from a 64-k-mer chunk when a k-mer enters at the low edge of the band */
-    double pxReg = track[(long long) (tvalid ? xs : 0) * CP_ROW + CP_GAPX];
-    int xinB = bxmin - 1; /* k-mers above xinB are installed */
-    int pxBase = (xinB >= 0 ? xinB : 0) & ~63;
-    double pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
+        int bxmin, bxmax;                 /* band of diagonal t   */
+        band.range(dTop, bxmin, bxmax);
+        int nxmin = bxmin, nxmax = bxmax; /* band of diagonal t+1 */
+        int pxmin, pxmax;                 /* band of diagonal t-1 */
+        band.range(dTop - 1, pxmin, pxmax);
 
-    Pending pd;
-    pd.any = false;
-    /* forward match cell and the two emissions are fetched one diagonal ahead of their use */
-    const bool aTop = row_active(wave, bxmin, bxmax);
-    double fMc = aTop ? *g.rp(dTop, 0) : CP_NEG_INF;
-    double pmc = aTop ? *g.rp(dTop, 3) : 0.0, pyc = aTop ? *g.rp(dTop, 4) : 0.0;
-    double fMn = CP_NEG_INF, pmn = 0.0, pyn = 0.0;
-    double total = CP_NEG_INF;
-    int calcs = 0;
-    for (int t = dTop; t > tracedBackTo; t--) {
-        const bool active = row_active(wave, bxmin, bxmax);
-        const bool activeP = t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax);
-        if (activeP) { /* issue the loads for t-1 now, consume them next iteration */
-            fMn = *g.rp(t - 1, 0);
-            pmn = *g.rp(t - 1, 3);
-            pyn = *g.rp(t - 1, 4);
-        } else {
-            fMn = CP_NEG_INF; pmn = 0.0; pyn = 0.0;
+        int xs = wave * 64 + lane;        /* backward representative: xmax-P < x <= xmax */
+        xs += ((bxmin - xs + SY_P - 1) / SY_P) * SY_P;
+        if (xs > bxmax) xs -= SY_P;
+        bool tvalid = xs >= bxmin;        /* slot in band on diagonal t */
+        double Bm, Bx, By;                                        /* backward cell on diagonal t        */
+        double Hm = CP_NEG_INF, Hx = CP_NEG_INF, Hy = CP_NEG_INF; /* middle-block msgs from t+2 (moved) */
+        double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1      */
+        double Um = CP_NEG_INF, Uy = CP_NEG_INF;                  /* upper-block msgs from t+1 (same slot) */
+        double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1       */
+        double pmPrev = 0.0, BmPrev = CP_NEG_INF;                 /* match emission / backward match of t+1 */
+        {
+            double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
+            if (atEnd && it.raggedR) {
+                e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
+                e1 = T[T_GAP_EXTEND_X];
+                e2 = T[T_GAP_EXTEND_Y];
+            } else {
+                e0 = T[T_MATCH_CONTINUE];
+                e1 = T[T_MATCH_FROM_GAP_X];
+                e2 = T[T_MATCH_FROM_GAP_Y];
+            }
+            Bm = tvalid ? e0 : CP_NEG_INF;
+            Bx = tvalid ? e1 : CP_NEG_INF;
+            By = tvalid ? e2 : CP_NEG_INF;
         }
-        if (t < dTop) {
-            lds_barrier();
-            const double *xa = sh.xch[(t + 1) & 1][g.waveAbove];
-            const double gm = shl1(xa[0], Gm), gx_ = shl1(xa[1], Gx), gy_ = shl1(xa[2], Gy);
-            const double hm = shl1(xa[3], Mm), hx = shl1(xa[4], Mx), hy = shl1(xa[5], My);
-            flush_pending(pd, sh, out, wave, xs);
-            if (xs > bxmax) xs -= SY_P;
-            const bool bvalid = xs >= bxmin;
-            while (xinB >= bxmin) {
-                if (xinB < pxBase) {
-                    pxBase -= 64;
-                    pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
+        /* the sweep needs one constant per k-mer, its gap-X emission: held per slot, refreshed from
+         * a 64-k-mer chunk when a k-mer enters at the low edge of the band */
+        double pxReg = track[(long long) (tvalid ? xs : 0) * CP_ROW + CP_GAPX];
+        int xinB = bxmin - 1; /* k-mers above xinB are installed */
+        int pxBase = (xinB >= 0 ? xinB : 0) & ~63;
+        double pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
+
+        /* forward match cell and the two emissions are fetched one diagonal ahead of their use */
+        const bool aTop = row_active(wave, bxmin, bxmax);
+        double fMc = aTop ? *g.rp(dTop, 0) : CP_NEG_INF;
+        double pmc = aTop ? *g.rp(dTop, 3) : 0.0, pyc = aTop ? *g.rp(dTop, 4) : 0.0;
+        double fMn = CP_NEG_INF, pmn = 0.0, pyn = 0.0;
+        int calcs = 0, nTotWin = 0;
+        for (int t = dTop; t > tracedBackTo; t--) {
+            const bool active = row_active(wave, bxmin, bxmax);
+            const bool activeN = row_active(wave, nxmin, nxmax);
+            const bool activeP = t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax);
+            if (activeP) { /* issue the loads for t-1 now, consume them next iteration */
+                fMn = *g.rp(t - 1, 0);
+                pmn = *g.rp(t - 1, 3);
+                pyn = *g.rp(t - 1, 4);
+            } else {
+                fMn = CP_NEG_INF; pmn = 0.0; pyn = 0.0;
+            }
+            if (t < dTop) {
+                lds_barrier();
+                const double *xa = sh.xch[(t + 1) & 1][g.waveAbove];
+                const double gm = shl1(xa[0], Gm), gx_ = shl1(xa[1], Gx), gy_ = shl1(xa[2], Gy);
+                const double hm = shl1(xa[3], Mm), hx = shl1(xa[4], Mx), hy = shl1(xa[5], My);
+                if (xs > bxmax) xs -= SY_P;
+                const bool bvalid = xs >= bxmin;
+                while (xinB >= bxmin) {
+                    if (xinB < pxBase) {
+                        pxBase -= 64;
+                        pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
+                    }
+                    const double v = bcast(pxChunk, xinB - pxBase);
+                    if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) pxReg = v;
+                    xinB--;
                 }
-                const double v = bcast(pxChunk, xinB - pxBase);
-                if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) pxReg = v;
-                xinB--;
-            }
-            BmPrev = Bm;
-            validPrev = tvalid;
-            tvalid = bvalid;
-            double bm = CP_NEG_INF, bx = CP_NEG_INF, by = CP_NEG_INF;
-            if (active) {
-                /* gather form of cell_calculateBackward: (t+2) middle block, then (t+1, smaller
-                 * x-y) upper block, then (t+1, larger x-y) lower block */
-                bm = ladd(ladd(Hm, Um, cf), gm, cf);
-                bx = ladd(Hx, gx_, cf);
-                by = ladd(Hy, Uy, cf);
-                if (hasSwitchX) by = ladd(by, gy_, cf);
-                bm = bvalid ? bm : CP_NEG_INF;
-                bx = bvalid ? bx : CP_NEG_INF;
-                by = bvalid ? by : CP_NEG_INF;
-            }
-            Bm = bm; Bx = bx; By = by;
-            Hm = hm; Hx = hx; Hy = hy;
-        }
-        /* messages this diagonal sends to t-1 and t-2 */
-        Mm = Mx = My = Um = Uy = Gm = Gx = Gy = CP_NEG_INF;
-        if (active) {
-            Mm = Bm + (pmc + T[T_MATCH_CONTINUE]);
-            Mx = Bm + (pmc + T[T_MATCH_FROM_GAP_X]);
-            My = Bm + (pmc + T[T_MATCH_FROM_GAP_Y]);
-            Um = By + (pyc + T[T_GAP_OPEN_Y]);
-            Uy = By + (pyc + T[T_GAP_EXTEND_Y]);
-            Gm = Bx + (pxReg + T[T_GAP_OPEN_X]);
-            Gx = Bx + (pxReg + T[T_GAP_EXTEND_X]);
-            Gy = Bx + (pxReg + T[T_GAP_SWITCH_TO_X]);
-        }
-        if (lane == 0) {
-            double *x = sh.xch[t & 1][wave];
-            x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My;
-        }
-
-        if (t <= tracedBackFrom) {
-            const double fM = fMc;
-            const int r0 = (bxmin >> 6) & (SY_R - 1), l0 = bxmin & 63;
-            if (calcs++ % 10 == 0) {
-                /* diagonalCalculationTotalProbability :736-754 */
-                double v = CP_NEG_INF, w_ = CP_NEG_INF;
+                BmPrev = Bm;
+                tvalid = bvalid;
+                double bm = CP_NEG_INF, bx = CP_NEG_INF, by = CP_NEG_INF;
                 if (active) {
-                    const double fx = *g.rp(t, 1), fy = *g.rp(t, 2);
-                    v = fM + Bm; /* cell_dotProduct :391-397 */
-                    v = ladd(v, fx + Bx, cf);
-                    v = ladd(v, fy + By, cf);
+                    /* gather form of cell_calculateBackward: (t+2) middle block, then (t+1, smaller
+                     * x-y) upper block, then (t+1, larger x-y) lower block */
+                    bm = ladd(ladd(Hm, Um, cf), gm, cf);
+                    bx = ladd(Hx, gx_, cf);
+                    by = ladd(Hy, Uy, cf);
+                    if (hasSwitchX) by = ladd(by, gy_, cf);
+                    bm = bvalid ? bm : CP_NEG_INF;
+                    bx = bvalid ? bx : CP_NEG_INF;
+                    by = bvalid ? by : CP_NEG_INF;
                 }
-                const bool second = t + 1 <= dTop;
-                if (second) {
-                    /* matches stepping over t: forward[t-1] --match--> cells of t+1, dotted with
-                     * backward[t+1]; only the match state of that clone is ever above -inf */
-                    double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
-                    if (row_active(lane == 0 ? g.waveBelow : wave, pxmin, pxmax)) {
-                        s0 = *g.rpb(t - 1, 0);
-                        s1 = *g.rpb(t - 1, 1);
-                        s2 = *g.rpb(t - 1, 2);
-                    }
-                    double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
-                    mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);
-                    mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]), cf);
-                    w_ = mm + BmPrev;
-                }
-                sh.vbuf[wave * 64 + lane] = v;
-                sh.wbuf[wave * 64 + lane] = w_;
-                const unsigned long long vm = __ballot(tvalid), wm = __ballot(validPrev);
-                if (lane == 0) { sh.vmask[wave] = vm; sh.wmask[wave] = wm; }
-                lds_barrier();
-                if (wave == 0) {
-                    double acc = CP_NEG_INF;
-                    for (int k = 0; k <= SY_R; k++) {
-                        const int r = (r0 + k) & (SY_R - 1);
-                        const bool inSeg = k == 0 ? lane >= l0 : (k == SY_R ? lane < l0 : true);
-                        const bool ok = ((sh.vmask[r] >> lane) & 1ull) && inSeg;
-                        acc = cp_wave_seq_fold(acc, sh.vbuf[r * 64 + lane], ok);
-                    }
-                    if (second) {
-                        const int q0 = (nxmin >> 6) & (SY_R - 1), m0 = nxmin & 63;
-                        double acc2 = CP_NEG_INF;
-                        for (int k = 0; k <= SY_R; k++) {
-                            const int r = (q0 + k) & (SY_R - 1);
-                            const bool inSeg = k == 0 ? lane >= m0 : (k == SY_R ? lane < m0 : true);
-                            const bool ok = ((sh.wmask[r] >> lane) & 1ull) && inSeg;
-                            acc2 = cp_wave_seq_fold(acc2, sh.wbuf[r * 64 + lane], ok);
-                        }
-                        acc = cp_logAdd(acc, acc2);
-                    }
-                    if (lane == 0) {
-                        sh.total = acc;
-                        if (out.nTot < out.totCap) {
-                            out.totXay[out.nTot] = t;
-                            out.totVal[out.nTot] = acc;
-                        }
-                    }
-                }
-                lds_barrier();
-                total = sh.total;
-                out.nTot++;
+                Bm = bm; Bx = bx; By = by;
+                Hm = hm; Hx = hx; Hy = hy;
             }
-            /* diagonalCalculationPosteriorMatchProbs :756-795; pairs are written after the next
-             * barrier, when every wave's count for this diagonal is visible */
-            {
-                const int y = t - xs;
-                bool hit = false;
-                double e = 0.0, p = 0.0;
-                if (active && tvalid && xs > 0 && y > 0) {
-                    e = (fM + Bm) - total;
-                    if (e >= P.logThrSlack) {
-                        p = exp(e);
-                        hit = p >= P.threshold;
+            /* messages this diagonal sends to t-1 and t-2 */
+            Mm = Mx = My = Um = Uy = Gm = Gx = Gy = CP_NEG_INF;
+            if (active) {
+                Mm = Bm + (pmc + T[T_MATCH_CONTINUE]);
+                Mx = Bm + (pmc + T[T_MATCH_FROM_GAP_X]);
+                My = Bm + (pmc + T[T_MATCH_FROM_GAP_Y]);
+                Um = By + (pyc + T[T_GAP_OPEN_Y]);
+                Uy = By + (pyc + T[T_GAP_EXTEND_Y]);
+                Gm = Bx + (pxReg + T[T_GAP_OPEN_X]);
+                Gx = Bx + (pxReg + T[T_GAP_EXTEND_X]);
+                Gy = Bx + (pxReg + T[T_GAP_SWITCH_TO_X]);
+            }
+            if (lane == 0) {
+                double *x = sh.xch[t & 1][wave];
+                x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My;
+            }
+
+            if (t <= tracedBackFrom) {
+                if (calcs++ % 10 == 0) {
+                    /* per-cell terms of diagonalCalculationTotalProbability (:736-754), folded in
+                     * phase T: v = cell_dotProduct(forward[t], backward[t]) (:391-397) ... */
+                    const bool second = t + 1 <= dTop;
+                    if (active) {
+                        const double fx = *g.rp(t, 1), fy = *g.rp(t, 2);
+                        double v = fMc + Bm;
+                        v = ladd(v, fx + Bx, cf);
+                        v = ladd(v, fy + By, cf);
+                        vw[((long long) nTotWin * 2 + 0) * SY_P + wave * 64 + lane] = v;
                     }
+                    if (second && activeN) {
+                        /* ... and w = matches stepping over t: forward[t-1] --match--> the cells of
+                         * t+1, dotted with backward[t+1] (only the match state of that clone is
+                         * ever above -inf) */
+                        double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
+                        if (row_active(lane == 0 ? g.waveBelow : wave, pxmin, pxmax)) {
+                            s0 = *g.rpb(t - 1, 0);
+                            s1 = *g.rpb(t - 1, 1);
+                            s2 = *g.rpb(t - 1, 2);
+                        }
+                        double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
+                        mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);
+                        mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]), cf);
+                        vw[((long long) nTotWin * 2 + 1) * SY_P + wave * 64 + lane] = mm + BmPrev;
+                    }
+                    if (threadIdx.x == 0) {
+                        WinTotal w;
+                        w.t = t; w.xmin = bxmin; w.xmax = bxmax; w.nxmin = nxmin; w.nxmax = nxmax;
+                        w.second = second ? 1 : 0;
+                        w.total = CP_NEG_INF;
+                        wtot[nTotWin] = w;
+                    }
+                    nTotWin++;
                 }
-                const bool isR0 = wave == r0;
-                const bool segB = isR0 && lane < l0;
-                const unsigned long long hm_ = __ballot(hit);
-                const unsigned long long mB = isR0 ? ((1ull << l0) - 1ull) : 0ull;
-                const unsigned long long hitsA = hm_ & ~mB, hitsB = hm_ & mB;
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (p > 1.0) p = 1.0;
-                pd.any = true;
-                pd.hit = hit;
-                pd.segB = segB;
-                pd.r0 = r0;
-                pd.par = t & 1;
-                pd.prefix = segB ? __popcll(hitsB & below) : __popcll(hitsA & below);
-                pd.p = (int) floor(p * 10000000.0);
-                pd.t = t;
-                pd.e = e;
-                if (lane == 0) {
-                    sh.cnt[t & 1][wave][0] = __popcll(hitsA);
-                    sh.cnt[t & 1][wave][1] = __popcll(hitsB);
-                }
+                /* exponent of the posterior, less the total: parked in the emission slot this diagonal
+                 * no longer needs (the forward cells themselves stay intact: the next window's
+                 * refresh at its lowest diagonal reads forward[tracedBackFrom], :944,:985) */
+                if (active) *g.rp(t, 3) = fMc + Bm;
+            }
+            pmPrev = pmc;
+            fMc = fMn; pmc = pmn; pyc = pyn;
+            nxmin = bxmin; nxmax = bxmax;
+            bxmin = pxmin; bxmax = pxmax;
+            if (t - 2 > tracedBackTo) band.range(t - 2, pxmin, pxmax);
+        }
+        sh.item = nTotWin;
+    }
+    __syncthreads(); /* the ring rows written above are read by other waves below */
+    const int nTotWin = sh.item;
+    const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
+    const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
+
+    /* ------------------------------ phase T: the totals ------------------------------ */
+#pragma unroll 1
+    for (int k = threadIdx.x; k < 2 * nTotWin; k += 256) {
+        const WinTotal w = wtot[k >> 1];
+        const int f = k & 1;
+        double acc = CP_NEG_INF;
+        if (f == 0 || w.second) {
+            const int lo = f ? w.nxmin : w.xmin, hi = f ? w.nxmax : w.xmax;
+#pragma unroll 1
+            for (int x0 = lo; x0 <= hi; x0 += 8) {
+                double v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    v[j] = x0 + j <= hi ? vw[((long long) (k >> 1) * 2 + f) * SY_P + ((x0 + j) & (SY_P - 1))]
+                                        : CP_NEG_INF;
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc = cp_logAdd(acc, v[j]); /* dpDiagonal_dotProduct :587-597 */
             }
         }
-        pmPrev = pmc;
-        fMc = fMn; pmc = pmn; pyc = pyn;
-        nxmin = bxmin; nxmax = bxmax;
-        bxmin = pxmin; bxmax = pxmax;
-        if (t - 2 > tracedBackTo) band.range(t - 2, pxmin, pxmax);
+        sh.vbuf[threadIdx.x] = acc;
+        __builtin_amdgcn_wave_barrier();
+        if (f == 0) {
+            double tot = acc;
+            if (w.second) tot = cp_logAdd(acc, sh.vbuf[threadIdx.x + 1]);
+            wtot[k >> 1].total = tot;
+            const long long o = out.nTot + (k >> 1);
+            if (o < out.totCap) {
+                out.totXay[o] = w.t;
+                out.totVal[o] = tot;
+            }
+        }
     }
-    lds_barrier();
-    flush_pending(pd, sh, out, wave, xs);
-    (void) nxmax;
+    out.nTot += nTotWin;
+    __syncthreads();
+
+    /* ------------------------------ phase D: the aligned pairs ------------------------------ */
+    if (P.mode == 0 && nPost > 0) {
+        for (int pass = 0; pass < 2; pass++) {
+            make_band(band, it, P, anchors, bandAiTop);
+#pragma unroll 1
+            for (int k = wave; k < nPost; k += SY_R) {
+                const int t = tPost0 - k;
+                int xmin, xmax;
+                band.range(t, xmin, xmax);
+                const double total = wtot[k / 10].total;
+                const int r0 = (xmin >> 6) & (SY_R - 1), l0 = xmin & 63;
+                int n = 0;
+                const long long base = pass ? out.nPairs + cntBuf[k] : 0;
+#pragma unroll 1
+                for (int j = 0; j <= SY_R; j++) {
+                    const int r = (r0 + j) & (SY_R - 1);
+                    if (!row_active(r, xmin, xmax)) continue;
+                    const bool inSeg = j == 0 ? lane >= l0 : (j == SY_R ? lane < l0 : true);
+                    if (j == SY_R && l0 == 0) continue;
+                    int x = r * 64 + lane;
+                    x += ((xmin - x + SY_P - 1) / SY_P) * SY_P;
+                    const int y = t - x;
+                    bool hit = false;
+                    double e = 0.0, p = 0.0;
+                    if (inSeg && x <= xmax && x > 0 && y > 0) {
+                        e = ring_at(ring, g.ringMask, t, 3, x) - total;
+                        if (e >= P.logThrSlack) {
+                            p = exp(e);
+                            hit = p >= P.threshold;
+                        }
+                    }
+                    const unsigned long long m = __ballot(hit);
+                    if (pass && hit) {
+                        const long long idx = base + n + __popcll(m & ((1ull << lane) - 1ull));
+                        if (idx < out.pairCap) {
+                            if (p > 1.0) p = 1.0;
+                            long long *o = out.pairs + idx * 3;
+                            o[0] = (long long) floor(p * 10000000.0);
+                            o[1] = x - 1;
+                            o[2] = y - 1;
+                            out.logp[idx] = e;
+                        }
+                    }
+                    n += __popcll(m);
+                }
+                if (!pass && lane == 0) cntBuf[k] = n;
+            }
+            __syncthreads();
+            if (!pass) {
+                /* exclusive prefix over the window's diagonals, in emission order */
+                const int per = (nPost + 255) / 256;
+                const int b0 = threadIdx.x * per, b1 = min(b0 + per, nPost);
+                int sum = 0;
+#pragma unroll 1
+                for (int k = b0; k < b1; k++) sum += cntBuf[k];
+                int *part = (int *) sh.wbuf;
+                part[threadIdx.x] = sum;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    int run = 0;
+#pragma unroll 1
+                    for (int q = 0; q < 256; q++) {
+                        const int c = part[q];
+                        part[q] = run;
+                        run += c;
+                    }
+                    sh.cnt[0][0][0] = run;
+                }
+                __syncthreads();
+                int off = part[threadIdx.x];
+#pragma unroll 1
+                for (int k = b0; k < b1; k++) {
+                    const int c = cntBuf[k];
+                    cntBuf[k] = off;
+                    off += c;
+                }
+                __syncthreads();
+            }
+        }
+        out.nPairs += sh.cnt[0][0][0];
+    }
 }
 
 } // namespace
@@ -752,7 +813,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
     const long long *__restrict__ anchors, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
     long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
-    long long *totXay, double *totVal) {
+    long long *totXay, double *totVal, char *scratch, long long scratchBytes) {
     __shared__ Shared sh;
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
@@ -772,7 +833,10 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
     out.nTot = state->nTot;
     backward_window(it, P, anchors, track + trackBase[idx] * CP_ROW,
                     models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD,
-                    state, out, sh);
+                    state, out, sh, (int *) (scratch + idx * scratchBytes),
+                    (WinTotal *) (scratch + idx * scratchBytes + (long long) ringD * sizeof(int)),
+                    (double *) (scratch + idx * scratchBytes + (long long) ringD * sizeof(int)
+                                + ((long long) ringD / 10 + 8) * sizeof(WinTotal)));
     if (threadIdx.x == 0) {
         state->nPairs = out.nPairs;
         state->nTot = out.nTot;
@@ -852,6 +916,11 @@ extern "C" int cpecan_systolic_rows(void) { return SY_R; }
 extern "C" int cpecan_systolic_ring_row_doubles(void) { return SY_R * SY_RING_VALUES * 64; }
 
 extern "C" int cpecan_systolic_state_bytes(void) { return (int) sizeof(SyState); }
+/* HBM scratch per alignment: one hit count per ring diagonal, and per refresh of the window one
+ * WinTotal and the two rows of per-cell terms */
+extern "C" long long cpecan_systolic_scratch_bytes(int ringD) {
+    return (long long) ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * SY_P * sizeof(double));
+}
 
 /* One pass over a batch: track of emission constants, then `windows` rounds of
  * {forward to the next traceback point, backward + decode of that window} for every alignment. */
@@ -862,7 +931,8 @@ extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, 
                                       long long ringDoubles, int ringD, void *states, int windows,
                                       long long *pairs, double *pairLogp, long long *nPairs,
                                       long long *totXay, double *totVal, long long *nTot,
-                                      long long *nCells, int maxLX) {
+                                      long long *nCells, int maxLX, char *scratch,
+                                      long long scratchBytes) {
     int bx = (int) ((((long long) maxLX + 1) * CP_ROW + 255) / 256);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(cpecan_k_track, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items,
@@ -874,7 +944,7 @@ extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, 
                            ringD, (SyState *) states);
         hipLaunchKernelGGL(cpecan_k_sy_backward, dim3((unsigned) nItems), dim3(256), 0, stream, items,
                            nItems, P, anchors, track, trackBase, models, Fring, ringDoubles, ringD,
-                           (SyState *) states, pairs, pairLogp, totXay, totVal);
+                           (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes);
     }
     hipLaunchKernelGGL(cpecan_k_sy_counts, dim3((unsigned) ((nItems + 255) / 256)), dim3(256), 0, stream,
                        (const SyState *) states, nItems, nPairs, nTot, nCells);
