@@ -70,6 +70,22 @@ __device__ __forceinline__ double bcast(double v, int srcLane) { /* srcLane wave
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    const int hi = __builtin_amdgcn_readfirstlane((int) (v >> 32));
+    return ((long long) hi << 32) | lo;
+}
+/* the work item as wave-uniform (scalar) values: everything derived from it -- band geometry, loop
+ * bounds, base addresses -- then stays on the scalar unit instead of occupying vector lanes */
+__device__ __forceinline__ DevItem uniform_item(const DevItem &s) {
+    DevItem d;
+    d.lX = uni64(s.lX); d.lY = uni64(s.lY); d.xOff = uni64(s.xOff); d.yOff = uni64(s.yOff);
+    d.anchorOff = uni64(s.anchorOff); d.nAnchors = uni64(s.nAnchors); d.diagBase = 0; d.cellBase = 0;
+    d.nCells = 0; d.pairBase = uni64(s.pairBase); d.pairCap = uni64(s.pairCap);
+    d.totBase = uni64(s.totBase); d.totCap = uni64(s.totCap); d.bwsBase = 0;
+    d.model = uni(s.model); d.raggedL = uni(s.raggedL); d.raggedR = uni(s.raggedR); d.maxWidth = 0;
+    return d;
+}
 
 /* Workgroup barrier that orders LDS traffic only.  __syncthreads() would also drain every global
  * store of the forward ring (s_waitcnt vmcnt(0)) on each anti-diagonal; nothing the waves exchange
@@ -84,10 +100,14 @@ __device__ __forceinline__ void lds_barrier() {
  * float-literal coefficients come from a 128-byte LDS table indexed by the piece (<=1, <=2.5,
  * <=4.5, else): two ds_read_b128 instead of a 24-select chain. */
 __device__ __forceinline__ double ladd(double x, double y, const double *coef) {
-    const double hi = __builtin_fmax(x, y), lo = __builtin_fmin(x, y);
+    double hi, lo;
+    /* plain v_max/v_min: operands are never NaN, so the canonicalising pre-ops fmax()/fmin() emit
+     * are dead weight in a loop that is bound by instruction issue */
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
     const double d = hi - lo;
-    const int idx = (d > 1.00f ? 4 : 0) + (d > 2.50f ? 4 : 0) + (d > 4.50f ? 4 : 0);
-    const double *c = coef + idx;
+    const int idx = (int) (d > 1.00f) + (int) (d > 2.50f) + (int) (d > 4.50f);
+    const double *c = coef + idx * 4;
     const double r = ((c[0] * d + c[1]) * d + c[2]) * d + c[3] + lo;
     return d < 7.5 ? r : hi;
 }
@@ -217,12 +237,20 @@ __device__ __forceinline__ void load_params(double (&dst)[SY_NPRM], const double
 __device__ __forceinline__ double stage_row(const double *__restrict__ track, int x, int lane) {
     return track[(long long) x * CP_ROW + (lane < CP_ROW ? lane : 0)];
 }
-__device__ __forceinline__ void install_row(double (&prm)[SY_NPRM], double staged, bool mine) {
+/* lane `dst` (wave-uniform) of prm[] takes constant j from lane j of the staged row: 34 readlanes
+ * into scalar registers, then 34 moves under a one-lane exec mask */
+__device__ __forceinline__ void install_row(double (&prm)[SY_NPRM], double staged, int dst) {
+    double v[SY_NPRM];
 #pragma unroll
-    for (int j = 0; j < SY_NPRM; j++) {
-        const double v = bcast(staged, j);
-        prm[j] = mine ? v : prm[j];
+    for (int j = 0; j < SY_NPRM; j++) v[j] = bcast(staged, j);
+    if ((int) (threadIdx.x & 63) == dst) {
+#pragma unroll
+        for (int j = 0; j < SY_NPRM; j++) prm[j] = v[j];
     }
+}
+__device__ __forceinline__ double set_lane(double v, int dst, double x) { /* x, dst wave-uniform */
+    if ((int) (threadIdx.x & 63) == dst) v = x;
+    return v;
 }
 
 /* aligned pairs found on a diagonal, written one barrier later when every wave's count is known */
@@ -310,11 +338,11 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
 
-    const int d0 = state->d;
-    int tracedBackTo = state->tracedBackTo;
-    long long cells = state->cells;
+    const int d0 = uni(state->d);
+    int tracedBackTo = uni(state->tracedBackTo);
+    long long cells = uni64(state->cells);
     Band band;
-    make_band(band, it, P, anchors, state->bandAi);
+    make_band(band, it, P, anchors, uni(state->bandAi));
 
     /* ---- per-slot state (this lane's k-mer) ---- */
     int xs;
@@ -336,7 +364,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
         Fm = Fx = Fy = Lm = Lx = Ly = CP_NEG_INF;
         em = en = 0.0;
         st = stage_row(track, 0, lane);
-        install_row(prm, st, wave == 0 && lane == 0);
+        if (wave == 0) install_row(prm, st, 0);
         if (wave == 0 && lane == 0) {
             Fm = it.raggedL ? CP_NEG_INF : 0.0;
             Fx = it.raggedL ? 0.0 : CP_NEG_INF;
@@ -397,14 +425,15 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
         if (xs < xmin) xs += SY_P;
         const bool valid = xs <= xmax;
         while (xin <= xmax) { /* the entering k-mer's constants (at most one k-mer per step) */
-            if (((xin >> 6) & (SY_R - 1)) == wave) install_row(prm, st, lane == (xin & 63));
+            if (((xin >> 6) & (SY_R - 1)) == wave) install_row(prm, st, xin & 63);
             xin++;
             if (((xin >> 6) & (SY_R - 1)) == wave) st = stage_row(track, xin <= lX ? xin : lX, lane);
         }
         if (xmin == xminP && ((xmin >> 6) & (SY_R - 1)) == wave) { /* the top cell's event is new */
             double nm, nn;
             fwdEv.get_up(d - xmin - 1, nm, nn, lane);
-            if (lane == (xmin & 63)) { em = nm; en = nn; }
+            em = set_lane(em, xmin & 63, nm);
+            en = set_lane(en, xmin & 63, nn);
         }
         double nmv = CP_NEG_INF, nxv = CP_NEG_INF, nyv = CP_NEG_INF;
         if (row_active(wave, xmin, xmax)) {
@@ -500,9 +529,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
 
-    const int dTop = state->winTop, tracedBackFrom = state->winFrom, tracedBackTo = state->winTo;
-    const bool atEnd = state->winAtEnd != 0;
-    const int bandAiTop = state->bandAi;
+    const int dTop = uni(state->winTop), tracedBackFrom = uni(state->winFrom), tracedBackTo = uni(state->winTo);
+    const bool atEnd = uni(state->winAtEnd) != 0;
+    const int bandAiTop = uni(state->bandAi);
     Band band;
     make_band(band, it, P, anchors, bandAiTop);
 
@@ -576,7 +605,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                         pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
                     }
                     const double v = bcast(pxChunk, xinB - pxBase);
-                    if (((xinB >> 6) & (SY_R - 1)) == wave && lane == (xinB & 63)) pxReg = v;
+                    if (((xinB >> 6) & (SY_R - 1)) == wave) pxReg = set_lane(pxReg, xinB & 63, v);
                     xinB--;
                 }
                 BmPrev = Bm;
@@ -704,6 +733,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
 
     /* ------------------------------ phase D: the aligned pairs ------------------------------ */
     if (P.mode == 0 && nPost > 0) {
+        int *const cnt = cntBuf, *const off = cntBuf + ringD;
         for (int pass = 0; pass < 2; pass++) {
             make_band(band, it, P, anchors, bandAiTop);
 #pragma unroll 1
@@ -711,27 +741,29 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                 const int t = tPost0 - k;
                 int xmin, xmax;
                 band.range(t, xmin, xmax);
+                long long base = 0;
+                if (pass) {
+                    if (uni(cnt[k]) == 0) continue;
+                    base = out.nPairs + uni(off[k]);
+                }
                 const double total = wtot[k / 10].total;
-                const int r0 = (xmin >> 6) & (SY_R - 1), l0 = xmin & 63;
+                const int xlo = xmin > 1 ? xmin : 1, xhi = xmax < t - 1 ? xmax : t - 1;
+                /* F.match + B.match of this diagonal, parked by the sweep in ring slot 3; rows are
+                 * walked in ascending k-mer order, which is the reference's x-y order */
+                const double *row = ring + (long long) (t & g.ringMask) * (SY_R * SY_RING_VALUES * 64)
+                                    + 3 * 64 + lane;
                 int n = 0;
-                const long long base = pass ? out.nPairs + cntBuf[k] : 0;
 #pragma unroll 1
-                for (int j = 0; j <= SY_R; j++) {
-                    const int r = (r0 + j) & (SY_R - 1);
-                    if (!row_active(r, xmin, xmax)) continue;
-                    const bool inSeg = j == 0 ? lane >= l0 : (j == SY_R ? lane < l0 : true);
-                    if (j == SY_R && l0 == 0) continue;
-                    int x = r * 64 + lane;
-                    x += ((xmin - x + SY_P - 1) / SY_P) * SY_P;
-                    const int y = t - x;
+                for (int ra = xmin >> 6; ra <= (xmax >> 6); ra++) {
+                    const int x = ra * 64 + lane;
+                    const double e = row[(ra & (SY_R - 1)) * (SY_RING_VALUES * 64)] - total;
+                    const bool ok = x >= xlo && x <= xhi && e >= P.logThrSlack;
+                    if (__ballot(ok) == 0ull) continue;
+                    double p = 0.0;
                     bool hit = false;
-                    double e = 0.0, p = 0.0;
-                    if (inSeg && x <= xmax && x > 0 && y > 0) {
-                        e = ring_at(ring, g.ringMask, t, 3, x) - total;
-                        if (e >= P.logThrSlack) {
-                            p = exp(e);
-                            hit = p >= P.threshold;
-                        }
+                    if (ok) {
+                        p = exp(e);
+                        hit = p >= P.threshold;
                     }
                     const unsigned long long m = __ballot(hit);
                     if (pass && hit) {
@@ -741,13 +773,13 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                             long long *o = out.pairs + idx * 3;
                             o[0] = (long long) floor(p * 10000000.0);
                             o[1] = x - 1;
-                            o[2] = y - 1;
+                            o[2] = t - x - 1;
                             out.logp[idx] = e;
                         }
                     }
                     n += __popcll(m);
                 }
-                if (!pass && lane == 0) cntBuf[k] = n;
+                if (!pass && lane == 0) cnt[k] = n;
             }
             __syncthreads();
             if (!pass) {
@@ -756,7 +788,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                 const int b0 = threadIdx.x * per, b1 = min(b0 + per, nPost);
                 int sum = 0;
 #pragma unroll 1
-                for (int k = b0; k < b1; k++) sum += cntBuf[k];
+                for (int k = b0; k < b1; k++) sum += cnt[k];
                 int *part = (int *) sh.wbuf;
                 part[threadIdx.x] = sum;
                 __syncthreads();
@@ -771,12 +803,11 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                     sh.cnt[0][0][0] = run;
                 }
                 __syncthreads();
-                int off = part[threadIdx.x];
+                int o = part[threadIdx.x];
 #pragma unroll 1
                 for (int k = b0; k < b1; k++) {
-                    const int c = cntBuf[k];
-                    cntBuf[k] = off;
-                    off += c;
+                    off[k] = o;
+                    o += cnt[k];
                 }
                 __syncthreads();
             }
@@ -798,7 +829,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
     SyState *state = states + idx;
-    const DevItem it = items[idx];
+    const DevItem it = uniform_item(items[idx]);
     if (state->finished || it.lX + it.lY == 0) return;
     init_coef(sh.coef);
     __syncthreads();
@@ -819,7 +850,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
     if (idx >= nItems) return;
     SyState *state = states + idx;
     if (!state->winValid) return;
-    const DevItem it = items[idx];
+    const DevItem it = uniform_item(items[idx]);
     init_coef(sh.coef);
     __syncthreads();
     ItemOut out;
@@ -829,13 +860,13 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
     out.totXay = totXay + it.totBase;
     out.totVal = totVal + it.totBase;
     out.totCap = it.totCap;
-    out.nPairs = state->nPairs;
-    out.nTot = state->nTot;
+    out.nPairs = uni64(state->nPairs);
+    out.nTot = uni64(state->nTot);
     backward_window(it, P, anchors, track + trackBase[idx] * CP_ROW,
                     models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD,
                     state, out, sh, (int *) (scratch + idx * scratchBytes),
-                    (WinTotal *) (scratch + idx * scratchBytes + (long long) ringD * sizeof(int)),
-                    (double *) (scratch + idx * scratchBytes + (long long) ringD * sizeof(int)
+                    (WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int)),
+                    (double *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int)
                                 + ((long long) ringD / 10 + 8) * sizeof(WinTotal)));
     if (threadIdx.x == 0) {
         state->nPairs = out.nPairs;
@@ -916,10 +947,10 @@ extern "C" int cpecan_systolic_rows(void) { return SY_R; }
 extern "C" int cpecan_systolic_ring_row_doubles(void) { return SY_R * SY_RING_VALUES * 64; }
 
 extern "C" int cpecan_systolic_state_bytes(void) { return (int) sizeof(SyState); }
-/* HBM scratch per alignment: one hit count per ring diagonal, and per refresh of the window one
+/* HBM scratch per alignment: a hit count and an output offset per ring diagonal, and per refresh of the window one
  * WinTotal and the two rows of per-cell terms */
 extern "C" long long cpecan_systolic_scratch_bytes(int ringD) {
-    return (long long) ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * SY_P * sizeof(double));
+    return 2ll * ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * SY_P * sizeof(double));
 }
 
 /* One pass over a batch: track of emission constants, then `windows` rounds of
