@@ -90,12 +90,14 @@ def main():
         b.run()
         b.sync()
     sync_all()
-    kernel_ms = []
+    kernel_ms, stage = [], []
     t_start = time.perf_counter()
     for _ in range(args.steps):
         b.run()
         b.sync()
         kernel_ms.append(b.elapsed_ms()[1])
+        if b.info()["kernel"] == "systolic":
+            stage.append(b.stage_ms())
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -124,10 +126,40 @@ def main():
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     bytes_per_cell = 48.0
     achieved = cells * bytes_per_cell / avg_kernel_s / 1e9
+    # HBM traffic of one pass from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
+    # rocprofv3 --pmc passes of this same command; summary committed under profiles/)
+    traffic, traffic_note = None, None
+    prof = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_summary.json")
+    if os.path.exists(prof) and args.reads == 1024 and args.events == 10000 and args.kmers == 5000:
+        pm = json.load(open(prof))
+        rd = sum(v["sum_KiB"] for v in pm["FETCH_SIZE"].values()) * 1024
+        wr = sum(v["sum_KiB"] for v in pm["WRITE_SIZE"].values()) * 1024
+        traffic = rd + wr
+        traffic_note = ("bytes per pass over the batch, FETCH_SIZE %.1f GB (8-byte-per-lane loads: not "
+                        "doubled, the guide's x2 is calibrated for 16-byte loads only) + WRITE_SIZE %.1f GB"
+                        % (rd / 1e9, wr / 1e9))
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None,
+                "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_note": traffic_note,
+                "scope": "whole pass (all kernels of the path), 48 B per cell",
                 "kernel_ms": round(1e3 * avg_kernel_s, 3), "bytes_per_cell": bytes_per_cell,
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 5)}
+    if stage:
+        f_ms = float(np.mean([x[0] for x in stage]))
+        k_ms = float(np.mean([x[1] for x in stage]))
+        n_l = stage[0][2]
+        # dominant kernel: the backward-window kernel re-reads the 3 forward states of every cell
+        # once (24 B per cell); the forward-window kernel writes them once (24 B per cell)
+        roofline["dominant_kernel"] = {
+            "name": "cpecan_k_sy_backward", "launches_per_pass": n_l,
+            "avg_launch_ms": round(k_ms / n_l, 4),
+            "algorithmic_bytes_per_launch": round(cells * 24.0 / n_l),
+            "achieved": round(cells * 24.0 / (k_ms / 1e3) / 1e9, 2),
+            "frac": round(cells * 24.0 / (k_ms / 1e3) / 1e9 / 8000.0, 5)}
+        roofline["forward_kernel"] = {
+            "name": "cpecan_k_sy_forward", "launches_per_pass": n_l,
+            "avg_launch_ms": round(f_ms / n_l, 4),
+            "achieved": round(cells * 24.0 / (f_ms / 1e3) / 1e9, 2),
+            "frac": round(cells * 24.0 / (f_ms / 1e3) / 1e9 / 8000.0, 5)}
 
     # ---- parity spot check + CPU baseline (oracle = checker / baseline only) -------------------
     check = {"reads": 0}

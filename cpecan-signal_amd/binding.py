@@ -34,7 +34,7 @@ EXPORTS = [
     "cpecan_hip_batch_elapsed_ms", "cpecan_hip_batch_counts", "cpecan_hip_batch_fetch_pairs",
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
-    "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info",
+    "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
             getattr(L, "cpecan_hip_batch_" + name).argtypes = [C.c_void_p]
         L.cpecan_hip_batch_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.cpecan_hip_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.cpecan_hip_batch_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.cpecan_hip_batch_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cpecan_hip_batch_fetch_pairs.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
         L.cpecan_hip_batch_fetch_totals.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
@@ -226,6 +227,11 @@ class Batch:
         a, k = C.c_float(), C.c_float()
         _check(lib().cpecan_hip_batch_elapsed_ms(self.h, C.byref(a), C.byref(k)))
         return a.value, k.value
+
+    def stage_ms(self):
+        f, k, n = C.c_float(), C.c_float(), C.c_int32()
+        _check(lib().cpecan_hip_batch_stage_ms(self.h, C.byref(f), C.byref(k), C.byref(n)))
+        return f.value, k.value, n.value
 
     def info(self):
         k, w, m = C.c_int32(), C.c_int32(), C.c_int32()

@@ -35,15 +35,24 @@ extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned
                                        unsigned long long *bad);
 extern "C" int cpecan_systolic_state_bytes(void);
 extern "C" long long cpecan_systolic_scratch_bytes(int ringD);
-extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, long long nItems,
-                                      DevParams P, const long long *anchors, const double *track,
-                                      const long long *trackBase, const unsigned short *kidx,
-                                      const double *events, const double *models, double *Fring,
-                                      long long ringDoubles, int ringD, void *states, int windows,
-                                      long long *pairs, double *pairLogp, long long *nPairs,
-                                      long long *totXay, double *totVal, long long *nTot,
-                                      long long *nCells, int maxLX, char *scratch,
-                                      long long scratchBytes);
+extern "C" int cpecan_systolic_launch_track(hipStream_t stream, const DevItem *items, long long nItems,
+                                            const double *track, const long long *trackBase,
+                                            const unsigned short *kidx, const double *models,
+                                            void *states, int maxLX);
+extern "C" int cpecan_systolic_launch_forward(hipStream_t stream, const DevItem *items, long long nItems,
+                                              DevParams P, const long long *anchors, const double *track,
+                                              const long long *trackBase, const double *events,
+                                              const double *models, double *Fring,
+                                              long long ringDoubles, int ringD, void *states);
+extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem *items, long long nItems,
+                                               DevParams P, const long long *anchors, const double *track,
+                                               const long long *trackBase, const double *models,
+                                               double *Fring, long long ringDoubles, int ringD,
+                                               void *states, long long *pairs, double *pairLogp,
+                                               long long *totXay, double *totVal, char *scratch,
+                                               long long scratchBytes);
+extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
+                                             long long *nPairs, long long *nTot, long long *nCells);
 
 namespace {
 
@@ -124,6 +133,7 @@ struct cpecan_batch {
     int nWorkers = 0, maxWidth = 0;
     int nModels = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+    std::vector<hipEvent_t> evStage; /* systolic path: one event after every kernel of a pass */
     std::vector<long long> hNPairs, hNTot, hNCells;
     bool countsValid = false, ran = false;
 };
@@ -268,6 +278,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (b->ev0) (void) hipEventDestroy(b->ev0);
     if (b->ev1) (void) hipEventDestroy(b->ev1);
     if (b->ev2) (void) hipEventDestroy(b->ev2);
+    for (hipEvent_t e : b->evStage) (void) hipEventDestroy(e);
     delete b;
     return CPECAN_OK;
 }
@@ -514,19 +525,59 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            b->dbgB.p, b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
     } else {
-        /* the per-item track of emission constants is rebuilt every run: it is a function of the
-         * inputs (k-mers x model), so it belongs inside the timed region */
-        int rc = cpecan_systolic_launch(c->stream, b->items.p, b->nItems, b->P, b->anchors.p,
-                                        b->track.p, b->trackBase.p, b->kidx.p, b->events.p,
-                                        c->models.p, b->Fstore.p, b->ringDoubles, b->ringD,
-                                        b->syStates.p, b->nWindows, b->pairs.p, b->pairLogp.p,
-                                        b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
-                                        b->nCells.p, b->maxLX, b->syScratch.p, b->scratchBytes);
+        /* one pass: the per-item track of emission constants (a function of the inputs, rebuilt
+         * every run inside the timed region), then for every traceback window the forward kernel
+         * followed by the backward kernel; an event after each kernel gives per-kernel times */
+        if (b->evStage.size() != (size_t) (2 * b->nWindows + 1)) {
+            for (hipEvent_t e : b->evStage) (void) hipEventDestroy(e);
+            b->evStage.assign((size_t) (2 * b->nWindows + 1), nullptr);
+            for (auto &e : b->evStage) HIP_TRY(hipEventCreate(&e));
+        }
+        int rc = cpecan_systolic_launch_track(c->stream, b->items.p, b->nItems, b->track.p,
+                                              b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
+                                              b->maxLX);
+        HIP_TRY(hipEventRecord(b->evStage[0], c->stream));
+        for (int w = 0; w < b->nWindows && rc == 0; w++) {
+            rc = cpecan_systolic_launch_forward(c->stream, b->items.p, b->nItems, b->P, b->anchors.p,
+                                                b->track.p, b->trackBase.p, b->events.p, c->models.p,
+                                                b->Fstore.p, b->ringDoubles, b->ringD, b->syStates.p);
+            HIP_TRY(hipEventRecord(b->evStage[(size_t) (2 * w + 1)], c->stream));
+            if (rc == 0)
+                rc = cpecan_systolic_launch_backward(c->stream, b->items.p, b->nItems, b->P,
+                                                     b->anchors.p, b->track.p, b->trackBase.p,
+                                                     c->models.p, b->Fstore.p, b->ringDoubles, b->ringD,
+                                                     b->syStates.p, b->pairs.p, b->pairLogp.p,
+                                                     b->totXay.p, b->totVal.p, b->syScratch.p,
+                                                     b->scratchBytes);
+            HIP_TRY(hipEventRecord(b->evStage[(size_t) (2 * w + 2)], c->stream));
+        }
+        if (rc == 0)
+            rc = cpecan_systolic_launch_counts(c->stream, b->syStates.p, b->nItems, b->nPairs.p,
+                                               b->nTot.p, b->nCells.p);
         if (rc != 0) return fail(CPECAN_EHIP, "systolic kernel launch failed: %s",
                                  hipGetErrorString(hipGetLastError()));
     }
     HIP_TRY(hipEventRecord(b->ev2, c->stream));
     b->ran = true;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_stage_ms(cpecan_batch *b, float *msForward, float *msBackward, int32_t *launchesEach) {
+    if (!b || !b->ran) return fail(CPECAN_EINVAL, "batch has not run");
+    if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "only the systolic path has stages");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    HIP_TRY(hipEventSynchronize(b->ev2));
+    float f = 0, k = 0;
+    for (int w = 0; w < b->nWindows; w++) {
+        float a = 0, c2 = 0;
+        HIP_TRY(hipEventElapsedTime(&a, b->evStage[(size_t) (2 * w)], b->evStage[(size_t) (2 * w + 1)]));
+        HIP_TRY(hipEventElapsedTime(&c2, b->evStage[(size_t) (2 * w + 1)], b->evStage[(size_t) (2 * w + 2)]));
+        f += a;
+        k += c2;
+    }
+    if (msForward) *msForward = f;
+    if (msBackward) *msBackward = k;
+    if (launchesEach) *launchesEach = b->nWindows;
     return CPECAN_OK;
 }
 

@@ -953,30 +953,43 @@ extern "C" long long cpecan_systolic_scratch_bytes(int ringD) {
     return 2ll * ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * SY_P * sizeof(double));
 }
 
-/* One pass over a batch: track of emission constants, then `windows` rounds of
- * {forward to the next traceback point, backward + decode of that window} for every alignment. */
-extern "C" int cpecan_systolic_launch(hipStream_t stream, const DevItem *items, long long nItems,
-                                      DevParams P, const long long *anchors, const double *track,
-                                      const long long *trackBase, const unsigned short *kidx,
-                                      const double *events, const double *models, double *Fring,
-                                      long long ringDoubles, int ringD, void *states, int windows,
-                                      long long *pairs, double *pairLogp, long long *nPairs,
-                                      long long *totXay, double *totVal, long long *nTot,
-                                      long long *nCells, int maxLX, char *scratch,
-                                      long long scratchBytes) {
+/* Launchers of the four stages of one pass over a batch (the C-ABI layer sequences them:
+ * track, then per window {forward, backward}, then counts). */
+extern "C" int cpecan_systolic_launch_track(hipStream_t stream, const DevItem *items, long long nItems,
+                                            const double *track, const long long *trackBase,
+                                            const unsigned short *kidx, const double *models,
+                                            void *states, int maxLX) {
     int bx = (int) ((((long long) maxLX + 1) * CP_ROW + 255) / 256);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(cpecan_k_track, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items,
                        nItems, trackBase, kidx, models, (double *) track);
     if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(SyState), stream) != hipSuccess) return -1;
-    for (int w = 0; w < windows; w++) {
-        hipLaunchKernelGGL(cpecan_k_sy_forward, dim3((unsigned) nItems), dim3(256), 0, stream, items,
-                           nItems, P, anchors, track, trackBase, events, models, Fring, ringDoubles,
-                           ringD, (SyState *) states);
-        hipLaunchKernelGGL(cpecan_k_sy_backward, dim3((unsigned) nItems), dim3(256), 0, stream, items,
-                           nItems, P, anchors, track, trackBase, models, Fring, ringDoubles, ringD,
-                           (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes);
-    }
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int cpecan_systolic_launch_forward(hipStream_t stream, const DevItem *items, long long nItems,
+                                              DevParams P, const long long *anchors, const double *track,
+                                              const long long *trackBase, const double *events,
+                                              const double *models, double *Fring,
+                                              long long ringDoubles, int ringD, void *states) {
+    hipLaunchKernelGGL(cpecan_k_sy_forward, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems,
+                       P, anchors, track, trackBase, events, models, Fring, ringDoubles, ringD,
+                       (SyState *) states);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem *items, long long nItems,
+                                               DevParams P, const long long *anchors, const double *track,
+                                               const long long *trackBase, const double *models,
+                                               double *Fring, long long ringDoubles, int ringD,
+                                               void *states, long long *pairs, double *pairLogp,
+                                               long long *totXay, double *totVal, char *scratch,
+                                               long long scratchBytes) {
+    hipLaunchKernelGGL(cpecan_k_sy_backward, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems,
+                       P, anchors, track, trackBase, models, Fring, ringDoubles, ringD,
+                       (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
+                                             long long *nPairs, long long *nTot, long long *nCells) {
     hipLaunchKernelGGL(cpecan_k_sy_counts, dim3((unsigned) ((nItems + 255) / 256)), dim3(256), 0, stream,
                        (const SyState *) states, nItems, nPairs, nTot, nCells);
     return hipGetLastError() == hipSuccess ? 0 : -1;

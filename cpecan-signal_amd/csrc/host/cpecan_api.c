@@ -1,0 +1,498 @@
+/*
+ * cpecan_api.c -- host C code behind include/cpecan_api.h: the reference-shaped entry points of the
+ * banded pair-HMM posterior path, implemented on top of the C-ABI of cpecan_hip.h.
+ *
+ * What runs here is control plane only: argument checking, the reference's split of an alignment at
+ * large anchor-free gaps (getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps,
+ * impl/pairwiseAligner.c:1356-1422), packing of reads into one GPU batch, and the reference's
+ * result-list conventions (coordinate shift + tail-first append, :1342-1354,:1447-1454).  No DP
+ * cell is computed on the host; a missing GPU or a C-ABI error aborts with a message, which is the
+ * reference's own error convention (st_errAbort).
+ */
+#include "cpecan_api.h"
+
+#include "cpecan_hip.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void die(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+    exit(1);
+}
+#define CHECK(call)                                                                              \
+    do {                                                                                         \
+        int rc_ = (call);                                                                        \
+        if (rc_ != CPECAN_OK) die("cpecan: %s failed (%d): %s", #call, rc_, cpecan_hip_last_error()); \
+    } while (0)
+
+/* ------------------------------------------------------------------------------------------------ */
+/* minimal stList / stIntTuple                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+#ifndef CPECAN_WITH_SONLIB
+struct _stList {
+    void **items;
+    int64_t n, cap;
+    void (*destruct)(void *);
+};
+struct _stIntTuple {
+    int64_t n;
+    int64_t v[4];
+};
+stList *stList_construct3(int64_t size, void (*destructElement)(void *)) {
+    stList *l = calloc(1, sizeof(stList));
+    l->cap = size > 8 ? size : 8;
+    l->items = calloc((size_t) l->cap, sizeof(void *));
+    l->n = size;
+    l->destruct = destructElement;
+    return l;
+}
+stList *stList_construct(void) { return stList_construct3(0, NULL); }
+void stList_destruct(stList *l) {
+    if (!l) return;
+    if (l->destruct)
+        for (int64_t i = 0; i < l->n; i++)
+            if (l->items[i]) l->destruct(l->items[i]);
+    free(l->items);
+    free(l);
+}
+int64_t stList_length(stList *l) { return l ? l->n : 0; }
+void *stList_get(stList *l, int64_t i) { return l->items[i]; }
+void stList_append(stList *l, void *item) {
+    if (l->n == l->cap) {
+        l->cap *= 2;
+        l->items = realloc(l->items, (size_t) l->cap * sizeof(void *));
+    }
+    l->items[l->n++] = item;
+}
+stIntTuple *stIntTuple_construct2(int64_t a, int64_t b) {
+    stIntTuple *t = malloc(sizeof(stIntTuple));
+    t->n = 2; t->v[0] = a; t->v[1] = b;
+    return t;
+}
+stIntTuple *stIntTuple_construct3(int64_t a, int64_t b, int64_t c) {
+    stIntTuple *t = malloc(sizeof(stIntTuple));
+    t->n = 3; t->v[0] = a; t->v[1] = b; t->v[2] = c;
+    return t;
+}
+static stIntTuple *tuple4(int64_t a, int64_t b, int64_t c, int64_t d) {
+    stIntTuple *t = malloc(sizeof(stIntTuple));
+    t->n = 4; t->v[0] = a; t->v[1] = b; t->v[2] = c; t->v[3] = d;
+    return t;
+}
+int64_t stIntTuple_get(stIntTuple *t, int64_t i) { return t->v[i]; }
+int64_t stIntTuple_length(stIntTuple *t) { return t->n; }
+void stIntTuple_destruct(stIntTuple *t) { free(t); }
+#endif
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Sequence, parameters                                                                             */
+/* ------------------------------------------------------------------------------------------------ */
+static double NULLEVENT_[] = { -INFINITY, 0 };
+
+Sequence *sequence_construct(int64_t length, void *elements, void *(*getFcn)(void *, int64_t)) {
+    return sequence_construct2(length, elements, getFcn, NULL);
+}
+Sequence *sequence_construct2(int64_t length, void *elements, void *(*getFcn)(void *, int64_t),
+                              Sequence *(*sliceFcn)(Sequence *, int64_t, int64_t)) {
+    Sequence *s = malloc(sizeof(Sequence));
+    s->length = length; s->elements = elements; s->get = getFcn; s->sliceFcn = sliceFcn;
+    return s;
+}
+Sequence *sequence_sliceNucleotideSequence2(Sequence *in, int64_t start, int64_t sliceLength) {
+    return sequence_construct2(sliceLength, (char *) in->elements + start, in->get, in->sliceFcn);
+}
+Sequence *sequence_sliceEventSequence2(Sequence *in, int64_t start, int64_t sliceLength) {
+    return sequence_construct2(sliceLength, (double *) in->elements + start * NB_EVENT_PARAMS, in->get,
+                               in->sliceFcn);
+}
+void sequence_sequenceDestroy(Sequence *seq) { free(seq); }
+void *sequence_getKmer(void *elements, int64_t index) {
+    static char n[KMER_LENGTH + 1] = "nnnnnn";
+    return index >= 0 ? (void *) &((char *) elements)[index] : (void *) n;
+}
+void *sequence_getEvent(void *elements, int64_t index) {
+    return index >= 0 ? (void *) &((double *) elements)[index * NB_EVENT_PARAMS] : (void *) NULLEVENT_;
+}
+int64_t sequence_correctSeqLength(int64_t length, SequenceType type) {
+    if (length <= 0) return 0;
+    return type == nucleotide ? length : length - (KMER_LENGTH - 1);
+}
+
+PairwiseAlignmentParameters *pairwiseAlignmentBandingParameters_construct(void) {
+    PairwiseAlignmentParameters *p = malloc(sizeof(PairwiseAlignmentParameters));
+    p->threshold = 0.01;
+    p->minDiagsBetweenTraceBack = 1000;
+    p->traceBackDiagonals = 40;
+    p->diagonalExpansion = 20;
+    p->constraintDiagonalTrim = 14;
+    p->anchorMatrixBiggerThanThis = 500 * 500;
+    p->repeatMaskMatrixBiggerThanThis = 500 * 500;
+    p->splitMatrixBiggerThanThis = (int64_t) 3000 * 3000;
+    p->alignAmbiguityCharacters = 0;
+    p->gapGamma = 0.5;
+    return p;
+}
+void pairwiseAlignmentBandingParameters_destruct(PairwiseAlignmentParameters *p) { free(p); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* StateMachine3 (strawMan)                                                                         */
+/* ------------------------------------------------------------------------------------------------ */
+void stateMachine3_setTransitionsToNanoporeDefaults(StateMachine *sM) {
+    StateMachine3 *s = (StateMachine3 *) sM;
+    s->TRANSITION_MATCH_CONTINUE = -0.23552123624314988;
+    s->TRANSITION_MATCH_FROM_GAP_X = -0.21880828092192281;
+    s->TRANSITION_MATCH_FROM_GAP_Y = -0.013406326748077823;
+    s->TRANSITION_GAP_OPEN_X = -1.6269694202638481;
+    s->TRANSITION_GAP_OPEN_Y = -4.3187242127300092;
+    s->TRANSITION_GAP_EXTEND_X = -1.6269694202638481;
+    s->TRANSITION_GAP_EXTEND_Y = -4.3187242127239411;
+    s->TRANSITION_GAP_SWITCH_TO_X = -INFINITY;
+    s->TRANSITION_GAP_SWITCH_TO_Y = -INFINITY;
+}
+
+static int read_doubles(FILE *f, double *dst, int64_t n) {
+    for (int64_t i = 0; i < n; i++)
+        if (fscanf(f, "%lf", &dst[i]) != 1) return 0;
+    return 1;
+}
+
+StateMachine *getStrawManStateMachine3(const char *modelFile) {
+    StateMachine3 *s = calloc(1, sizeof(StateMachine3));
+    s->model.type = threeState;
+    s->model.stateNumber = 3;
+    s->model.matchState = match;
+    s->model.parameterSetSize = NUM_OF_KMERS;
+    const int64_t tableLen = 1 + NUM_OF_KMERS * MODEL_PARAMS;
+    s->model.EMISSION_MATCH_PROBS = calloc((size_t) tableLen, sizeof(double));
+    s->model.EMISSION_GAP_Y_PROBS = calloc((size_t) tableLen, sizeof(double));
+    s->model.EMISSION_GAP_X_PROBS = calloc(NUM_OF_KMERS, sizeof(double));
+    stateMachine3_setTransitionsToNanoporeDefaults((StateMachine *) s);
+    for (int64_t i = 0; i < NUM_OF_KMERS; i++) s->model.EMISSION_GAP_X_PROBS[i] = -2.3025850929940455;
+    if (modelFile) {
+        /* 3 lines: match table, 30 skip bins (used by the vanilla/echelon models only), Y-gap table */
+        FILE *f = fopen(modelFile, "r");
+        double skip[30];
+        if (!f) die("cpecan: cannot open pore model %s", modelFile);
+        if (!read_doubles(f, s->model.EMISSION_MATCH_PROBS, tableLen) || !read_doubles(f, skip, 30) ||
+            !read_doubles(f, s->model.EMISSION_GAP_Y_PROBS, tableLen))
+            die("This stateMachine is not correct for signal model (%s)", modelFile);
+        fclose(f);
+    }
+    return (StateMachine *) s;
+}
+
+void emissions_signal_scaleModel(StateMachine *sM, double scale, double shift, double var,
+                                 double scale_sd, double var_sd) {
+    double *m = sM->EMISSION_MATCH_PROBS;
+    for (int64_t i = 1; i < (sM->parameterSetSize * MODEL_PARAMS) + 1; i += MODEL_PARAMS) {
+        m[i] = m[i] * scale + shift;
+        m[i + 1] = m[i + 1] * var;
+        m[i + 2] = m[i + 2] * scale_sd;
+        m[i + 4] = m[i + 4] * var_sd;
+        m[i + 3] = sqrt(pow(m[i + 2], 3.0) / m[i + 4]);
+    }
+}
+
+int64_t emissions_discrete_getKmerIndex(void *kmer) {
+    const char *k = kmer;
+    int64_t x = 0, l = NUM_OF_KMERS / 4;
+    for (int i = 0; i < KMER_LENGTH; i++) {
+        int64_t b = k[i] == 'A' ? 0 : k[i] == 'C' ? 1 : k[i] == 'G' ? 2 : k[i] == 'T' ? 3 : NUM_OF_KMERS + 1;
+        x += (i < KMER_LENGTH - 1 ? l : 1) * b;
+        l /= 4;
+    }
+    return x;
+}
+
+void stateMachine_destruct(StateMachine *sM) {
+    if (!sM) return;
+    free(sM->EMISSION_MATCH_PROBS);
+    free(sM->EMISSION_GAP_X_PROBS);
+    free(sM->EMISSION_GAP_Y_PROBS);
+    free(sM);
+}
+
+void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *f, DpMatrix *b,
+                                            Sequence *sX, Sequence *sY, double total,
+                                            PairwiseAlignmentParameters *p, void *extraArgs) {
+    (void) sM; (void) xay; (void) f; (void) b; (void) sX; (void) sY; (void) total; (void) p; (void) extraArgs;
+    die("cpecan: diagonalCalculationPosteriorMatchProbs is a marker for the GPU path, not a host function");
+}
+
+stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize,
+                       bool raggedL, bool raggedR) {
+    int64_t n = stList_length(anchorPairs);
+    int64_t *a = malloc(sizeof(int64_t) * 2 * (size_t) (n + 1));
+    for (int64_t i = 0; i < n; i++) {
+        a[2 * i] = stIntTuple_get(stList_get(anchorPairs, i), 0);
+        a[2 * i + 1] = stIntTuple_get(stList_get(anchorPairs, i), 1);
+    }
+    int64_t *out = malloc(sizeof(int64_t) * 4 * (size_t) (n + 2));
+    int64_t m = cpecan_split_points(a, n, lX, lY, maxMatrixSize, raggedL, raggedR, out, n + 2);
+    stList *l = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    for (int64_t i = 0; i < m; i++) stList_append(l, tuple4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]));
+    free(a);
+    free(out);
+    return l;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* the GPU context of this process                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static cpecan_ctx *g_ctx = NULL;
+
+static cpecan_ctx *context(void) {
+    if (!g_ctx) {
+        const char *dev = getenv("CPECAN_DEVICE");
+        CHECK(cpecan_hip_ctx_create(dev ? atoi(dev) : 0, &g_ctx));
+    }
+    return g_ctx;
+}
+
+static void check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY) {
+    if (sM->type != threeState || sM->stateNumber != 3)
+        die("cpecan: only the threeState (strawMan) signal StateMachine runs on the GPU path (type %d)", sM->type);
+    if (sX->get != sequence_getKmer || sY->get != sequence_getEvent)
+        die("cpecan: the GPU path needs sequence_getKmer / sequence_getEvent element getters");
+}
+
+typedef struct {
+    int64_t read, x1, y1;
+} ItemOrigin;
+
+/* Shared driver: n reads -> one batch.  mode 0: aligned pairs into lists[i]; mode 1: expectations
+ * added into hmm (all reads must then share sMs[0]). */
+static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **sYs, stList **anchorLists,
+                      PairwiseAlignmentParameters *p, bool raggedL, bool raggedR, int mode, int unbanded,
+                      stList **lists, ContinuousPairHmmExpectations *hmm) {
+    pthread_mutex_lock(&g_lock); /* one batch at a time per process; calls from several threads queue */
+    cpecan_ctx *ctx = context();
+    int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
+    for (int64_t i = 0; i < n; i++) {
+        check_known_combination(sMs[i], sXs[i], sYs[i]);
+        nX += sXs[i]->length + (sXs[i]->length > 0 ? KMER_LENGTH - 1 : 0);
+        nY += sYs[i]->length;
+        nA += anchorLists && anchorLists[i] ? stList_length(anchorLists[i]) : 0;
+    }
+    char *chars = malloc((size_t) nX + 8);
+    double *events = malloc(sizeof(double) * 3 * (size_t) (nY + 1));
+    int64_t *anchors = malloc(sizeof(int64_t) * 2 * (size_t) (nA + 1));
+    cpecan_item *items = NULL;
+    ItemOrigin *origin = NULL;
+    int64_t *firstItem = malloc(sizeof(int64_t) * (size_t) (n + 1));
+
+    /* models: one per distinct StateMachine pointer */
+    cpecan_sm3_model *models = malloc(sizeof(cpecan_sm3_model) * (size_t) n);
+    int32_t *modelOf = malloc(sizeof(int32_t) * (size_t) n);
+    int32_t nModels = 0;
+    for (int64_t i = 0; i < n; i++) {
+        StateMachine3 *s3 = (StateMachine3 *) sMs[i];
+        const double t[9] = { s3->TRANSITION_MATCH_CONTINUE, s3->TRANSITION_MATCH_FROM_GAP_X,
+                              s3->TRANSITION_MATCH_FROM_GAP_Y, s3->TRANSITION_GAP_OPEN_X,
+                              s3->TRANSITION_GAP_OPEN_Y, s3->TRANSITION_GAP_EXTEND_X,
+                              s3->TRANSITION_GAP_EXTEND_Y, s3->TRANSITION_GAP_SWITCH_TO_X,
+                              s3->TRANSITION_GAP_SWITCH_TO_Y };
+        int32_t found = -1;
+        for (int32_t k = 0; k < nModels && found < 0; k++)
+            if (models[k].match_probs == sMs[i]->EMISSION_MATCH_PROBS &&
+                models[k].gap_x_probs == sMs[i]->EMISSION_GAP_X_PROBS &&
+                models[k].gap_y_probs == sMs[i]->EMISSION_GAP_Y_PROBS &&
+                memcmp(models[k].transitions, t, sizeof t) == 0)
+                found = k;
+        if (found < 0) {
+            cpecan_sm3_model *m = &models[nModels];
+            memcpy(m->transitions, t, sizeof t);
+            m->match_probs = sMs[i]->EMISSION_MATCH_PROBS;
+            m->gap_x_probs = sMs[i]->EMISSION_GAP_X_PROBS;
+            m->gap_y_probs = sMs[i]->EMISSION_GAP_Y_PROBS;
+            found = nModels++;
+        }
+        modelOf[i] = found;
+    }
+    int32_t *ids = malloc(sizeof(int32_t) * (size_t) nModels);
+    CHECK(cpecan_hip_models_clear(ctx));
+    CHECK(cpecan_hip_models_create(ctx, models, nModels, 0, ids));
+
+    int64_t xo = 0, yo = 0, ao = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t lX = sXs[i]->length, lY = sYs[i]->length;
+        const int64_t na = anchorLists && anchorLists[i] ? stList_length(anchorLists[i]) : 0;
+        if (lX > 0) memcpy(chars + xo, sXs[i]->elements, (size_t) lX + KMER_LENGTH - 1);
+        if (lY > 0) memcpy(events + 3 * yo, sYs[i]->elements, sizeof(double) * 3 * (size_t) lY);
+        int64_t *ra = malloc(sizeof(int64_t) * 2 * (size_t) (na + 1));
+        for (int64_t k = 0; k < na; k++) {
+            ra[2 * k] = stIntTuple_get(stList_get(anchorLists[i], k), 0);
+            ra[2 * k + 1] = stIntTuple_get(stList_get(anchorLists[i], k), 1);
+        }
+        /* getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps :1356-1422 */
+        int64_t *sp = malloc(sizeof(int64_t) * 4 * (size_t) (na + 2));
+        int64_t nSp;
+        if (unbanded) {
+            nSp = 1; sp[0] = 0; sp[1] = 0; sp[2] = lX; sp[3] = lY;
+        } else {
+            nSp = cpecan_split_points(ra, na, lX, lY, p->splitMatrixBiggerThanThis, raggedL, raggedR, sp, na + 2);
+        }
+        firstItem[i] = nItems;
+        int64_t j = 0;
+        for (int64_t r = 0; r < nSp; r++) {
+            const int64_t x1 = sp[4 * r], y1 = sp[4 * r + 1], x2 = sp[4 * r + 2], y2 = sp[4 * r + 3];
+            if (nItems == capItems) {
+                capItems = capItems ? capItems * 2 : 64;
+                items = realloc(items, sizeof(cpecan_item) * (size_t) capItems);
+                origin = realloc(origin, sizeof(ItemOrigin) * (size_t) capItems);
+            }
+            cpecan_item *it = &items[nItems];
+            memset(it, 0, sizeof *it);
+            it->x_offset = xo + x1; it->lX = x2 - x1;
+            it->y_offset = yo + y1; it->lY = y2 - y1;
+            it->anchor_offset = ao;
+            while (j < na && ra[2 * j] + ra[2 * j + 1] < x2 + y2) {
+                anchors[2 * ao] = ra[2 * j] - x1;
+                anchors[2 * ao + 1] = ra[2 * j + 1] - y1;
+                ao++; j++;
+            }
+            it->n_anchors = ao - it->anchor_offset;
+            it->model_id = ids[modelOf[i]];
+            it->ragged_left = raggedL || r > 0;
+            it->ragged_right = raggedR || r < nSp - 1;
+            origin[nItems].read = i; origin[nItems].x1 = x1; origin[nItems].y1 = y1;
+            nItems++;
+        }
+        xo += lX + (lX > 0 ? KMER_LENGTH - 1 : 0);
+        yo += lY;
+        free(ra);
+        free(sp);
+    }
+    firstItem[n] = nItems;
+
+    if (nItems > 0) {
+        cpecan_band_params bp = { p->threshold, p->minDiagsBetweenTraceBack, p->traceBackDiagonals,
+                                  p->diagonalExpansion };
+        cpecan_batch *batch = NULL;
+        CHECK(cpecan_hip_batch_create(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
+                                      mode ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
+                                      CPECAN_KERNEL_AUTO, unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+        CHECK(cpecan_hip_batch_run(batch));
+        CHECK(cpecan_hip_batch_sync(batch));
+        if (mode == 0) {
+            int64_t *np = malloc(sizeof(int64_t) * (size_t) nItems);
+            CHECK(cpecan_hip_batch_counts(batch, np, NULL, NULL));
+            for (int64_t i = 0; i < n; i++) {
+                lists[i] = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+                for (int64_t k = firstItem[i]; k < firstItem[i + 1]; k++) {
+                    int64_t *tri = malloc(sizeof(int64_t) * 3 * (size_t) (np[k] + 1));
+                    CHECK(cpecan_hip_batch_fetch_pairs(batch, k, tri, NULL, np[k] + 1));
+                    if (unbanded) {
+                        /* getAlignedPairsWithoutBanding walks the diagonals upwards (:1560): groups of
+                         * equal x+y in reverse group order, order inside a group kept */
+                        int64_t e = np[k];
+                        while (e > 0) {
+                            int64_t s = e - 1;
+                            const int64_t d = tri[3 * s + 1] + tri[3 * s + 2];
+                            while (s > 0 && tri[3 * (s - 1) + 1] + tri[3 * (s - 1) + 2] == d) s--;
+                            for (int64_t q = s; q < e; q++)
+                                stList_append(lists[i], stIntTuple_construct3(tri[3 * q], tri[3 * q + 1], tri[3 * q + 2]));
+                            e = s;
+                        }
+                    } else {
+                        /* shift back to the read's coordinates, then tail first (stList_pop, :1451-1453) */
+                        for (int64_t q = np[k] - 1; q >= 0; q--)
+                            stList_append(lists[i], stIntTuple_construct3(tri[3 * q], tri[3 * q + 1] + origin[k].x1,
+                                                                          tri[3 * q + 2] + origin[k].y1));
+                    }
+                    free(tri);
+                }
+            }
+            free(np);
+        } else {
+            double *e = malloc(sizeof(double) * CPECAN_EXPECTATION_LEN);
+            for (int32_t k = 0; k < nModels; k++) {
+                CHECK(cpecan_hip_batch_fetch_expectations(batch, ids[k], e));
+                for (int q = 0; q < 9; q++) hmm->transitions[q] += e[q];
+                for (int q = 0; q < NUM_OF_KMERS; q++) hmm->individualKmerGapProbs[q] += e[9 + q];
+                hmm->likelihood += e[9 + NUM_OF_KMERS];
+            }
+            free(e);
+        }
+        CHECK(cpecan_hip_batch_destroy(batch));
+    } else if (mode == 0) {
+        for (int64_t i = 0; i < n; i++) lists[i] = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    }
+    free(chars); free(events); free(anchors); free(items); free(origin); free(firstItem);
+    free(models); free(modelOf); free(ids);
+    pthread_mutex_unlock(&g_lock);
+}
+
+stList *getAlignedPairsUsingAnchors(StateMachine *sM, Sequence *SsX, Sequence *SsY, stList *anchorPairs,
+                                    PairwiseAlignmentParameters *p, DiagonalPosteriorProbFn fn,
+                                    bool raggedL, bool raggedR) {
+    if (fn != diagonalCalculationPosteriorMatchProbs)
+        die("cpecan: the GPU path implements diagonalCalculationPosteriorMatchProbs only");
+    stList *out = NULL;
+    run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 0, 0, &out, NULL);
+    return out;
+}
+
+stList **getAlignedPairsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **sYs,
+                                          stList **anchors, PairwiseAlignmentParameters *p, bool raggedL,
+                                          bool raggedR) {
+    stList **out = calloc((size_t) (n > 0 ? n : 1), sizeof(stList *));
+    if (n > 0) run_reads(n, sMs, sXs, sYs, anchors, p, raggedL, raggedR, 0, 0, out, NULL);
+    return out;
+}
+
+stList *getAlignedPairsWithoutBanding(StateMachine *sM, void *cX, void *cY, int64_t lX, int64_t lY,
+                                      PairwiseAlignmentParameters *p, void *(*getXFcn)(void *, int64_t),
+                                      void *(*getYFcn)(void *, int64_t), DiagonalPosteriorProbFn fn,
+                                      bool raggedL, bool raggedR) {
+    if (fn != diagonalCalculationPosteriorMatchProbs)
+        die("cpecan: the GPU path implements diagonalCalculationPosteriorMatchProbs only");
+    Sequence *sX = sequence_construct(lX, cX, getXFcn), *sY = sequence_construct(lY, cY, getYFcn);
+    stList *out = NULL, *none = NULL;
+    run_reads(1, &sM, &sX, &sY, &none, p, raggedL, raggedR, 0, 1, &out, NULL);
+    sequence_sequenceDestroy(sX);
+    sequence_sequenceDestroy(sY);
+    return out;
+}
+
+void getSignalExpectationsUsingAnchors(StateMachine *sM, ContinuousPairHmmExpectations *hmm, Sequence *SsX,
+                                       Sequence *SsY, stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                       bool raggedL, bool raggedR) {
+    run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmm);
+}
+
+void continuousPairHmm_normalize(ContinuousPairHmmExpectations *hmm) {
+    for (int from = 0; from < 3; from++) { /* hmmDiscrete_normalize2, impl/discreteHmm.c:125-136 */
+        double total = 0.0;
+        for (int to = 0; to < 3; to++) total += hmm->transitions[from * 3 + to];
+        for (int to = 0; to < 3; to++) hmm->transitions[from * 3 + to] = hmm->transitions[from * 3 + to] / total;
+    }
+    double total = 0.0;
+    for (int i = 0; i < NUM_OF_KMERS; i++) total += hmm->individualKmerGapProbs[i];
+    for (int i = 0; i < NUM_OF_KMERS; i++) hmm->individualKmerGapProbs[i] = hmm->individualKmerGapProbs[i] / total;
+}
+
+void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM, ContinuousPairHmmExpectations *hmm) {
+    StateMachine3 *s = (StateMachine3 *) sM;
+    const double *t = hmm->transitions;
+    s->TRANSITION_MATCH_CONTINUE = log(t[match * 3 + match]);
+    s->TRANSITION_GAP_OPEN_X = log(t[match * 3 + shortGapX]);
+    s->TRANSITION_GAP_OPEN_Y = log(t[match * 3 + shortGapY]);
+    s->TRANSITION_MATCH_FROM_GAP_X = log(t[shortGapX * 3 + match]);
+    s->TRANSITION_GAP_EXTEND_X = log(1 - t[shortGapX * 3 + match]);
+    s->TRANSITION_GAP_SWITCH_TO_Y = -INFINITY;
+    s->TRANSITION_MATCH_FROM_GAP_Y = log(t[shortGapY * 3 + match]);
+    s->TRANSITION_GAP_EXTEND_Y = log(t[shortGapY * 3 + shortGapY]);
+    s->TRANSITION_GAP_SWITCH_TO_X = log(t[shortGapY * 3 + shortGapX]);
+    for (int64_t i = 0; i < NUM_OF_KMERS; i++) sM->EMISSION_GAP_X_PROBS[i] = log(hmm->individualKmerGapProbs[i]);
+}

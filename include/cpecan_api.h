@@ -1,0 +1,176 @@
+/*
+ * cpecan_api.h -- host-side C mirror of the part of cPecan's public API that sits on the banded
+ * pair-HMM posterior path (reference: inc/pairwiseAligner.h, inc/stateMachine.h, inc/nanopore.h).
+ *
+ * Same names, argument meaning and ownership rules as the reference so that its callers
+ * (vanillaAlign.c:179-255, the CuTest suites) read unchanged; the DP itself runs on the GPU through
+ * the C-ABI of cpecan_hip.h.  The reference's base library sonLib is not part of this build, so the
+ * two container types its API returns (stList of stIntTuple) are provided here in minimal form
+ * under the reference's names; build with -DCPECAN_WITH_SONLIB to use a real sonLib instead.
+ *
+ * What is NOT mirrored: function-pointer plug-ins cannot run on the device.  The entry points accept
+ * the reference's known combinations -- a threeState (strawMan) StateMachine, sequence_getKmer /
+ * sequence_getEvent getters, diagonalCalculationPosteriorMatchProbs -- and abort with a message (the
+ * reference's st_errAbort convention) on anything else.  There is no CPU fallback.
+ */
+#ifndef CPECAN_API_H_
+#define CPECAN_API_H_
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- minimal sonLib containers (inc/sonLibList.h, sonLibTuples.h in sonLib) -------------------- */
+#ifndef CPECAN_WITH_SONLIB
+typedef struct _stList stList;
+typedef struct _stIntTuple stIntTuple;
+stList *stList_construct(void);
+stList *stList_construct3(int64_t size, void (*destructElement)(void *));
+void stList_destruct(stList *list);
+int64_t stList_length(stList *list);
+void *stList_get(stList *list, int64_t index);
+void stList_append(stList *list, void *item);
+stIntTuple *stIntTuple_construct2(int64_t a, int64_t b);
+stIntTuple *stIntTuple_construct3(int64_t a, int64_t b, int64_t c);
+int64_t stIntTuple_get(stIntTuple *t, int64_t index);
+int64_t stIntTuple_length(stIntTuple *t);
+void stIntTuple_destruct(stIntTuple *t);
+#endif
+
+#define PAIR_ALIGNMENT_PROB_1 10000000 /* inc/pairwiseAligner.h:26 */
+#define NB_EVENT_PARAMS 3               /* inc/nanopore.h:4 */
+#define KMER_LENGTH 6                   /* inc/emissionMatrix.h:4 */
+#define NUM_OF_KMERS 4096
+#define MODEL_PARAMS 5                  /* inc/stateMachine.h:17 */
+
+/* ---- Sequence (inc/pairwiseAligner.h:29-77) ----------------------------------------------------- */
+typedef enum { nucleotide = 0, kmer = 1, event = 2 } SequenceType;
+typedef struct _sequence Sequence;
+struct _sequence {
+    int64_t length;
+    void *elements;
+    void *(*get)(void *elements, int64_t index);
+    Sequence *(*sliceFcn)(Sequence *, int64_t, int64_t);
+};
+Sequence *sequence_construct(int64_t length, void *elements, void *(*getFcn)(void *, int64_t));
+Sequence *sequence_construct2(int64_t length, void *elements, void *(*getFcn)(void *, int64_t),
+                              Sequence *(*sliceFcn)(Sequence *, int64_t, int64_t));
+Sequence *sequence_sliceNucleotideSequence2(Sequence *inputSequence, int64_t start, int64_t sliceLength);
+Sequence *sequence_sliceEventSequence2(Sequence *inputSequence, int64_t start, int64_t sliceLength);
+void sequence_sequenceDestroy(Sequence *seq);
+void *sequence_getKmer(void *elements, int64_t index);
+void *sequence_getEvent(void *elements, int64_t index);
+int64_t sequence_correctSeqLength(int64_t length, SequenceType type);
+
+/* ---- PairwiseAlignmentParameters (inc/pairwiseAligner.h:80-95) ---------------------------------- */
+typedef struct _pairwiseAlignmentBandingParameters {
+    double threshold;
+    int64_t minDiagsBetweenTraceBack;
+    int64_t traceBackDiagonals;
+    int64_t diagonalExpansion;
+    int64_t constraintDiagonalTrim;
+    int64_t anchorMatrixBiggerThanThis;
+    int64_t repeatMaskMatrixBiggerThanThis;
+    int64_t splitMatrixBiggerThanThis;
+    bool alignAmbiguityCharacters;
+    float gapGamma;
+} PairwiseAlignmentParameters;
+PairwiseAlignmentParameters *pairwiseAlignmentBandingParameters_construct(void);
+void pairwiseAlignmentBandingParameters_destruct(PairwiseAlignmentParameters *p);
+
+/* ---- StateMachine (inc/stateMachine.h:20-102, 174-195) ------------------------------------------ */
+typedef enum {
+    fiveState = 0, fiveStateAsymmetric = 1, threeState = 2, threeStateAsymmetric = 3, vanilla = 4,
+    echelon = 5, fourState = 6, threeStateHdp = 7,
+} StateMachineType;
+typedef enum { match = 0, shortGapX = 1, shortGapY = 2, longGapX = 3, longGapY = 4 } State;
+
+typedef struct _stateMachine StateMachine;
+struct _stateMachine { /* data members in the reference's order; the reference's function-pointer
+                          members follow them there and are not mirrored (they cannot run on the GPU) */
+    StateMachineType type;
+    int64_t stateNumber;
+    int64_t matchState;
+    int64_t parameterSetSize;
+    double *EMISSION_MATCH_PROBS;
+    double *EMISSION_GAP_X_PROBS;
+    double *EMISSION_GAP_Y_PROBS;
+};
+typedef struct _StateMachine3 {
+    StateMachine model;
+    double TRANSITION_MATCH_CONTINUE;
+    double TRANSITION_MATCH_FROM_GAP_X;
+    double TRANSITION_MATCH_FROM_GAP_Y;
+    double TRANSITION_GAP_OPEN_X;
+    double TRANSITION_GAP_OPEN_Y;
+    double TRANSITION_GAP_EXTEND_X;
+    double TRANSITION_GAP_EXTEND_Y;
+    double TRANSITION_GAP_SWITCH_TO_X;
+    double TRANSITION_GAP_SWITCH_TO_Y;
+} StateMachine3;
+
+/* getStrawManStateMachine3 (impl/stateMachine.c:1725): 3-state machine with nanopore default
+ * transitions (:1278), log(0.1) k-mer gap table (:1506), emission tables from a 3-line .model file */
+StateMachine *getStrawManStateMachine3(const char *modelFile);
+void stateMachine3_setTransitionsToNanoporeDefaults(StateMachine *sM);
+void emissions_signal_scaleModel(StateMachine *sM, double scale, double shift, double var,
+                                 double scale_sd, double var_sd); /* :631-651 */
+int64_t emissions_discrete_getKmerIndex(void *kmer);              /* :120-139 */
+void stateMachine_destruct(StateMachine *stateMachine);
+
+/* ---- the path (inc/pairwiseAligner.h:249-311) ---------------------------------------------------- */
+typedef struct _dpMatrix DpMatrix; /* opaque, never instantiated: kept for the callback signature */
+typedef void (*DiagonalPosteriorProbFn)(StateMachine *, int64_t, DpMatrix *, DpMatrix *, Sequence *,
+                                        Sequence *, double, PairwiseAlignmentParameters *, void *);
+/* marker: pass this as diagonalPosteriorProbFn, exactly as the reference's callers do */
+void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,
+                                            DpMatrix *backwardDpMatrix, Sequence *sX, Sequence *sY,
+                                            double totalProbability, PairwiseAlignmentParameters *p,
+                                            void *extraArgs);
+
+stList *getAlignedPairsUsingAnchors(StateMachine *sM, Sequence *SsX, Sequence *SsY, stList *anchorPairs,
+                                    PairwiseAlignmentParameters *p,
+                                    DiagonalPosteriorProbFn diagonalPosteriorProbFn,
+                                    bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+
+stList *getAlignedPairsWithoutBanding(StateMachine *sM, void *cX, void *cY, int64_t lX, int64_t lY,
+                                      PairwiseAlignmentParameters *p,
+                                      void *(*getXFcn)(void *, int64_t), void *(*getYFcn)(void *, int64_t),
+                                      DiagonalPosteriorProbFn diagonalPosteriorProbFn,
+                                      bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+
+stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize,
+                       bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+
+/* ---- expectations for Baum-Welch (inc/continuousHmm.h:17-23, impl/continuousHmm.c:90-232) ------- */
+typedef struct _continuousPairHmmExpectations {
+    double likelihood;
+    double transitions[9];              /* [from * 3 + to] */
+    double individualKmerGapProbs[NUM_OF_KMERS];
+} ContinuousPairHmmExpectations;
+/* getExpectationsUsingAnchors (:1571) with diagonalCalculation_Expectations for the strawMan model:
+ * adds this alignment's expectations to *hmm */
+void getSignalExpectationsUsingAnchors(StateMachine *sM, ContinuousPairHmmExpectations *hmm,
+                                       Sequence *SsX, Sequence *SsY, stList *anchorPairs,
+                                       PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,
+                                       bool alignmentHasRaggedRightEnd);
+void continuousPairHmm_normalize(ContinuousPairHmmExpectations *hmm);                 /* :174-191 */
+void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM,
+                                                      ContinuousPairHmmExpectations *hmm); /* :206-232 */
+
+/* ---- additive batch entry (many reads, one call; SURVEY section 8b last row) ---------------------
+ * Aligns n reads; read i uses state machine sMs[i] (already scaled for that read), sequences
+ * sXs[i] (sequence_getKmer) / sYs[i] (sequence_getEvent) and anchor list anchors[i].  Returns an
+ * array of n stLists (caller destructs each, then free()s the array). */
+stList **getAlignedPairsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **sYs,
+                                          stList **anchors, PairwiseAlignmentParameters *p,
+                                          bool alignmentHasRaggedLeftEnd,
+                                          bool alignmentHasRaggedRightEnd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+"""ctypes view of libcpecan_host.so (include/cpecan_api.h), for the tests.  Mirrors how a C caller of
+the reference (vanillaAlign.c:179-255) uses the API."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from cpecan_load import ROOT
+
+LIB_PATH = os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_host.so")
+NUM_KMERS = 4096
+
+
+class Params(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("minDiagsBetweenTraceBack", C.c_int64),
+                ("traceBackDiagonals", C.c_int64), ("diagonalExpansion", C.c_int64),
+                ("constraintDiagonalTrim", C.c_int64), ("anchorMatrixBiggerThanThis", C.c_int64),
+                ("repeatMaskMatrixBiggerThanThis", C.c_int64), ("splitMatrixBiggerThanThis", C.c_int64),
+                ("alignAmbiguityCharacters", C.c_bool), ("gapGamma", C.c_float)]
+
+
+class StateMachine(C.Structure):
+    _fields_ = [("type", C.c_int), ("stateNumber", C.c_int64), ("matchState", C.c_int64),
+                ("parameterSetSize", C.c_int64), ("EMISSION_MATCH_PROBS", C.POINTER(C.c_double)),
+                ("EMISSION_GAP_X_PROBS", C.POINTER(C.c_double)),
+                ("EMISSION_GAP_Y_PROBS", C.POINTER(C.c_double))]
+
+
+class StateMachine3(C.Structure):
+    _fields_ = [("model", StateMachine)] + [(n, C.c_double) for n in (
+        "TRANSITION_MATCH_CONTINUE", "TRANSITION_MATCH_FROM_GAP_X", "TRANSITION_MATCH_FROM_GAP_Y",
+        "TRANSITION_GAP_OPEN_X", "TRANSITION_GAP_OPEN_Y", "TRANSITION_GAP_EXTEND_X",
+        "TRANSITION_GAP_EXTEND_Y", "TRANSITION_GAP_SWITCH_TO_X", "TRANSITION_GAP_SWITCH_TO_Y")]
+
+
+class Expectations(C.Structure):
+    _fields_ = [("likelihood", C.c_double), ("transitions", C.c_double * 9),
+                ("individualKmerGapProbs", C.c_double * NUM_KMERS)]
+
+
+EXPORTS = [
+    "stList_construct", "stList_construct3", "stList_destruct", "stList_length", "stList_get",
+    "stList_append", "stIntTuple_construct2", "stIntTuple_construct3", "stIntTuple_get",
+    "stIntTuple_length", "stIntTuple_destruct", "sequence_construct", "sequence_construct2",
+    "sequence_sliceNucleotideSequence2", "sequence_sliceEventSequence2", "sequence_sequenceDestroy",
+    "sequence_getKmer", "sequence_getEvent", "sequence_correctSeqLength",
+    "pairwiseAlignmentBandingParameters_construct", "pairwiseAlignmentBandingParameters_destruct",
+    "getStrawManStateMachine3", "stateMachine3_setTransitionsToNanoporeDefaults",
+    "emissions_signal_scaleModel", "emissions_discrete_getKmerIndex", "stateMachine_destruct",
+    "diagonalCalculationPosteriorMatchProbs", "getAlignedPairsUsingAnchors",
+    "getAlignedPairsWithoutBanding", "getSplitPoints", "getSignalExpectationsUsingAnchors",
+    "continuousPairHmm_normalize", "continuousPairHmm_loadTransitionsAndKmerGapProbs",
+    "getAlignedPairsUsingAnchorsBatch",
+]
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.stList_construct3.restype = vp
+        L.stList_construct3.argtypes = [C.c_int64, vp]
+        L.stList_destruct.argtypes = [vp]
+        L.stList_length.restype = C.c_int64
+        L.stList_length.argtypes = [vp]
+        L.stList_get.restype = vp
+        L.stList_get.argtypes = [vp, C.c_int64]
+        L.stList_append.argtypes = [vp, vp]
+        L.stIntTuple_construct2.restype = vp
+        L.stIntTuple_construct2.argtypes = [C.c_int64, C.c_int64]
+        L.stIntTuple_get.restype = C.c_int64
+        L.stIntTuple_get.argtypes = [vp, C.c_int64]
+        L.sequence_construct2.restype = vp
+        L.sequence_construct2.argtypes = [C.c_int64, vp, vp, vp]
+        L.sequence_sequenceDestroy.argtypes = [vp]
+        L.sequence_correctSeqLength.restype = C.c_int64
+        L.sequence_correctSeqLength.argtypes = [C.c_int64, C.c_int]
+        L.pairwiseAlignmentBandingParameters_construct.restype = C.POINTER(Params)
+        L.pairwiseAlignmentBandingParameters_destruct.argtypes = [C.POINTER(Params)]
+        L.getStrawManStateMachine3.restype = C.POINTER(StateMachine3)
+        L.getStrawManStateMachine3.argtypes = [C.c_char_p]
+        L.emissions_signal_scaleModel.argtypes = [vp] + [C.c_double] * 5
+        L.emissions_discrete_getKmerIndex.restype = C.c_int64
+        L.emissions_discrete_getKmerIndex.argtypes = [C.c_char_p]
+        L.stateMachine_destruct.argtypes = [vp]
+        L.getAlignedPairsUsingAnchors.restype = vp
+        L.getAlignedPairsUsingAnchors.argtypes = [vp, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
+        L.getAlignedPairsWithoutBanding.restype = vp
+        L.getAlignedPairsWithoutBanding.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.POINTER(Params),
+                                                    vp, vp, vp, C.c_bool, C.c_bool]
+        L.getSplitPoints.restype = vp
+        L.getSplitPoints.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_bool, C.c_bool]
+        L.getSignalExpectationsUsingAnchors.argtypes = [vp, C.POINTER(Expectations), vp, vp, vp,
+                                                        C.POINTER(Params), C.c_bool, C.c_bool]
+        L.continuousPairHmm_normalize.argtypes = [C.POINTER(Expectations)]
+        L.continuousPairHmm_loadTransitionsAndKmerGapProbs.argtypes = [vp, C.POINTER(Expectations)]
+        L.getAlignedPairsUsingAnchorsBatch.restype = C.POINTER(vp)
+        L.getAlignedPairsUsingAnchorsBatch.argtypes = [C.c_int64, C.POINTER(vp), C.POINTER(vp),
+                                                       C.POINTER(vp), C.POINTER(vp), C.POINTER(Params),
+                                                       C.c_bool, C.c_bool]
+        _LIB = L
+    return _LIB
+
+
+def fn_ptr(name):
+    return C.cast(getattr(lib(), name), C.c_void_p)
+
+
+def make_anchor_list(anchors):
+    L = lib()
+    lst = L.stList_construct3(0, fn_ptr("stIntTuple_destruct"))
+    for x, y in anchors:
+        L.stList_append(lst, L.stIntTuple_construct2(int(x), int(y)))
+    return lst
+
+
+def list_to_array(lst, width=3):
+    L = lib()
+    n = L.stList_length(lst)
+    out = np.zeros((n, width), np.int64)
+    for i in range(n):
+        t = L.stList_get(lst, i)
+        for j in range(width):
+            out[i, j] = L.stIntTuple_get(t, j)
+    return out
+
+
+class Read:
+    """keeps the C buffers of one read alive: k-mer Sequence over chars, event Sequence over doubles"""
+
+    def __init__(self, x_chars, events):
+        L = lib()
+        self.xbuf = C.create_string_buffer(x_chars if isinstance(x_chars, bytes) else x_chars.encode())
+        self.ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+        self.lX = L.sequence_correctSeqLength(len(self.xbuf.value), 2)
+        self.lY = self.ev.size // 3
+        self.sX = L.sequence_construct2(self.lX, C.cast(self.xbuf, C.c_void_p), fn_ptr("sequence_getKmer"),
+                                        fn_ptr("sequence_sliceNucleotideSequence2"))
+        self.sY = L.sequence_construct2(self.lY, self.ev.ctypes.data_as(C.c_void_p),
+                                        fn_ptr("sequence_getEvent"), fn_ptr("sequence_sliceEventSequence2"))

@@ -1,0 +1,161 @@
+"""The reference-shaped host library (include/cpecan_api.h -> libcpecan_host.so): exports and host-side
+integer logic on CPU; the alignment entry points against the oracle on the GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import pyoracle as o
+import synth
+from cpecan_load import ROOT
+import host_api as h
+
+
+def test_host_library_exports_declared_symbols():
+    header = open(os.path.join(ROOT, "include", "cpecan_api.h")).read()
+    declared = set(re.findall(r"\b([A-Za-z_0-9]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S)))
+    declared = {d for d in declared if d in h.EXPORTS or d.startswith(("get", "sequence_", "stList_",
+                                                                        "stIntTuple_", "emissions_",
+                                                                        "continuousPairHmm_",
+                                                                        "pairwiseAlignment",
+                                                                        "stateMachine", "diagonalCalc"))}
+    assert declared == set(h.EXPORTS), declared ^ set(h.EXPORTS)
+    lib = C.CDLL(h.LIB_PATH)
+    for name in h.EXPORTS:
+        assert hasattr(lib, name), name
+
+
+def test_host_defaults_and_split_points_golden():
+    L = h.lib()
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    assert (p.contents.threshold, p.contents.minDiagsBetweenTraceBack, p.contents.traceBackDiagonals,
+            p.contents.diagonalExpansion, p.contents.splitMatrixBiggerThanThis) == (0.01, 1000, 40, 20, 9000000)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    # tests/pairwiseAlignerTest.c:634-661
+    anchors = [(2000, 2000), (4002, 4001), (5000, 5000), (8000, 6000), (9000, 9000), (10000, 14000),
+               (15000, 15000), (16000, 16000)]
+    lst = h.make_anchor_list(anchors)
+    sp = L.getSplitPoints(lst, 20000, 25000, 2000 * 2000, False, False)
+    assert h.list_to_array(sp, 4).tolist() == [
+        [0, 0, 3001, 3001], [3002, 3001, 9500, 11001], [9501, 12000, 12001, 14500],
+        [13000, 14501, 18000, 18001], [18001, 23000, 20000, 25000]]
+    L.stList_destruct(sp)
+    L.stList_destruct(lst)
+    assert L.emissions_discrete_getKmerIndex(b"AAAAAC") == 1
+    assert L.emissions_discrete_getKmerIndex(b"TTTTTT") == 4095
+    assert L.emissions_discrete_getKmerIndex(b"ACNTAA") > 4096
+    assert L.sequence_correctSeqLength(13, 2) == 8
+
+
+def test_model_loader_and_scaling_match_reference_semantics(golden_dir, zymo_read, template_model):
+    L = h.lib()
+    sm = L.getStrawManStateMachine3(os.path.join(golden_dir, "template_median68pA.model").encode())
+    match = np.ctypeslib.as_array(sm.contents.model.EMISSION_MATCH_PROBS, shape=(1 + 4096 * 5,))
+    assert np.array_equal(match, template_model[0])
+    assert sm.contents.TRANSITION_GAP_OPEN_Y == -4.3187242127300092
+    L.emissions_signal_scaleModel(sm, *zymo_read["template_params"])
+    ref = template_model[0].copy()
+    o.lib().orc_scale_model(ref.ctypes.data, *zymo_read["template_params"])
+    assert np.array_equal(match, ref)  # tests/signalPairwiseTest.c:1007-1040, exact
+    L.stateMachine_destruct(sm)
+
+
+@pytest.mark.gpu
+def test_zymo_read_through_host_api(golden_dir, zymo_read, template_model):
+    """vanillaAlign-style use of the API on the reference's own read: 986 un-banded pairs
+    (signalPairwiseTest.c:1166-1173) and a banded, split alignment identical to the oracle's."""
+    L = h.lib()
+    sm = L.getStrawManStateMachine3(os.path.join(golden_dir, "template_median68pA.model").encode())
+    L.emissions_signal_scaleModel(sm, *zymo_read["template_params"])
+    rd = h.Read(zymo_read["reference"], zymo_read["template_events"])
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    pairs = L.getAlignedPairsWithoutBanding(sm, C.cast(rd.xbuf, C.c_void_p), rd.ev.ctypes.data_as(C.c_void_p),
+                                            rd.lX, rd.lY, p, h.fn_ptr("sequence_getKmer"),
+                                            h.fn_ptr("sequence_getEvent"),
+                                            h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), False, False)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    assert len(got) == 986
+    om = o.Sm3Model(template_model[0], template_model[2]).scaled(*zymo_read["template_params"])
+    ref = o.aligned_pairs_without_banding(om, zymo_read["reference"], rd.lX, zymo_read["template_events"],
+                                          o.default_params())
+    assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])          # same pairs, same order
+    assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1         # device exp vs host exp
+
+    # banded, with anchors from the un-banded result and a small split threshold => several sub-alignments
+    best = {}
+    for q, x, y in ref["triples"]:
+        if q > 9000000:
+            best[int(x)] = int(y)
+    anchors, py = [], -1
+    for x in sorted(best)[::30]:
+        if best[x] > py:
+            anchors.append((x, best[x]))
+            py = best[x]
+    anchors = [a for i, a in enumerate(anchors) if not 8 <= i <= 14]   # a big anchor-free gap
+    p.contents.splitMatrixBiggerThanThis = 100 * 100
+    p.contents.diagonalExpansion = 40
+    p.contents.minDiagsBetweenTraceBack = 150
+    lst = h.make_anchor_list(anchors)
+    pairs = L.getAlignedPairsUsingAnchors(sm, rd.sX, rd.sY, lst, p,
+                                          h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), True, True)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    op = o.default_params(minDiagsBetweenTraceBack=150, diagonalExpansion=40,
+                          splitMatrixBiggerThanThis=100 * 100)
+    assert len(o.split_points(anchors, rd.lX, rd.lY, 100 * 100, 1, 1)) > 1
+    ref = o.aligned_pairs_using_anchors(om, zymo_read["reference"], rd.lX, zymo_read["template_events"],
+                                        anchors, op, True, True)
+    assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
+    assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+
+    # expectations for Baum-Welch on the same alignment
+    e = h.Expectations()
+    L.getSignalExpectationsUsingAnchors(sm, C.byref(e), rd.sX, rd.sY, lst, p, True, True)
+    oe = o.OrcExpectations()
+    o.aligned_pairs_using_anchors(om, zymo_read["reference"], rd.lX, zymo_read["template_events"], anchors,
+                                  op, True, True, expectations=oe)
+    assert np.allclose(np.array(e.transitions[:]), np.array(oe.transitions[:]), rtol=1e-9)
+    assert np.allclose(np.array(e.individualKmerGapProbs[:]), np.array(oe.kmerGap[:]), rtol=1e-9, atol=1e-300)
+    assert np.isclose(e.likelihood, oe.likelihood, rtol=1e-12)
+    L.continuousPairHmm_normalize(C.byref(e))
+    assert np.allclose(np.array(e.transitions[:]).reshape(3, 3).sum(1), 1.0)
+    L.stList_destruct(lst)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)
+
+
+@pytest.mark.gpu
+def test_batch_entry_matches_single_calls(golden_dir):
+    L = h.lib()
+    batch = synth.make_batch(31, 5, 150, 310, anchor_every=30, distinct_models=False)
+    sm = L.getStrawManStateMachine3(None)
+    m, gx, gy = batch["models"][0]
+    C.memmove(sm.contents.model.EMISSION_MATCH_PROBS, m.ctypes.data, m.nbytes)
+    C.memmove(sm.contents.model.EMISSION_GAP_Y_PROBS, gy.ctypes.data, gy.nbytes)
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    p.contents.diagonalExpansion = 40
+    p.contents.minDiagsBetweenTraceBack = 120
+    reads, lists = [], []
+    for it in batch["items"]:
+        x = batch["x_chars"][it["x_offset"]: it["x_offset"] + it["lX"] + 5]
+        ev = batch["events"][it["y_offset"]: it["y_offset"] + it["lY"]]
+        reads.append(h.Read(x, ev))
+        lists.append(h.make_anchor_list(batch["anchors"][it["anchor_offset"]: it["anchor_offset"] + it["n_anchors"]]))
+    n = len(reads)
+    vp = C.c_void_p
+    sms = (vp * n)(*[C.cast(sm, vp)] * n)
+    sxs = (vp * n)(*[r.sX for r in reads])
+    sys_ = (vp * n)(*[r.sY for r in reads])
+    ans = (vp * n)(*lists)
+    out = L.getAlignedPairsUsingAnchorsBatch(n, sms, sxs, sys_, ans, p, True, True)
+    for i in range(n):
+        a = h.list_to_array(out[i])
+        single = L.getAlignedPairsUsingAnchors(sm, reads[i].sX, reads[i].sY, lists[i], p,
+                                               h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), True, True)
+        b = h.list_to_array(single)
+        assert np.array_equal(a, b) and len(a) > 0
+        L.stList_destruct(single)
+        L.stList_destruct(out[i])
