@@ -161,6 +161,15 @@ def main():
             "achieved": round(cells * 24.0 / (f_ms / 1e3) / 1e9, 2),
             "frac": round(cells * 24.0 / (f_ms / 1e3) / 1e9 / 8000.0, 5)}
 
+    if os.environ.get("CPECAN_PROF"):  # timing build (-DSY_PROFILE) only
+        import ctypes
+        buf = (ctypes.c_ulonglong * 64)()
+        if hasattr(cp.lib(), "cpecan_systolic_prof_fetch") and cp.lib().cpecan_systolic_prof_fetch(buf) == 0:
+            for w in range(4):
+                v = [buf[w * 16 + k] for k in range(12)]
+                na, ni = max(v[10], 1), max(v[11], 1)
+                sys.stderr.write("prof wave %d: active steps %d  cycles/step by section %s | inactive steps %d cycles/step %.0f\n"
+                                 % (w, v[10], " ".join("%.0f" % (x / na) for x in v[:9]), v[11], v[9] / ni))
     # ---- parity spot check + CPU baseline (oracle = checker / baseline only) -------------------
     check = {"reads": 0}
     cpu = None

@@ -477,6 +477,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
         b->ringD = 64;
         while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernels mask with ringD-1 */
         b->ringDoubles = (long long) b->ringD * cpecan_systolic_ring_row_doubles();
+        if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));

@@ -35,7 +35,24 @@
 #define SY_R 4
 #define SY_P (64 * SY_R)
 #define SY_NPRM 17
+#define SY_PREFETCH 4     /* diagonals the backward sweep fetches ahead (== its unroll factor) */
 #define SY_RING_VALUES 5 /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
+
+#ifdef SY_PROFILE
+/* timing build only: cycles per section of the forward step, summed over all waves */
+__device__ unsigned long long sy_prof[4 * 16];
+#define PROF_DECL unsigned long long prof_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tprev_ = __builtin_readcyclecounter(); bool pact_ = false;
+#define PROF(k) { const unsigned long long now_ = __builtin_readcyclecounter(); if (pact_) prof_[k] += now_ - tprev_; else prof_[9] += now_ - tprev_; tprev_ = now_; }
+#define PROF_ACTIVE(a) { pact_ = (a); if (pact_) prof_[10]++; else prof_[11]++; }
+#define PROF_FENCE(x) asm volatile("" : "+v"(x));
+#define PROF_FLUSH(wave) if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; k_++) atomicAdd(&sy_prof[(wave) * 16 + k_], prof_[k_]); }
+#else
+#define PROF_DECL
+#define PROF(k)
+#define PROF_ACTIVE(a)
+#define PROF_FENCE(x)
+#define PROF_FLUSH(wave)
+#endif
 
 namespace {
 
@@ -48,6 +65,22 @@ struct Shared {
     double total;
     int cnt[2][SY_R][2];     /* aligned-pair counts per wave, double-buffered */
     int item;
+};
+
+/*
+ * Inputs of the forward sweep, staged in LDS.  Inside the sweep a wave must never wait on a
+ * global load: vmcnt counts loads and stores in one in-order queue, so waiting for any load also
+ * waits for the acknowledgement of every ring store issued before it -- a full HBM round trip per
+ * anti-diagonal.  Events and k-mer constants are therefore fetched in bulk once every SY_FEED
+ * diagonals, for the next two such blocks (both move by at most one index per diagonal), and the
+ * sweep itself only reads LDS.
+ */
+#define SY_FEED 32
+#define SY_FEED_EV 128  /* ring of events, by event index            */
+#define SY_FEED_ROW 64  /* ring of k-mer constant rows, by k-mer index */
+struct Feed {
+    double ev[SY_FEED_EV * 2];
+    double row[SY_FEED_ROW * CP_ROW];
 };
 
 /* lane i <- lane i-1 (lane 0 <- lane 63) */
@@ -91,7 +124,11 @@ __device__ __forceinline__ DevItem uniform_item(const DevItem &s) {
  * store of the forward ring (s_waitcnt vmcnt(0)) on each anti-diagonal; nothing the waves exchange
  * inside an alignment goes through global memory, so only lgkmcnt has to reach zero. */
 __device__ __forceinline__ void lds_barrier() {
+#ifdef SY_ABLATE_BARRIER
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 /* logAdd (impl/pairwiseAligner.c:238-255), branch-free and bit-identical: hi/lo are the operands
@@ -100,13 +137,20 @@ __device__ __forceinline__ void lds_barrier() {
  * float-literal coefficients come from a 128-byte LDS table indexed by the piece (<=1, <=2.5,
  * <=4.5, else): two ds_read_b128 instead of a 24-select chain. */
 __device__ __forceinline__ double ladd(double x, double y, const double *coef) {
+#ifdef SY_ABLATE_LADD
+    return x > y ? x : y;
+#endif
     double hi, lo;
     /* plain v_max/v_min: operands are never NaN, so the canonicalising pre-ops fmax()/fmin() emit
      * are dead weight in a loop that is bound by instruction issue */
     asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
     const double d = hi - lo;
+#ifdef SY_ABLATE_COEF
+    const int idx = 0;
+#else
     const int idx = (int) (d > 1.00f) + (int) (d > 2.50f) + (int) (d > 4.50f);
+#endif
     const double *c = coef + idx * 4;
     const double r = ((c[0] * d + c[1]) * d + c[2]) * d + c[3] + lo;
     return d < 7.5 ? r : hi;
@@ -325,7 +369,7 @@ __device__ __forceinline__ void make_band(Band &band, const DevItem &it, const D
 __device__ void forward_window(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
                                const double *__restrict__ track, const double *__restrict__ events,
                                const double *__restrict__ model, double *ring, int ringD,
-                               SyState *state, Shared &sh) {
+                               SyState *state, Shared &sh, Feed &fd) {
     const Geometry g = make_geometry(ring, ringD);
     const int lane = g.lane, wave = g.wave;
     const int lX = (int) it.lX, lY = (int) it.lY, D = lX + lY;
@@ -350,11 +394,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
     double Fm, Fx, Fy; /* forward cell, current diagonal   */
     double Lm, Lx, Ly; /* slot-1's cell, previous diagonal */
     double em, en;     /* event scored on this diagonal    */
-    double st;         /* constants of the next k-mer to enter the band */
     int xin, xminP;
-    EvChunk fwdEv;
-    fwdEv.ev = ev;
-    fwdEv.lY = lY;
 
     if (d0 == 0) {
         /* diagonal 0: the single cell (0,0) holds the start vector (:897-898, stateMachine.c:1168-1177) */
@@ -363,14 +403,13 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
         for (int j = 0; j < SY_NPRM; j++) prm[j] = 0.0;
         Fm = Fx = Fy = Lm = Lx = Ly = CP_NEG_INF;
         em = en = 0.0;
-        st = stage_row(track, 0, lane);
-        if (wave == 0) install_row(prm, st, 0);
         if (wave == 0 && lane == 0) {
+            load_params(prm, track, 0);
             Fm = it.raggedL ? CP_NEG_INF : 0.0;
             Fx = it.raggedL ? 0.0 : CP_NEG_INF;
             Fy = Fx;
         }
-        if (wave == 0) {
+        if (wave == 0 && lane == 0) { /* only cells of the band are ever stored to the ring */
             *g.rp(0, 0) = Fm;
             *g.rp(0, 1) = Fx;
             *g.rp(0, 2) = Fy;
@@ -380,7 +419,6 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
         cells += 1;
         xin = 1;
         xminP = 0;
-        fwdEv.init_up(0, lane);
     } else {
         /* resume at d0: constants of the k-mers in the band, forward cells of d0 and d0-1, events */
         int xmin, xmax, qmin, qmax;
@@ -390,11 +428,11 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
         xs += ((xmin - xs + SY_P - 1) / SY_P) * SY_P; /* the k-mer >= xmin that lives in this slot */
         const bool v = xs <= xmax;
         load_params(prm, track, xs <= lX ? xs : lX);
-        const bool a = row_active(wave, xmin, xmax);
-        Fm = a ? *g.rp(d0, 0) : CP_NEG_INF;
-        Fx = a ? *g.rp(d0, 1) : CP_NEG_INF;
-        Fy = a ? *g.rp(d0, 2) : CP_NEG_INF;
-        const bool a1 = row_active(lane == 0 ? g.waveBelow : wave, qmin, qmax);
+        /* ring slots of cells outside the band hold stale data: mask per lane */
+        Fm = v ? *g.rp(d0, 0) : CP_NEG_INF;
+        Fx = v ? *g.rp(d0, 1) : CP_NEG_INF;
+        Fy = v ? *g.rp(d0, 2) : CP_NEG_INF;
+        const bool a1 = xs - 1 >= qmin && xs - 1 <= qmax;
         Lm = a1 ? *g.rpb(d0 - 1, 0) : CP_NEG_INF;
         Lx = a1 ? *g.rpb(d0 - 1, 1) : CP_NEG_INF;
         Ly = a1 ? *g.rpb(d0 - 1, 2) : CP_NEG_INF;
@@ -404,44 +442,82 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
         en = okE ? ev[3 * (long long) ei + 1] : 0.0;
         xin = xmax + 1;
         xminP = xmin;
-        fwdEv.init_up(d0 - xmin, lane);
     }
-    st = stage_row(track, xin <= lX ? xin : lX, lane);
+    int evHi = d0 - xminP - 1, rowHi = xin; /* first event / k-mer row not yet staged */
     if (lane == 63) {
         double *x = sh.xch[d0 & 1][wave];
         x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
     }
 
-    for (int d = d0 + 1; d <= D; d++) {
+    PROF_DECL
+    /* blocks of SY_FEED diagonals: the loads sit between the blocks, the inner loop has none */
+#pragma unroll 1
+    for (int db = d0 + 1; db <= D; db += SY_FEED) {
+        {
+            /* stage what the next two blocks of diagonals can ask for: the top cell's event index
+             * d-xmin-1 and the entering k-mer xin each advance by at most one per diagonal */
+            int fxmin, fxmax;
+            band.range(db, fxmin, fxmax);
+            const int evTo = db - fxmin - 1 + 3 * SY_FEED, rowTo = xin + 2 * SY_FEED;
+#pragma unroll 1
+            for (int i = evHi * 2 + (int) threadIdx.x; i < evTo * 2; i += 256) {
+                const int e = i >> 1;
+                fd.ev[(i & (2 * SY_FEED_EV - 1))] = e >= 0 && e < lY ? ev[3 * (long long) e + (i & 1)] : 0.0;
+            }
+#pragma unroll 1
+            for (int i = rowHi * CP_ROW + (int) threadIdx.x; i < rowTo * CP_ROW; i += 256) {
+                const int x = i / CP_ROW, j = i - x * CP_ROW;
+                fd.row[(x & (SY_FEED_ROW - 1)) * CP_ROW + j] = track[(long long) (x <= lX ? x : lX) * CP_ROW + j];
+            }
+            evHi = evTo;
+            rowHi = rowTo;
+            __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): nothing pending past this point */
+        }
+        const int dbEnd = db + SY_FEED - 1 < D ? db + SY_FEED - 1 : D;
+#pragma unroll 1
+        for (int d = db; d <= dbEnd; d++) {
+        PROF(0)
         int xmin, xmax;
         band.range(d, xmin, xmax);
         cells += xmax - xmin + 1;
-
+        PROF_ACTIVE(row_active(wave, xmin, xmax))
+        PROF(1)
         lds_barrier();
+        PROF(2)
         const double *xb = sh.xch[(d - 1) & 1][g.waveBelow];
         const double rm = shr1(xb[0], Fm), rx = shr1(xb[1], Fx), ry = shr1(xb[2], Fy);
         em = shr1(xb[3], em);
         en = shr1(xb[4], en);
+        PROF_FENCE(em) PROF_FENCE(en)
+        PROF(3)
         if (xs < xmin) xs += SY_P;
         const bool valid = xs <= xmax;
         while (xin <= xmax) { /* the entering k-mer's constants (at most one k-mer per step) */
-            if (((xin >> 6) & (SY_R - 1)) == wave) install_row(prm, st, xin & 63);
+            if (((xin >> 6) & (SY_R - 1)) == wave && lane == (xin & 63)) {
+                const double *r = fd.row + (xin & (SY_FEED_ROW - 1)) * CP_ROW;
+#pragma unroll
+                for (int j = 0; j < SY_NPRM; j++) prm[j] = r[j];
+            }
             xin++;
-            if (((xin >> 6) & (SY_R - 1)) == wave) st = stage_row(track, xin <= lX ? xin : lX, lane);
         }
-        if (xmin == xminP && ((xmin >> 6) & (SY_R - 1)) == wave) { /* the top cell's event is new */
-            double nm, nn;
-            fwdEv.get_up(d - xmin - 1, nm, nn, lane);
-            em = set_lane(em, xmin & 63, nm);
-            en = set_lane(en, xmin & 63, nn);
+        if (xmin == xminP && ((xmin >> 6) & (SY_R - 1)) == wave && lane == (xmin & 63)) {
+            /* the top cell's event is new.  Index -1 is NULLEVENT (:261): its emissions only ever
+             * meet -inf cells, the staged 0.0 keeps NaN out */
+            const double *e = fd.ev + ((2 * (d - xmin - 1)) & (2 * SY_FEED_EV - 1));
+            em = e[0];
+            en = e[1];
         }
+        PROF_FENCE(em) PROF_FENCE(en) PROF_FENCE(prm[0])
+        PROF(4)
         double nmv = CP_NEG_INF, nxv = CP_NEG_INF, nyv = CP_NEG_INF;
         if (row_active(wave, xmin, xmax)) {
             const double px = prm[CP_GAPX];
-            const double pm = lgauss(em, prm[CP_MU], prm[CP_SD], prm[CP_RSD], prm[CP_K1])
+            double pm = lgauss(em, prm[CP_MU], prm[CP_SD], prm[CP_RSD], prm[CP_K1])
                             + lgauss(en, prm[CP_NMU], prm[CP_NSD], prm[CP_RNSD], prm[CP_K2]);
-            const double py = lgauss(em, prm[CP_YMU], prm[CP_YSD], prm[CP_RYSD], prm[CP_YK1])
+            double py = lgauss(em, prm[CP_YMU], prm[CP_YSD], prm[CP_RYSD], prm[CP_YK1])
                             + lgauss(en, prm[CP_YNMU], prm[CP_YNSD], prm[CP_RYNSD], prm[CP_YK2]);
+            PROF_FENCE(pm) PROF_FENCE(py)
+            PROF(5)
             /* cell_calculateForward: to[t] = logAdd(to[t], from[f] + (eP + tP)) (:365-376) in the
              * order of stateMachine3_cellCalculate (stateMachine.c:1314-1333) */
             double gx = rm + (px + T[T_GAP_OPEN_X]);
@@ -452,15 +528,24 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
             mm = ladd(mm, Ly + (pm + T[T_MATCH_FROM_GAP_Y]), cf);
             double gy = Fm + (py + T[T_GAP_OPEN_Y]);
             gy = ladd(gy, Fy + (py + T[T_GAP_EXTEND_Y]), cf);
+            PROF_FENCE(mm) PROF_FENCE(gx) PROF_FENCE(gy)
+            PROF(6)
             nmv = valid ? mm : CP_NEG_INF;
             nxv = valid ? gx : CP_NEG_INF;
             nyv = valid ? gy : CP_NEG_INF;
-            *g.rp(d, 0) = nmv;
-            *g.rp(d, 1) = nxv;
-            *g.rp(d, 2) = nyv;
-            *g.rp(d, 3) = pm; /* the sweep back re-uses the two event-dependent emissions */
-            *g.rp(d, 4) = py;
+#ifdef SY_ABLATE_STORE
+            if (valid && d == -1) {
+#else
+            if (valid) { /* cells outside the band cost no HBM traffic */
+#endif
+                *g.rp(d, 0) = mm;
+                *g.rp(d, 1) = gx;
+                *g.rp(d, 2) = gy;
+                *g.rp(d, 3) = pm; /* the sweep back re-uses the two event-dependent emissions */
+                *g.rp(d, 4) = py;
+            }
         }
+        PROF(7)
         Lm = rm; Lx = rx; Ly = ry;
         Fm = nmv; Fx = nxv; Fy = nyv;
         if (lane == 63) {
@@ -468,6 +553,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
             x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
         }
         xminP = xmin;
+        PROF(8)
 
         const bool atEnd = d == D;
         const bool tb = d >= tracedBackTo + P.minDiags && (xmax - xmin + 1) <= P.expansion * 2 + 1;
@@ -485,7 +571,9 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
                 state->tracedBackTo = from;
                 state->cells = cells;
             }
+            PROF_FLUSH(wave)
             return;
+        }
         }
     }
 }
@@ -575,29 +663,41 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
         int pxBase = (xinB >= 0 ? xinB : 0) & ~63;
         double pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
 
-        /* forward match cell and the two emissions are fetched one diagonal ahead of their use */
-        const bool aTop = row_active(wave, bxmin, bxmax);
-        double fMc = aTop ? *g.rp(dTop, 0) : CP_NEG_INF;
-        double pmc = aTop ? *g.rp(dTop, 3) : 0.0, pyc = aTop ? *g.rp(dTop, 4) : 0.0;
-        double fMn = CP_NEG_INF, pmn = 0.0, pyn = 0.0;
+        /*
+         * The forward match cell and the two emissions of a diagonal are fetched SY_PREFETCH diagonals
+         * before the sweep reaches it: a wave that waits for a load also waits for everything issued
+         * before it (vmcnt is one in-order queue), so a fetch consumed one diagonal later costs a full
+         * HBM round trip per diagonal.  The loop is unrolled by the prefetch depth so that each
+         * in-flight diagonal has registers of its own and the waits are exact counts.  The loads are
+         * unconditional (no branch, so the counts hold): a lane whose slot cannot be in the band on
+         * that diagonal reads a fixed dummy line instead, and every value is masked when consumed
+         * (only cells of the band are ever stored to the ring; other slots hold stale data).
+         */
+        auto fetch = [&](const int tt, const bool want, double &f, double &pm, double &py)
+                         __attribute__((always_inline)) {
+            const double *p = want ? g.rp(tt, 0) : g.rw;
+            f = p[0];
+            pm = p[3 * 64];
+            py = p[4 * 64];
+        };
         int calcs = 0, nTotWin = 0;
-        for (int t = dTop; t > tracedBackTo; t--) {
+        int xsN = xs; /* this slot's k-mer on diagonal t+1 */
+        auto step = [&](const int t, double &qF, double &qPm, double &qPy) __attribute__((always_inline)) {
             const bool active = row_active(wave, bxmin, bxmax);
             const bool activeN = row_active(wave, nxmin, nxmax);
-            const bool activeP = t - 1 > tracedBackTo && row_active(wave, pxmin, pxmax);
-            if (activeP) { /* issue the loads for t-1 now, consume them next iteration */
-                fMn = *g.rp(t - 1, 0);
-                pmn = *g.rp(t - 1, 3);
-                pyn = *g.rp(t - 1, 4);
-            } else {
-                fMn = CP_NEG_INF; pmn = 0.0; pyn = 0.0;
+            if (t < dTop) {
+                xsN = xs;
+                if (xs > bxmax) xs -= SY_P;
             }
+            const bool vt = xs >= bxmin;
+            const double fMc = vt ? qF : CP_NEG_INF, pmc = vt ? qPm : 0.0, pyc = vt ? qPy : 0.0;
+            /* the slot's k-mer SY_PREFETCH diagonals down is xs or out of band (bands <= 256 - depth) */
+            fetch(t - SY_PREFETCH, xs >= bxmin - SY_PREFETCH, qF, qPm, qPy);
             if (t < dTop) {
                 lds_barrier();
                 const double *xa = sh.xch[(t + 1) & 1][g.waveAbove];
                 const double gm = shl1(xa[0], Gm), gx_ = shl1(xa[1], Gx), gy_ = shl1(xa[2], Gy);
                 const double hm = shl1(xa[3], Mm), hx = shl1(xa[4], Mx), hy = shl1(xa[5], My);
-                if (xs > bxmax) xs -= SY_P;
                 const bool bvalid = xs >= bxmin;
                 while (xinB >= bxmin) {
                     if (xinB < pxBase) {
@@ -647,7 +747,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                     /* per-cell terms of diagonalCalculationTotalProbability (:736-754), folded in
                      * phase T: v = cell_dotProduct(forward[t], backward[t]) (:391-397) ... */
                     const bool second = t + 1 <= dTop;
-                    if (active) {
+                    if (tvalid) {
                         const double fx = *g.rp(t, 1), fy = *g.rp(t, 2);
                         double v = fMc + Bm;
                         v = ladd(v, fx + Bx, cf);
@@ -659,7 +759,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                          * t+1, dotted with backward[t+1] (only the match state of that clone is
                          * ever above -inf) */
                         double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
-                        if (row_active(lane == 0 ? g.waveBelow : wave, pxmin, pxmax)) {
+                        if (xsN - 1 >= pxmin && xsN - 1 <= pxmax) {
                             s0 = *g.rpb(t - 1, 0);
                             s1 = *g.rpb(t - 1, 1);
                             s2 = *g.rpb(t - 1, 2);
@@ -681,13 +781,35 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                 /* exponent of the posterior, less the total: parked in the emission slot this diagonal
                  * no longer needs (the forward cells themselves stay intact: the next window's
                  * refresh at its lowest diagonal reads forward[tracedBackFrom], :944,:985) */
-                if (active) *g.rp(t, 3) = fMc + Bm;
+                if (tvalid) *g.rp(t, 3) = fMc + Bm;
             }
             pmPrev = pmc;
-            fMc = fMn; pmc = pmn; pyc = pyn;
             nxmin = bxmin; nxmax = bxmax;
             bxmin = pxmin; bxmax = pxmax;
-            if (t - 2 > tracedBackTo) band.range(t - 2, pxmin, pxmax);
+            if (t - 2 >= tracedBackTo) band.range(t - 2, pxmin, pxmax);
+        };
+        double q0F, q0Pm, q0Py, q1F, q1Pm, q1Py, q2F, q2Pm, q2Py, q3F, q3Pm, q3Py;
+        {
+            const bool want = xs >= bxmin - SY_PREFETCH;
+            fetch(dTop, want, q0F, q0Pm, q0Py);
+            fetch(dTop - 1, want, q1F, q1Pm, q1Py);
+            fetch(dTop - 2, want, q2F, q2Pm, q2Py);
+            fetch(dTop - 3, want, q3F, q3Pm, q3Py);
+        }
+        int t = dTop;
+#pragma unroll 1
+        for (; t - (SY_PREFETCH - 1) > tracedBackTo; t -= SY_PREFETCH) {
+            step(t, q0F, q0Pm, q0Py);
+            step(t - 1, q1F, q1Pm, q1Py);
+            step(t - 2, q2F, q2Pm, q2Py);
+            step(t - 3, q3F, q3Pm, q3Py);
+        }
+        /* the last diagonals of the window (fewer than the prefetch depth): fetched on the spot */
+#pragma unroll 1
+        for (; t > tracedBackTo; t--) {
+            double f, pm, py;
+            fetch(t, true, f, pm, py);
+            step(t, f, pm, py);
         }
         sh.item = nTotWin;
     }
@@ -826,6 +948,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
     const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD,
     SyState *states) {
     __shared__ Shared sh;
+    __shared__ Feed fd;
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
     SyState *state = states + idx;
@@ -835,7 +958,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
     __syncthreads();
     forward_window(it, P, anchors, track + trackBase[idx] * CP_ROW, events,
                    models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD,
-                   state, sh);
+                   state, sh, fd);
 }
 
 /* One workgroup per alignment: backward sweep + posterior decode of the window just described. */
@@ -942,7 +1065,14 @@ extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-extern "C" int cpecan_systolic_max_width(void) { return SY_P; }
+#ifdef SY_PROFILE
+extern "C" int cpecan_systolic_prof_fetch(unsigned long long *dst) {
+    unsigned long long zero[64] = {0};
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(sy_prof), sizeof(zero)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(sy_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
+}
+#endif
+extern "C" int cpecan_systolic_max_width(void) { return SY_P - 2 * SY_PREFETCH; }
 extern "C" int cpecan_systolic_rows(void) { return SY_R; }
 extern "C" int cpecan_systolic_ring_row_doubles(void) { return SY_R * SY_RING_VALUES * 64; }
 
