@@ -163,8 +163,14 @@ def main():
 
     if os.environ.get("CPECAN_PROF"):  # timing build (-DSY_PROFILE) only
         import ctypes
-        buf = (ctypes.c_ulonglong * 64)()
+        buf = (ctypes.c_ulonglong * 80)()
         if hasattr(cp.lib(), "cpecan_systolic_prof_fetch") and cp.lib().cpecan_systolic_prof_fetch(buf) == 0:
+            n = max(buf[72], 1)
+            sys.stderr.write("prof backward: %d windows, cycles per window: sweep %.0f totals %.0f | decode: pass0 %.0f sync %.0f prefix %.0f pass1 %.0f sync %.0f tail %.0f\n"
+                             % tuple([buf[72]] + [buf[64 + k] / n for k in range(8)]))
+            sys.stderr.write("prof backward: windows decoded by the scan %d, candidates per window %.0f\n" % (buf[73], buf[74] / n))
+            sys.stderr.write("prof backward: slowest window %d cycles (max over all windows; the device counter is cumulative over launches)\n" % buf[75])
+            sys.stderr.write("prof backward: window wall time (100 MHz ticks): mean %.0f max %d\n" % (buf[76] / n, buf[77]))
             for w in range(4):
                 v = [buf[w * 16 + k] for k in range(12)]
                 na, ni = max(v[10], 1), max(v[11], 1)

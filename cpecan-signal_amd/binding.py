@@ -21,6 +21,7 @@ MODE_POSTERIOR, MODE_EXPECTATIONS = 0, 1
 KERNEL_AUTO, KERNEL_GENERAL, KERNEL_SYSTOLIC = 0, 1, 2
 FLAG_DEBUG_DUMP = 1
 FLAG_UNBANDED = 2
+FLAG_SCAN_DECODE = 4
 NUM_KMERS = 4096
 MODEL_TABLE_LEN = 1 + NUM_KMERS * 5
 EXPECTATION_LEN = 9 + NUM_KMERS + 1

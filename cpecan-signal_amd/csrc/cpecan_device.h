@@ -64,7 +64,8 @@ struct DevItem {
 struct DevParams {
     double threshold;
     long long minDiags, tbDiags, expansion;
-    int mode, debug, unbanded, pad;
+    int mode, debug, unbanded;
+    int scanDecode; /* systolic kernels: decode posteriors by the full scan (diagnostic) */
     double logThrSlack; /* log(threshold) minus a safety margin: cells below it skip exp() */
 };
 

@@ -40,12 +40,12 @@ extern "C" int cpecan_systolic_launch_track(hipStream_t stream, const DevItem *i
                                             const unsigned short *kidx, const double *models,
                                             void *states, int maxLX);
 extern "C" int cpecan_systolic_launch_forward(hipStream_t stream, const DevItem *items, long long nItems,
-                                              DevParams P, const long long *anchors, const double *track,
+                                              DevParams P, const void *bandTab, const double *track,
                                               const long long *trackBase, const double *events,
                                               const double *models, double *Fring,
                                               long long ringDoubles, int ringD, void *states);
 extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem *items, long long nItems,
-                                               DevParams P, const long long *anchors, const double *track,
+                                               DevParams P, const void *bandTab, const double *track,
                                                const long long *trackBase, const double *models,
                                                double *Fring, long long ringDoubles, int ringD,
                                                void *states, long long *pairs, double *pairLogp,
@@ -124,6 +124,7 @@ struct cpecan_batch {
     DevBuf<double> expect;
     DevBuf<int> workCounter;
     DevBuf<char> syStates, syScratch;
+    DevBuf<int> bandTab; /* systolic kernels: (first, last) matrix column of every diagonal of every item */
     long long scratchBytes = 0;
     int nWindows = 0;
     DevBuf<double> track;
@@ -411,6 +412,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     b->P.mode = mode;
     b->P.debug = (flags & CPECAN_FLAG_DEBUG_DUMP) ? 1 : 0;
     b->P.unbanded = unbanded ? 1 : 0;
+    b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
     int useKernel = kernel;
@@ -480,6 +482,19 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
         if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
+        {   /* the band as matrix columns per diagonal, from the x-y intervals built above */
+            std::vector<int> tab(hL.size() * 2);
+            for (int64_t i = 0; i < nItems; i++) {
+                const DevItem &d = hItems[(size_t) i];
+                const long long nDiag = d.lX + d.lY + 1;
+                for (long long k = 0; k < nDiag; k++) {
+                    tab[(size_t) (d.diagBase + k) * 2] = (int) ((k + hL[(size_t) (d.diagBase + k)]) / 2);
+                    tab[(size_t) (d.diagBase + k) * 2 + 1] = (int) ((k + hR[(size_t) (d.diagBase + k)]) / 2);
+                }
+            }
+            B_TRY(b->bandTab.alloc(tab.size() + 2));
+            B_TRY(hipMemcpy(b->bandTab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
         b->scratchBytes = (cpecan_systolic_scratch_bytes(b->ringD) + 63) / 64 * 64;
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
@@ -539,13 +554,13 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                               b->maxLX);
         HIP_TRY(hipEventRecord(b->evStage[0], c->stream));
         for (int w = 0; w < b->nWindows && rc == 0; w++) {
-            rc = cpecan_systolic_launch_forward(c->stream, b->items.p, b->nItems, b->P, b->anchors.p,
+            rc = cpecan_systolic_launch_forward(c->stream, b->items.p, b->nItems, b->P, b->bandTab.p,
                                                 b->track.p, b->trackBase.p, b->events.p, c->models.p,
                                                 b->Fstore.p, b->ringDoubles, b->ringD, b->syStates.p);
             HIP_TRY(hipEventRecord(b->evStage[(size_t) (2 * w + 1)], c->stream));
             if (rc == 0)
                 rc = cpecan_systolic_launch_backward(c->stream, b->items.p, b->nItems, b->P,
-                                                     b->anchors.p, b->track.p, b->trackBase.p,
+                                                     b->bandTab.p, b->track.p, b->trackBase.p,
                                                      c->models.p, b->Fstore.p, b->ringDoubles, b->ringD,
                                                      b->syStates.p, b->pairs.p, b->pairLogp.p,
                                                      b->totXay.p, b->totVal.p, b->syScratch.p,

@@ -36,15 +36,21 @@
 #define SY_P (64 * SY_R)
 #define SY_NPRM 17
 #define SY_PREFETCH 4     /* diagonals the backward sweep fetches ahead (== its unroll factor) */
+#define SY_CAND_SLACK 0.25 /* candidates: cells within this (log units) below the posterior threshold */
+#define SY_CAND_PER_DIAG 4 /* candidate capacity per wave, in records per ring diagonal */
+#define SY_DECODE_U 2     /* diagonals per batch of the posterior decode */
 #define SY_RING_VALUES 5 /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
 
 #ifdef SY_PROFILE
 /* timing build only: cycles per section of the forward step, summed over all waves */
-__device__ unsigned long long sy_prof[4 * 16];
+__device__ unsigned long long sy_prof[80];
 #define PROF_DECL unsigned long long prof_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tprev_ = __builtin_readcyclecounter(); bool pact_ = false;
 #define PROF(k) { const unsigned long long now_ = __builtin_readcyclecounter(); if (pact_) prof_[k] += now_ - tprev_; else prof_[9] += now_ - tprev_; tprev_ = now_; }
 #define PROF_ACTIVE(a) { pact_ = (a); if (pact_) prof_[10]++; else prof_[11]++; }
 #define PROF_FENCE(x) asm volatile("" : "+v"(x));
+#define BPROF_DECL unsigned long long bt_[9]; for (int k_ = 0; k_ < 9; k_++) bt_[k_] = 0; bt_[0] = __builtin_readcyclecounter(); const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#define BPROF(k) bt_[k] = __builtin_readcyclecounter();
+#define BPROF_FLUSH if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&sy_prof[64 + k_], bt_[k_ + 1] - bt_[k_]); atomicMax(&sy_prof[75], bt_[8] - bt_[0]); { const unsigned long long rd_ = __builtin_amdgcn_s_memrealtime() - rt0_; atomicAdd(&sy_prof[76], rd_); atomicMax(&sy_prof[77], rd_); } atomicAdd(&sy_prof[72], 1ull); atomicAdd(&sy_prof[73], (unsigned long long) (sh.scan != 0)); atomicAdd(&sy_prof[74], (unsigned long long) (sh.cnt[1][0][0] + sh.cnt[1][1][0] + sh.cnt[1][2][0] + sh.cnt[1][3][0])); }
 #define PROF_FLUSH(wave) if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; k_++) atomicAdd(&sy_prof[(wave) * 16 + k_], prof_[k_]); }
 #else
 #define PROF_DECL
@@ -52,6 +58,9 @@ __device__ unsigned long long sy_prof[4 * 16];
 #define PROF_ACTIVE(a)
 #define PROF_FENCE(x)
 #define PROF_FLUSH(wave)
+#define BPROF_DECL
+#define BPROF(k)
+#define BPROF_FLUSH
 #endif
 
 namespace {
@@ -65,6 +74,7 @@ struct Shared {
     double total;
     int cnt[2][SY_R][2];     /* aligned-pair counts per wave, double-buffered */
     int item;
+    int scan;                /* this window's posteriors must be decoded by the full scan */
 };
 
 /*
@@ -113,7 +123,7 @@ __device__ __forceinline__ long long uni64(long long v) {
 __device__ __forceinline__ DevItem uniform_item(const DevItem &s) {
     DevItem d;
     d.lX = uni64(s.lX); d.lY = uni64(s.lY); d.xOff = uni64(s.xOff); d.yOff = uni64(s.yOff);
-    d.anchorOff = uni64(s.anchorOff); d.nAnchors = uni64(s.nAnchors); d.diagBase = 0; d.cellBase = 0;
+    d.anchorOff = uni64(s.anchorOff); d.nAnchors = uni64(s.nAnchors); d.diagBase = uni64(s.diagBase); d.cellBase = 0;
     d.nCells = 0; d.pairBase = uni64(s.pairBase); d.pairCap = uni64(s.pairCap);
     d.totBase = uni64(s.totBase); d.totCap = uni64(s.totCap); d.bwsBase = 0;
     d.model = uni(s.model); d.raggedL = uni(s.raggedL); d.raggedR = uni(s.raggedR); d.maxWidth = 0;
@@ -174,35 +184,32 @@ __device__ __forceinline__ double lgauss(double x, double mu, double sd, double 
     return K + (-0.5 * a * a);
 }
 
-struct Band {
-    const long long *an;
-    int nA, lX, lY, e2; /* e2 = diagonalExpansion / 2 */
-    int ai, pxay, nxay, xLo, xHi, yLo, yHi;
-
-    __device__ __forceinline__ static int clampi(int z, int hi) { return z < 0 ? 0 : (z > hi ? hi : z); }
-    /* rectangle between anchor a-1 and anchor a (a == nA: up to the end point): the closed form of
-     * band_construct, impl/pairwiseAligner.c:132-184 (see cpecan_geometry.c) */
-    __device__ __forceinline__ void load(int a) {
-        int px = 0, py = 0, nx = lX, ny = lY;
-        if (a > 0) { px = (int) an[2 * (a - 1)] + 1; py = (int) an[2 * (a - 1) + 1] + 1; }
-        if (a < nA) { nx = (int) an[2 * a] + 1; ny = (int) an[2 * a + 1] + 1; }
-        ai = uni(a);
-        pxay = uni(px + py);
-        nxay = uni(nx + ny);
-        xLo = uni(clampi(px - e2, lX));
-        yLo = uni(clampi(py - e2, lY));
-        xHi = uni(clampi(nx + e2, lX));
-        yHi = uni(clampi(ny + e2, lY));
-    }
-    __device__ __forceinline__ void range(int d, int &xmin, int &xmax) {
-        if (d <= 0) { xmin = 0; xmax = 0; return; }
-        while (d > nxay && ai < nA) load(ai + 1);
-        while (d <= pxay && ai > 0) load(ai - 1);
-        int a = d - yHi, b = d - yLo;
-        xmin = a > xLo ? a : xLo;
-        xmax = b < xHi ? b : xHi;
-    }
+/*
+ * The band: first and last matrix column (k-mer index) of every anti-diagonal, one int2 per diagonal
+ * in HBM, built by the host from band_construct's output (cpecan_hip.hip).  The sweeps read it
+ * through a 128-entry LDS ring that the whole workgroup refills every 32 diagonals, so a step costs
+ * one LDS read instead of walking the anchor rectangles on the scalar unit.
+ */
+#define SY_BAND_RING 128
+struct BandFeed {
+    int2 e[SY_BAND_RING];
 };
+/* entries of diagonals lo..hi (clipped to 0..D) into the ring; all 256 threads */
+__device__ __forceinline__ void band_stage(BandFeed &bf, const int2 *__restrict__ tab, int D, int lo, int hi) {
+    for (int d = lo + (int) threadIdx.x; d <= hi; d += 256)
+        if (d >= 0 && d <= D) bf.e[d & (SY_BAND_RING - 1)] = tab[d];
+}
+__device__ __forceinline__ void band_get(const BandFeed &bf, int d, int &xmin, int &xmax) {
+    const int2 v = bf.e[d & (SY_BAND_RING - 1)];
+    xmin = uni(v.x);
+    xmax = uni(v.y);
+}
+/* straight from HBM (start-up paths only) */
+__device__ __forceinline__ void band_load(const int2 *__restrict__ tab, int d, int &xmin, int &xmax) {
+    const int2 v = tab[d > 0 ? d : 0];
+    xmin = uni(v.x);
+    xmax = uni(v.y);
+}
 
 /* does wave w hold an in-band slot: waves (xmin>>6) .. (xmax>>6), modulo R */
 __device__ __forceinline__ bool row_active(int w, int xmin, int xmax) {
@@ -260,6 +267,24 @@ struct EvChunk {
         n = bcast(an, e - base);
     }
 };
+
+/* logAdd-fold of one value per lane into acc (wave-uniform in and out), lanes in ascending order;
+ * visits only the lanes that can change the running value (cp_wave_seq_fold with the LDS-table
+ * logAdd, so that no coefficient constants occupy registers around the call) */
+__device__ __forceinline__ double wave_fold(double acc, double v, const double *coef) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long after = ~0ull;
+#pragma unroll 1
+    for (;;) {
+        const bool eff = ((after >> lane) & 1ull) && (v > CP_NEG_INF) && !(acc - v >= 7.5);
+        const unsigned long long m = __ballot(eff);
+        if (m == 0ull) break;
+        const int first = __ffsll((long long) m) - 1;
+        acc = ladd(acc, bcast(v, first), coef);
+        after = first >= 63 ? 0ull : (~0ull << (first + 1));
+    }
+    return acc;
+}
 
 struct ItemOut {
     long long *pairs;
@@ -354,22 +379,12 @@ __device__ __forceinline__ Geometry make_geometry(double *ring, int ringD) {
     return g;
 }
 
-__device__ __forceinline__ void make_band(Band &band, const DevItem &it, const DevParams &P,
-                                          const long long *__restrict__ anchors, int ai) {
-    band.an = anchors + 2 * it.anchorOff;
-    band.nA = (int) it.nAnchors;
-    band.lX = (int) it.lX;
-    band.lY = (int) it.lY;
-    band.e2 = (int) (P.expansion / 2);
-    band.load(ai);
-}
-
 /* Forward sweep of one alignment from its saved diagonal up to (and including) the next traceback
  * point; describes the window for the backward kernel. */
-__device__ void forward_window(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
+__device__ void forward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
                                const double *__restrict__ track, const double *__restrict__ events,
                                const double *__restrict__ model, double *ring, int ringD,
-                               SyState *state, Shared &sh, Feed &fd) {
+                               SyState *state, Shared &sh, Feed &fd, BandFeed &bf) {
     const Geometry g = make_geometry(ring, ringD);
     const int lane = g.lane, wave = g.wave;
     const int lX = (int) it.lX, lY = (int) it.lY, D = lX + lY;
@@ -385,8 +400,6 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
     const int d0 = uni(state->d);
     int tracedBackTo = uni(state->tracedBackTo);
     long long cells = uni64(state->cells);
-    Band band;
-    make_band(band, it, P, anchors, uni(state->bandAi));
 
     /* ---- per-slot state (this lane's k-mer) ---- */
     int xs;
@@ -422,8 +435,8 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
     } else {
         /* resume at d0: constants of the k-mers in the band, forward cells of d0 and d0-1, events */
         int xmin, xmax, qmin, qmax;
-        band.range(d0 - 1, qmin, qmax);
-        band.range(d0, xmin, xmax);
+        band_load(bandTab, d0 - 1, qmin, qmax);
+        band_load(bandTab, d0, xmin, xmax);
         xs = wave * 64 + lane;
         xs += ((xmin - xs + SY_P - 1) / SY_P) * SY_P; /* the k-mer >= xmin that lives in this slot */
         const bool v = xs <= xmax;
@@ -457,7 +470,8 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
             /* stage what the next two blocks of diagonals can ask for: the top cell's event index
              * d-xmin-1 and the entering k-mer xin each advance by at most one per diagonal */
             int fxmin, fxmax;
-            band.range(db, fxmin, fxmax);
+            band_load(bandTab, db, fxmin, fxmax);
+            band_stage(bf, bandTab, D, db, db + 2 * SY_FEED - 1);
             const int evTo = db - fxmin - 1 + 3 * SY_FEED, rowTo = xin + 2 * SY_FEED;
 #pragma unroll 1
             for (int i = evHi * 2 + (int) threadIdx.x; i < evTo * 2; i += 256) {
@@ -477,12 +491,12 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
 #pragma unroll 1
         for (int d = db; d <= dbEnd; d++) {
         PROF(0)
+        PROF(1)
+        lds_barrier(); /* also orders the band/event/k-mer staging above before the reads below */
         int xmin, xmax;
-        band.range(d, xmin, xmax);
+        band_get(bf, d, xmin, xmax);
         cells += xmax - xmin + 1;
         PROF_ACTIVE(row_active(wave, xmin, xmax))
-        PROF(1)
-        lds_barrier();
         PROF(2)
         const double *xb = sh.xch[(d - 1) & 1][g.waveBelow];
         const double rm = shr1(xb[0], Fm), rx = shr1(xb[1], Fx), ry = shr1(xb[2], Fy);
@@ -561,7 +575,6 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const long
             if (threadIdx.x == 0) {
                 const int from = d - (atEnd ? 0 : (int) P.tbDiags + 1);
                 state->d = d;
-                state->bandAi = band.ai;
                 state->finished = atEnd ? 1 : 0;
                 state->winValid = 1;
                 state->winTop = d;
@@ -604,13 +617,14 @@ struct WinTotal {
  *  D  diagonalCalculationPosteriorMatchProbs (:756-795) for the window: hits are counted per
  *     diagonal, prefix-summed in emission order (diagonals descending, x-y ascending) and written.
  */
-__device__ void backward_window(const DevItem &it, const DevParams &P, const long long *__restrict__ anchors,
+__device__ void backward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
                                 const double *__restrict__ track, const double *__restrict__ model,
                                 double *ring, int ringD, SyState *state, ItemOut &out, Shared &sh,
-                                int *cntBuf, WinTotal *wtot, double *vw) {
+                                BandFeed &bf, int *cntBuf, WinTotal *wtot, double *vw,
+                                unsigned long long *msk, int2 *candKx, double *candFb) {
     const Geometry g = make_geometry(ring, ringD);
     const int lane = g.lane, wave = g.wave;
-    const int lX = (int) it.lX;
+    const int lX = (int) it.lX, D = (int) (it.lX + it.lY);
     const double *cf = sh.coef;
     const bool hasSwitchX = model[T_GAP_SWITCH_TO_X] > CP_NEG_INF;
     double T[9];
@@ -619,17 +633,29 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
 
     const int dTop = uni(state->winTop), tracedBackFrom = uni(state->winFrom), tracedBackTo = uni(state->winTo);
     const bool atEnd = uni(state->winAtEnd) != 0;
-    const int bandAiTop = uni(state->bandAi);
-    Band band;
-    make_band(band, it, P, anchors, bandAiTop);
+    BPROF_DECL
+    const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
+    const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
+    band_stage(bf, bandTab, D, dTop - (SY_BAND_RING - 1), dTop);
+    if (threadIdx.x == 0) sh.scan = 0;
+    __syncthreads();
+    /* Candidates for the posterior decode, collected by the sweep: a cell whose F.match + B.match
+     * lies within SY_CAND_SLACK of the threshold, measured against an estimate of the window's
+     * totalProbability taken at its first refresh.  Phase T checks every exact total of the window
+     * against the estimate; if one strays (or a list overflows) the window is decoded by the scan. */
+    const int candCap = SY_CAND_PER_DIAG * ringD;
+    int2 *const myKx = candKx + (long long) wave * candCap;
+    double *const myFb = candFb + (long long) wave * candCap;
+    int nCand = 0;
+    double candThr = CP_NEG_INF, totEst = CP_NEG_INF;
 
     /* ------------------------------ phase S: the sweep back ------------------------------ */
     {
         int bxmin, bxmax;                 /* band of diagonal t   */
-        band.range(dTop, bxmin, bxmax);
+        band_get(bf, dTop, bxmin, bxmax);
         int nxmin = bxmin, nxmax = bxmax; /* band of diagonal t+1 */
         int pxmin, pxmax;                 /* band of diagonal t-1 */
-        band.range(dTop - 1, pxmin, pxmax);
+        band_get(bf, dTop - 1, pxmin, pxmax);
 
         int xs = wave * 64 + lane;        /* backward representative: xmax-P < x <= xmax */
         xs += ((bxmin - xs + SY_P - 1) / SY_P) * SY_P;
@@ -743,13 +769,15 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
             }
 
             if (t <= tracedBackFrom) {
+                const double fb = fMc + Bm;
                 if (calcs++ % 10 == 0) {
                     /* per-cell terms of diagonalCalculationTotalProbability (:736-754), folded in
                      * phase T: v = cell_dotProduct(forward[t], backward[t]) (:391-397) ... */
                     const bool second = t + 1 <= dTop;
+                    double v = CP_NEG_INF, w = CP_NEG_INF;
                     if (tvalid) {
                         const double fx = *g.rp(t, 1), fy = *g.rp(t, 2);
-                        double v = fMc + Bm;
+                        v = fb;
                         v = ladd(v, fx + Bx, cf);
                         v = ladd(v, fy + By, cf);
                         vw[((long long) nTotWin * 2 + 0) * SY_P + wave * 64 + lane] = v;
@@ -767,7 +795,21 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                         double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
                         mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);
                         mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]), cf);
-                        vw[((long long) nTotWin * 2 + 1) * SY_P + wave * 64 + lane] = mm + BmPrev;
+                        w = mm + BmPrev;
+                        vw[((long long) nTotWin * 2 + 1) * SY_P + wave * 64 + lane] = w;
+                    }
+                    if (nTotWin == 0) {
+                        /* the estimate: the same terms folded in any order (it only steers the
+                         * candidate test; the exact, ordered folds are phase T's) */
+                        double acc = wave_fold(CP_NEG_INF, v, cf);
+                        acc = wave_fold(acc, w, cf);
+                        if (lane == 0) sh.vbuf[wave] = acc;
+                        lds_barrier();
+                        double est = sh.vbuf[0];
+#pragma unroll
+                        for (int q = 1; q < SY_R; q++) est = ladd(est, sh.vbuf[q], cf);
+                        totEst = est;
+                        candThr = est + (P.logThrSlack - SY_CAND_SLACK);
                     }
                     if (threadIdx.x == 0) {
                         WinTotal w;
@@ -781,12 +823,22 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
                 /* exponent of the posterior, less the total: parked in the emission slot this diagonal
                  * no longer needs (the forward cells themselves stay intact: the next window's
                  * refresh at its lowest diagonal reads forward[tracedBackFrom], :944,:985) */
-                if (tvalid) *g.rp(t, 3) = fMc + Bm;
+                if (tvalid) *g.rp(t, 3) = fb;
+                const bool cand = tvalid && fb >= candThr && fb > CP_NEG_INF;
+                const unsigned long long cm = __ballot(cand);
+                if (cm != 0ull) {
+                    const int ci = nCand + __popcll(cm & ((1ull << lane) - 1ull));
+                    if (cand && ci < candCap) {
+                        myKx[ci] = make_int2(tPost0 - t, xs);
+                        myFb[ci] = fb;
+                    }
+                    nCand += __popcll(cm);
+                }
             }
             pmPrev = pmc;
             nxmin = bxmin; nxmax = bxmax;
             bxmin = pxmin; bxmax = pxmax;
-            if (t - 2 >= tracedBackTo) band.range(t - 2, pxmin, pxmax);
+            if (t - 2 >= tracedBackTo) band_get(bf, t - 2, pxmin, pxmax);
         };
         double q0F, q0Pm, q0Py, q1F, q1Pm, q1Py, q2F, q2Pm, q2Py, q3F, q3Pm, q3Py;
         {
@@ -796,9 +848,13 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
             fetch(dTop - 2, want, q2F, q2Pm, q2Py);
             fetch(dTop - 3, want, q3F, q3Pm, q3Py);
         }
-        int t = dTop;
+        int t = dTop, bandLo = dTop - (SY_BAND_RING - 1); /* lowest diagonal whose band is staged */
 #pragma unroll 1
         for (; t - (SY_PREFETCH - 1) > tracedBackTo; t -= SY_PREFETCH) {
+            if (t - 64 < bandLo) { /* 32 more band entries, long before the sweep reads them */
+                band_stage(bf, bandTab, D, bandLo - 32, bandLo - 1);
+                bandLo -= 32;
+            }
             step(t, q0F, q0Pm, q0Py);
             step(t - 1, q1F, q1Pm, q1Py);
             step(t - 2, q2F, q2Pm, q2Py);
@@ -812,12 +868,13 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
             step(t, f, pm, py);
         }
         sh.item = nTotWin;
+        if (lane == 0) sh.cnt[1][wave][0] = nCand;
+        if (nCand > candCap) sh.scan = 1;
     }
     __syncthreads(); /* the ring rows written above are read by other waves below */
     const int nTotWin = sh.item;
-    const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
-    const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
 
+    BPROF(1)
     /* ------------------------------ phase T: the totals ------------------------------ */
 #pragma unroll 1
     for (int k = threadIdx.x; k < 2 * nTotWin; k += 256) {
@@ -843,6 +900,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
             double tot = acc;
             if (w.second) tot = cp_logAdd(acc, sh.vbuf[threadIdx.x + 1]);
             wtot[k >> 1].total = tot;
+            if (!(fabs(tot - totEst) <= SY_CAND_SLACK)) sh.scan = 1; /* also catches NaN and infinities */
             const long long o = out.nTot + (k >> 1);
             if (o < out.totCap) {
                 out.totXay[o] = w.t;
@@ -853,64 +911,41 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
     out.nTot += nTotWin;
     __syncthreads();
 
+    BPROF(2)
     /* ------------------------------ phase D: the aligned pairs ------------------------------ */
+    /*
+     * Two passes over the window's diagonals; in both, every wave walks ALL diagonals but looks only
+     * at its own 64 slots (the sweep's mapping), SY_DECODE_U diagonals per iteration with their loads
+     * issued together, so HBM latency is paid once per batch instead of once per diagonal.
+     *   pass 0  marks the hits: one 64-bit lane mask per (diagonal, wave) to scratch;
+     *   prefix  hits per diagonal -> exclusive offsets in emission order (diagonals descending);
+     *   pass 1  re-reads only the hit lanes, ranks each hit inside its diagonal by k-mer index
+     *           (the reference's x-y order) from the four masks, and writes the triples.
+     */
     if (P.mode == 0 && nPost > 0) {
-        int *const cnt = cntBuf, *const off = cntBuf + ringD;
-        for (int pass = 0; pass < 2; pass++) {
-            make_band(band, it, P, anchors, bandAiTop);
-#pragma unroll 1
-            for (int k = wave; k < nPost; k += SY_R) {
-                const int t = tPost0 - k;
-                int xmin, xmax;
-                band.range(t, xmin, xmax);
-                long long base = 0;
-                if (pass) {
-                    if (uni(cnt[k]) == 0) continue;
-                    base = out.nPairs + uni(off[k]);
-                }
-                const double total = wtot[k / 10].total;
-                const int xlo = xmin > 1 ? xmin : 1, xhi = xmax < t - 1 ? xmax : t - 1;
-                /* F.match + B.match of this diagonal, parked by the sweep in ring slot 3; rows are
-                 * walked in ascending k-mer order, which is the reference's x-y order */
-                const double *row = ring + (long long) (t & g.ringMask) * (SY_R * SY_RING_VALUES * 64)
-                                    + 3 * 64 + lane;
-                int n = 0;
-#pragma unroll 1
-                for (int ra = xmin >> 6; ra <= (xmax >> 6); ra++) {
-                    const int x = ra * 64 + lane;
-                    const double e = row[(ra & (SY_R - 1)) * (SY_RING_VALUES * 64)] - total;
-                    const bool ok = x >= xlo && x <= xhi && e >= P.logThrSlack;
-                    if (__ballot(ok) == 0ull) continue;
-                    double p = 0.0;
-                    bool hit = false;
-                    if (ok) {
-                        p = exp(e);
-                        hit = p >= P.threshold;
-                    }
-                    const unsigned long long m = __ballot(hit);
-                    if (pass && hit) {
-                        const long long idx = base + n + __popcll(m & ((1ull << lane) - 1ull));
-                        if (idx < out.pairCap) {
-                            if (p > 1.0) p = 1.0;
-                            long long *o = out.pairs + idx * 3;
-                            o[0] = (long long) floor(p * 10000000.0);
-                            o[1] = x - 1;
-                            o[2] = t - x - 1;
-                            out.logp[idx] = e;
-                        }
-                    }
-                    n += __popcll(m);
-                }
-                if (!pass && lane == 0) cnt[k] = n;
-            }
-            __syncthreads();
-            if (!pass) {
-                /* exclusive prefix over the window's diagonals, in emission order */
+        int *const off = cntBuf;
+        auto lane64 = [&](const unsigned long long v, const int src) __attribute__((always_inline)) {
+            const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) v, src);
+            const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (v >> 32), src);
+            return ((unsigned long long) hi << 32) | lo;
+        };
+        /* masks are written by one wave (or by atomics) and read by the others: read them at agent
+         * scope so that a line cached by this CU earlier cannot be served stale */
+        auto ld_msk = [&](const long long i) __attribute__((always_inline)) {
+            return __hip_atomic_load(msk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto hits_of = [&](const int k) __attribute__((always_inline)) {
+            return __popcll(ld_msk(k * 4ll)) + __popcll(ld_msk(k * 4ll + 1)) + __popcll(ld_msk(k * 4ll + 2))
+                   + __popcll(ld_msk(k * 4ll + 3));
+        };
+        auto prefix = [&]() __attribute__((always_inline)) {
+                /* hits per diagonal from the masks; exclusive prefix in emission order */
                 const int per = (nPost + 255) / 256;
                 const int b0 = threadIdx.x * per, b1 = min(b0 + per, nPost);
                 int sum = 0;
 #pragma unroll 1
-                for (int k = b0; k < b1; k++) sum += cnt[k];
+                for (int k = b0; k < b1; k++)
+                    sum += hits_of(k);
                 int *part = (int *) sh.wbuf;
                 part[threadIdx.x] = sum;
                 __syncthreads();
@@ -929,26 +964,213 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const lon
 #pragma unroll 1
                 for (int k = b0; k < b1; k++) {
                     off[k] = o;
-                    o += cnt[k];
+                    o += hits_of(k);
                 }
                 __syncthreads();
+                BPROF(5)
+        };
+        const bool scan = P.scanDecode != 0 || sh.scan != 0;
+        if (!scan) {
+            /*
+             * Decode from the sweep's candidate lists (a few cells per diagonal instead of the whole
+             * band): every wave walks its own list twice.  First the exact test of
+             * diagonalCalculationPosteriorMatchProbs marks the hits in the (diagonal, wave) masks, then,
+             * with the per-diagonal offsets known, each hit is ranked inside its diagonal and written.
+             */
+            const int nC = sh.cnt[1][wave][0];
+            for (int i = threadIdx.x; i < nPost * 4; i += 256) msk[i] = 0ull;
+            __syncthreads();
+            for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+                for (int i = lane; i < nC; i += 64) {
+                    const int2 kx = myKx[i];
+                    const int k = kx.x, x = kx.y, t = tPost0 - k;
+                    const double ee = myFb[i] - wtot[k / 10].total;
+                    if (!(x >= 1 && x <= t - 1 && ee >= P.logThrSlack)) continue;
+                    double p = exp(ee);
+                    if (!(p >= P.threshold)) continue;
+                    if (!pass) {
+                        atomicOr(msk + k * 4ll + wave, 1ull << (x & 63));
+                        continue;
+                    }
+                    /* rank inside the diagonal, as in the scan below */
+                    const int xmin = bandTab[t].x;
+                    const int W0 = (xmin >> 6) & (SY_R - 1), s0 = xmin & 63, c = (wave - W0) & (SY_R - 1);
+                    const unsigned long long fromS0 = ~0ull << s0, below = (1ull << lane) - 1ull;
+                    const unsigned long long own = ld_msk(k * 4ll + wave);
+                    int first = 0, beforeMine = 0, others = 0;
+#pragma unroll
+                    for (int w2 = 0; w2 < SY_R; w2++) {
+                        const unsigned long long m2 = ld_msk(k * 4ll + w2);
+                        const int c2 = (w2 - W0) & (SY_R - 1);
+                        if (c2 == 0) first = __popcll(m2 & fromS0);
+                        else {
+                            others += __popcll(m2);
+                            if (c2 < c) beforeMine += __popcll(m2);
+                        }
+                    }
+                    const int xl = x & 63;
+                    const unsigned long long belowX = (1ull << xl) - 1ull;
+                    int rank;
+                    if (c != 0) rank = first + beforeMine + __popcll(own & belowX);
+                    else if (xl >= s0) rank = __popcll(own & fromS0 & belowX);
+                    else rank = first + others + __popcll(own & belowX);
+                    const long long idx = out.nPairs + off[k] + rank;
+                    if (idx < out.pairCap) {
+                        if (p > 1.0) p = 1.0;
+                        long long *o = out.pairs + idx * 3;
+                        o[0] = (long long) floor(p * 10000000.0);
+                        o[1] = x - 1;
+                        o[2] = t - x - 1;
+                        out.logp[idx] = ee;
+                    }
+                    (void) below;
+                }
+                if (!pass) { BPROF(3) } else { BPROF(6) }
+                __syncthreads();
+                if (!pass) { BPROF(4) } else { BPROF(7) }
+                if (!pass) prefix();
             }
+        } else
+        for (int pass = 0; pass < 2; pass++) {
+            int xs = wave * 64 + lane; /* this slot's k-mer: the one in (xmax-P, xmax] */
+            {
+                int a, b;
+                band_load(bandTab, tPost0, a, b);
+                xs += ((a - xs + SY_P - 1) / SY_P) * SY_P;
+                if (xs > b) xs -= SY_P;
+            }
+            /* pass 1 works from the masks and offsets of a batch, fetched one batch ahead, one
+             * (diagonal, wave) mask per lane 0..4U-1 and one offset per lane 0..U-1 */
+            unsigned long long mvNext = 0ull;
+            int ovNext = 0;
+            /* the band of a batch's diagonals: one entry per lane 0..U-1, also a batch ahead */
+            int2 bvNext = make_int2(1, 0);
+            if (lane < SY_DECODE_U && lane < nPost) bvNext = bandTab[tPost0 - lane];
+            if (pass) {
+                const int kk = lane >> 2;
+                if (lane < 4 * SY_DECODE_U && kk < nPost) mvNext = ld_msk(kk * 4ll + (lane & 3));
+                if (lane < SY_DECODE_U && lane < nPost) ovNext = off[lane];
+            }
+#pragma unroll 1
+            for (int k0 = 0; k0 < nPost; k0 += SY_DECODE_U) {
+                const unsigned long long mv = mvNext;
+                const int ov = ovNext;
+                const int2 bv = bvNext;
+                int xminA[SY_DECODE_U], xmaxA[SY_DECODE_U], xsA[SY_DECODE_U];
+                double e[SY_DECODE_U], tot[SY_DECODE_U];
+                unsigned long long own[SY_DECODE_U];
+#pragma unroll
+                for (int j = 0; j < SY_DECODE_U; j++) {
+                    const int k = k0 + j, t = tPost0 - k;
+                    const bool live = k < nPost;
+                    xminA[j] = __builtin_amdgcn_readlane(bv.x, j);
+                    xmaxA[j] = __builtin_amdgcn_readlane(bv.y, j);
+                    if (live && xs > xmaxA[j]) xs -= SY_P;
+                    xsA[j] = xs;
+                    bool want = live && xs >= xminA[j];
+                    own[j] = 0ull;
+                    if (pass) {
+                        own[j] = lane64(mv, j * 4 + wave);
+                        want = ((own[j] >> lane) & 1ull) != 0ull;
+                    }
+                    /* F.match + B.match, parked by the sweep in ring slot 3 */
+                    const double *p = want ? g.rp(t, 3) : g.rw;
+                    e[j] = *p;
+                    tot[j] = wtot[(live ? k : 0) / 10].total;
+                }
+                {
+                    const int ko = k0 + SY_DECODE_U + lane;
+                    bvNext = make_int2(1, 0);
+                    if (lane < SY_DECODE_U && ko < nPost) bvNext = bandTab[tPost0 - ko];
+                }
+                if (pass) {
+                    const int kk = k0 + SY_DECODE_U + (lane >> 2), ko = k0 + SY_DECODE_U + lane;
+                    mvNext = 0ull;
+                    ovNext = 0;
+                    if (lane < 4 * SY_DECODE_U && kk < nPost) mvNext = ld_msk(kk * 4ll + (lane & 3));
+                    if (lane < SY_DECODE_U && ko < nPost) ovNext = off[ko];
+                }
+#pragma unroll
+                for (int j = 0; j < SY_DECODE_U; j++) {
+                    const int k = k0 + j, t = tPost0 - k, x = xsA[j];
+                    const double ee = e[j] - tot[j];
+                    if (!pass) {
+                        if (k < nPost) {
+                            const int xlo = xminA[j] > 1 ? xminA[j] : 1, xhi = xmaxA[j] < t - 1 ? xmaxA[j] : t - 1;
+                            const bool ok = x >= xlo && x <= xhi && ee >= P.logThrSlack;
+                            unsigned long long m = 0ull;
+                            if (__ballot(ok) != 0ull) {
+                                bool hit = false;
+                                if (ok) hit = exp(ee) >= P.threshold;
+                                m = __ballot(hit);
+                            }
+                            if (lane == 0) msk[k * 4 + wave] = m;
+                        }
+                    } else if (own[j] != 0ull) {
+                        /* hits of this diagonal with a smaller k-mer index: the band starts in wave W0 at
+                         * lane s0 and wraps around the four waves, possibly back into W0's low lanes */
+                        const int W0 = (xminA[j] >> 6) & (SY_R - 1), s0 = xminA[j] & 63;
+                        const unsigned long long fromS0 = ~0ull << s0;
+                        const int c = (wave - W0) & (SY_R - 1);
+                        int first = 0, beforeMine = 0, others = 0;
+#pragma unroll
+                        for (int w2 = 0; w2 < SY_R; w2++) {
+                            const unsigned long long m2 = lane64(mv, j * 4 + w2);
+                            const int c2 = (w2 - W0) & (SY_R - 1);
+                            if (c2 == 0) first = __popcll(m2 & fromS0);
+                            else {
+                                others += __popcll(m2);
+                                if (c2 < c) beforeMine += __popcll(m2);
+                            }
+                        }
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        int rank;
+                        if (c != 0) rank = first + beforeMine + __popcll(own[j] & below);
+                        else if (lane >= s0) rank = __popcll(own[j] & fromS0 & below);
+                        else rank = first + others + __popcll(own[j] & below);
+                        const long long idx = out.nPairs + __builtin_amdgcn_readlane(ov, j) + rank;
+                        if (((own[j] >> lane) & 1ull) != 0ull && idx < out.pairCap) {
+                            double p = exp(ee);
+                            if (p > 1.0) p = 1.0;
+                            long long *o = out.pairs + idx * 3;
+                            o[0] = (long long) floor(p * 10000000.0);
+                            o[1] = x - 1;
+                            o[2] = t - x - 1;
+                            out.logp[idx] = ee;
+                        }
+                    }
+                }
+            }
+            if (!pass) { BPROF(3) } else { BPROF(6) }
+            __syncthreads();
+            if (!pass) { BPROF(4) } else { BPROF(7) }
+            if (!pass) prefix();
         }
         out.nPairs += sh.cnt[0][0][0];
     }
+    BPROF(8)
+    BPROF_FLUSH
 }
 
 } // namespace
 
+/* per-alignment scratch: [hit offsets | window totals | their terms | hit masks | candidate lists] */
+static __host__ __device__ long long scratch_cand_offset(int ringD) {
+    return 2ll * ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * SY_P * sizeof(double))
+           + 4ll * ringD * sizeof(unsigned long long);
+}
+
 /* One workgroup per alignment: forward sweep up to its next traceback point. */
 extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
-    const long long *__restrict__ anchors, const double *__restrict__ track,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
     const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD,
     SyState *states) {
     __shared__ Shared sh;
     __shared__ Feed fd;
+    __shared__ BandFeed bf;
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
     SyState *state = states + idx;
@@ -956,19 +1178,20 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
     if (state->finished || it.lX + it.lY == 0) return;
     init_coef(sh.coef);
     __syncthreads();
-    forward_window(it, P, anchors, track + trackBase[idx] * CP_ROW, events,
+    forward_window(it, P, bandTab + it.diagBase, track + trackBase[idx] * CP_ROW, events,
                    models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD,
-                   state, sh, fd);
+                   state, sh, fd, bf);
 }
 
 /* One workgroup per alignment: backward sweep + posterior decode of the window just described. */
 extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
-    const long long *__restrict__ anchors, const double *__restrict__ track,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
     long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
     long long *totXay, double *totVal, char *scratch, long long scratchBytes) {
     __shared__ Shared sh;
+    __shared__ BandFeed bf;
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
     SyState *state = states + idx;
@@ -985,12 +1208,18 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
     out.totCap = it.totCap;
     out.nPairs = uni64(state->nPairs);
     out.nTot = uni64(state->nTot);
-    backward_window(it, P, anchors, track + trackBase[idx] * CP_ROW,
+    backward_window(it, P, bandTab + it.diagBase, track + trackBase[idx] * CP_ROW,
                     models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD,
-                    state, out, sh, (int *) (scratch + idx * scratchBytes),
+                    state, out, sh, bf, (int *) (scratch + idx * scratchBytes),
                     (WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int)),
                     (double *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int)
-                                + ((long long) ringD / 10 + 8) * sizeof(WinTotal)));
+                                + ((long long) ringD / 10 + 8) * sizeof(WinTotal)),
+                    (unsigned long long *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int)
+                                            + ((long long) ringD / 10 + 8)
+                                                  * (sizeof(WinTotal) + 2 * SY_P * sizeof(double))),
+                    (int2 *) (scratch + idx * scratchBytes + scratch_cand_offset(ringD)),
+                    (double *) (scratch + idx * scratchBytes + scratch_cand_offset(ringD)
+                                + (long long) SY_R * SY_CAND_PER_DIAG * ringD * sizeof(int2)));
     if (threadIdx.x == 0) {
         state->nPairs = out.nPairs;
         state->nTot = out.nTot;
@@ -1067,7 +1296,7 @@ extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned
 
 #ifdef SY_PROFILE
 extern "C" int cpecan_systolic_prof_fetch(unsigned long long *dst) {
-    unsigned long long zero[64] = {0};
+    unsigned long long zero[80] = {0};
     if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(sy_prof), sizeof(zero)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(sy_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
@@ -1080,7 +1309,8 @@ extern "C" int cpecan_systolic_state_bytes(void) { return (int) sizeof(SyState);
 /* HBM scratch per alignment: a hit count and an output offset per ring diagonal, and per refresh of the window one
  * WinTotal and the two rows of per-cell terms */
 extern "C" long long cpecan_systolic_scratch_bytes(int ringD) {
-    return 2ll * ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * SY_P * sizeof(double));
+    return scratch_cand_offset(ringD)
+           + (long long) SY_R * SY_CAND_PER_DIAG * ringD * (sizeof(int2) + sizeof(double));
 }
 
 /* Launchers of the four stages of one pass over a batch (the C-ABI layer sequences them:
@@ -1097,24 +1327,24 @@ extern "C" int cpecan_systolic_launch_track(hipStream_t stream, const DevItem *i
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int cpecan_systolic_launch_forward(hipStream_t stream, const DevItem *items, long long nItems,
-                                              DevParams P, const long long *anchors, const double *track,
+                                              DevParams P, const void *bandTab, const double *track,
                                               const long long *trackBase, const double *events,
                                               const double *models, double *Fring,
                                               long long ringDoubles, int ringD, void *states) {
     hipLaunchKernelGGL(cpecan_k_sy_forward, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems,
-                       P, anchors, track, trackBase, events, models, Fring, ringDoubles, ringD,
+                       P, (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
                        (SyState *) states);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem *items, long long nItems,
-                                               DevParams P, const long long *anchors, const double *track,
+                                               DevParams P, const void *bandTab, const double *track,
                                                const long long *trackBase, const double *models,
                                                double *Fring, long long ringDoubles, int ringD,
                                                void *states, long long *pairs, double *pairLogp,
                                                long long *totXay, double *totVal, char *scratch,
                                                long long scratchBytes) {
     hipLaunchKernelGGL(cpecan_k_sy_backward, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems,
-                       P, anchors, track, trackBase, models, Fring, ringDoubles, ringD,
+                       P, (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
                        (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -105,6 +105,9 @@ typedef struct {
 #define CPECAN_FLAG_UNBANDED 2   /* getAlignedPairsWithoutBanding (:1512): full matrix, one traceback from
                                     the last diagonal, one totalProbability taken there; anchors and
                                     diagonalExpansion are ignored (general kernel only) */
+#define CPECAN_FLAG_SCAN_DECODE 4 /* systolic kernel, diagnostic: decode posteriors by scanning every cell of
+                                    the band instead of the sweep's candidate lists (the path a window falls
+                                    back to by itself when its totals drift or a list overflows) */
 
 /* Copies the inputs to HBM and builds per-item band tables.  All host pointers may be released
  * after the call returns. */

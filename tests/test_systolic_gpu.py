@@ -47,6 +47,21 @@ def test_systolic_matches_oracle(ctx, case):
         assert_same_pairs(res[i], ref)
 
 
+@pytest.mark.parametrize("threshold", [0.01, 1e-4, 1e-7])
+def test_systolic_decode_paths_agree(ctx, threshold):
+    # the candidate-list decode (default) and the full-scan decode (CPECAN_FLAG_SCAN_DECODE, also the
+    # path a window falls back to by itself; a tiny threshold makes long candidate lists)
+    batch = synth.make_batch(25, 3, 300, 620, anchor_every=50)
+    bp = band_params(threshold, 100, 40, 60)
+    a, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=(1, 1))
+    s, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, flags=cp.FLAG_SCAN_DECODE, ragged=(1, 1))
+    for i, (x, y) in enumerate(zip(a, s)):
+        assert np.array_equal(x["triples"], y["triples"])
+        assert np.array_equal(x["logp"], y["logp"])
+        ref = run_oracle_item(batch, i, bp, (1, 1))
+        assert_same_pairs(x, ref)
+
+
 def test_systolic_ragged_batch_and_degenerate_items(ctx):
     batch = synth.make_batch(22, 12, 200, 400, anchor_every=40, length_sigma=0.6)
     base = batch["items"][0]
