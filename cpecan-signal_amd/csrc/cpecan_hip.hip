@@ -134,7 +134,13 @@ struct cpecan_batch {
     int nWorkers = 0, maxWidth = 0;
     int nModels = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
-    std::vector<hipEvent_t> evStage; /* systolic path: one event after every kernel of a pass */
+    /* systolic path: the batch runs as nGroups independent groups of alignments, each on a stream of
+     * its own, so that the tail of one group's kernel overlaps the other groups' kernels (a launch
+     * lasts as long as its slowest workgroup).  evStage: per group, one event after every kernel. */
+    int nGroups = 1;
+    std::vector<hipStream_t> gStream;
+    std::vector<hipEvent_t> evStage, evJoin;
+    hipEvent_t evFork = nullptr;
     std::vector<long long> hNPairs, hNTot, hNCells;
     bool countsValid = false, ran = false;
 };
@@ -280,6 +286,9 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (b->ev1) (void) hipEventDestroy(b->ev1);
     if (b->ev2) (void) hipEventDestroy(b->ev2);
     for (hipEvent_t e : b->evStage) (void) hipEventDestroy(e);
+    for (hipEvent_t e : b->evJoin) (void) hipEventDestroy(e);
+    if (b->evFork) (void) hipEventDestroy(b->evFork);
+    for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     delete b;
     return CPECAN_OK;
 }
@@ -495,6 +504,19 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
             B_TRY(b->bandTab.alloc(tab.size() + 2));
             B_TRY(hipMemcpy(b->bandTab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
         }
+        {
+            const char *g = getenv("CPECAN_SYSTOLIC_GROUPS");
+            int G = g ? atoi(g) : 2;
+            if (G < 1) G = 1;
+            if (G > 8) G = 8;
+            if ((int64_t) G > nItems) G = (int) nItems;
+            b->nGroups = G;
+            b->gStream.assign((size_t) G, nullptr);
+            b->evJoin.assign((size_t) G, nullptr);
+            for (auto &st : b->gStream) B_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            for (auto &e : b->evJoin) B_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            B_TRY(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
+        }
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
         b->scratchBytes = (cpecan_systolic_scratch_bytes(b->ringD) + 63) / 64 * 64;
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
@@ -544,28 +566,44 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
         /* one pass: the per-item track of emission constants (a function of the inputs, rebuilt
          * every run inside the timed region), then for every traceback window the forward kernel
          * followed by the backward kernel; an event after each kernel gives per-kernel times */
-        if (b->evStage.size() != (size_t) (2 * b->nWindows + 1)) {
+        const int G = b->nGroups, perGroup = 2 * b->nWindows + 1;
+        if (b->evStage.size() != (size_t) (G * perGroup)) {
             for (hipEvent_t e : b->evStage) (void) hipEventDestroy(e);
-            b->evStage.assign((size_t) (2 * b->nWindows + 1), nullptr);
+            b->evStage.assign((size_t) (G * perGroup), nullptr);
             for (auto &e : b->evStage) HIP_TRY(hipEventCreate(&e));
         }
         int rc = cpecan_systolic_launch_track(c->stream, b->items.p, b->nItems, b->track.p,
                                               b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
                                               b->maxLX);
-        HIP_TRY(hipEventRecord(b->evStage[0], c->stream));
-        for (int w = 0; w < b->nWindows && rc == 0; w++) {
-            rc = cpecan_systolic_launch_forward(c->stream, b->items.p, b->nItems, b->P, b->bandTab.p,
-                                                b->track.p, b->trackBase.p, b->events.p, c->models.p,
-                                                b->Fstore.p, b->ringDoubles, b->ringD, b->syStates.p);
-            HIP_TRY(hipEventRecord(b->evStage[(size_t) (2 * w + 1)], c->stream));
-            if (rc == 0)
-                rc = cpecan_systolic_launch_backward(c->stream, b->items.p, b->nItems, b->P,
-                                                     b->bandTab.p, b->track.p, b->trackBase.p,
-                                                     c->models.p, b->Fstore.p, b->ringDoubles, b->ringD,
-                                                     b->syStates.p, b->pairs.p, b->pairLogp.p,
-                                                     b->totXay.p, b->totVal.p, b->syScratch.p,
-                                                     b->scratchBytes);
-            HIP_TRY(hipEventRecord(b->evStage[(size_t) (2 * w + 2)], c->stream));
+        HIP_TRY(hipEventRecord(b->evFork, c->stream));
+        const long long per = (b->nItems + G - 1) / G;
+        for (int gi = 0; gi < G && rc == 0; gi++) {
+            const long long i0 = gi * per, n = std::min<long long>(per, b->nItems - i0);
+            hipStream_t st = b->gStream[(size_t) gi];
+            hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup;
+            HIP_TRY(hipStreamWaitEvent(st, b->evFork, 0));
+            HIP_TRY(hipEventRecord(ev[0], st));
+            for (int w = 0; w < b->nWindows && rc == 0; w++) {
+                /* the kernels index everything per alignment by blockIdx: shift the bases */
+                if (n > 0)
+                    rc = cpecan_systolic_launch_forward(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                                                        b->trackBase.p + i0, b->events.p, c->models.p,
+                                                        b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
+                                                        b->ringD,
+                                                        b->syStates.p + i0 * cpecan_systolic_state_bytes());
+                HIP_TRY(hipEventRecord(ev[2 * w + 1], st));
+                if (rc == 0 && n > 0)
+                    rc = cpecan_systolic_launch_backward(st, b->items.p + i0, n, b->P, b->bandTab.p,
+                                                         b->track.p, b->trackBase.p + i0, c->models.p,
+                                                         b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
+                                                         b->ringD,
+                                                         b->syStates.p + i0 * cpecan_systolic_state_bytes(),
+                                                         b->pairs.p, b->pairLogp.p, b->totXay.p, b->totVal.p,
+                                                         b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes);
+                HIP_TRY(hipEventRecord(ev[2 * w + 2], st));
+            }
+            HIP_TRY(hipEventRecord(b->evJoin[(size_t) gi], st));
+            HIP_TRY(hipStreamWaitEvent(c->stream, b->evJoin[(size_t) gi], 0));
         }
         if (rc == 0)
             rc = cpecan_systolic_launch_counts(c->stream, b->syStates.p, b->nItems, b->nPairs.p,
@@ -584,16 +622,19 @@ int cpecan_hip_batch_stage_ms(cpecan_batch *b, float *msForward, float *msBackwa
     HIP_TRY(hipSetDevice(b->ctx->device));
     HIP_TRY(hipEventSynchronize(b->ev2));
     float f = 0, k = 0;
-    for (int w = 0; w < b->nWindows; w++) {
-        float a = 0, c2 = 0;
-        HIP_TRY(hipEventElapsedTime(&a, b->evStage[(size_t) (2 * w)], b->evStage[(size_t) (2 * w + 1)]));
-        HIP_TRY(hipEventElapsedTime(&c2, b->evStage[(size_t) (2 * w + 1)], b->evStage[(size_t) (2 * w + 2)]));
-        f += a;
-        k += c2;
-    }
+    const int perGroup = 2 * b->nWindows + 1;
+    for (int gi = 0; gi < b->nGroups; gi++)
+        for (int w = 0; w < b->nWindows; w++) {
+            const hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup;
+            float a = 0, c2 = 0;
+            HIP_TRY(hipEventElapsedTime(&a, ev[2 * w], ev[2 * w + 1]));
+            HIP_TRY(hipEventElapsedTime(&c2, ev[2 * w + 1], ev[2 * w + 2]));
+            f += a;
+            k += c2;
+        }
     if (msForward) *msForward = f;
     if (msBackward) *msBackward = k;
-    if (launchesEach) *launchesEach = b->nWindows;
+    if (launchesEach) *launchesEach = b->nWindows * b->nGroups;
     return CPECAN_OK;
 }
 

@@ -343,6 +343,12 @@ __device__ __forceinline__ double shl1(double old, double src) {
     return __hiloint2double(hi, lo);
 }
 
+/* a load that cannot be served from a line this CU cached before another wave (or an earlier phase
+ * of the same workgroup) rewrote it */
+template <typename V> __device__ __forceinline__ V ld_agent(V *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 /* Per-alignment state handed between the forward-window and backward-window kernels. */
 struct SyState {
     int d;            /* last forward diagonal completed */
@@ -397,9 +403,9 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
 
-    const int d0 = uni(state->d);
-    int tracedBackTo = uni(state->tracedBackTo);
-    long long cells = uni64(state->cells);
+    const int d0 = uni(ld_agent(&state->d));
+    int tracedBackTo = uni(ld_agent(&state->tracedBackTo));
+    long long cells = uni64(ld_agent(&state->cells));
 
     /* ---- per-slot state (this lane's k-mer) ---- */
     int xs;
@@ -553,8 +559,10 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
             if (valid) { /* cells outside the band cost no HBM traffic */
 #endif
                 *g.rp(d, 0) = mm;
+#ifndef SY_ABLATE_FXY
                 *g.rp(d, 1) = gx;
                 *g.rp(d, 2) = gy;
+#endif
                 *g.rp(d, 3) = pm; /* the sweep back re-uses the two event-dependent emissions */
                 *g.rp(d, 4) = py;
             }
@@ -631,8 +639,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
 
-    const int dTop = uni(state->winTop), tracedBackFrom = uni(state->winFrom), tracedBackTo = uni(state->winTo);
-    const bool atEnd = uni(state->winAtEnd) != 0;
+    const int dTop = uni(ld_agent(&state->winTop)), tracedBackFrom = uni(ld_agent(&state->winFrom)),
+              tracedBackTo = uni(ld_agent(&state->winTo));
+    const bool atEnd = uni(ld_agent(&state->winAtEnd)) != 0;
     BPROF_DECL
     const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
     const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
@@ -823,7 +832,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 /* exponent of the posterior, less the total: parked in the emission slot this diagonal
                  * no longer needs (the forward cells themselves stay intact: the next window's
                  * refresh at its lowest diagonal reads forward[tracedBackFrom], :944,:985) */
+#ifndef SY_ABLATE_FB
                 if (tvalid) *g.rp(t, 3) = fb;
+#endif
                 const bool cand = tvalid && fb >= candThr && fb > CP_NEG_INF;
                 const unsigned long long cm = __ballot(cand);
                 if (cm != 0ull) {

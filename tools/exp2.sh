@@ -1,0 +1,5 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+run() { timeout -k 10 150 python bench.py --steps 4 --warmup 1 --check 0 --cpu-reads 0 "$@" 2>/dev/null | python -c "
+import json,sys;j=json.loads(sys.stdin.read());r=j['roofline'];print(j['ms_per_step'],r['dominant_kernel']['avg_launch_ms'],r['forward_kernel']['avg_launch_ms'])"; }
+for g in 1 2 3 4 8; do echo "groups=$g  $(CPECAN_SYSTOLIC_GROUPS=$g run)"; done
