@@ -385,6 +385,30 @@ __device__ __forceinline__ Geometry make_geometry(double *ring, int ringD) {
     return g;
 }
 
+/* The next traceback point (:917-921) from the band alone: the first diagonal above dAfter that is at
+ * least dMin and narrow enough, or the last diagonal D.  Whole workgroup, 256 diagonals per round. */
+__device__ int next_traceback_point(const int2 *__restrict__ tab, int D, int dAfter, long long dMin,
+                                    long long widthLimit, Shared &sh) {
+    long long b0 = dAfter + 1 > dMin ? dAfter + 1 : dMin;
+    if (b0 >= D) return D;
+    int base = (int) b0;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sh.item = 0x7fffffff;
+        __syncthreads();
+        const int d = base + (int) threadIdx.x;
+        if (d >= D) atomicMin(&sh.item, D);
+        else {
+            const int2 v = tab[d];
+            if ((long long) (v.y - v.x + 1) <= widthLimit) atomicMin(&sh.item, d);
+        }
+        __syncthreads();
+        const int r = uni(sh.item);
+        if (r != 0x7fffffff) return r;
+        base += 256;
+    }
+}
+
 /* Forward sweep of one alignment from its saved diagonal up to (and including) the next traceback
  * point; describes the window for the backward kernel. */
 __device__ void forward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
@@ -463,6 +487,36 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         xminP = xmin;
     }
     int evHi = d0 - xminP - 1, rowHi = xin; /* first event / k-mer row not yet staged */
+
+    /*
+     * Which diagonals need all three states in the ring.  The sweep back reads only the match cell of
+     * a diagonal, except where it refreshes totalProbability (every 10th decoded diagonal, counted
+     * down from the first one of ITS window: it then reads every state of that diagonal and of the
+     * one below), and this sweep resumes from the last two diagonals of a launch.  Where the windows
+     * will start is a function of the band alone, so it is known here: this launch ends at topW; its
+     * diagonals up to fromW are decoded by window W (first decoded diagonal tpA), the ones above by
+     * the next window (tpB).  Everywhere else the two gap states are not stored: 16 of the 40 bytes
+     * a cell costs on the way up.
+     */
+    const long long widthLimit = P.expansion * 2 + 1;
+    const int topW = next_traceback_point(bandTab, D, d0, tracedBackTo + P.minDiags, widthLimit, sh);
+    const bool endW = topW == D;
+    const int fromW = topW - (endW ? 0 : (int) P.tbDiags + 1);
+    const int tpA = topW < fromW ? topW : fromW;
+    int tpB = tpA;
+    bool allFull = false;
+    if (!endW) {
+        const int topN = next_traceback_point(bandTab, D, topW, fromW + P.minDiags, widthLimit, sh);
+        const int fromN = topN - (topN == D ? 0 : (int) P.tbDiags + 1);
+        tpB = topN < fromN ? topN : fromN;
+        allFull = tpB < topW; /* windows shorter than the traceback margin: keep everything */
+    }
+    /* (tpA - d) mod 10 and (tpB - d) mod 10 for the diagonal being computed, kept incrementally */
+    auto needs_all_states = [&](const int d) __attribute__((always_inline)) {
+        const bool refreshHere = d <= fromW ? (tpA - d) % 10 == 0 : (!endW && (tpB - d) % 10 == 0);
+        const bool refreshAbove = d + 1 <= fromW ? (tpA - d - 1) % 10 == 0 : (!endW && (tpB - d - 1) % 10 == 0);
+        return allFull || d >= topW - 1 || refreshHere || refreshAbove;
+    };
     if (lane == 63) {
         double *x = sh.xch[d0 & 1][wave];
         x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
@@ -494,6 +548,10 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
             __builtin_amdgcn_s_waitcnt(0x0F70); /* vmcnt(0): nothing pending past this point */
         }
         const int dbEnd = db + SY_FEED - 1 < D ? db + SY_FEED - 1 : D;
+        unsigned fullMask = 0u; /* bit j: diagonal db + j keeps all three states */
+#pragma unroll 1
+        for (int j = 0; j < SY_FEED; j++) fullMask |= (needs_all_states(db + j) ? 1u : 0u) << j;
+        fullMask = (unsigned) uni((int) fullMask);
 #pragma unroll 1
         for (int d = db; d <= dbEnd; d++) {
         PROF(0)
@@ -502,6 +560,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         int xmin, xmax;
         band_get(bf, d, xmin, xmax);
         cells += xmax - xmin + 1;
+        const bool full = ((fullMask >> (d - db)) & 1u) != 0u;
         PROF_ACTIVE(row_active(wave, xmin, xmax))
         PROF(2)
         const double *xb = sh.xch[(d - 1) & 1][g.waveBelow];
@@ -559,10 +618,10 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
             if (valid) { /* cells outside the band cost no HBM traffic */
 #endif
                 *g.rp(d, 0) = mm;
-#ifndef SY_ABLATE_FXY
-                *g.rp(d, 1) = gx;
-                *g.rp(d, 2) = gy;
-#endif
+                if (full) {
+                    *g.rp(d, 1) = gx;
+                    *g.rp(d, 2) = gy;
+                }
                 *g.rp(d, 3) = pm; /* the sweep back re-uses the two event-dependent emissions */
                 *g.rp(d, 4) = py;
             }
