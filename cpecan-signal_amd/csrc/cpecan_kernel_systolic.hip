@@ -161,8 +161,12 @@ __device__ __forceinline__ double ladd(double x, double y, const double *coef) {
 #else
     const int idx = (int) (d > 1.00f) + (int) (d > 2.50f) + (int) (d > 4.50f);
 #endif
-    const double *c = coef + idx * 4;
-    const double r = ((c[0] * d + c[1]) * d + c[2]) * d + c[3] + lo;
+    /* one LDS address, two 16-byte reads (the compiler would form two addresses) */
+    const unsigned a = (unsigned) (size_t) (const __attribute__((address_space(3))) double *) coef + idx * 32u;
+    double2 c32, c10;
+    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(c32), "=&v"(c10) : "v"(a));
+    const double r = ((c32.x * d + c32.y) * d + c10.x) * d + c10.y + lo;
     return d < 7.5 ? r : hi;
 }
 __device__ __forceinline__ void init_coef(double *coef) {
@@ -512,11 +516,9 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         allFull = tpB < topW; /* windows shorter than the traceback margin: keep everything */
     }
     /* (tpA - d) mod 10 and (tpB - d) mod 10 for the diagonal being computed, kept incrementally */
-    auto needs_all_states = [&](const int d) __attribute__((always_inline)) {
-        const bool refreshHere = d <= fromW ? (tpA - d) % 10 == 0 : (!endW && (tpB - d) % 10 == 0);
-        const bool refreshAbove = d + 1 <= fromW ? (tpA - d - 1) % 10 == 0 : (!endW && (tpB - d - 1) % 10 == 0);
-        return allFull || d >= topW - 1 || refreshHere || refreshAbove;
-    };
+    /* (tpA - d) mod 10 and (tpB - d) mod 10 for the next diagonal whose mask bit is computed */
+    int rA = ((tpA - (d0 + 1)) % 10 + 10) % 10, rB = endW ? 0x40000000 : ((tpB - (d0 + 1)) % 10 + 10) % 10;
+    const int fullFrom = allFull ? -0x40000000 : topW - 1;
     if (lane == 63) {
         double *x = sh.xch[d0 & 1][wave];
         x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
@@ -550,7 +552,13 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         const int dbEnd = db + SY_FEED - 1 < D ? db + SY_FEED - 1 : D;
         unsigned fullMask = 0u; /* bit j: diagonal db + j keeps all three states */
 #pragma unroll 1
-        for (int j = 0; j < SY_FEED; j++) fullMask |= (needs_all_states(db + j) ? 1u : 0u) << j;
+        for (int j = 0; j < SY_FEED; j++) {
+            const int dj = db + j;
+            const int rHere = dj <= fromW ? rA : rB, rAbove = dj + 1 <= fromW ? rA : rB;
+            fullMask |= (dj >= fullFrom || rHere == 0 || rAbove == 1 ? 1u : 0u) << j;
+            rA = rA == 0 ? 9 : rA - 1;
+            rB = rB == 0 ? 9 : rB - 1;
+        }
         fullMask = (unsigned) uni((int) fullMask);
 #pragma unroll 1
         for (int d = db; d <= dbEnd; d++) {
