@@ -128,21 +128,28 @@ def main():
     achieved = cells * bytes_per_cell / avg_kernel_s / 1e9
     # HBM traffic of one pass from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
     # rocprofv3 --pmc passes of this same command; summary committed under profiles/)
-    traffic, traffic_note = None, None
+    traffic, traffic_note, valu = None, None, None
     prof = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_summary.json")
     if os.path.exists(prof) and args.reads == 1024 and args.events == 10000 and args.kmers == 5000:
         pm = json.load(open(prof))
-        rd = sum(v["sum_KiB"] for v in pm["FETCH_SIZE"].values()) * 1024
-        wr = sum(v["sum_KiB"] for v in pm["WRITE_SIZE"].values()) * 1024
+        # FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (the guide's rule; the
+        # calibration kernels in the same profile confirm it for this path's 8-byte-per-lane loads:
+        # reported/true = 0.5); WRITE_SIZE is exact
+        rd = 2.0 * pm["FETCH_SIZE_GB_per_pass"] * 1e9
+        wr = pm["WRITE_SIZE_GB_per_pass"] * 1e9
         traffic = rd + wr
-        traffic_note = ("bytes per pass over the batch, FETCH_SIZE %.1f GB (8-byte-per-lane loads: not "
-                        "doubled, the guide's x2 is calibrated for 16-byte loads only) + WRITE_SIZE %.1f GB"
-                        % (rd / 1e9, wr / 1e9))
+        traffic_note = ("HBM bytes per pass over the batch from rocprofv3 --pmc (separate passes): "
+                        "2 x FETCH_SIZE = %.1f GB + WRITE_SIZE = %.1f GB; algorithmic %.1f GB"
+                        % (rd / 1e9, wr / 1e9, cells * 48.0 / 1e9))
+        valu = {k: round(v.get("valu_busy_fraction_of_simd_time", 0.0), 3) for k, v in pm.get("SQ", {}).items()}
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_note": traffic_note,
                 "scope": "whole pass (all kernels of the path), 48 B per cell",
                 "kernel_ms": round(1e3 * avg_kernel_s, 3), "bytes_per_cell": bytes_per_cell,
-                "frac_of_measured_copy_6290": round(achieved / 6290.0, 5)}
+                "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
+                "fp64_valu_busy": valu,
+                "note": "fp64 log-space recurrence: the kernels are bound by fp64 vector issue (fraction of SIMD "
+                        "time with a VALU instruction executing, from the committed PMC profile), not by HBM"}
     if stage:
         f_ms = float(np.mean([x[0] for x in stage]))
         k_ms = float(np.mean([x[1] for x in stage]))
@@ -151,6 +158,8 @@ def main():
         # once (24 B per cell); the forward-window kernel writes them once (24 B per cell)
         roofline["dominant_kernel"] = {
             "name": "cpecan_k_sy_backward", "launches_per_pass": n_l,
+            "note": "the batch runs as groups on separate streams: launches of different groups overlap, so the "
+                    "sum of launch durations exceeds the pass time",
             "avg_launch_ms": round(k_ms / n_l, 4),
             "algorithmic_bytes_per_launch": round(cells * 24.0 / n_l),
             "achieved": round(cells * 24.0 / (k_ms / 1e3) / 1e9, 2),

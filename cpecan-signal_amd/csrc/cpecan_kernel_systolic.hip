@@ -1,34 +1,35 @@
 /*
- * cpecan_kernel_systolic.hip -- the throughput kernel: banded forward / backward / posterior DP
+ * cpecan_kernel_systolic.hip -- the throughput kernels: banded forward / backward / posterior DP
  * with the anti-diagonal wavefront of the recurrence held in registers.
  *
  * Mapping (designed for CDNA4's 64-lane waves, not translated from anything):
  *   - one 256-thread workgroup per alignment; lanes own reference k-mers, not DP cells: slot
- *     s = x mod 256 is lane s % 64 of wave s / 64 (bands up to 256 k-mers wide).  A k-mer's 17
- *     emission constants stay in its lane's VGPRs while x is inside the band, so the inner loop
- *     loads nothing per cell.
+ *     s = x mod 256 is lane s % 64 of wave s / 64 (bands up to 248 k-mers wide).  A k-mer's 17
+ *     emission constants stay in its lane's VGPRs while x is inside the band.
  *   - one loop iteration = one anti-diagonal.  Forward: a cell needs (x-1,y) and (x-1,y-1) from the
- *     lane below (one DPP wave-rotate per value) and (x,y-1) from itself; only lane 0 of a wave
- *     takes its neighbour from the wave below through 40 bytes of LDS (one barrier per diagonal).
- *     The event a lane scores also moves up one lane per diagonal, so events travel with the cells;
- *     only the event that enters the band is fetched, from a 64-event register chunk that is
- *     refilled two chunks ahead.
+ *     lane below (one DPP wave-shift per value) and (x,y-1) from itself; only lane 0 of a wave
+ *     takes its neighbour from the wave below through 40 bytes of LDS (one LDS-only barrier per
+ *     diagonal).  The event a lane scores also moves up one lane per diagonal.
  *   - backward is the mirror image (messages travel down one lane); it is a gather, with the
  *     reference's scatter order of accumulation kept per state (see cpecan_kernel_general.hip).
- *   - forward cells go to HBM once ([diagonal][wave][state][lane]: 512-byte coalesced stores) into
- *     a per-workgroup ring holding one traceback window, and are read once by the backward sweep:
- *     2 x 3 x 8 = 48 bytes per cell, the kernel's algorithmic HBM traffic.
- *   - a wave whose 64 slots hold no in-band cell on a diagonal skips the arithmetic.
- *   - band geometry is recomputed from the anchors in scalar registers; per-diagonal band tables
- *     never exist in memory.
- *   - workgroups are persistent: each pulls the next alignment from an atomic counter (the host
- *     orders items longest-first), so ragged batches balance over the chip.
+ *   - forward cells go to HBM once into a per-alignment ring holding one traceback window
+ *     ([diagonal][wave][Fm,Fx,Fy,pm,py][lane]) and are read once by the sweep back.
+ *   - neither sweep waits for a global load inside its loop: the forward sweep stages its inputs
+ *     (events, k-mer rows, band) in LDS every 32 diagonals, the backward sweep fetches ring rows
+ *     four diagonals ahead with the loop unrolled by four (see Feed, BandFeed, backward_window).
+ *   - the posterior decode works from candidate lists the sweep back collects (backward_window).
+ *   - two kernels per traceback window, launched by the C-ABI layer (cpecan_hip.hip): forward to
+ *     the next traceback point, then backward + decode of that window; per-alignment state
+ *     (SyState) and the ring carry over.
  * MFMA is not used: the recurrence is a scan with an approximate log-add, not a contraction.
  *
  * Numerics: identical to the general kernel and the CPU oracle, bit for bit.  The only algebraic
  * change is the division (x - mu) / sigma, done as a Markstein-corrected multiply by the
  * host-rounded reciprocal (two fused multiply-adds), which returns the correctly rounded quotient
  * (tests/test_systolic_gpu.py checks it against IEEE division on 10^8 operands).
+ *
+ * -DSY_ABLATE_* and -DSY_PROFILE are timing-study switches (tools/ablate.sh, tools/prof.sh); the
+ * ablations compute wrong results by construction and are never built into the product.
  */
 #include "cpecan_device.h"
 
@@ -68,9 +69,8 @@ namespace {
 struct Shared {
     double coef[16];         /* lookup() cubics, [piece][c3,c2,c1,c0]: one ds_read_b128 pair per logAdd */
     double xch[2][SY_R][8];  /* boundary-lane values, double-buffered by diagonal parity */
-    double vbuf[SY_P];       /* totalProbability terms of the current diagonal, by slot  */
-    double wbuf[SY_P];
-    unsigned long long vmask[SY_R], wmask[SY_R];
+    double vbuf[SY_P];       /* phase T: per-thread fold results; the sweep's estimate of the total */
+    double wbuf[SY_P];       /* decode: partial hit counts */
     double total;
     int cnt[2][SY_R][2];     /* aligned-pair counts per wave, double-buffered */
     int item;
@@ -93,20 +93,6 @@ struct Feed {
     double row[SY_FEED_ROW * CP_ROW];
 };
 
-/* lane i <- lane i-1 (lane 0 <- lane 63) */
-__device__ __forceinline__ double ror1(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x13C, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x13C, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-/* lane i <- lane i+1 (lane 63 <- lane 0) */
-__device__ __forceinline__ double rol1(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double bcast(double v, int srcLane) { /* srcLane wave-uniform */
     int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
@@ -221,57 +207,6 @@ __device__ __forceinline__ bool row_active(int w, int xmin, int xmax) {
     return ((w - first) & (SY_R - 1)) <= n;
 }
 
-/* 64 consecutive events (mean, noise) held one per lane, plus the neighbouring 64 prefetched */
-struct EvChunk {
-    double am, an, bm, bn;
-    int base; /* event index held by lane 0 of chunk a */
-    const double *ev;
-    int lY;
-
-    __device__ __forceinline__ void fetch(int b, double &m, double &n, int lane) {
-        int i = b + lane;
-        bool ok = i >= 0 && i < lY;
-        m = ok ? ev[3 * (long long) i] : 0.0;
-        n = ok ? ev[3 * (long long) i + 1] : 0.0;
-    }
-    __device__ __forceinline__ void init_up(int first, int lane) {
-        base = uni(first);
-        fetch(base, am, an, lane);
-        fetch(base + 64, bm, bn, lane);
-    }
-    __device__ __forceinline__ void init_down(int first, int lane) {
-        base = uni(first - 63);
-        fetch(base, am, an, lane);
-        fetch(base - 64, bm, bn, lane);
-    }
-    /* event e (wave-uniform; non-decreasing over calls in steady state).  e < 0 is NULLEVENT
-     * (:261): its emissions only ever meet -inf cells, a finite stand-in keeps NaN out */
-    __device__ __forceinline__ void get_up(int e, double &m, double &n, int lane) {
-        if (e < 0) { m = 0.0; n = 0.0; return; }
-        if (e < base || e >= base + 64) {
-            if (e >= base + 64 && e < base + 128) {
-                am = bm; an = bn; base = uni(base + 64); fetch(base + 64, bm, bn, lane);
-            } else {
-                init_up(e, lane);
-            }
-        }
-        m = bcast(am, e - base);
-        n = bcast(an, e - base);
-    }
-    __device__ __forceinline__ void get_down(int e, double &m, double &n, int lane) {
-        if (e < 0) { m = 0.0; n = 0.0; return; }
-        if (e < base || e >= base + 64) {
-            if (e < base && e >= base - 64) {
-                am = bm; an = bn; base = uni(base - 64); fetch(base - 64, bm, bn, lane);
-            } else {
-                init_down(e, lane);
-            }
-        }
-        m = bcast(am, e - base);
-        n = bcast(an, e - base);
-    }
-};
-
 /* logAdd-fold of one value per lane into acc (wave-uniform in and out), lanes in ascending order;
  * visits only the lanes that can change the running value (cp_wave_seq_fold with the LDS-table
  * logAdd, so that no coefficient constants occupy registers around the call) */
@@ -305,34 +240,10 @@ __device__ __forceinline__ void load_params(double (&dst)[SY_NPRM], const double
 #pragma unroll
     for (int j = 0; j < SY_NPRM; j++) dst[j] = p[j];
 }
-/* staging of the next k-mer to enter the band: ONE coalesced 144-byte load per wave, lane j keeps
- * constant j; the lane that owns the k-mer's slot takes them with readlanes a few diagonals later */
-__device__ __forceinline__ double stage_row(const double *__restrict__ track, int x, int lane) {
-    return track[(long long) x * CP_ROW + (lane < CP_ROW ? lane : 0)];
-}
-/* lane `dst` (wave-uniform) of prm[] takes constant j from lane j of the staged row: 34 readlanes
- * into scalar registers, then 34 moves under a one-lane exec mask */
-__device__ __forceinline__ void install_row(double (&prm)[SY_NPRM], double staged, int dst) {
-    double v[SY_NPRM];
-#pragma unroll
-    for (int j = 0; j < SY_NPRM; j++) v[j] = bcast(staged, j);
-    if ((int) (threadIdx.x & 63) == dst) {
-#pragma unroll
-        for (int j = 0; j < SY_NPRM; j++) prm[j] = v[j];
-    }
-}
 __device__ __forceinline__ double set_lane(double v, int dst, double x) { /* x, dst wave-uniform */
     if ((int) (threadIdx.x & 63) == dst) v = x;
     return v;
 }
-
-/* aligned pairs found on a diagonal, written one barrier later when every wave's count is known */
-struct Pending {
-    bool any, hit, segB;
-    int r0, par, prefix, t;
-    int p; /* floor(posterior * 1e7) */
-    double e;
-};
 
 /* lane i <- lane i-1 of src, lane 0 <- old (DPP wave_shr:1 leaves lanes without a source untouched) */
 __device__ __forceinline__ double shr1(double old, double src) {
@@ -664,13 +575,6 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         }
         }
     }
-}
-
-/* value of ring row `s` of diagonal d for matrix column x (any thread may ask for any column) */
-__device__ __forceinline__ double ring_at(const double *ring, int ringMask, int d, int s, int x) {
-    const int slot = x & (SY_P - 1);
-    return ring[(long long) (d & ringMask) * (SY_R * SY_RING_VALUES * 64) + (slot >> 6) * (SY_RING_VALUES * 64)
-                + s * 64 + (slot & 63)];
 }
 
 /* per-window bookkeeping kept in HBM scratch (private to the alignment's workgroup) */
