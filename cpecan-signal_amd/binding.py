@@ -36,6 +36,7 @@ EXPORTS = [
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
+    "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
 ]
 
 
@@ -48,6 +49,11 @@ class CpecanError(RuntimeError):
 class Sm3ModelDesc(C.Structure):
     _fields_ = [("transitions", C.c_double * 9), ("match_probs", C.c_void_p),
                 ("gap_x_probs", C.c_void_p), ("gap_y_probs", C.c_void_p)]
+
+
+class Sm5ModelDesc(C.Structure):
+    _fields_ = [("transitions", C.c_double * 17), ("match_probs", C.c_double * 16),
+                ("gap_x_probs", C.c_double * 4), ("gap_y_probs", C.c_double * 4)]
 
 
 class Item(C.Structure):
@@ -102,6 +108,10 @@ def lib():
             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
             C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.c_int32, C.c_int32,
             C.POINTER(C.c_void_p)]
+        L.cpecan_hip_models5_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.cpecan_hip_batch_create_dna.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
         for name in ("run", "sync", "destroy"):
             getattr(L, "cpecan_hip_batch_" + name).argtypes = [C.c_void_p]
         L.cpecan_hip_batch_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -192,6 +202,22 @@ class Context:
         _check(lib().cpecan_hip_models_create(self.h, C.cast(descs, C.c_void_p), n, threads, _ptr(ids)))
         return ids
 
+    def models5_create(self, models):
+        """models: list of (transitions[17], match[16], gap_x[4], gap_y[4]) -> ids (5-state symbol machine)"""
+        n = len(models)
+        descs = (Sm5ModelDesc * n)()
+        for i, (t, match, gx, gy) in enumerate(models):
+            for j in range(17):
+                descs[i].transitions[j] = t[j]
+            for j in range(16):
+                descs[i].match_probs[j] = match[j]
+            for j in range(4):
+                descs[i].gap_x_probs[j] = gx[j]
+                descs[i].gap_y_probs[j] = gy[j]
+        ids = np.zeros(n, np.int32)
+        _check(lib().cpecan_hip_models5_create(self.h, C.cast(descs, C.c_void_p), n, _ptr(ids)))
+        return ids
+
     def models_clear(self):
         _check(lib().cpecan_hip_models_clear(self.h))
 
@@ -205,16 +231,23 @@ class Batch:
     """cpecan_batch: items is a numpy array of ITEM_DTYPE."""
 
     def __init__(self, ctx, items, x_chars, events, anchors, params, mode=MODE_POSTERIOR,
-                 kernel=KERNEL_AUTO, flags=0):
+                 kernel=KERNEL_AUTO, flags=0, y_chars=None):
+        """events: double[n][3] for a signal batch; y_chars (str/bytes) instead for a DNA batch."""
         self.ctx = ctx
         items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
         xb = np.frombuffer(x_chars.encode() if isinstance(x_chars, str) else bytes(x_chars), np.uint8)
-        ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
         an = np.ascontiguousarray(anchors, dtype=np.int64).reshape(-1, 2)
         h = C.c_void_p()
-        _check(lib().cpecan_hip_batch_create(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
-                                             _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
-                                             C.byref(params), mode, kernel, flags, C.byref(h)))
+        if y_chars is not None:
+            yb = np.frombuffer(y_chars.encode() if isinstance(y_chars, str) else bytes(y_chars), np.uint8)
+            _check(lib().cpecan_hip_batch_create_dna(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
+                                                     _ptr(yb), yb.size, _ptr(an), an.shape[0],
+                                                     C.byref(params), flags, C.byref(h)))
+        else:
+            ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+            _check(lib().cpecan_hip_batch_create(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
+                                                 _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
+                                                 C.byref(params), mode, kernel, flags, C.byref(h)))
         self.h = h
         self.n = items.shape[0]
 

@@ -34,6 +34,7 @@
 #define CP_RYNSD 14
 #define CP_YK2 15
 #define CP_GAPX 16
+#define CP_MODEL5_STRIDE 48 /* 5-state symbol model: 17 transitions, pad to 24, 16 match, 4 gapX, 4 gapY */
 #define CP_MODEL_HEADER 16 /* doubles in front of the rows: the 9 transitions */
 #define CP_MODEL_STRIDE (CP_MODEL_HEADER + 4097 * CP_ROW)
 

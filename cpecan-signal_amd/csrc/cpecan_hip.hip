@@ -26,6 +26,10 @@ extern "C" __global__ void cpecan_k_general(const DevItem *, DevParams, const in
                                             const double *, const double *, double *, double *,
                                             long long *, double *, long long *, long long *,
                                             double *, long long *, double *, double *);
+extern "C" __global__ void cpecan_k_general5(const DevItem *, DevParams, const int *, const int *,
+                                             const long long *, const char *, const char *, const double *,
+                                             double *, double *, long long *, double *, long long *,
+                                             long long *, double *, long long *, double *);
 extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned short *);
 
 extern "C" int cpecan_systolic_max_width(void);
@@ -101,6 +105,9 @@ struct cpecan_ctx {
     DevBuf<double> models; /* nModels * CP_MODEL_STRIDE */
     std::vector<double> hostModels;
     int nModels = 0;
+    DevBuf<double> models5; /* 5-state symbol models, nModels5 * CP_MODEL5_STRIDE */
+    std::vector<double> hostModels5;
+    int nModels5 = 0;
 };
 
 struct cpecan_batch {
@@ -112,7 +119,8 @@ struct cpecan_batch {
     DevBuf<DevItem> items;
     DevBuf<int> bandL, bandR;
     DevBuf<long long> cellPrefix;
-    DevBuf<char> chars;
+    DevBuf<char> chars, charsY; /* charsY: DNA batches (5-state machine) */
+    bool dna = false;
     DevBuf<unsigned short> kidx;
     DevBuf<double> events;
     DevBuf<long long> anchors;
@@ -270,12 +278,36 @@ int cpecan_hip_selftest_division(cpecan_ctx *c, int64_t n, uint64_t seed, int64_
     return CPECAN_OK;
 }
 
+int cpecan_hip_models5_create(cpecan_ctx *c, const cpecan_sm5_model *models, int32_t n, int32_t *ids) {
+    if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t old = c->hostModels5.size();
+    c->hostModels5.resize(old + (size_t) n * CP_MODEL5_STRIDE, 0.0);
+    for (int i = 0; i < n; i++) {
+        double *m = c->hostModels5.data() + old + (size_t) i * CP_MODEL5_STRIDE;
+        for (int k = 0; k < 17; k++) m[k] = models[i].transitions[k];
+        for (int k = 0; k < 16; k++) m[24 + k] = models[i].match_probs[k];
+        for (int k = 0; k < 4; k++) m[40 + k] = models[i].gap_x_probs[k];
+        for (int k = 0; k < 4; k++) m[44 + k] = models[i].gap_y_probs[k];
+        ids[i] = c->nModels5 + i;
+    }
+    c->nModels5 += n;
+    hipError_t e = c->models5.alloc(c->hostModels5.size());
+    if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(c->models5.p, c->hostModels5.data(), c->hostModels5.size() * sizeof(double),
+                      hipMemcpyHostToDevice));
+    return CPECAN_OK;
+}
+
 int cpecan_hip_models_clear(cpecan_ctx *c) {
     if (!c) return fail(CPECAN_EINVAL, "ctx is NULL");
     (void) hipSetDevice(c->device);
     c->models.release();
     c->hostModels.clear();
     c->nModels = 0;
+    c->models5.release();
+    c->hostModels5.clear();
+    c->nModels5 = 0;
     return CPECAN_OK;
 }
 
@@ -304,13 +336,19 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
         }                                                                                    \
     } while (0)
 
-int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
-                            const char *xChars, int64_t nX, const double *events, int64_t nEvents,
-                            const int64_t *anchors, int64_t nAnchorPairs,
-                            const cpecan_band_params *params, int32_t mode, int32_t kernel,
-                            int32_t flags, cpecan_batch **out) {
-    if (!c || !items || nItems <= 0 || !xChars || !events || !params || !out)
+/* events != NULL: k-mers against events with a 3-state signal model; yChars != NULL: DNA against DNA
+ * with a 5-state symbol model (nEvents then counts the bases of yChars) */
+static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
+                             const char *xChars, int64_t nX, const double *events, const char *yChars,
+                             int64_t nEvents, const int64_t *anchors, int64_t nAnchorPairs,
+                             const cpecan_band_params *params, int32_t mode, int32_t kernel,
+                             int32_t flags, cpecan_batch **out) {
+    const bool dna = yChars != nullptr;
+    const int S = dna ? 5 : 3; /* states per cell */
+    if (!c || !items || nItems <= 0 || !xChars || (!events && !yChars) || !params || !out)
         return fail(CPECAN_EINVAL, "bad argument");
+    if (dna && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
+        return fail(CPECAN_EINVAL, "DNA batches: posterior decode only, no cell dumps");
     if (nAnchorPairs > 0 && !anchors) return fail(CPECAN_EINVAL, "anchors is NULL");
     if (mode != CPECAN_MODE_POSTERIOR && mode != CPECAN_MODE_EXPECTATIONS)
         return fail(CPECAN_EINVAL, "unknown mode %d", mode);
@@ -336,10 +374,10 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     for (int64_t i = 0; i < nItems; i++) {
         const cpecan_item &s = items[i];
         if (s.lX < 0 || s.lY < 0 || s.x_offset < 0 || s.y_offset < 0 || s.n_anchors < 0 ||
-            s.anchor_offset < 0 || s.x_offset + s.lX + (s.lX > 0 ? 5 : 0) > nX ||
+            s.anchor_offset < 0 || s.x_offset + s.lX + (!dna && s.lX > 0 ? 5 : 0) > nX ||
             s.y_offset + s.lY > nEvents || s.anchor_offset + s.n_anchors > nAnchorPairs)
             return fail(CPECAN_EINVAL, "item %lld points outside the supplied buffers", (long long) i);
-        if (s.model_id < 0 || s.model_id >= c->nModels)
+        if (s.model_id < 0 || s.model_id >= (dna ? c->nModels5 : c->nModels))
             return fail(CPECAN_EINVAL, "item %lld: unknown model id %d", (long long) i, s.model_id);
         if (s.lX + s.lY >= (1ll << 30)) return fail(CPECAN_EINVAL, "item %lld too long", (long long) i);
         DevItem &d = hItems[(size_t) i];
@@ -404,7 +442,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
                                                                      params->traceBackDiagonals - 1) + 4;
         totTotal += d.totCap;
         d.bwsBase = bwsTotal;
-        bwsTotal += 3ll * maxW * 3;
+        bwsTotal += 3ll * maxW * S;
     }
 
     cpecan_batch *b = new (std::nothrow) cpecan_batch();
@@ -424,7 +462,8 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
-    int useKernel = kernel;
+    int useKernel = dna ? CPECAN_KERNEL_GENERAL : kernel;
+    b->dna = dna;
     if (useKernel == CPECAN_KERNEL_AUTO)
         useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && systolicOk && !b->P.debug &&
                      !unbanded && mode == CPECAN_MODE_POSTERIOR)
@@ -449,8 +488,14 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     B_TRY(hipMemset(b->chars.p, 0, (size_t) nX + 8));
     B_TRY(hipMemcpy(b->chars.p, xChars, (size_t) nX, hipMemcpyHostToDevice));
     B_TRY(b->kidx.alloc((size_t) nX + 8));
-    B_TRY(b->events.alloc((size_t) 3 * nEvents + 8));
-    B_TRY(hipMemcpy(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+    if (dna) {
+        B_TRY(b->charsY.alloc((size_t) nEvents + 8));
+        B_TRY(hipMemset(b->charsY.p, 0, (size_t) nEvents + 8));
+        B_TRY(hipMemcpy(b->charsY.p, yChars, (size_t) nEvents, hipMemcpyHostToDevice));
+    } else {
+        B_TRY(b->events.alloc((size_t) 3 * nEvents + 8));
+        B_TRY(hipMemcpy(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+    }
     B_TRY(b->anchors.alloc((size_t) 2 * nAnchorPairs + 2));
     if (nAnchorPairs > 0)
         B_TRY(hipMemcpy(b->anchors.p, anchors, (size_t) 2 * nAnchorPairs * sizeof(long long),
@@ -474,7 +519,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
         B_TRY(hipMemcpy(b->bandL.p, hL.data(), hL.size() * sizeof(int), hipMemcpyHostToDevice));
         B_TRY(hipMemcpy(b->bandR.p, hR.data(), hR.size() * sizeof(int), hipMemcpyHostToDevice));
         B_TRY(hipMemcpy(b->cellPrefix.p, hPre.data(), hPre.size() * sizeof(long long), hipMemcpyHostToDevice));
-        B_TRY(b->Fstore.alloc((size_t) cellTotal * 3));
+        B_TRY(b->Fstore.alloc((size_t) cellTotal * S));
         B_TRY(b->Bstore.alloc((size_t) bwsTotal));
         if (b->P.debug) {
             B_TRY(b->dbgB.alloc((size_t) cellTotal * 3));
@@ -530,7 +575,7 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     B_TRY(hipEventCreate(&b->ev2));
 
     /* k-mer indices are part of input preparation (done once, like H2D) */
-    {
+    if (!dna) {
         long long n = (long long) nX;
         int threads = 256;
         int blocks = (int) ((n + threads - 1) / threads);
@@ -544,6 +589,25 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
     return CPECAN_OK;
 }
 
+int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
+                            const char *xChars, int64_t nX, const double *events, int64_t nEvents,
+                            const int64_t *anchors, int64_t nAnchorPairs,
+                            const cpecan_band_params *params, int32_t mode, int32_t kernel,
+                            int32_t flags, cpecan_batch **out) {
+    if (!events) return fail(CPECAN_EINVAL, "bad argument");
+    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs,
+                             params, mode, kernel, flags, out);
+}
+
+int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
+                                const char *xChars, int64_t nX, const char *yChars, int64_t nY,
+                                const int64_t *anchors, int64_t nAnchorPairs,
+                                const cpecan_band_params *params, int32_t flags, cpecan_batch **out) {
+    if (!yChars) return fail(CPECAN_EINVAL, "bad argument");
+    return batch_create_impl(c, items, nItems, xChars, nX, nullptr, yChars, nY, anchors, nAnchorPairs,
+                             params, CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out);
+}
+
 int cpecan_hip_batch_run(cpecan_batch *b) {
     if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
     cpecan_ctx *c = b->ctx;
@@ -553,7 +617,16 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
     if (b->mode == CPECAN_MODE_EXPECTATIONS)
         HIP_TRY(hipMemsetAsync(b->expect.p, 0, b->expect.n * sizeof(double), c->stream));
     HIP_TRY(hipEventRecord(b->ev1, c->stream));
-    if (b->kernel == CPECAN_KERNEL_GENERAL) {
+    if (b->dna) {
+        hipLaunchKernelGGL(cpecan_k_general5, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
+                           (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
+                           (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
+                           (const char *) b->chars.p, (const char *) b->charsY.p,
+                           (const double *) c->models5.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
+                           b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
+                           (double *) nullptr);
+        HIP_TRY(hipGetLastError());
+    } else if (b->kernel == CPECAN_KERNEL_GENERAL) {
         hipLaunchKernelGGL(cpecan_k_general, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
                            (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
                            (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,

@@ -756,7 +756,11 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                     const bool second = t + 1 <= dTop;
                     double v = CP_NEG_INF, w = CP_NEG_INF;
                     if (tvalid) {
+#ifdef SY_ABLATE_TOTLOADS
+                        const double fx = fMc, fy = fMc;
+#else
                         const double fx = *g.rp(t, 1), fy = *g.rp(t, 2);
+#endif
                         v = fb;
                         v = ladd(v, fx + Bx, cf);
                         v = ladd(v, fy + By, cf);
@@ -768,9 +772,13 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                          * ever above -inf) */
                         double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
                         if (xsN - 1 >= pxmin && xsN - 1 <= pxmax) {
+#ifdef SY_ABLATE_TOTLOADS
+                            s0 = s1 = s2 = fMc;
+#else
                             s0 = *g.rpb(t - 1, 0);
                             s1 = *g.rpb(t - 1, 1);
                             s2 = *g.rpb(t - 1, 2);
+#endif
                         }
                         double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
                         mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);

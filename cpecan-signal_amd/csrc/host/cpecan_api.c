@@ -119,6 +119,12 @@ void *sequence_getKmer(void *elements, int64_t index) {
     static char n[KMER_LENGTH + 1] = "nnnnnn";
     return index >= 0 ? (void *) &((char *) elements)[index] : (void *) n;
 }
+void *sequence_getBase(void *elements, int64_t index) {
+    return index >= 0 ? (void *) ((char *) elements + index) : (void *) "n";
+}
+Sequence *sequence_sliceNucleotideSequence(Sequence *in, int64_t start, int64_t sliceLength) {
+    return sequence_construct2(sliceLength, (char *) in->elements + start, in->get, in->sliceFcn);
+}
 void *sequence_getEvent(void *elements, int64_t index) {
     return index >= 0 ? (void *) &((double *) elements)[index * NB_EVENT_PARAMS] : (void *) NULLEVENT_;
 }
@@ -157,6 +163,82 @@ void stateMachine3_setTransitionsToNanoporeDefaults(StateMachine *sM) {
     s->TRANSITION_GAP_EXTEND_Y = -4.3187242127239411;
     s->TRANSITION_GAP_SWITCH_TO_X = -INFINITY;
     s->TRANSITION_GAP_SWITCH_TO_Y = -INFINITY;
+}
+
+/* ---- 5-state symbol machine (impl/stateMachine.c:896-965, :60-82, :155-173) ------------------- */
+static int base_index(void *base) { /* emissions_discrete_getBaseIndex :104-118 */
+    switch (*(char *) base) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+double emissions_symbol_getGapProb(const double *emissionGapProbs, void *base) {
+    const int i = base_index(base);
+    return i < 4 ? emissionGapProbs[i] : -INFINITY;
+}
+double emissions_symbol_getMatchProb(const double *emissionMatchProbs, void *x, void *y) {
+    const int iX = base_index(x), iY = base_index(y);
+    return iX < 4 && iY < 4 ? emissionMatchProbs[iX * 4 + iY] : -INFINITY;
+}
+void cell_updateExpectations(double *fromCells, double *toCells, int64_t from, int64_t to, double eP,
+                             double tP, void *extraArgs) {
+    (void) fromCells; (void) toCells; (void) from; (void) to; (void) eP; (void) tP; (void) extraArgs;
+    die("cpecan: cell_updateExpectations is a marker; discrete-HMM expectations are not on the GPU path");
+}
+void emissions_symbol_setEmissionsToDefaults(StateMachine *sM) {
+    const double EMISSION_MATCH = -2.1149196655034745, EMISSION_TRANSVERSION = -4.5691014376830479,
+                 EMISSION_TRANSITION = -3.9833860032220842;
+    const double M[16] = { EMISSION_MATCH, EMISSION_TRANSVERSION, EMISSION_TRANSITION, EMISSION_TRANSVERSION,
+                           EMISSION_TRANSVERSION, EMISSION_MATCH, EMISSION_TRANSVERSION, EMISSION_TRANSITION,
+                           EMISSION_TRANSITION, EMISSION_TRANSVERSION, EMISSION_MATCH, EMISSION_TRANSVERSION,
+                           EMISSION_TRANSVERSION, EMISSION_TRANSITION, EMISSION_TRANSVERSION, EMISSION_MATCH };
+    memcpy(sM->EMISSION_MATCH_PROBS, M, sizeof M);
+    for (int i = 0; i < 4; i++) sM->EMISSION_GAP_X_PROBS[i] = sM->EMISSION_GAP_Y_PROBS[i] = -1.6094379124341003;
+}
+StateMachine *stateMachine5_construct(StateMachineType type, int64_t parameterSetSize,
+                                      void (*setEmissionsDefaults)(StateMachine *sM),
+                                      double (*gapXProbFcn)(const double *, void *),
+                                      double (*gapYProbFcn)(const double *, void *),
+                                      double (*matchProbFcn)(const double *, void *, void *),
+                                      void (*cellCalcUpdateExpFcn)(double *, double *, int64_t, int64_t, double,
+                                                                   double, void *)) {
+    (void) cellCalcUpdateExpFcn;
+    if (type != fiveState && type != fiveStateAsymmetric) die("Wrong type for five state %i", (int) type);
+    if (parameterSetSize != SYMBOL_NUMBER_NO_N)
+        die("cpecan: the 5-state machine on the GPU path works on single bases (parameterSetSize 4)");
+    if (gapXProbFcn != emissions_symbol_getGapProb || gapYProbFcn != emissions_symbol_getGapProb ||
+        matchProbFcn != emissions_symbol_getMatchProb)
+        die("cpecan: the 5-state machine on the GPU path needs the emissions_symbol_* getters");
+    StateMachine5 *s = calloc(1, sizeof *s);
+    s->TRANSITION_MATCH_CONTINUE = -0.030064059121770816;
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_X = -1.272871422049609;
+    s->TRANSITION_MATCH_FROM_LONG_GAP_X = -5.673280173170473;
+    s->TRANSITION_GAP_SHORT_OPEN_X = -4.34381910900448;
+    s->TRANSITION_GAP_SHORT_EXTEND_X = -0.3388262689231553;
+    s->TRANSITION_GAP_SHORT_SWITCH_TO_X = -4.910694825551255;
+    s->TRANSITION_GAP_LONG_OPEN_X = -6.30810595366929;
+    s->TRANSITION_GAP_LONG_EXTEND_X = -0.003442492794189331;
+    s->TRANSITION_GAP_LONG_SWITCH_TO_X = -6.30810595366929;
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_Y = s->TRANSITION_MATCH_FROM_SHORT_GAP_X;
+    s->TRANSITION_MATCH_FROM_LONG_GAP_Y = s->TRANSITION_MATCH_FROM_LONG_GAP_X;
+    s->TRANSITION_GAP_SHORT_OPEN_Y = s->TRANSITION_GAP_SHORT_OPEN_X;
+    s->TRANSITION_GAP_SHORT_EXTEND_Y = s->TRANSITION_GAP_SHORT_EXTEND_X;
+    s->TRANSITION_GAP_SHORT_SWITCH_TO_Y = s->TRANSITION_GAP_SHORT_SWITCH_TO_X;
+    s->TRANSITION_GAP_LONG_OPEN_Y = s->TRANSITION_GAP_LONG_OPEN_X;
+    s->TRANSITION_GAP_LONG_EXTEND_Y = s->TRANSITION_GAP_LONG_EXTEND_X;
+    s->TRANSITION_GAP_LONG_SWITCH_TO_Y = s->TRANSITION_GAP_LONG_SWITCH_TO_X;
+    s->model.type = type;
+    s->model.parameterSetSize = parameterSetSize;
+    s->model.stateNumber = 5;
+    s->model.matchState = match;
+    s->model.EMISSION_MATCH_PROBS = calloc(16, sizeof(double));
+    s->model.EMISSION_GAP_X_PROBS = calloc(4, sizeof(double));
+    s->model.EMISSION_GAP_Y_PROBS = calloc(4, sizeof(double));
+    if (setEmissionsDefaults) setEmissionsDefaults((StateMachine *) s);
+    return (StateMachine *) s;
 }
 
 static int read_doubles(FILE *f, double *dst, int64_t n) {
@@ -259,11 +341,20 @@ static cpecan_ctx *context(void) {
     return g_ctx;
 }
 
-static void check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY) {
+/* returns 1 for the DNA-against-DNA combination (5-state machine, sequence_getBase on both sides),
+ * 0 for k-mers against events (3-state strawMan machine); anything else is not on the GPU path */
+static int check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY) {
+    if ((sM->type == fiveState || sM->type == fiveStateAsymmetric) && sM->stateNumber == 5) {
+        if (sX->get != sequence_getBase || sY->get != sequence_getBase)
+            die("cpecan: the 5-state machine needs sequence_getBase element getters on both sequences");
+        return 1;
+    }
     if (sM->type != threeState || sM->stateNumber != 3)
-        die("cpecan: only the threeState (strawMan) signal StateMachine runs on the GPU path (type %d)", sM->type);
+        die("cpecan: only the threeState (strawMan) signal and the fiveState symbol StateMachines run on "
+            "the GPU path (type %d)", sM->type);
     if (sX->get != sequence_getKmer || sY->get != sequence_getEvent)
         die("cpecan: the GPU path needs sequence_getKmer / sequence_getEvent element getters");
+    return 0;
 }
 
 typedef struct {
@@ -278,14 +369,19 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     pthread_mutex_lock(&g_lock); /* one batch at a time per process; calls from several threads queue */
     cpecan_ctx *ctx = context();
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
+    const int dna = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
+    if (dna && mode != 0) die("cpecan: expectations of the 5-state machine are not on the GPU path");
+    const int64_t xPad = dna ? 0 : KMER_LENGTH - 1; /* a k-mer sequence of lX elements spans lX + 5 chars */
     for (int64_t i = 0; i < n; i++) {
-        check_known_combination(sMs[i], sXs[i], sYs[i]);
-        nX += sXs[i]->length + (sXs[i]->length > 0 ? KMER_LENGTH - 1 : 0);
+        if (check_known_combination(sMs[i], sXs[i], sYs[i]) != dna)
+            die("cpecan: one call cannot mix DNA and signal alignments");
+        nX += sXs[i]->length + (sXs[i]->length > 0 ? xPad : 0);
         nY += sYs[i]->length;
         nA += anchorLists && anchorLists[i] ? stList_length(anchorLists[i]) : 0;
     }
     char *chars = malloc((size_t) nX + 8);
-    double *events = malloc(sizeof(double) * 3 * (size_t) (nY + 1));
+    double *events = malloc(dna ? 8 : sizeof(double) * 3 * (size_t) (nY + 1));
+    char *ychars = malloc(dna ? (size_t) nY + 8 : 8);
     int64_t *anchors = malloc(sizeof(int64_t) * 2 * (size_t) (nA + 1));
     cpecan_item *items = NULL;
     ItemOrigin *origin = NULL;
@@ -295,7 +391,25 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     cpecan_sm3_model *models = malloc(sizeof(cpecan_sm3_model) * (size_t) n);
     int32_t *modelOf = malloc(sizeof(int32_t) * (size_t) n);
     int32_t nModels = 0;
-    for (int64_t i = 0; i < n; i++) {
+    cpecan_sm5_model *models5 = malloc(sizeof(cpecan_sm5_model) * (size_t) (dna ? n : 1));
+    StateMachine **owner5 = malloc(sizeof(StateMachine *) * (size_t) (n + 1));
+    for (int64_t i = 0; dna && i < n; i++) { /* one model per distinct StateMachine5 */
+        int32_t found = -1;
+        for (int32_t k = 0; k < nModels && found < 0; k++)
+            if (owner5[k] == sMs[i]) found = k;
+        if (found < 0) {
+            const StateMachine5 *s5 = (const StateMachine5 *) sMs[i];
+            cpecan_sm5_model *m = &models5[nModels];
+            memcpy(m->transitions, &s5->TRANSITION_MATCH_CONTINUE, sizeof m->transitions);
+            memcpy(m->match_probs, sMs[i]->EMISSION_MATCH_PROBS, sizeof m->match_probs);
+            memcpy(m->gap_x_probs, sMs[i]->EMISSION_GAP_X_PROBS, sizeof m->gap_x_probs);
+            memcpy(m->gap_y_probs, sMs[i]->EMISSION_GAP_Y_PROBS, sizeof m->gap_y_probs);
+            owner5[nModels] = sMs[i];
+            found = nModels++;
+        }
+        modelOf[i] = found;
+    }
+    for (int64_t i = 0; !dna && i < n; i++) {
         StateMachine3 *s3 = (StateMachine3 *) sMs[i];
         const double t[9] = { s3->TRANSITION_MATCH_CONTINUE, s3->TRANSITION_MATCH_FROM_GAP_X,
                               s3->TRANSITION_MATCH_FROM_GAP_Y, s3->TRANSITION_GAP_OPEN_X,
@@ -321,14 +435,16 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     }
     int32_t *ids = malloc(sizeof(int32_t) * (size_t) nModels);
     CHECK(cpecan_hip_models_clear(ctx));
-    CHECK(cpecan_hip_models_create(ctx, models, nModels, 0, ids));
+    if (dna) CHECK(cpecan_hip_models5_create(ctx, models5, nModels, ids));
+    else CHECK(cpecan_hip_models_create(ctx, models, nModels, 0, ids));
 
     int64_t xo = 0, yo = 0, ao = 0;
     for (int64_t i = 0; i < n; i++) {
         const int64_t lX = sXs[i]->length, lY = sYs[i]->length;
         const int64_t na = anchorLists && anchorLists[i] ? stList_length(anchorLists[i]) : 0;
-        if (lX > 0) memcpy(chars + xo, sXs[i]->elements, (size_t) lX + KMER_LENGTH - 1);
-        if (lY > 0) memcpy(events + 3 * yo, sYs[i]->elements, sizeof(double) * 3 * (size_t) lY);
+        if (lX > 0) memcpy(chars + xo, sXs[i]->elements, (size_t) (lX + xPad));
+        if (lY > 0 && dna) memcpy(ychars + yo, sYs[i]->elements, (size_t) lY);
+        if (lY > 0 && !dna) memcpy(events + 3 * yo, sYs[i]->elements, sizeof(double) * 3 * (size_t) lY);
         int64_t *ra = malloc(sizeof(int64_t) * 2 * (size_t) (na + 1));
         for (int64_t k = 0; k < na; k++) {
             ra[2 * k] = stIntTuple_get(stList_get(anchorLists[i], k), 0);
@@ -368,7 +484,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
             origin[nItems].read = i; origin[nItems].x1 = x1; origin[nItems].y1 = y1;
             nItems++;
         }
-        xo += lX + (lX > 0 ? KMER_LENGTH - 1 : 0);
+        xo += lX + (lX > 0 ? xPad : 0);
         yo += lY;
         free(ra);
         free(sp);
@@ -379,9 +495,13 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         cpecan_band_params bp = { p->threshold, p->minDiagsBetweenTraceBack, p->traceBackDiagonals,
                                   p->diagonalExpansion };
         cpecan_batch *batch = NULL;
-        CHECK(cpecan_hip_batch_create(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
-                                      mode ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
-                                      CPECAN_KERNEL_AUTO, unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+        if (dna)
+            CHECK(cpecan_hip_batch_create_dna(ctx, items, nItems, chars, xo, ychars, yo, anchors, ao, &bp,
+                                              unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+        else
+            CHECK(cpecan_hip_batch_create(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
+                                          mode ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
+                                          CPECAN_KERNEL_AUTO, unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
         CHECK(cpecan_hip_batch_run(batch));
         CHECK(cpecan_hip_batch_sync(batch));
         if (mode == 0) {
@@ -429,7 +549,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         for (int64_t i = 0; i < n; i++) lists[i] = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
     }
     free(chars); free(events); free(anchors); free(items); free(origin); free(firstItem);
-    free(models); free(modelOf); free(ids);
+    free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars);
     pthread_mutex_unlock(&g_lock);
 }
 

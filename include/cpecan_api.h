@@ -62,6 +62,8 @@ Sequence *sequence_sliceNucleotideSequence2(Sequence *inputSequence, int64_t sta
 Sequence *sequence_sliceEventSequence2(Sequence *inputSequence, int64_t start, int64_t sliceLength);
 void sequence_sequenceDestroy(Sequence *seq);
 void *sequence_getKmer(void *elements, int64_t index);
+void *sequence_getBase(void *elements, int64_t index); /* :308-312 */
+Sequence *sequence_sliceNucleotideSequence(Sequence *inputSequence, int64_t start, int64_t sliceLength);
 void *sequence_getEvent(void *elements, int64_t index);
 int64_t sequence_correctSeqLength(int64_t length, SequenceType type);
 
@@ -111,6 +113,46 @@ typedef struct _StateMachine3 {
     double TRANSITION_GAP_SWITCH_TO_X;
     double TRANSITION_GAP_SWITCH_TO_Y;
 } StateMachine3;
+
+/* 5-state symbol machine of DNA-against-DNA alignment (inc/stateMachine.h:104-124; data members) */
+typedef struct _StateMachine5 {
+    StateMachine model;
+    double TRANSITION_MATCH_CONTINUE;
+    double TRANSITION_MATCH_FROM_SHORT_GAP_X;
+    double TRANSITION_MATCH_FROM_LONG_GAP_X;
+    double TRANSITION_GAP_SHORT_OPEN_X;
+    double TRANSITION_GAP_SHORT_EXTEND_X;
+    double TRANSITION_GAP_SHORT_SWITCH_TO_X;
+    double TRANSITION_GAP_LONG_OPEN_X;
+    double TRANSITION_GAP_LONG_EXTEND_X;
+    double TRANSITION_GAP_LONG_SWITCH_TO_X;
+    double TRANSITION_MATCH_FROM_SHORT_GAP_Y;
+    double TRANSITION_MATCH_FROM_LONG_GAP_Y;
+    double TRANSITION_GAP_SHORT_OPEN_Y;
+    double TRANSITION_GAP_SHORT_EXTEND_Y;
+    double TRANSITION_GAP_SHORT_SWITCH_TO_Y;
+    double TRANSITION_GAP_LONG_OPEN_Y;
+    double TRANSITION_GAP_LONG_EXTEND_Y;
+    double TRANSITION_GAP_LONG_SWITCH_TO_Y;
+} StateMachine5;
+#define SYMBOL_NUMBER_NO_N 4 /* inc/emissionMatrix.h */
+/* stateMachine5_construct (impl/stateMachine.c:896-965), the reference's own signature.  The emission
+ * initialiser is called on the host; the three probability getters must be the symbol getters below
+ * (they name the emission model the device code implements); the expectation updater is ignored
+ * (posterior decode only). */
+StateMachine *stateMachine5_construct(StateMachineType type, int64_t parameterSetSize,
+                                      void (*setEmissionsDefaults)(StateMachine *sM),
+                                      double (*gapXProbFcn)(const double *, void *),
+                                      double (*gapYProbFcn)(const double *, void *),
+                                      double (*matchProbFcn)(const double *, void *, void *),
+                                      void (*cellCalcUpdateExpFcn)(double *fromCells, double *toCells,
+                                                                   int64_t from, int64_t to, double eP,
+                                                                   double tP, void *extraArgs));
+void emissions_symbol_setEmissionsToDefaults(StateMachine *sM);                            /* :60-82   */
+double emissions_symbol_getGapProb(const double *emissionGapProbs, void *base);            /* :155-163 */
+double emissions_symbol_getMatchProb(const double *emissionMatchProbs, void *x, void *y);  /* :165-173 */
+void cell_updateExpectations(double *fromCells, double *toCells, int64_t from, int64_t to, double eP,
+                             double tP, void *extraArgs); /* marker only (impl/pairwiseAligner.c:407) */
 
 /* getStrawManStateMachine3 (impl/stateMachine.c:1725): 3-state machine with nanopore default
  * transitions (:1278), log(0.1) k-mer gap table (:1506), emission tables from a 3-line .model file */

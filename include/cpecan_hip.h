@@ -62,6 +62,21 @@ int cpecan_hip_models_create(cpecan_ctx *ctx, const cpecan_sm3_model *models, in
                              int32_t threads, int32_t *ids);
 int cpecan_hip_models_clear(cpecan_ctx *ctx);
 
+/* The 5-state symbol machine of DNA-against-DNA alignment: stateMachine5_construct(fiveState)
+ * (impl/stateMachine.c:896-965; BASELINE configs[0]).  transitions in the order of struct
+ * _StateMachine5 (inc/stateMachine.h:108-124): MATCH_CONTINUE, MATCH_FROM_SHORT_GAP_X,
+ * MATCH_FROM_LONG_GAP_X, GAP_SHORT_OPEN_X, GAP_SHORT_EXTEND_X, GAP_SHORT_SWITCH_TO_X, GAP_LONG_OPEN_X,
+ * GAP_LONG_EXTEND_X, GAP_LONG_SWITCH_TO_X, then the same eight for Y; emissions as
+ * emissions_symbol_* reads them (:155-173): match [4x4] by (x base, y base), gaps [4].
+ * Ids live in their own space (used by cpecan_hip_batch_create_dna only). */
+typedef struct {
+    double transitions[17];
+    double match_probs[16];
+    double gap_x_probs[4];
+    double gap_y_probs[4];
+} cpecan_sm5_model;
+int cpecan_hip_models5_create(cpecan_ctx *ctx, const cpecan_sm5_model *models, int32_t n, int32_t *ids);
+
 /* ---- band / split geometry (host integer code, exported because the reference exports it) ----
  * cpecan_band_construct: band_construct (impl/pairwiseAligner.c:132); xmyL/xmyR hold lX+lY+1 entries.
  * cpecan_split_points: getSplitPoints (:1313); out holds up to cap 4-tuples; returns the count. */
@@ -99,7 +114,7 @@ typedef struct {
 
 #define CPECAN_KERNEL_AUTO 0
 #define CPECAN_KERNEL_GENERAL 1  /* any band width; diagonals live in HBM            */
-#define CPECAN_KERNEL_SYSTOLIC 2 /* band <= 192 k-mers wide; register-resident wavefront */
+#define CPECAN_KERNEL_SYSTOLIC 2 /* band <= 248 k-mers wide; register-resident wavefront */
 
 #define CPECAN_FLAG_DEBUG_DUMP 1 /* keep forward/backward cells for cpecan_hip_batch_debug_cells */
 #define CPECAN_FLAG_UNBANDED 2   /* getAlignedPairsWithoutBanding (:1512): full matrix, one traceback from
@@ -117,6 +132,16 @@ int cpecan_hip_batch_create(cpecan_ctx *ctx, const cpecan_item *items, int64_t n
                             const cpecan_band_params *params, int32_t mode, int32_t kernel,
                             int32_t flags, cpecan_batch **batch);
 /* Runs the DP for every item (asynchronous on the context's stream). */
+/* DNA against DNA with a 5-state model (getAlignedPairsUsingAnchors with a stateMachine5 and
+ * sequence_getBase on both sides, impl/pairwiseAligner.c:1456,:308): X and Y are nucleotide strings,
+ * lX / lY count bases, x_offset / y_offset index x_chars / y_chars, model_id is a
+ * cpecan_hip_models5_create id.  Posterior decode on the general kernel; flags: DEBUG_DUMP is not
+ * available, UNBANDED is. */
+int cpecan_hip_batch_create_dna(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
+                                const char *x_chars, int64_t n_x, const char *y_chars, int64_t n_y,
+                                const int64_t *anchors, int64_t n_anchor_pairs,
+                                const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
+
 int cpecan_hip_batch_run(cpecan_batch *batch);
 int cpecan_hip_batch_sync(cpecan_batch *batch);
 /* HIP-event time of the last run's kernels, in ms (after sync). */

@@ -50,7 +50,9 @@ EXPORTS = [
     "diagonalCalculationPosteriorMatchProbs", "getAlignedPairsUsingAnchors",
     "getAlignedPairsWithoutBanding", "getSplitPoints", "getSignalExpectationsUsingAnchors",
     "continuousPairHmm_normalize", "continuousPairHmm_loadTransitionsAndKmerGapProbs",
-    "getAlignedPairsUsingAnchorsBatch",
+    "getAlignedPairsUsingAnchorsBatch", "sequence_getBase", "sequence_sliceNucleotideSequence",
+    "stateMachine5_construct", "emissions_symbol_setEmissionsToDefaults", "emissions_symbol_getGapProb",
+    "emissions_symbol_getMatchProb", "cell_updateExpectations",
 ]
 
 _LIB = None
@@ -86,6 +88,8 @@ def lib():
         L.emissions_discrete_getKmerIndex.restype = C.c_int64
         L.emissions_discrete_getKmerIndex.argtypes = [C.c_char_p]
         L.stateMachine_destruct.argtypes = [vp]
+        L.stateMachine5_construct.restype = vp
+        L.stateMachine5_construct.argtypes = [C.c_int, C.c_int64, vp, vp, vp, vp, vp]
         L.getAlignedPairsUsingAnchors.restype = vp
         L.getAlignedPairsUsingAnchors.argtypes = [vp, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
         L.getAlignedPairsWithoutBanding.restype = vp

@@ -13,7 +13,7 @@ cp = binding()
 
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "cpecan_hip.h")).read()
-    declared = set(re.findall(r"\b(cpecan_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(cpecan_[a-z0-9_]+)\s*\(", header))
     assert declared == set(cp.EXPORTS), declared ^ set(cp.EXPORTS)
     lib = ctypes.CDLL(cp.LIB_PATH)
     for name in sorted(declared):

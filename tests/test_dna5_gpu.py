@@ -1,0 +1,110 @@
+"""GPU parity of the 5-state symbol machine (DNA against DNA, BASELINE configs[0]) against
+the oracle, through the C-ABI (cpecan_hip_batch_create_dna -> cpecan_k_general5).
+
+The oracle's 5-state machine is pinned by the reference's toy known answer
+(tests/pairwiseAlignerTest.c:278-373: "AGCG" / "AGTTCG", 4 aligned pairs) in test_oracle_golden.py.
+Bar: totalProbability refreshes and posterior exponents bit-identical, pairs in the reference's
+emission order, integer posteriors within 1 of 1e7 (device exp vs host libm exp)."""
+import numpy as np
+import pytest
+
+import pyoracle as o
+from harness import assert_same_pairs, band_params, cp, orc_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = cp.Context(0)
+    yield c
+    c.close()
+
+
+def evolve(rng, n, sub=0.2, indel=0.05):
+    """random ACGT string and a mutated copy (as the reference's tests do with evolveSequence,
+    tests/randomSequences.c); returns x, y and the (x, y) index pairs of the unmutated bases"""
+    x = rng.choice(list("ACGT"), n)
+    y, pairs = [], []
+    for i, ch in enumerate(x):
+        r = rng.random()
+        if r < indel:
+            continue                                   # deletion
+        if r < 2 * indel:
+            y.append(rng.choice(list("ACGT")))          # insertion, then the base itself
+        if rng.random() < sub:
+            y.append(rng.choice([b for b in "ACGT" if b != ch]))
+        else:
+            pairs.append((i, len(y)))
+            y.append(ch)
+    return "".join(x), "".join(y), np.array(pairs, np.int64).reshape(-1, 2)
+
+
+def run_case(ctx, seqs, bp, ragged, flags=0, unbanded=False):
+    model = o.Sm5Model()
+    ctx.models_clear()
+    ids = ctx.models5_create([(list(model.c.t), model.match, model.gx, model.gy)])
+    xs, ys, an = "", "", []
+    items = np.zeros(len(seqs), cp.ITEM_DTYPE)
+    for i, (x, y, a) in enumerate(seqs):
+        items[i] = (len(xs), len(x), len(ys), len(y), sum(len(q) for q in an), len(a), ids[0],
+                    ragged[0], ragged[1], 0)
+        xs += x
+        ys += y
+        an.append(a)
+    anchors = np.concatenate(an) if an else np.zeros((0, 2), np.int64)
+    b = cp.Batch(ctx, items, xs, None, anchors, bp, flags=flags, y_chars=ys)
+    b.run()
+    b.sync()
+    npairs, ntot, ncells = b.counts()
+    assert b.info()["kernel"] == "general"
+    p = orc_params(bp, split=1 << 60)
+    for i, (x, y, a) in enumerate(seqs):
+        tri, lp = b.pairs(i, npairs[i])
+        xay, tot = b.totals(i, ntot[i])
+        if unbanded:  # the oracle returns this list in the caller's (ascending) order
+            ref = o.aligned_pairs_without_banding(model, x, len(x), y, p, ragged[0], ragged[1])
+            order = np.lexsort((ref["triples"][:, 1], -(ref["triples"][:, 1] + ref["triples"][:, 2])))
+            ref["triples"], ref["logp"] = ref["triples"][order], ref["logp"][order]
+        else:
+            ref = o.aligned_pairs_using_anchors(model, x, len(x), y, a, p, ragged[0], ragged[1])
+            ref["triples"] = ref["triples"][::-1]  # undo the stList_pop reversal: emission order
+            ref["logp"] = ref["logp"][::-1]
+        assert int(ncells[i]) == ref["cells"]
+        assert np.array_equal(xay, ref["totals_xay"])
+        assert np.array_equal(tot, ref["totals"])
+        assert_same_pairs(dict(triples=tri, logp=lp), ref)
+        assert len(tri) > 0
+    b.close()
+
+
+def test_toy_known_answer(ctx):
+    # the reference's test_diagonalDPCalculations inputs (tests/pairwiseAlignerTest.c:278-373)
+    bp = band_params(0.2, 4, 1, 2)
+    run_case(ctx, [("AGCG", "AGTTCG", np.zeros((0, 2), np.int64))], bp, (0, 0), flags=cp.FLAG_UNBANDED,
+             unbanded=True)
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=3, length=60, e=20, md=30, tb=5, ragged=(0, 0), anchored=False),
+    dict(n=3, length=150, e=10, md=40, tb=8, ragged=(1, 1), anchored=True),
+    dict(n=2, length=300, e=20, md=100, tb=40, ragged=(1, 0), anchored=True),
+])
+def test_dna5_matches_oracle(ctx, case):
+    rng = np.random.default_rng(31 + case["length"])
+    seqs = []
+    for _ in range(case["n"]):
+        x, y, pairs = evolve(rng, case["length"])
+        a = pairs[5::12] if case["anchored"] else np.zeros((0, 2), np.int64)
+        seqs.append((x, y, a))
+    bp = band_params(0.01, case["md"], case["tb"], case["e"])
+    run_case(ctx, seqs, bp, case["ragged"])
+
+
+def test_config1_two_1kb_sequences(ctx):
+    # BASELINE configs[0]: two ~1 kb sequences, no anchors (full matrix), the reference's default
+    # banding parameters
+    rng = np.random.default_rng(41)
+    x, y, _ = evolve(rng, 1000)
+    bp = band_params(0.01, 1000, 40, 20)
+    run_case(ctx, [(x, y, np.zeros((0, 2), np.int64))], bp, (0, 0))

@@ -159,3 +159,40 @@ def test_batch_entry_matches_single_calls(golden_dir):
         assert np.array_equal(a, b) and len(a) > 0
         L.stList_destruct(single)
         L.stList_destruct(out[i])
+
+
+@pytest.mark.gpu
+def test_five_state_dna_through_host_api():
+    """the reference's DNA-against-DNA use of the API (tests/pairwiseAlignerTest.c:503-560 style):
+    stateMachine5_construct + sequence_getBase + getAlignedPairsUsingAnchors, against the oracle."""
+    L = h.lib()
+    rng = np.random.default_rng(5)
+    x = "".join(rng.choice(list("ACGT"), 180))
+    y = "".join(ch if rng.random() > 0.15 else rng.choice(list("ACGT")) for ch in x[:70] + x[78:])
+    sm = L.stateMachine5_construct(0, 4, h.fn_ptr("emissions_symbol_setEmissionsToDefaults"),
+                                   h.fn_ptr("emissions_symbol_getGapProb"), h.fn_ptr("emissions_symbol_getGapProb"),
+                                   h.fn_ptr("emissions_symbol_getMatchProb"), h.fn_ptr("cell_updateExpectations"))
+    xb, yb = C.create_string_buffer(x.encode()), C.create_string_buffer(y.encode())
+    sX = L.sequence_construct2(len(x), C.cast(xb, C.c_void_p), h.fn_ptr("sequence_getBase"),
+                               h.fn_ptr("sequence_sliceNucleotideSequence"))
+    sY = L.sequence_construct2(len(y), C.cast(yb, C.c_void_p), h.fn_ptr("sequence_getBase"),
+                               h.fn_ptr("sequence_sliceNucleotideSequence"))
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    p.contents.minDiagsBetweenTraceBack = 60
+    p.contents.traceBackDiagonals = 10
+    anchors = [(20, 20), (60, 60), (120, 112)]
+    lst = h.make_anchor_list(anchors)
+    pairs = L.getAlignedPairsUsingAnchors(sm, sX, sY, lst, p, h.fn_ptr("diagonalCalculationPosteriorMatchProbs"),
+                                          False, False)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    op = o.default_params(minDiagsBetweenTraceBack=60, traceBackDiagonals=10)
+    ref = o.aligned_pairs_using_anchors(o.Sm5Model(), x, len(x), y, anchors, op, False, False)
+    assert len(got) > 100
+    assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
+    assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+    L.stList_destruct(lst)
+    L.sequence_sequenceDestroy(sX)
+    L.sequence_sequenceDestroy(sY)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)
