@@ -31,6 +31,10 @@ CASES = [
     dict(n=3, lX=90, lY=200, e=0, md=30, tb=5, every=10, ragged=(0, 1)),
     dict(n=2, lX=520, lY=500, e=60, md=120, tb=20, every=40, ragged=(0, 0)),   # more k-mers than events
     dict(n=2, lX=64, lY=64, e=200, md=1000, tb=40, every=1000, ragged=(1, 1)),  # unanchored, full matrix
+    # windows shorter than the traceback margin: a launch's diagonals are decoded by windows two and
+    # more ahead, so the forward kernel keeps every state everywhere
+    dict(n=2, lX=200, lY=410, e=30, md=12, tb=10, every=40, ragged=(1, 1)),
+    dict(n=2, lX=200, lY=410, e=30, md=25, tb=10, every=40, ragged=(0, 0)),
 ]
 
 
