@@ -67,7 +67,7 @@ __device__ unsigned long long sy_prof[80];
 namespace {
 
 struct Shared {
-    double coef[16];         /* lookup() cubics, [piece][c3,c2,c1,c0]: one ds_read_b128 pair per logAdd */
+    double coef[64];         /* lookup() cubics [c3,c2,c1,c0] by n = ceil(2d), 0..15: one ds_read_b128 pair per logAdd */
     double xch[2][SY_R][8];  /* boundary-lane values, double-buffered by diagonal parity */
     double vbuf[SY_P];       /* phase T: per-thread fold results; the sweep's estimate of the total */
     double wbuf[SY_P];       /* decode: partial hit counts */
@@ -142,13 +142,19 @@ __device__ __forceinline__ double ladd(double x, double y, const double *coef) {
     asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
     asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
     const double d = hi - lo;
+    /* the piece of lookup() (d <= 1, <= 2.5, <= 4.5, else) from n = ceil(2d): the thresholds are
+     * multiples of 1/2 and 2d is exact, so d > 1 <=> n >= 3, d > 2.5 <=> n >= 6, d > 4.5 <=> n >= 10;
+     * the LDS table holds the cubic of n's piece at entry n (0..15), so no comparison is needed.
+     * NaN (both operands -inf) converts to 0, d >= 7.5 is clamped: either way the cubic is discarded. */
+    int n;
 #ifdef SY_ABLATE_COEF
-    const int idx = 0;
+    n = 0;
 #else
-    const int idx = (int) (d > 1.00f) + (int) (d > 2.50f) + (int) (d > 4.50f);
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(d + d)));
+    n = n < 15 ? n : 15;
 #endif
     /* one LDS address, two 16-byte reads (the compiler would form two addresses) */
-    const unsigned a = (unsigned) (size_t) (const __attribute__((address_space(3))) double *) coef + idx * 32u;
+    const unsigned a = (unsigned) (size_t) (const __attribute__((address_space(3))) double *) coef + n * 32u;
     double2 c32, c10;
     asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                  : "=&v"(c32), "=&v"(c10) : "v"(a));
@@ -160,7 +166,11 @@ __device__ __forceinline__ void init_coef(double *coef) {
                           -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
                           -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
                           -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f };
-    if (threadIdx.x < 16) coef[threadIdx.x] = (double) t[threadIdx.x];
+    /* entry n = ceil(2d) carries the cubic [c3,c2,c1,c0] of the piece d falls in */
+    if (threadIdx.x < 64) {
+        const int n = threadIdx.x >> 2, piece = n <= 2 ? 0 : n <= 5 ? 1 : n <= 9 ? 2 : 3;
+        coef[threadIdx.x] = (double) t[piece * 4 + (threadIdx.x & 3)];
+    }
 }
 
 /* log N(x; mu, sd) = K + (-0.5*a*a), a = (x-mu)/sd (impl/stateMachine.c:333-343); the quotient is

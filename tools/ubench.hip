@@ -60,6 +60,11 @@ KERNEL(k_barrier, asm volatile(".rept 8\n s_barrier\n .endr" ::: "memory");)
 // v_readlane + exec-masked move (install)
 KERNEL(k_readlane, asm volatile(".rept 32\n v_readlane_b32 %1, %0, 3\n s_nop 3\n v_mov_b32 %0, %1\n .endr" : "+v"(v0), "+s"(s0));)
 
+// rounding / conversion ops considered for the logAdd piece index
+KERNEL(k_ceil_dep, asm volatile(".rept 64\n v_ceil_f64 %0, %0\n .endr" : "+v"(a));)
+KERNEL(k_cvt_pair, asm volatile(".rept 32\n v_cvt_i32_f64 %1, %0\n v_cvt_f64_i32 %0, %1\n .endr" : "+v"(a), "+v"(v0));)
+KERNEL(k_ldexp_dep, asm volatile(".rept 64\n v_ldexp_f64 %0, %0, 1\n .endr" : "+v"(a));)
+KERNEL(k_min_i32, asm volatile(".rept 64\n v_min_i32 %0, %0, %1\n .endr" : "+v"(v0) : "v"(v1));)
 // long straight-line bodies (several KB of code per iteration): instruction-fetch behaviour
 KERNEL(k_long_valu, asm volatile(".rept 704\n v_fma_f64 %0, %0, %1, %2\n .endr" : "+v"(a) : "v"(b), "v"(c));)
 // every 8th instruction a taken branch over 8 dead instructions (64 bytes: target in another fetch line)
@@ -84,7 +89,9 @@ int main() {
                {"add_f64+s_add 1:1", k_valu_salu, 64}, {"dpp wave_shr", k_dpp, 64},
                {"ds_read_b128 serial", k_lds_b128, 16}, {"ds_read_b128 x4", k_lds_b128_x4, 16},
                {"branch taken", k_branch, 16}, {"s_barrier", k_barrier, 8},
-               {"readlane+mov", k_readlane, 32}, {"long valu 704", k_long_valu, 704},
+               {"readlane+mov", k_readlane, 32}, {"ceil_f64 dependent", k_ceil_dep, 64}, {"cvt i32<->f64", k_cvt_pair, 64},
+               {"ldexp_f64 dependent", k_ldexp_dep, 64}, {"min_i32 dependent", k_min_i32, 64},
+               {"long valu 704", k_long_valu, 704},
                {"long branchy 88x(6+br)", k_long_branchy, 704}, {"long not-taken", k_long_nottaken, 704},
                {"long mixed 3v+1s", k_long_mixed, 704} };
     // occupancies: waves per SIMD = (threads per WG / 64 / 4) * WGs per CU; we launch 256 WGs (1 per CU)
