@@ -883,22 +883,26 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
         double acc = CP_NEG_INF;
         if (f == 0 || w.second) {
             const int lo = f ? w.nxmin : w.xmin, hi = f ? w.nxmax : w.xmax;
+            const double *src = vw + ((long long) (k >> 1) * 2 + f) * SY_P;
+            double v[8], nv[8]; /* the next eight terms are in flight while these eight are folded */
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = lo + j <= hi ? src[(lo + j) & (SY_P - 1)] : CP_NEG_INF;
 #pragma unroll 1
             for (int x0 = lo; x0 <= hi; x0 += 8) {
-                double v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    v[j] = x0 + j <= hi ? vw[((long long) (k >> 1) * 2 + f) * SY_P + ((x0 + j) & (SY_P - 1))]
-                                        : CP_NEG_INF;
+                    nv[j] = x0 + 8 + j <= hi ? src[(x0 + 8 + j) & (SY_P - 1)] : CP_NEG_INF;
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc = cp_logAdd(acc, v[j]); /* dpDiagonal_dotProduct :587-597 */
+                for (int j = 0; j < 8; j++) acc = ladd(acc, v[j], cf); /* dpDiagonal_dotProduct :587-597 */
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = nv[j];
             }
         }
         sh.vbuf[threadIdx.x] = acc;
         __builtin_amdgcn_wave_barrier();
         if (f == 0) {
             double tot = acc;
-            if (w.second) tot = cp_logAdd(acc, sh.vbuf[threadIdx.x + 1]);
+            if (w.second) tot = ladd(acc, sh.vbuf[threadIdx.x + 1], cf);
             wtot[k >> 1].total = tot;
             if (!(fabs(tot - totEst) <= SY_CAND_SLACK)) sh.scan = 1; /* also catches NaN and infinities */
             const long long o = out.nTot + (k >> 1);
@@ -940,32 +944,43 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
         };
         auto prefix = [&]() __attribute__((always_inline)) {
                 /* hits per diagonal from the masks; exclusive prefix in emission order */
-                const int per = (nPost + 255) / 256;
-                const int b0 = threadIdx.x * per, b1 = min(b0 + per, nPost);
-                int sum = 0;
-#pragma unroll 1
-                for (int k = b0; k < b1; k++)
-                    sum += hits_of(k);
                 int *part = (int *) sh.wbuf;
-                part[threadIdx.x] = sum;
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    int run = 0;
+                int carry = 0; /* hits of the rounds before this one */
 #pragma unroll 1
-                    for (int q = 0; q < 256; q++) {
-                        const int c = part[q];
-                        part[q] = run;
-                        run += c;
+                for (int base = 0; base < nPost; base += 8 * 256) { /* 2048 diagonals per round */
+                    const int b0 = base + (int) threadIdx.x * 8;
+                    int h[8];
+                    int sum = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        h[j] = b0 + j < nPost ? hits_of(b0 + j) : 0;
+                        sum += h[j];
                     }
-                    sh.cnt[0][0][0] = run;
+                    /* exclusive scan over the 256 threads: shuffles inside a wave, LDS across the four */
+                    int inc = sum;
+#pragma unroll
+                    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                        const int up = __shfl_up(inc, o2);
+                        if (lane >= o2) inc += up;
+                    }
+                    __syncthreads(); /* part[] of the previous round has been read */
+                    if (lane == 63) part[wave] = inc;
+                    __syncthreads();
+                    int o = carry + inc - sum;
+#pragma unroll
+                    for (int w2 = 0; w2 < SY_R; w2++) {
+                        const int c = part[w2];
+                        if (w2 < wave) o += c;
+                    }
+                    carry += part[0] + part[1] + part[2] + part[3];
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (b0 + j < nPost) {
+                            off[b0 + j] = o;
+                            o += h[j];
+                        }
                 }
-                __syncthreads();
-                int o = part[threadIdx.x];
-#pragma unroll 1
-                for (int k = b0; k < b1; k++) {
-                    off[k] = o;
-                    o += hits_of(k);
-                }
+                if (threadIdx.x == 0) sh.cnt[0][0][0] = carry;
                 __syncthreads();
                 BPROF(5)
         };
