@@ -37,6 +37,7 @@ EXPORTS = [
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
+    "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
 ]
 
 
@@ -54,6 +55,12 @@ class Sm3ModelDesc(C.Structure):
 class Sm5ModelDesc(C.Structure):
     _fields_ = [("transitions", C.c_double * 17), ("match_probs", C.c_double * 16),
                 ("gap_x_probs", C.c_double * 4), ("gap_y_probs", C.c_double * 4)]
+
+
+class VanillaModelDesc(C.Structure):
+    _fields_ = [("m_to_y_not_x", C.c_double), ("e_to_e", C.c_double), ("end_match_prob", C.c_double),
+                ("end_from_x_prob", C.c_double), ("end_from_y_prob", C.c_double),
+                ("match_probs", C.c_void_p), ("skip_probs", C.c_void_p), ("gap_y_probs", C.c_void_p)]
 
 
 class Item(C.Structure):
@@ -109,6 +116,10 @@ def lib():
             C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.c_int32, C.c_int32,
             C.POINTER(C.c_void_p)]
         L.cpecan_hip_models5_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.cpecan_hip_modelsv_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cpecan_hip_batch_create_vanilla.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
         L.cpecan_hip_batch_create_dna.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
             C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
@@ -218,6 +229,27 @@ class Context:
         _check(lib().cpecan_hip_models5_create(self.h, C.cast(descs, C.c_void_p), n, _ptr(ids)))
         return ids
 
+    def modelsv_create(self, models, threads=0):
+        """models: list of (scalars[5] = m_to_y_not_x, e_to_e, end_match, end_from_x, end_from_y;
+        match[20481], skip[60], gap_y[20481]) -> ids (vanilla signal machine)"""
+        n = len(models)
+        descs = (VanillaModelDesc * n)()
+        keep = []
+        for i, (sc, match, skip, gy) in enumerate(models):
+            match = np.ascontiguousarray(match, dtype=np.float64)
+            skip = np.ascontiguousarray(skip, dtype=np.float64)
+            gy = np.ascontiguousarray(gy, dtype=np.float64)
+            assert match.size == MODEL_TABLE_LEN and gy.size == MODEL_TABLE_LEN and skip.size == 60
+            keep += [match, skip, gy]
+            (descs[i].m_to_y_not_x, descs[i].e_to_e, descs[i].end_match_prob, descs[i].end_from_x_prob,
+             descs[i].end_from_y_prob) = [float(v) for v in sc]
+            descs[i].match_probs = match.ctypes.data
+            descs[i].skip_probs = skip.ctypes.data
+            descs[i].gap_y_probs = gy.ctypes.data
+        ids = np.zeros(n, np.int32)
+        _check(lib().cpecan_hip_modelsv_create(self.h, C.cast(descs, C.c_void_p), n, threads, _ptr(ids)))
+        return ids
+
     def models_clear(self):
         _check(lib().cpecan_hip_models_clear(self.h))
 
@@ -231,8 +263,9 @@ class Batch:
     """cpecan_batch: items is a numpy array of ITEM_DTYPE."""
 
     def __init__(self, ctx, items, x_chars, events, anchors, params, mode=MODE_POSTERIOR,
-                 kernel=KERNEL_AUTO, flags=0, y_chars=None):
-        """events: double[n][3] for a signal batch; y_chars (str/bytes) instead for a DNA batch."""
+                 kernel=KERNEL_AUTO, flags=0, y_chars=None, vanilla=False):
+        """events: double[n][3] for a signal batch (vanilla: with a modelsv_create model); y_chars
+        (str/bytes) instead for a DNA batch."""
         self.ctx = ctx
         items = np.ascontiguousarray(items, dtype=ITEM_DTYPE)
         xb = np.frombuffer(x_chars.encode() if isinstance(x_chars, str) else bytes(x_chars), np.uint8)
@@ -243,6 +276,11 @@ class Batch:
             _check(lib().cpecan_hip_batch_create_dna(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
                                                      _ptr(yb), yb.size, _ptr(an), an.shape[0],
                                                      C.byref(params), flags, C.byref(h)))
+        elif vanilla:
+            ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+            _check(lib().cpecan_hip_batch_create_vanilla(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
+                                                         _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
+                                                         C.byref(params), flags, C.byref(h)))
         else:
             ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
             _check(lib().cpecan_hip_batch_create(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,

@@ -35,6 +35,23 @@
 #define CP_YK2 15
 #define CP_GAPX 16
 #define CP_MODEL5_STRIDE 48 /* 5-state symbol model: 17 transitions, pad to 24, 16 match, 4 gapX, 4 gapY */
+/* vanilla signal model block: header (scalars, per-bin log transition probabilities), then one row per
+ * k-mer (4096 + the "not a k-mer" row): the match table's six values, then the extra-event table's */
+#define CP_VHDR 160
+#define CP_VHDR_END_M 2
+#define CP_VHDR_END_X 3
+#define CP_VHDR_END_Y 4
+#define CP_VHDR_LOG_YY 5
+#define CP_VHDR_LOG_YM 6
+#define CP_VHDR_BINS 8 /* 30 x [log a_mx, log a_xx, log a_mm, log a_xm, log a_my] */
+#define CP_VROW 12
+#define CP_V_MU 0
+#define CP_V_SD 1
+#define CP_V_K 2
+#define CP_V_NMU 3
+#define CP_V_LAMBDA 4
+#define CP_V_LLAMBDA 5
+#define CP_VMODEL_STRIDE (CP_VHDR + 4097 * CP_VROW)
 #define CP_MODEL_HEADER 16 /* doubles in front of the rows: the 9 transitions */
 #define CP_MODEL_STRIDE (CP_MODEL_HEADER + 4097 * CP_ROW)
 

@@ -30,6 +30,11 @@ extern "C" __global__ void cpecan_k_general5(const DevItem *, DevParams, const i
                                              const long long *, const char *, const char *, const double *,
                                              double *, double *, long long *, double *, long long *,
                                              long long *, double *, long long *, double *);
+extern "C" __global__ void cpecan_k_generalv(const DevItem *, DevParams, const int *, const int *,
+                                             const long long *, const unsigned short *, const double *,
+                                             const double *, const double *, double *, double *,
+                                             long long *, double *, long long *, long long *, double *,
+                                             long long *);
 extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned short *);
 
 extern "C" int cpecan_systolic_max_width(void);
@@ -108,6 +113,9 @@ struct cpecan_ctx {
     DevBuf<double> models5; /* 5-state symbol models, nModels5 * CP_MODEL5_STRIDE */
     std::vector<double> hostModels5;
     int nModels5 = 0;
+    DevBuf<double> modelsV; /* vanilla signal models, nModelsV * CP_VMODEL_STRIDE */
+    std::vector<double> hostModelsV;
+    int nModelsV = 0;
 };
 
 struct cpecan_batch {
@@ -121,6 +129,8 @@ struct cpecan_batch {
     DevBuf<long long> cellPrefix;
     DevBuf<char> chars, charsY; /* charsY: DNA batches (5-state machine) */
     bool dna = false;
+    bool vanilla = false;
+    DevBuf<double> logNoise; /* vanilla batches: log(event noise), host libm */
     DevBuf<unsigned short> kidx;
     DevBuf<double> events;
     DevBuf<long long> anchors;
@@ -278,6 +288,81 @@ int cpecan_hip_selftest_division(cpecan_ctx *c, int64_t n, uint64_t seed, int64_
     return CPECAN_OK;
 }
 
+/* Device block of one vanilla model.  Every log() the reference takes per cell
+ * (stateMachine3Vanilla_cellCalculate :1391-1407, logGaussPdf :338, logInvGaussPdf :328) depends on the
+ * skip bin or the k-mer only: taken here once, with the host libm the reference would call. */
+static void derive_vanilla(const cpecan_vanilla_model *m, double *dst) {
+    for (int i = 0; i < CP_VHDR; i++) dst[i] = 0.0;
+    dst[0] = m->m_to_y_not_x;
+    dst[1] = m->e_to_e;
+    dst[CP_VHDR_END_M] = m->end_match_prob;
+    dst[CP_VHDR_END_X] = m->end_from_x_prob;
+    dst[CP_VHDR_END_Y] = m->end_from_y_prob;
+    const double a_yy = m->e_to_e, a_ym = 1.0f - a_yy;
+    dst[CP_VHDR_LOG_YY] = log(a_yy);
+    dst[CP_VHDR_LOG_YM] = log(a_ym);
+    for (int bin = 0; bin < 30; bin++) {
+        const double a_mx = m->skip_probs[bin];
+        const double a_my = (1 - a_mx) * m->m_to_y_not_x;
+        const double a_mm = 1.0f - a_my - a_mx;
+        const double a_xx = m->skip_probs[bin + 30];
+        const double a_xm = 1.0f - a_xx;
+        double *b = dst + CP_VHDR_BINS + bin * 5;
+        b[0] = log(a_mx);
+        b[1] = log(a_xx);
+        b[2] = log(a_mm);
+        b[3] = log(a_xm);
+        b[4] = log(a_my);
+    }
+    const double c = -0.91893853320467267;
+    double *rows = dst + CP_VHDR;
+    for (int k = 0; k <= CPECAN_NUM_KMERS; k++) {
+        double *r = rows + (size_t) k * CP_VROW;
+        for (int t = 0; t < 2; t++) {
+            double *q = r + 6 * t;
+            if (k == CPECAN_NUM_KMERS) { /* not a k-mer: level -inf, the noise term kept finite */
+                q[CP_V_MU] = 0.0; q[CP_V_SD] = 0.0; q[CP_V_K] = -INFINITY;
+                q[CP_V_NMU] = 1.0; q[CP_V_LAMBDA] = 1.0; q[CP_V_LLAMBDA] = 0.0;
+                continue;
+            }
+            const double *a = (t ? m->gap_y_probs : m->match_probs) + 1 + (size_t) k * CPECAN_MODEL_PARAMS;
+            q[CP_V_MU] = a[0];
+            q[CP_V_SD] = a[1];
+            q[CP_V_K] = a[1] == 0.0 ? -INFINITY : c - log(a[1]);
+            q[CP_V_NMU] = a[2];
+            q[CP_V_LAMBDA] = a[4];
+            q[CP_V_LLAMBDA] = log(a[4]);
+        }
+    }
+}
+
+int cpecan_hip_modelsv_create(cpecan_ctx *c, const cpecan_vanilla_model *models, int32_t n, int32_t threads,
+                              int32_t *ids) {
+    if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++)
+        if (!models[i].match_probs || !models[i].skip_probs || !models[i].gap_y_probs)
+            return fail(CPECAN_EINVAL, "model %d has a NULL table", i);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t old = c->hostModelsV.size();
+    c->hostModelsV.resize(old + (size_t) n * CP_VMODEL_STRIDE);
+    int nt = threads > 0 ? threads : (int) std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, (int) n));
+    std::vector<std::thread> pool;
+    for (int w = 0; w < nt; w++)
+        pool.emplace_back([&, w]() {
+            for (int i = w; i < n; i += nt)
+                derive_vanilla(&models[i], c->hostModelsV.data() + old + (size_t) i * CP_VMODEL_STRIDE);
+        });
+    for (auto &t : pool) t.join();
+    for (int i = 0; i < n; i++) ids[i] = c->nModelsV + i;
+    c->nModelsV += n;
+    hipError_t e = c->modelsV.alloc(c->hostModelsV.size());
+    if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpy(c->modelsV.p, c->hostModelsV.data(), c->hostModelsV.size() * sizeof(double),
+                      hipMemcpyHostToDevice));
+    return CPECAN_OK;
+}
+
 int cpecan_hip_models5_create(cpecan_ctx *c, const cpecan_sm5_model *models, int32_t n, int32_t *ids) {
     if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -308,6 +393,9 @@ int cpecan_hip_models_clear(cpecan_ctx *c) {
     c->models5.release();
     c->hostModels5.clear();
     c->nModels5 = 0;
+    c->modelsV.release();
+    c->hostModelsV.clear();
+    c->nModelsV = 0;
     return CPECAN_OK;
 }
 
@@ -342,8 +430,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                              const char *xChars, int64_t nX, const double *events, const char *yChars,
                              int64_t nEvents, const int64_t *anchors, int64_t nAnchorPairs,
                              const cpecan_band_params *params, int32_t mode, int32_t kernel,
-                             int32_t flags, cpecan_batch **out) {
+                             int32_t flags, cpecan_batch **out, bool vanilla = false) {
     const bool dna = yChars != nullptr;
+    if (vanilla && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
+        return fail(CPECAN_EINVAL, "vanilla batches: posterior decode only, no cell dumps");
     const int S = dna ? 5 : 3; /* states per cell */
     if (!c || !items || nItems <= 0 || !xChars || (!events && !yChars) || !params || !out)
         return fail(CPECAN_EINVAL, "bad argument");
@@ -377,7 +467,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             s.anchor_offset < 0 || s.x_offset + s.lX + (!dna && s.lX > 0 ? 5 : 0) > nX ||
             s.y_offset + s.lY > nEvents || s.anchor_offset + s.n_anchors > nAnchorPairs)
             return fail(CPECAN_EINVAL, "item %lld points outside the supplied buffers", (long long) i);
-        if (s.model_id < 0 || s.model_id >= (dna ? c->nModels5 : c->nModels))
+        if (s.model_id < 0 || s.model_id >= (dna ? c->nModels5 : vanilla ? c->nModelsV : c->nModels))
             return fail(CPECAN_EINVAL, "item %lld: unknown model id %d", (long long) i, s.model_id);
         if (s.lX + s.lY >= (1ll << 30)) return fail(CPECAN_EINVAL, "item %lld too long", (long long) i);
         DevItem &d = hItems[(size_t) i];
@@ -462,8 +552,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
-    int useKernel = dna ? CPECAN_KERNEL_GENERAL : kernel;
+    int useKernel = dna || vanilla ? CPECAN_KERNEL_GENERAL : kernel;
     b->dna = dna;
+    b->vanilla = vanilla;
     if (useKernel == CPECAN_KERNEL_AUTO)
         useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && systolicOk && !b->P.debug &&
                      !unbanded && mode == CPECAN_MODE_POSTERIOR)
@@ -495,6 +586,12 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     } else {
         B_TRY(b->events.alloc((size_t) 3 * nEvents + 8));
         B_TRY(hipMemcpy(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+        if (vanilla) { /* emissions_signal_logInvGaussPdf takes log(eventNoise) per cell (:325) */
+            std::vector<double> ln((size_t) nEvents + 1);
+            for (int64_t i = 0; i < nEvents; i++) ln[(size_t) i] = log(events[3 * i + 1]);
+            B_TRY(b->logNoise.alloc((size_t) nEvents + 8));
+            B_TRY(hipMemcpy(b->logNoise.p, ln.data(), (size_t) nEvents * sizeof(double), hipMemcpyHostToDevice));
+        }
     }
     B_TRY(b->anchors.alloc((size_t) 2 * nAnchorPairs + 2));
     if (nAnchorPairs > 0)
@@ -599,6 +696,15 @@ int cpecan_hip_batch_create(cpecan_ctx *c, const cpecan_item *items, int64_t nIt
                              params, mode, kernel, flags, out);
 }
 
+int cpecan_hip_batch_create_vanilla(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
+                                    const char *xChars, int64_t nX, const double *events, int64_t nEvents,
+                                    const int64_t *anchors, int64_t nAnchorPairs,
+                                    const cpecan_band_params *params, int32_t flags, cpecan_batch **out) {
+    if (!events) return fail(CPECAN_EINVAL, "bad argument");
+    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs,
+                             params, CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out, true);
+}
+
 int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
                                 const char *xChars, int64_t nX, const char *yChars, int64_t nY,
                                 const int64_t *anchors, int64_t nAnchorPairs,
@@ -625,6 +731,15 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            (const double *) c->models5.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
                            b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
                            (double *) nullptr);
+        HIP_TRY(hipGetLastError());
+    } else if (b->vanilla) {
+        hipLaunchKernelGGL(cpecan_k_generalv, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
+                           (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
+                           (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
+                           (const unsigned short *) b->kidx.p, (const double *) b->events.p,
+                           (const double *) b->logNoise.p, (const double *) c->modelsV.p, b->Fstore.p,
+                           b->Bstore.p, b->pairs.p, b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p,
+                           b->nTot.p);
         HIP_TRY(hipGetLastError());
     } else if (b->kernel == CPECAN_KERNEL_GENERAL) {
         hipLaunchKernelGGL(cpecan_k_general, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,

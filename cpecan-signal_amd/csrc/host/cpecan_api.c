@@ -119,6 +119,10 @@ void *sequence_getKmer(void *elements, int64_t index) {
     static char n[KMER_LENGTH + 1] = "nnnnnn";
     return index >= 0 ? (void *) &((char *) elements)[index] : (void *) n;
 }
+void *sequence_getKmer2(void *elements, int64_t index) {
+    if (index < 0) return (char *) elements;
+    return index > 0 ? (char *) elements + index - 1 : (char *) elements + index;
+}
 void *sequence_getBase(void *elements, int64_t index) {
     return index >= 0 ? (void *) ((char *) elements + index) : (void *) "n";
 }
@@ -272,6 +276,39 @@ StateMachine *getStrawManStateMachine3(const char *modelFile) {
     return (StateMachine *) s;
 }
 
+StateMachine *getSignalStateMachine3Vanilla(const char *modelFile) {
+    StateMachine3Vanilla *s = calloc(1, sizeof(StateMachine3Vanilla));
+    s->model.type = vanilla;
+    s->model.stateNumber = 3;
+    s->model.matchState = match;
+    s->model.parameterSetSize = NUM_OF_KMERS;
+    s->TRANSITION_M_TO_Y_NOT_X = 0.17;
+    s->TRANSITION_E_TO_E = 0.55f;
+    s->DEFAULT_END_MATCH_PROB = -0.23552123624314988;
+    s->DEFAULT_END_FROM_X_PROB = -1.6269694202638481;
+    s->DEFAULT_END_FROM_Y_PROB = -4.3187242127300092;
+    const int64_t tableLen = 1 + NUM_OF_KMERS * MODEL_PARAMS;
+    s->model.EMISSION_MATCH_PROBS = calloc((size_t) tableLen, sizeof(double));
+    s->model.EMISSION_GAP_Y_PROBS = calloc((size_t) tableLen, sizeof(double));
+    s->model.EMISSION_GAP_X_PROBS = calloc(60, sizeof(double)); /* skip bins: beta[30] | alpha[30] */
+    if (modelFile) {
+        FILE *f = fopen(modelFile, "r");
+        if (!f) die("cpecan: cannot open pore model %s", modelFile);
+        if (!read_doubles(f, s->model.EMISSION_MATCH_PROBS, tableLen) ||
+            !read_doubles(f, s->model.EMISSION_GAP_X_PROBS, 30) ||
+            !read_doubles(f, s->model.EMISSION_GAP_Y_PROBS, tableLen))
+            die("This stateMachine is not correct for signal model (%s)", modelFile);
+        fclose(f);
+        for (int i = 0; i < 30; i++) s->model.EMISSION_GAP_X_PROBS[i + 30] = s->model.EMISSION_GAP_X_PROBS[i];
+    }
+    return (StateMachine *) s;
+}
+void stateMachine3Vanilla_setStrandTransitionsToDefaults(StateMachine *sM, Strand strand) {
+    StateMachine3Vanilla *s = (StateMachine3Vanilla *) sM;
+    s->TRANSITION_M_TO_Y_NOT_X = strand == template ? 0.17f : 0.14f;
+    s->TRANSITION_E_TO_E = strand == template ? 0.55f : 0.49f;
+}
+
 void emissions_signal_scaleModel(StateMachine *sM, double scale, double shift, double var,
                                  double scale_sd, double var_sd) {
     double *m = sM->EMISSION_MATCH_PROBS;
@@ -342,16 +379,22 @@ static cpecan_ctx *context(void) {
 }
 
 /* returns 1 for the DNA-against-DNA combination (5-state machine, sequence_getBase on both sides),
- * 0 for k-mers against events (3-state strawMan machine); anything else is not on the GPU path */
+ * 2 for k-mers against events under the vanilla machine (sequence_getKmer2), 0 under the 3-state strawMan
+ * machine (sequence_getKmer); anything else is not on the GPU path */
 static int check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY) {
     if ((sM->type == fiveState || sM->type == fiveStateAsymmetric) && sM->stateNumber == 5) {
         if (sX->get != sequence_getBase || sY->get != sequence_getBase)
             die("cpecan: the 5-state machine needs sequence_getBase element getters on both sequences");
         return 1;
     }
+    if (sM->type == vanilla && sM->stateNumber == 3) {
+        if (sX->get != sequence_getKmer2 || sY->get != sequence_getEvent)
+            die("cpecan: the vanilla machine needs sequence_getKmer2 / sequence_getEvent element getters");
+        return 2;
+    }
     if (sM->type != threeState || sM->stateNumber != 3)
-        die("cpecan: only the threeState (strawMan) signal and the fiveState symbol StateMachines run on "
-            "the GPU path (type %d)", sM->type);
+        die("cpecan: only the threeState (strawMan) and vanilla signal StateMachines and the fiveState "
+            "symbol StateMachine run on the GPU path (type %d)", sM->type);
     if (sX->get != sequence_getKmer || sY->get != sequence_getEvent)
         die("cpecan: the GPU path needs sequence_getKmer / sequence_getEvent element getters");
     return 0;
@@ -369,12 +412,13 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     pthread_mutex_lock(&g_lock); /* one batch at a time per process; calls from several threads queue */
     cpecan_ctx *ctx = context();
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
-    const int dna = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
-    if (dna && mode != 0) die("cpecan: expectations of the 5-state machine are not on the GPU path");
+    const int kind = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
+    const int dna = kind == 1, van = kind == 2;
+    if (kind != 0 && mode != 0) die("cpecan: expectations run on the GPU path for the strawMan machine only");
     const int64_t xPad = dna ? 0 : KMER_LENGTH - 1; /* a k-mer sequence of lX elements spans lX + 5 chars */
     for (int64_t i = 0; i < n; i++) {
-        if (check_known_combination(sMs[i], sXs[i], sYs[i]) != dna)
-            die("cpecan: one call cannot mix DNA and signal alignments");
+        if (check_known_combination(sMs[i], sXs[i], sYs[i]) != kind)
+            die("cpecan: one call cannot mix state machine kinds");
         nX += sXs[i]->length + (sXs[i]->length > 0 ? xPad : 0);
         nY += sYs[i]->length;
         nA += anchorLists && anchorLists[i] ? stList_length(anchorLists[i]) : 0;
@@ -409,7 +453,28 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         }
         modelOf[i] = found;
     }
-    for (int64_t i = 0; !dna && i < n; i++) {
+    cpecan_vanilla_model *modelsV = malloc(sizeof(cpecan_vanilla_model) * (size_t) (van ? n : 1));
+    for (int64_t i = 0; van && i < n; i++) { /* one model per distinct StateMachine3Vanilla */
+        int32_t found = -1;
+        for (int32_t k = 0; k < nModels && found < 0; k++)
+            if (owner5[k] == sMs[i]) found = k;
+        if (found < 0) {
+            const StateMachine3Vanilla *sv = (const StateMachine3Vanilla *) sMs[i];
+            cpecan_vanilla_model *m = &modelsV[nModels];
+            m->m_to_y_not_x = sv->TRANSITION_M_TO_Y_NOT_X;
+            m->e_to_e = sv->TRANSITION_E_TO_E;
+            m->end_match_prob = sv->DEFAULT_END_MATCH_PROB;
+            m->end_from_x_prob = sv->DEFAULT_END_FROM_X_PROB;
+            m->end_from_y_prob = sv->DEFAULT_END_FROM_Y_PROB;
+            m->match_probs = sMs[i]->EMISSION_MATCH_PROBS;
+            m->skip_probs = sMs[i]->EMISSION_GAP_X_PROBS;
+            m->gap_y_probs = sMs[i]->EMISSION_GAP_Y_PROBS;
+            owner5[nModels] = sMs[i];
+            found = nModels++;
+        }
+        modelOf[i] = found;
+    }
+    for (int64_t i = 0; kind == 0 && i < n; i++) {
         StateMachine3 *s3 = (StateMachine3 *) sMs[i];
         const double t[9] = { s3->TRANSITION_MATCH_CONTINUE, s3->TRANSITION_MATCH_FROM_GAP_X,
                               s3->TRANSITION_MATCH_FROM_GAP_Y, s3->TRANSITION_GAP_OPEN_X,
@@ -436,6 +501,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     int32_t *ids = malloc(sizeof(int32_t) * (size_t) nModels);
     CHECK(cpecan_hip_models_clear(ctx));
     if (dna) CHECK(cpecan_hip_models5_create(ctx, models5, nModels, ids));
+    else if (van) CHECK(cpecan_hip_modelsv_create(ctx, modelsV, nModels, 0, ids));
     else CHECK(cpecan_hip_models_create(ctx, models, nModels, 0, ids));
 
     int64_t xo = 0, yo = 0, ao = 0;
@@ -498,6 +564,9 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         if (dna)
             CHECK(cpecan_hip_batch_create_dna(ctx, items, nItems, chars, xo, ychars, yo, anchors, ao, &bp,
                                               unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+        else if (van)
+            CHECK(cpecan_hip_batch_create_vanilla(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
+                                                  unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
         else
             CHECK(cpecan_hip_batch_create(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                           mode ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
@@ -549,7 +618,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         for (int64_t i = 0; i < n; i++) lists[i] = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
     }
     free(chars); free(events); free(anchors); free(items); free(origin); free(firstItem);
-    free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars);
+    free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars); free(modelsV);
     pthread_mutex_unlock(&g_lock);
 }
 

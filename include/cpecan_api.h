@@ -63,6 +63,7 @@ Sequence *sequence_sliceEventSequence2(Sequence *inputSequence, int64_t start, i
 void sequence_sequenceDestroy(Sequence *seq);
 void *sequence_getKmer(void *elements, int64_t index);
 void *sequence_getBase(void *elements, int64_t index); /* :308-312 */
+void *sequence_getKmer2(void *elements, int64_t index); /* :320-325: previous + current k-mer */
 Sequence *sequence_sliceNucleotideSequence(Sequence *inputSequence, int64_t start, int64_t sliceLength);
 void *sequence_getEvent(void *elements, int64_t index);
 int64_t sequence_correctSeqLength(int64_t length, SequenceType type);
@@ -153,6 +154,21 @@ double emissions_symbol_getGapProb(const double *emissionGapProbs, void *base); 
 double emissions_symbol_getMatchProb(const double *emissionMatchProbs, void *x, void *y);  /* :165-173 */
 void cell_updateExpectations(double *fromCells, double *toCells, int64_t from, int64_t to, double eP,
                              double tP, void *extraArgs); /* marker only (impl/pairwiseAligner.c:407) */
+
+/* 3-state vanilla signal machine (inc/stateMachine.h:219-231; data members) */
+typedef enum _strand { template = 0, complement = 1 } Strand;
+typedef struct _StateMachine3vanilla {
+    StateMachine model;
+    double TRANSITION_M_TO_Y_NOT_X;
+    double TRANSITION_E_TO_E;
+    double DEFAULT_END_MATCH_PROB;
+    double DEFAULT_END_FROM_X_PROB;
+    double DEFAULT_END_FROM_Y_PROB;
+} StateMachine3Vanilla;
+/* getSignalStateMachine3Vanilla (impl/stateMachine.c:1761): tables from a 3-line .model file, the 30
+ * skip bins of its second line stored as beta and alpha (:284-297) */
+StateMachine *getSignalStateMachine3Vanilla(const char *modelFile);
+void stateMachine3Vanilla_setStrandTransitionsToDefaults(StateMachine *sM, Strand strand); /* :1291 */
 
 /* getStrawManStateMachine3 (impl/stateMachine.c:1725): 3-state machine with nanopore default
  * transitions (:1278), log(0.1) k-mer gap table (:1506), emission tables from a 3-line .model file */

@@ -77,6 +77,23 @@ typedef struct {
 } cpecan_sm5_model;
 int cpecan_hip_models5_create(cpecan_ctx *ctx, const cpecan_sm5_model *models, int32_t n, int32_t *ids);
 
+/* The 3-state "vanilla" signal machine: getSignalStateMachine3Vanilla() (impl/stateMachine.c:1761) after
+ * emissions_signal_scaleModel().  Fields as in struct _StateMachine3Vanilla (inc/stateMachine.h:189-205):
+ * the two transition fudge factors (stateMachine3Vanilla_setStrandTransitionsToDefaults :1291), the three
+ * end-state log-probabilities, the match and extra-event tables in the reference's layout and the 60
+ * skip-bin values of EMISSION_GAP_X_PROBS (beta[30] | alpha[30], :284-297).  X elements are read as
+ * sequence_getKmer2 does (:320-325); k-mers must be ACGT-only (the reference computes NaN otherwise).
+ * Ids live in their own space (used by cpecan_hip_batch_create_vanilla only). */
+typedef struct {
+    double m_to_y_not_x, e_to_e;
+    double end_match_prob, end_from_x_prob, end_from_y_prob;
+    const double *match_probs; /* [CPECAN_MODEL_TABLE_LEN] */
+    const double *skip_probs;  /* [60]                     */
+    const double *gap_y_probs; /* [CPECAN_MODEL_TABLE_LEN] */
+} cpecan_vanilla_model;
+int cpecan_hip_modelsv_create(cpecan_ctx *ctx, const cpecan_vanilla_model *models, int32_t n,
+                              int32_t threads, int32_t *ids);
+
 /* ---- band / split geometry (host integer code, exported because the reference exports it) ----
  * cpecan_band_construct: band_construct (impl/pairwiseAligner.c:132); xmyL/xmyR hold lX+lY+1 entries.
  * cpecan_split_points: getSplitPoints (:1313); out holds up to cap 4-tuples; returns the count. */
@@ -141,6 +158,14 @@ int cpecan_hip_batch_create_dna(cpecan_ctx *ctx, const cpecan_item *items, int64
                                 const char *x_chars, int64_t n_x, const char *y_chars, int64_t n_y,
                                 const int64_t *anchors, int64_t n_anchor_pairs,
                                 const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
+
+/* k-mers against events with a vanilla model (getAlignedPairsUsingAnchors with a StateMachine3Vanilla,
+ * sequence_getKmer2 / sequence_getEvent): same buffers as cpecan_hip_batch_create, model_id is a
+ * cpecan_hip_modelsv_create id.  Posterior decode on the general kernel; flags: UNBANDED only. */
+int cpecan_hip_batch_create_vanilla(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
+                                    const char *x_chars, int64_t n_x, const double *events, int64_t n_events,
+                                    const int64_t *anchors, int64_t n_anchor_pairs,
+                                    const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
 
 int cpecan_hip_batch_run(cpecan_batch *batch);
 int cpecan_hip_batch_sync(cpecan_batch *batch);

@@ -99,6 +99,29 @@ double orc_strawman_match(const double *model, int64_t k, const double *event) {
     return l_probEventMean + l_probEventNoise;
 }
 
+/* emissions_signal_logInvGaussPdf :322-331 */
+static inline double log_inv_gauss(double eventNoise, double modelNoiseMean, double modelNoiseLambda) {
+    double l_twoPi = 1.8378770664093453;
+    double l_eventNoise = log(eventNoise);
+    double a = (eventNoise - modelNoiseMean) / modelNoiseMean;
+    double l_modelNoseLambda = log(modelNoiseLambda);
+    return (l_modelNoseLambda - l_twoPi - 3 * l_eventNoise - modelNoiseLambda * a * a / eventNoise) / 2;
+}
+
+/* emissions_signal_getEventMatchProbWithTwoDists :499-528 for k-mer index k */
+double orc_vanilla_match(const double *model, int64_t k, const double *event) {
+    double levelProb = orc_logGaussPdf(event[0], model_get(model, k, 0), model_get(model, k, 1));
+    double noiseProb = log_inv_gauss(event[1], model_get(model, k, 2), model_get(model, k, 4));
+    return levelProb + noiseProb;
+}
+
+/* emissions_signal_getKmerSkipBin :388-419 */
+static inline int64_t skip_bin(const double *matchModel, int64_t k_im1, int64_t k_i) {
+    double d = fabs(model_get(matchModel, k_i, 0) - model_get(matchModel, k_im1, 0));
+    int64_t bin = (int64_t) (d / 0.5);
+    return bin >= 30 ? 29 : bin;
+}
+
 /* emissions_kmer_getGapProb :175-187 */
 double orc_kmer_gap(const double *gapX, int64_t k) {
     return k > ORC_NUM_KMERS ? LOG_ZERO : gapX[k];
@@ -139,6 +162,16 @@ enum {
     T5_GAP_SHORT_OPEN_Y, T5_GAP_SHORT_EXTEND_Y, T5_GAP_SHORT_SWITCH_TO_Y, T5_GAP_LONG_OPEN_Y,
     T5_GAP_LONG_EXTEND_Y, T5_GAP_LONG_SWITCH_TO_Y
 };
+
+void orc_defaults_vanilla(orc_model *m) {
+    m->kind = ORC_SM3_VANILLA;
+    m->stateNumber = 3;
+    m->t[0] = 0.17;                 /* TRANSITION_M_TO_Y_NOT_X (:1575) */
+    m->t[1] = 0.55f;                /* TRANSITION_E_TO_E, a float literal (:1576) */
+    m->t[2] = -0.23552123624314988; /* DEFAULT_END_MATCH_PROB  */
+    m->t[3] = -1.6269694202638481;  /* DEFAULT_END_FROM_X_PROB */
+    m->t[4] = -4.3187242127300092;  /* DEFAULT_END_FROM_Y_PROB */
+}
 
 void orc_defaults_sm5(orc_model *m, double *match16, double *gap4x, double *gap4y) {
     /* stateMachine5_construct :920-937 and emissions_symbol_setEmissionsToDefaults :60-82 */
@@ -195,11 +228,21 @@ static const double NULLEVENT[2] = { LOG_ZERO, 0 }; /* :261 */
 typedef struct {
     int64_t kx;        /* sm3: k-mer index of X element (>4096 invalid); sm5: base index */
     int64_t ky;        /* sm5: base index of Y */
+    int64_t kp;        /* vanilla: index of the k-mer before kx (sequence_getKmer2) */
     const double *ev;  /* sm3: event */
 } symbols_t;
 
 static inline void get_symbols(const seqs_t *s, int64_t ix, int64_t iy, symbols_t *o) {
-    if (s->m->kind == ORC_SM3_STRAWMAN) {
+    o->kp = 0;
+    if (s->m->kind == ORC_SM3_VANILLA) {
+        /* sequence_getKmer2 (:320-325): a pointer to char max(ix-1, 0); the emission code reads the
+         * k-mer at +1 and the skip-bin code the k-mers at +0 and +1 (so element 0 is scored as k-mer 1) */
+        const char *p = s->x + (ix > 0 ? ix - 1 : 0);
+        o->kp = orc_kmer_index(p);
+        o->kx = orc_kmer_index(p + 1);
+        o->ev = iy >= 0 ? ((const double *) s->y) + 3 * iy : NULLEVENT;
+        o->ky = 0;
+    } else if (s->m->kind == ORC_SM3_STRAWMAN) {
         /* index < 0 yields the literal "n" (:315-317): first char non-ACGT => index > 4096 */
         o->kx = ix >= 0 ? orc_kmer_index(s->x + ix) : (int64_t) ORC_NUM_KMERS * 4097;
         o->ev = iy >= 0 ? ((const double *) s->y) + 3 * iy : NULLEVENT;
@@ -270,6 +313,34 @@ static void cell_sm3(const orc_model *m, double *cur, double *lower, double *mid
     }
 }
 
+/* stateMachine3Vanilla_cellCalculate impl/stateMachine.c:1368-1409 */
+static void cell_vanilla(const orc_model *m, double *cur, double *lower, double *middle, double *upper,
+                         const symbols_t *s, trans_fn fn, void *extra) {
+    const int64_t bin = skip_bin(m->match, s->kp, s->kx);
+    double a_mx = m->gapX[bin];      /* beta  */
+    double a_my = (1 - a_mx) * m->t[0];
+    double a_mm = 1.0f - a_my - a_mx;
+    double a_yy = m->t[1];
+    double a_ym = 1.0f - a_yy;
+    double a_xx = m->gapX[bin + 30]; /* alpha */
+    double a_xm = 1.0f - a_xx;
+    if (lower != NULL) {
+        fn(lower, cur, ST_MATCH, ST_SHORT_GAP_X, 0, log(a_mx), extra);
+        fn(lower, cur, ST_SHORT_GAP_X, ST_SHORT_GAP_X, 0, log(a_xx), extra);
+    }
+    if (middle != NULL) {
+        double eP = orc_vanilla_match(m->match, s->kx, s->ev);
+        fn(middle, cur, ST_MATCH, ST_MATCH, eP, log(a_mm), extra);
+        fn(middle, cur, ST_SHORT_GAP_X, ST_MATCH, eP, log(a_xm), extra);
+        fn(middle, cur, ST_SHORT_GAP_Y, ST_MATCH, eP, log(a_ym), extra);
+    }
+    if (upper != NULL) {
+        double eP = orc_vanilla_match(m->gapY, s->kx, s->ev);
+        fn(upper, cur, ST_MATCH, ST_SHORT_GAP_Y, eP, log(a_my), extra);
+        fn(upper, cur, ST_SHORT_GAP_Y, ST_SHORT_GAP_Y, eP, log(a_yy), extra);
+    }
+}
+
 /* emissions_symbol_getGapProb / getMatchProb :155-173; the i==4 branches never fire because the
  * base index of N is 4097 (quirk Q3): N-free input is a precondition here. */
 static inline double sym_gap(const double *g, int64_t i) { return i < 4 ? g[i] : LOG_ZERO; }
@@ -307,7 +378,8 @@ static void cell_sm5(const orc_model *m, double *cur, double *lower, double *mid
 
 static inline void cell_calc(const orc_model *m, double *cur, double *lower, double *middle,
                              double *upper, const symbols_t *s, trans_fn fn, void *extra) {
-    if (m->kind == ORC_SM3_STRAWMAN) cell_sm3(m, cur, lower, middle, upper, s, fn, extra);
+    if (m->kind == ORC_SM3_VANILLA) cell_vanilla(m, cur, lower, middle, upper, s, fn, extra);
+    else if (m->kind == ORC_SM3_STRAWMAN) cell_sm3(m, cur, lower, middle, upper, s, fn, extra);
     else cell_sm5(m, cur, lower, middle, upper, s, fn, extra);
 }
 
@@ -315,6 +387,14 @@ static inline void cell_calc(const orc_model *m, double *cur, double *lower, dou
 static double state_value(const orc_model *m, int which, int s) {
     /* which: 0 start, 1 raggedStart, 2 end, 3 raggedEnd */
     const double *t = m->t;
+    if (m->kind == ORC_SM3_VANILLA) { /* start as sm3; end :1209-1235 */
+        switch (which) {
+        case 0: return s == ST_MATCH ? 0 : LOG_ZERO;
+        case 1: return (s == ST_SHORT_GAP_X || s == ST_SHORT_GAP_Y) ? 0 : LOG_ZERO;
+        case 2: return s == ST_MATCH ? t[2] : s == ST_SHORT_GAP_X ? t[3] : t[4];
+        default: return s == ST_MATCH ? (t[3] + t[4]) / 2.0 : s == ST_SHORT_GAP_X ? t[3] : t[4];
+        }
+    }
     if (m->kind == ORC_SM3_STRAWMAN) {
         switch (which) {
         case 0: return s == ST_MATCH ? 0 : LOG_ZERO;
@@ -691,7 +771,7 @@ static void make_seqs(seqs_t *s, const orc_model *m, const char *x, int64_t lX, 
 
 /* slices: sequence_sliceNucleotideSequence2 / sequence_sliceEventSequence2 :287-301 */
 static const void *slice_y(const orc_model *m, const void *y, int64_t start) {
-    if (m->kind == ORC_SM3_STRAWMAN) return ((const double *) y) + 3 * start;
+    if (m->kind != ORC_SM5_SYMBOL) return ((const double *) y) + 3 * start;
     return ((const char *) y) + start;
 }
 

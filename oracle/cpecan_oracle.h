@@ -27,6 +27,11 @@ extern "C" {
 /* model kinds */
 #define ORC_SM3_STRAWMAN 0 /* stateMachine3_cellCalculate + strawMan emissions */
 #define ORC_SM5_SYMBOL 1   /* stateMachine5_cellCalculate + symbol emissions   */
+#define ORC_SM3_VANILLA 2  /* stateMachine3Vanilla_cellCalculate (impl/stateMachine.c:1368-1409): skip-bin
+                              transitions, Gaussian level + inverse-Gaussian noise emissions; X elements are
+                              read with sequence_getKmer2.  t[0..4] = TRANSITION_M_TO_Y_NOT_X,
+                              TRANSITION_E_TO_E, DEFAULT_END_MATCH_PROB, _FROM_X_PROB, _FROM_Y_PROB;
+                              gapX = the 60 skip-bin values (beta[30] | alpha[30]) */
 
 /* sm3 transition slots (log space), order of struct _StateMachine3 inc/stateMachine.h:179-187 */
 enum {
@@ -72,6 +77,8 @@ typedef struct {
 
 void orc_defaults_sm3_nanopore(orc_model *m);   /* impl/stateMachine.c:1278-1289 */
 void orc_defaults_sm5(orc_model *m, double *match16, double *gap4x, double *gap4y); /* :60-82,:920-937 */
+void orc_defaults_vanilla(orc_model *m);       /* stateMachine3Vanilla_construct :1560-1600 */
+double orc_vanilla_match(const double *model, int64_t k, const double *event); /* :499-528 */
 void orc_params_default(orc_params *p);         /* impl/pairwiseAligner.c:1428-1441 */
 
 double orc_logAdd(double x, double y);           /* impl/pairwiseAligner.c:238-255 */

@@ -14,7 +14,7 @@ _LIB = None
 
 NUM_KMERS = 4096
 MODEL_LEN = 1 + NUM_KMERS * 5
-SM3, SM5 = 0, 1
+SM3, SM5, VANILLA = 0, 1, 2
 
 
 class OrcModel(C.Structure):
@@ -73,6 +73,7 @@ def lib():
         L.orc_result_free.argtypes = [C.POINTER(OrcResult)]
         L.orc_defaults_sm3_nanopore.argtypes = [C.POINTER(OrcModel)]
         L.orc_defaults_sm5.argtypes = [C.POINTER(OrcModel), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_defaults_vanilla.argtypes = [C.POINTER(OrcModel)]
         L.orc_params_default.argtypes = [C.POINTER(OrcParams)]
         L.orc_aligned_pairs_using_anchors.restype = C.c_int
         L.orc_aligned_pairs_using_anchors.argtypes = [
@@ -133,6 +134,37 @@ class Sm3Model:
         return Sm3Model(m, self.gap_y, self.gap_x, self.transitions)
 
 
+class VanillaModel:
+    """3-state vanilla signal model (getSignalStateMachine3Vanilla, stateMachine.c:1761): match and
+    extra-event tables as loaded, the 30 skip-bin values of the model file's second line used as both
+    beta (0..29) and alpha (30..59), as emissions_signal_loadPoreModel stores them (:284-297)."""
+
+    def __init__(self, match, skip30, gap_y, m_to_y_not_x=None, e_to_e=None):
+        self.match = np.ascontiguousarray(match, dtype=np.float64)
+        self.gap_y = np.ascontiguousarray(gap_y, dtype=np.float64)
+        skip30 = np.asarray(skip30, dtype=np.float64)
+        self.skip = np.ascontiguousarray(np.concatenate([skip30, skip30]) if skip30.size == 30 else skip30)
+        assert self.match.size == MODEL_LEN and self.gap_y.size == MODEL_LEN and self.skip.size == 60
+        self.c = OrcModel()
+        lib().orc_defaults_vanilla(C.byref(self.c))
+        if m_to_y_not_x is not None:
+            self.c.t[0] = m_to_y_not_x
+        if e_to_e is not None:
+            self.c.t[1] = e_to_e
+        self.c.match = self.match.ctypes.data
+        self.c.gapX = self.skip.ctypes.data
+        self.c.gapY = self.gap_y.ctypes.data
+
+    @property
+    def scalars(self):
+        return np.array([self.c.t[i] for i in range(5)])
+
+    def scaled(self, scale, shift, var, scale_sd, var_sd):
+        m = self.match.copy()
+        lib().orc_scale_model(_ptr(m), scale, shift, var, scale_sd, var_sd)
+        return VanillaModel(m, self.skip, self.gap_y, self.c.t[0], self.c.t[1])
+
+
 class Sm5Model:
     def __init__(self):
         self.match = np.zeros(16)
@@ -157,7 +189,7 @@ def _collect(res):
 
 def _xy(model, x, y):
     xb = x.encode() if isinstance(x, str) else bytes(x)
-    if model.c.kind == SM3:
+    if model.c.kind != SM5:
         ya = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
         return xb, ya, ya.ctypes.data_as(C.c_void_p), ya.size // 3
     yb = y.encode() if isinstance(y, str) else bytes(y)

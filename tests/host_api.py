@@ -52,7 +52,8 @@ EXPORTS = [
     "continuousPairHmm_normalize", "continuousPairHmm_loadTransitionsAndKmerGapProbs",
     "getAlignedPairsUsingAnchorsBatch", "sequence_getBase", "sequence_sliceNucleotideSequence",
     "stateMachine5_construct", "emissions_symbol_setEmissionsToDefaults", "emissions_symbol_getGapProb",
-    "emissions_symbol_getMatchProb", "cell_updateExpectations",
+    "emissions_symbol_getMatchProb", "cell_updateExpectations", "sequence_getKmer2",
+    "getSignalStateMachine3Vanilla", "stateMachine3Vanilla_setStrandTransitionsToDefaults",
 ]
 
 _LIB = None
@@ -88,6 +89,9 @@ def lib():
         L.emissions_discrete_getKmerIndex.restype = C.c_int64
         L.emissions_discrete_getKmerIndex.argtypes = [C.c_char_p]
         L.stateMachine_destruct.argtypes = [vp]
+        L.getSignalStateMachine3Vanilla.restype = vp
+        L.getSignalStateMachine3Vanilla.argtypes = [C.c_char_p]
+        L.stateMachine3Vanilla_setStrandTransitionsToDefaults.argtypes = [vp, C.c_int]
         L.stateMachine5_construct.restype = vp
         L.stateMachine5_construct.argtypes = [C.c_int, C.c_int64, vp, vp, vp, vp, vp]
         L.getAlignedPairsUsingAnchors.restype = vp

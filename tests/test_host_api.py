@@ -196,3 +196,67 @@ def test_five_state_dna_through_host_api():
     L.sequence_sequenceDestroy(sY)
     L.pairwiseAlignmentBandingParameters_destruct(p)
     L.stateMachine_destruct(sm)
+
+
+@pytest.mark.gpu
+def test_vanilla_zymo_read_through_host_api(golden_dir, zymo_read, template_model):
+    """test_vanilla_strandAlignmentNoBanding (tests/signalPairwiseTest.c:1042-1075) through the host API:
+    getSignalStateMachine3Vanilla + scaleModel + sequence_getKmer2, un-banded, then banded with anchors and
+    split sub-alignments; both identical to the oracle."""
+    L = h.lib()
+    sm = L.getSignalStateMachine3Vanilla(os.path.join(golden_dir, "template_median68pA.model").encode())
+    L.emissions_signal_scaleModel(sm, *zymo_read["template_params"])
+    L.stateMachine3Vanilla_setStrandTransitionsToDefaults(sm, 0)
+    ref_seq = zymo_read["reference"]
+    xbuf = C.create_string_buffer(ref_seq.encode())
+    ev = np.ascontiguousarray(zymo_read["template_events"], dtype=np.float64).reshape(-1)
+    lX, lY = len(ref_seq) - 5, ev.size // 3
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    p.contents.threshold = 0.2
+    pairs = L.getAlignedPairsWithoutBanding(sm, C.cast(xbuf, C.c_void_p), ev.ctypes.data_as(C.c_void_p), lX, lY, p,
+                                            h.fn_ptr("sequence_getKmer2"), h.fn_ptr("sequence_getEvent"),
+                                            h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), False, False)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    match, skip, gapy = template_model
+    om = o.VanillaModel(match, skip, gapy, float(np.float32(0.17)), float(np.float32(0.55))).scaled(
+        *zymo_read["template_params"])
+    ref = o.aligned_pairs_without_banding(om, ref_seq, lX, zymo_read["template_events"],
+                                          o.default_params(threshold=0.2))
+    assert len(got) > 500
+    assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
+    assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+
+    best = {}
+    for q, x, y in ref["triples"]:
+        if q > 9000000:
+            best[int(x)] = int(y)
+    anchors, py = [], -1
+    for x in sorted(best)[::30]:
+        if best[x] > py:
+            anchors.append((x, best[x]))
+            py = best[x]
+    anchors = [a for i, a in enumerate(anchors) if not 8 <= i <= 14]
+    p.contents.threshold = 0.01
+    p.contents.splitMatrixBiggerThanThis = 100 * 100
+    p.contents.diagonalExpansion = 40
+    p.contents.minDiagsBetweenTraceBack = 150
+    sX = L.sequence_construct2(lX, C.cast(xbuf, C.c_void_p), h.fn_ptr("sequence_getKmer2"),
+                               h.fn_ptr("sequence_sliceNucleotideSequence2"))
+    sY = L.sequence_construct2(lY, ev.ctypes.data_as(C.c_void_p), h.fn_ptr("sequence_getEvent"),
+                               h.fn_ptr("sequence_sliceEventSequence2"))
+    lst = h.make_anchor_list(anchors)
+    pairs = L.getAlignedPairsUsingAnchors(sm, sX, sY, lst, p, h.fn_ptr("diagonalCalculationPosteriorMatchProbs"),
+                                          True, True)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    op = o.default_params(minDiagsBetweenTraceBack=150, diagonalExpansion=40, splitMatrixBiggerThanThis=100 * 100)
+    assert len(o.split_points(anchors, lX, lY, 100 * 100, 1, 1)) > 1
+    ref = o.aligned_pairs_using_anchors(om, ref_seq, lX, zymo_read["template_events"], anchors, op, True, True)
+    assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
+    assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+    L.stList_destruct(lst)
+    L.sequence_sequenceDestroy(sX)
+    L.sequence_sequenceDestroy(sY)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)

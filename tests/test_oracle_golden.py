@@ -108,6 +108,20 @@ def test_strawman_toy_pairs(template_model):
     assert pairs == [(0, 0), (1, 1), (2, 2), (3, 3), (4, 3), (5, 4), (6, 5), (7, 6)]
 
 
+def test_vanilla_toy_pairs(template_model):
+    # tests/signalPairwiseTest.c:795-892 (test_vanilla_diagonalDPCalculations): the same toy read under
+    # the vanilla machine, exactly these 5 pairs >= 0.5
+    match, skip, gapy = template_model
+    m = o.VanillaModel(match, skip, gapy)
+    sX = "ACGATACGGACAT"
+    sY = [58.743435, 0.887833, 0.0571, 53.604965, 0.816836, 0.0571, 58.432015, 0.735143, 0.0571,
+          63.684352, 0.795437, 0.0571, 58.921430, 0.812959, 0.0571, 59.895882, 0.740952, 0.0571,
+          61.684303, 0.722332, 0.0571]
+    r = o.aligned_pairs_without_banding(m, sX, len(sX) - 5, sY, o.default_params(threshold=0.5))
+    pairs = sorted((int(x), int(y)) for _, x, y in r["triples"])
+    assert pairs == [(2, 0), (3, 3), (5, 4), (6, 5), (7, 6)]
+
+
 def test_five_state_toy_pairs():
     # tests/pairwiseAlignerTest.c:278-373: "AGCG" vs "AGTTCG", exactly 4 pairs >= 0.2
     r = o.aligned_pairs_without_banding(o.Sm5Model(), "AGCG", 4, "AGTTCG",
