@@ -59,7 +59,15 @@ extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem
                                                double *Fring, long long ringDoubles, int ringD,
                                                void *states, long long *pairs, double *pairLogp,
                                                long long *totXay, double *totVal, char *scratch,
-                                               long long scratchBytes);
+                                               long long scratchBytes, double *Bring);
+extern "C" int cpecan_systolic_launch_expect(hipStream_t stream, const DevItem *items, long long nItems,
+                                             DevParams P, const void *bandTab, const double *track,
+                                             const long long *trackBase, const unsigned short *kidx,
+                                             const double *models, const double *Fring,
+                                             long long ringDoubles, const double *Bring, int ringD,
+                                             void *states, const char *scratch, long long scratchBytes,
+                                             double *expect);
+extern "C" int cpecan_systolic_bring_row_doubles(void);
 extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
                                              long long *nPairs, long long *nTot, long long *nCells);
 
@@ -135,6 +143,7 @@ struct cpecan_batch {
     DevBuf<double> events;
     DevBuf<long long> anchors;
     DevBuf<double> Fstore, Bstore, dbgB;
+    DevBuf<double> Bring; /* systolic Baum-Welch: backward cells of one window per item */
     DevBuf<long long> pairs;
     DevBuf<double> pairLogp;
     DevBuf<long long> nPairs, totXay, nTot, nCells;
@@ -556,8 +565,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->dna = dna;
     b->vanilla = vanilla;
     if (useKernel == CPECAN_KERNEL_AUTO)
-        useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && systolicOk && !b->P.debug &&
-                     !unbanded && mode == CPECAN_MODE_POSTERIOR)
+        useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && systolicOk && !b->P.debug && !unbanded)
                         ? CPECAN_KERNEL_SYSTOLIC : CPECAN_KERNEL_GENERAL;
     if (useKernel == CPECAN_KERNEL_SYSTOLIC &&
         (globalMaxWidth > cpecan_systolic_max_width() || !systolicOk)) {
@@ -565,9 +573,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         return fail(CPECAN_EINVAL, "band is %d cells wide (systolic kernel: at most %d, edges moving "
                     "one k-mer per diagonal)", globalMaxWidth, cpecan_systolic_max_width());
     }
-    if (useKernel == CPECAN_KERNEL_SYSTOLIC && (b->P.debug || mode != CPECAN_MODE_POSTERIOR)) {
+    if (useKernel == CPECAN_KERNEL_SYSTOLIC && b->P.debug) {
         delete b;
-        return fail(CPECAN_EINVAL, "cell dumps and expectations are only available from the general kernel");
+        return fail(CPECAN_EINVAL, "cell dumps are only available from the general kernel");
     }
     b->kernel = useKernel;
     b->maxWidth = globalMaxWidth;
@@ -659,6 +667,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             for (auto &e : b->evJoin) B_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             B_TRY(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         }
+        if (mode == CPECAN_MODE_EXPECTATIONS)
+            B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) cpecan_systolic_bring_row_doubles()));
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
         b->scratchBytes = (cpecan_systolic_scratch_bytes(b->ringD) + 63) / 64 * 64;
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
@@ -787,7 +797,19 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                                          b->ringD,
                                                          b->syStates.p + i0 * cpecan_systolic_state_bytes(),
                                                          b->pairs.p, b->pairLogp.p, b->totXay.p, b->totVal.p,
-                                                         b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes);
+                                                         b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
+                                                         b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD *
+                                                                          cpecan_systolic_bring_row_doubles()
+                                                                    : nullptr);
+                if (rc == 0 && n > 0 && b->mode == CPECAN_MODE_EXPECTATIONS)
+                    rc = cpecan_systolic_launch_expect(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                                                       b->trackBase.p + i0, b->kidx.p, c->models.p,
+                                                       b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
+                                                       b->Bring.p + i0 * (long long) b->ringD *
+                                                           cpecan_systolic_bring_row_doubles(),
+                                                       b->ringD, b->syStates.p + i0 * cpecan_systolic_state_bytes(),
+                                                       b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
+                                                       b->expect.p);
                 HIP_TRY(hipEventRecord(ev[2 * w + 2], st));
             }
             HIP_TRY(hipEventRecord(b->evJoin[(size_t) gi], st));

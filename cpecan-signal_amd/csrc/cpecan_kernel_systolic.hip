@@ -281,7 +281,7 @@ struct SyState {
     int finished;     /* forward reached the last diagonal */
     int bandAi;       /* band cursor (anchor rectangle) at diagonal d */
     int winValid, winTop, winFrom, winTo, winAtEnd; /* traceback window for the backward kernel */
-    int pad;
+    int expectPending; /* Baum-Welch: the window's backward cells are in the B ring, not yet summed */
     long long nPairs, nTot, cells;
 };
 
@@ -436,6 +436,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         tpB = topN < fromN ? topN : fromN;
         allFull = tpB < topW; /* windows shorter than the traceback margin: keep everything */
     }
+    if (P.mode != 0) allFull = true; /* the expectation pass reads every state of every diagonal */
     /* (tpA - d) mod 10 and (tpB - d) mod 10 for the diagonal being computed, kept incrementally */
     /* (tpA - d) mod 10 and (tpB - d) mod 10 for the next diagonal whose mask bit is computed */
     int rA = ((tpA - (d0 + 1)) % 10 + 10) % 10, rB = endW ? 0x40000000 : ((tpB - (d0 + 1)) % 10 + 10) % 10;
@@ -610,7 +611,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                                 const double *__restrict__ track, const double *__restrict__ model,
                                 double *ring, int ringD, SyState *state, ItemOut &out, Shared &sh,
                                 BandFeed &bf, int *cntBuf, WinTotal *wtot, double *vw,
-                                unsigned long long *msk, int2 *candKx, double *candFb) {
+                                unsigned long long *msk, int2 *candKx, double *candFb, double *bring) {
     const Geometry g = make_geometry(ring, ringD);
     const int lane = g.lane, wave = g.wave;
     const int lX = (int) it.lX, D = (int) (it.lX + it.lY);
@@ -821,10 +822,20 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 /* exponent of the posterior, less the total: parked in the emission slot this diagonal
                  * no longer needs (the forward cells themselves stay intact: the next window's
                  * refresh at its lowest diagonal reads forward[tracedBackFrom], :944,:985) */
+                if (P.mode != 0) {
+                    /* Baum-Welch: the backward cell goes to its own ring for the expectation kernel
+                     * (the emissions in slots 3, 4 stay: that kernel re-uses them) */
+                    if (tvalid) {
+                        double *b = bring + (long long) (t & g.ringMask) * (SY_R * 3 * 64) + wave * (3 * 64) + lane;
+                        b[0] = Bm;
+                        b[64] = Bx;
+                        b[128] = By;
+                    }
+                }
 #ifndef SY_ABLATE_FB
-                if (tvalid) *g.rp(t, 3) = fb;
+                else if (tvalid) *g.rp(t, 3) = fb;
 #endif
-                const bool cand = tvalid && fb >= candThr && fb > CP_NEG_INF;
+                const bool cand = P.mode == 0 && tvalid && fb >= candThr && fb > CP_NEG_INF;
                 const unsigned long long cm = __ballot(cand);
                 if (cm != 0ull) {
                     const int ci = nCand + __popcll(cm & ((1ull << lane) - 1ull));
@@ -1204,7 +1215,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
     long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
-    long long *totXay, double *totVal, char *scratch, long long scratchBytes) {
+    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring) {
     __shared__ Shared sh;
     __shared__ BandFeed bf;
     const long long idx = blockIdx.x;
@@ -1234,11 +1245,136 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
                                                   * (sizeof(WinTotal) + 2 * SY_P * sizeof(double))),
                     (int2 *) (scratch + idx * scratchBytes + scratch_cand_offset(ringD)),
                     (double *) (scratch + idx * scratchBytes + scratch_cand_offset(ringD)
-                                + (long long) SY_R * SY_CAND_PER_DIAG * ringD * sizeof(int2)));
+                                + (long long) SY_R * SY_CAND_PER_DIAG * ringD * sizeof(int2)),
+                    Bring ? Bring + idx * ((long long) ringD * SY_R * 3 * 64) : nullptr);
     if (threadIdx.x == 0) {
         state->nPairs = out.nPairs;
         state->nTot = out.nTot;
         state->winValid = 0;
+        state->expectPending = P.mode != 0 ? 1 : 0;
+    }
+}
+
+/*
+ * Baum-Welch expectations of the traceback window the backward kernel just swept
+ * (diagonalCalculation_Expectations :841-863 with cell_signal_updateTransAndKmerSkipExpectations
+ * :426-443).  By now every operand is in HBM -- forward cells and the two event-dependent emissions in
+ * the forward ring, backward cells in the B ring, the window's exact totals in scratch -- so this is
+ * an element-wise pass with no recurrence and no barrier: per cell eight exp(F.from + B.to + (eP + tP)
+ * - total), summed per thread and reduced once per window.  A lane keeps the sum of its k-mer's
+ * gap-X expectations in a register and adds it to the k-mer's bin when its slot moves to another k-mer.
+ * The match block is skipped on the window's two lowest diagonals' worth of reach, as in the
+ * reference, where forward[t-2] has been freed by then (quirk kept by the general kernel too).
+ */
+extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_expect(
+    const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,
+    const double *__restrict__ track, const long long *__restrict__ trackBase,
+    const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
+    long long ringDoubles, const double *Bring, int ringD, SyState *states, const char *scratch,
+    long long scratchBytes, double *expect) {
+    __shared__ double sExp[16];
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    SyState *state = states + idx;
+    if (!state->expectPending) return;
+    const DevItem it = uniform_item(items[idx]);
+    const double *model = models + (long long) it.model * CP_MODEL_STRIDE;
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) T[i] = model[i];
+    const Geometry g = make_geometry(const_cast<double *>(Fring) + idx * ringDoubles, ringD);
+    const int lane = g.lane, wave = g.wave;
+    const double *bown = Bring + idx * ((long long) ringD * SY_R * 3 * 64) + wave * (3 * 64) + lane;
+    const double *tr = track + trackBase[idx] * CP_ROW;
+    const unsigned short *kx = kidx + it.xOff;
+    const int2 *tab = bandTab + it.diagBase;
+    const WinTotal *wtot = (const WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int));
+    const int dTop = uni(state->winTop), from = uni(state->winFrom), to = uni(state->winTo);
+    const int tPost0 = dTop < from ? dTop : from;
+    double *dst = expect + (long long) it.model * (9 + 4096 + 1);
+
+    double acc[8]; /* M>X X>X Y>X | M>M X>M Y>M | M>Y Y>Y */
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.0;
+    double lik = 0.0, gapSum = 0.0;
+    int gapX = -1; /* matrix column whose gap-X expectations gapSum holds */
+
+    int xs = wave * 64 + lane; /* this slot's k-mer: the one in (xmax-P, xmax] */
+    int b0min, b0max, b1min, b1max, b2min, b2max;
+    band_load(tab, tPost0, b0min, b0max);
+    band_load(tab, tPost0 - 1, b1min, b1max);
+    xs += ((b0min - xs + SY_P - 1) / SY_P) * SY_P;
+    if (xs > b0max) xs -= SY_P;
+#pragma unroll 1
+    for (int t = tPost0; t > to; t--) {
+        band_load(tab, t - 2, b2min, b2max);
+        if (xs > b0max) xs -= SY_P;
+        const int x = xs;
+        const double total = wtot[(tPost0 - t) / 10].total;
+        if (threadIdx.x == 0) lik += total;
+        if (x >= b0min) { /* the cell (t, x) exists */
+            const double *bc = bown + (long long) (t & g.ringMask) * (SY_R * 3 * 64);
+            const double Bm = bc[0], Bx = bc[64], By = bc[128];
+            const bool vLower = x - 1 >= b1min && x - 1 <= b1max;
+            const bool vMiddle = t - 2 >= to && x - 1 >= b2min && x - 1 <= b2max;
+            const bool vUpper = x >= b1min && x <= b1max;
+            if (vLower) {
+                const double l0 = *g.rpb(t - 1, 0), l1 = *g.rpb(t - 1, 1), l2 = *g.rpb(t - 1, 2);
+                const double eP = tr[(long long) x * CP_ROW + CP_GAPX];
+                const double p0 = exp(l0 + Bx + (eP + T[T_GAP_OPEN_X]) - total);
+                const double p1 = exp(l1 + Bx + (eP + T[T_GAP_EXTEND_X]) - total);
+                const double p2 = exp(l2 + Bx + (eP + T[T_GAP_SWITCH_TO_X]) - total);
+                acc[0] += p0;
+                acc[1] += p1;
+                acc[2] += p2;
+                if (x != gapX) {
+                    if (gapX > 0) {
+                        const int k = kx[gapX - 1];
+                        if (k < 4096) atomicAdd(dst + 9 + k, gapSum);
+                    }
+                    gapX = x;
+                    gapSum = 0.0;
+                }
+                gapSum += p0;
+                gapSum += p1;
+                gapSum += p2;
+            }
+            if (vMiddle) {
+                const double m0 = *g.rpb(t - 2, 0), m1 = *g.rpb(t - 2, 1), m2 = *g.rpb(t - 2, 2);
+                const double eP = *g.rp(t, 3);
+                acc[3] += exp(m0 + Bm + (eP + T[T_MATCH_CONTINUE]) - total);
+                acc[4] += exp(m1 + Bm + (eP + T[T_MATCH_FROM_GAP_X]) - total);
+                acc[5] += exp(m2 + Bm + (eP + T[T_MATCH_FROM_GAP_Y]) - total);
+            }
+            if (vUpper) {
+                const double u0 = *g.rp(t - 1, 0), u2 = *g.rp(t - 1, 2);
+                const double eP = *g.rp(t, 4);
+                acc[6] += exp(u0 + By + (eP + T[T_GAP_OPEN_Y]) - total);
+                acc[7] += exp(u2 + By + (eP + T[T_GAP_EXTEND_Y]) - total);
+            }
+        }
+        b0min = b1min; b0max = b1max;
+        b1min = b2min; b1max = b2max;
+    }
+    if (gapX > 0) {
+        const int k = kx[gapX - 1];
+        if (k < 4096) atomicAdd(dst + 9 + k, gapSum);
+    }
+    /* block reduction of the per-thread sums, then one atomic per value */
+    if (threadIdx.x < 16) sExp[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int slot[8] = { 0 * 3 + 1, 1 * 3 + 1, 2 * 3 + 1, 0 * 3 + 0, 1 * 3 + 0, 2 * 3 + 0, 0 * 3 + 2, 2 * 3 + 2 };
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        double v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (lane == 0) atomicAdd(&sExp[slot[i]], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) atomicAdd(dst + threadIdx.x, sExp[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        atomicAdd(dst + 9 + 4096, lik);
+        state->expectPending = 0;
     }
 }
 
@@ -1320,6 +1456,7 @@ extern "C" int cpecan_systolic_max_width(void) { return SY_P - 2 * SY_PREFETCH; 
 extern "C" int cpecan_systolic_rows(void) { return SY_R; }
 extern "C" int cpecan_systolic_ring_row_doubles(void) { return SY_R * SY_RING_VALUES * 64; }
 
+extern "C" int cpecan_systolic_bring_row_doubles(void) { return SY_R * 3 * 64; }
 extern "C" int cpecan_systolic_state_bytes(void) { return (int) sizeof(SyState); }
 /* HBM scratch per alignment: a hit count and an output offset per ring diagonal, and per refresh of the window one
  * WinTotal and the two rows of per-cell terms */
@@ -1357,10 +1494,22 @@ extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem
                                                double *Fring, long long ringDoubles, int ringD,
                                                void *states, long long *pairs, double *pairLogp,
                                                long long *totXay, double *totVal, char *scratch,
-                                               long long scratchBytes) {
+                                               long long scratchBytes, double *Bring) {
     hipLaunchKernelGGL(cpecan_k_sy_backward, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems,
                        P, (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
-                       (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes);
+                       (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int cpecan_systolic_launch_expect(hipStream_t stream, const DevItem *items, long long nItems,
+                                             DevParams P, const void *bandTab, const double *track,
+                                             const long long *trackBase, const unsigned short *kidx,
+                                             const double *models, const double *Fring,
+                                             long long ringDoubles, const double *Bring, int ringD,
+                                             void *states, const char *scratch, long long scratchBytes,
+                                             double *expect) {
+    hipLaunchKernelGGL(cpecan_k_sy_expect, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems, P,
+                       (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles, Bring, ringD,
+                       (SyState *) states, scratch, scratchBytes, expect);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,

@@ -99,3 +99,30 @@ def test_too_wide_band_is_refused_by_systolic_and_routed_by_auto(ctx):
     res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_AUTO)
     ref = run_oracle_item(batch, 0, bp)
     assert_same_pairs(res[0], ref)
+
+
+@pytest.mark.parametrize("case", [
+    dict(n=4, lX=150, lY=310, e=40, md=80, tb=20, every=25, ragged=(1, 1)),
+    dict(n=3, lX=400, lY=800, e=100, md=200, tb=40, every=50, ragged=(0, 0)),
+    dict(n=2, lX=200, lY=410, e=30, md=12, tb=10, every=40, ragged=(1, 0)),
+])
+def test_systolic_expectations_match_oracle(ctx, case):
+    # Baum-Welch sufficient statistics from the systolic kernels (forward, backward with the B ring,
+    # element-wise expectation kernel) against the oracle and against the general kernel
+    import pyoracle as o
+    batch = synth.make_batch(27, case["n"], case["lX"], case["lY"], anchor_every=case["every"],
+                             distinct_models=False)
+    bp = band_params(0.01, case["md"], case["tb"], case["e"])
+    res, b = run_gpu(ctx, batch, bp, mode=cp.MODE_EXPECTATIONS, kernel=cp.KERNEL_SYSTOLIC, ragged=case["ragged"])
+    assert b.info()["kernel"] == "systolic"
+    got = b.expectations(0)
+    hmm = o.OrcExpectations()
+    for i in range(case["n"]):
+        ref = run_oracle_item(batch, i, bp, case["ragged"], expectations=hmm)
+        assert np.array_equal(res[i]["totals"], ref["totals"])
+    # tolerance: the device sums in a different order and uses its own exp(): 1e-9 relative
+    assert np.allclose(got[:9], np.array(hmm.transitions[:]), rtol=1e-9, atol=1e-12)
+    assert np.allclose(got[9:9 + 4096], np.array(hmm.kmerGap[:]), rtol=1e-9, atol=1e-12)
+    assert np.isclose(got[-1], hmm.likelihood, rtol=1e-12)
+    _, g = run_gpu(ctx, batch, bp, mode=cp.MODE_EXPECTATIONS, kernel=cp.KERNEL_GENERAL, ragged=case["ragged"])
+    assert np.allclose(got, g.expectations(0), rtol=1e-9, atol=1e-12)
