@@ -260,3 +260,50 @@ def test_vanilla_zymo_read_through_host_api(golden_dir, zymo_read, template_mode
     L.sequence_sequenceDestroy(sY)
     L.pairwiseAlignmentBandingParameters_destruct(p)
     L.stateMachine_destruct(sm)
+
+
+@pytest.mark.gpu
+def test_baum_welch_iterations_on_the_zymo_read(golden_dir, zymo_read, template_model):
+    """test_continuousPairHmm_em (tests/signalPairwiseTest.c:1604-1714) through the host API: ten E/M rounds
+    on the reference's Zymo template read from a random model (anchors taken from the un-banded posterior
+    instead of lastz);
+    the expected likelihood must not fall, by the reference's own criterion."""
+    L = h.lib()
+    sm = L.getStrawManStateMachine3(os.path.join(golden_dir, "template_median68pA.model").encode())
+    L.emissions_signal_scaleModel(sm, *zymo_read["template_params"])
+    rd = h.Read(zymo_read["reference"], zymo_read["template_events"])
+    om = o.Sm3Model(template_model[0], template_model[2]).scaled(*zymo_read["template_params"])
+    ref = o.aligned_pairs_without_banding(om, zymo_read["reference"], rd.lX, zymo_read["template_events"],
+                                          o.default_params())
+    best = {int(x): int(y) for q, x, y in ref["triples"] if q > 9000000}
+    anchors, py = [], -1
+    for x in sorted(best)[::25]:
+        if best[x] > py:
+            anchors.append((x, best[x]))
+            py = best[x]
+    lst = h.make_anchor_list(anchors)
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    p.contents.minDiagsBetweenTraceBack = 300
+    # start from a random model, as the reference does (continuousPairHmm_randomize :193-204)
+    rng = np.random.default_rng(17)
+    e = h.Expectations()
+    for i in range(9):
+        e.transitions[i] = rng.random()
+    for i in range(h.NUM_KMERS):
+        e.individualKmerGapProbs[i] = rng.random()
+    L.continuousPairHmm_normalize(C.byref(e))
+    L.continuousPairHmm_loadTransitionsAndKmerGapProbs(sm, C.byref(e))
+    prev, first = -np.inf, None
+    for it in range(10):
+        e = h.Expectations()
+        L.getSignalExpectationsUsingAnchors(sm, C.byref(e), rd.sX, rd.sY, lst, p, False, False)   # E step
+        assert np.isfinite(e.likelihood)
+        assert prev <= e.likelihood * 0.95
+        prev = e.likelihood
+        first = first if first is not None else e.likelihood
+        L.continuousPairHmm_normalize(C.byref(e))
+        L.continuousPairHmm_loadTransitionsAndKmerGapProbs(sm, C.byref(e))                      # M step
+    assert prev > first  # ten rounds fit the read better than the random start did
+    L.stList_destruct(lst)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)
