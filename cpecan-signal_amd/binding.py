@@ -38,6 +38,7 @@ EXPORTS = [
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
     "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
+    "cpecan_hip_modelsh_create", "cpecan_hip_batch_create_hdp",
 ]
 
 
@@ -61,6 +62,12 @@ class VanillaModelDesc(C.Structure):
     _fields_ = [("m_to_y_not_x", C.c_double), ("e_to_e", C.c_double), ("end_match_prob", C.c_double),
                 ("end_from_x_prob", C.c_double), ("end_from_y_prob", C.c_double),
                 ("match_probs", C.c_void_p), ("skip_probs", C.c_void_p), ("gap_y_probs", C.c_void_p)]
+
+
+class HdpModelDesc(C.Structure):
+    _fields_ = [("transitions", C.c_double * 9), ("alphabet", C.c_char_p), ("alphabet_size", C.c_int32),
+                ("grid_length", C.c_int32), ("grid", C.c_void_p), ("n_rows", C.c_int64),
+                ("posterior_predictive", C.c_void_p), ("spline_slopes", C.c_void_p), ("kmer_row", C.c_void_p)]
 
 
 class Item(C.Structure):
@@ -117,6 +124,10 @@ def lib():
             C.POINTER(C.c_void_p)]
         L.cpecan_hip_models5_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.cpecan_hip_modelsv_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cpecan_hip_modelsh_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.cpecan_hip_batch_create_hdp.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
         L.cpecan_hip_batch_create_vanilla.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
             C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
@@ -250,6 +261,34 @@ class Context:
         _check(lib().cpecan_hip_modelsv_create(self.h, C.cast(descs, C.c_void_p), n, threads, _ptr(ids)))
         return ids
 
+    def modelsh_create(self, models):
+        """models: list of (transitions[9], alphabet str, grid[G], y[rows, G], slope[rows, G],
+        kmer_row[alphabet_size ** 6] int32) -> ids (HDP signal machine)"""
+        n = len(models)
+        descs = (HdpModelDesc * n)()
+        keep = []
+        for i, (t, alphabet, grid, y, slope, kmer_row) in enumerate(models):
+            grid = np.ascontiguousarray(grid, dtype=np.float64)
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            slope = np.ascontiguousarray(slope, dtype=np.float64)
+            kmer_row = np.ascontiguousarray(kmer_row, dtype=np.int32)
+            ab = alphabet.encode()
+            assert y.shape == slope.shape and y.shape[1] == grid.size and kmer_row.size == len(ab) ** 6
+            keep += [grid, y, slope, kmer_row, ab]
+            for j in range(9):
+                descs[i].transitions[j] = t[j]
+            descs[i].alphabet = ab
+            descs[i].alphabet_size = len(ab)
+            descs[i].grid_length = grid.size
+            descs[i].grid = grid.ctypes.data
+            descs[i].n_rows = y.shape[0]
+            descs[i].posterior_predictive = y.ctypes.data
+            descs[i].spline_slopes = slope.ctypes.data
+            descs[i].kmer_row = kmer_row.ctypes.data
+        ids = np.zeros(n, np.int32)
+        _check(lib().cpecan_hip_modelsh_create(self.h, C.cast(descs, C.c_void_p), n, _ptr(ids)))
+        return ids
+
     def models_clear(self):
         _check(lib().cpecan_hip_models_clear(self.h))
 
@@ -263,7 +302,7 @@ class Batch:
     """cpecan_batch: items is a numpy array of ITEM_DTYPE."""
 
     def __init__(self, ctx, items, x_chars, events, anchors, params, mode=MODE_POSTERIOR,
-                 kernel=KERNEL_AUTO, flags=0, y_chars=None, vanilla=False):
+                 kernel=KERNEL_AUTO, flags=0, y_chars=None, vanilla=False, hdp=False):
         """events: double[n][3] for a signal batch (vanilla: with a modelsv_create model); y_chars
         (str/bytes) instead for a DNA batch."""
         self.ctx = ctx
@@ -275,6 +314,11 @@ class Batch:
             yb = np.frombuffer(y_chars.encode() if isinstance(y_chars, str) else bytes(y_chars), np.uint8)
             _check(lib().cpecan_hip_batch_create_dna(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
                                                      _ptr(yb), yb.size, _ptr(an), an.shape[0],
+                                                     C.byref(params), flags, C.byref(h)))
+        elif hdp:
+            ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+            _check(lib().cpecan_hip_batch_create_hdp(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
+                                                     _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
                                                      C.byref(params), flags, C.byref(h)))
         elif vanilla:
             ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)

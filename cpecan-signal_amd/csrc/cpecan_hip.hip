@@ -35,6 +35,18 @@ extern "C" __global__ void cpecan_k_generalv(const DevItem *, DevParams, const i
                                              const double *, const double *, double *, double *,
                                              long long *, double *, long long *, long long *, double *,
                                              long long *);
+struct DevHdpModel { /* as in cpecan_kernel_generalh.hip */
+    double t[9];
+    int gridLength, pad;
+    const int *kmerRow;
+    const double *grid, *y, *slope;
+};
+extern "C" __global__ void cpecan_k_generalh(const DevItem *, DevParams, const int *, const int *,
+                                             const long long *, const int *, const double *,
+                                             const DevHdpModel *, double *, double *, long long *, double *,
+                                             long long *, long long *, double *, long long *);
+extern "C" __global__ void cpecan_k_hdp_kmer_id(const char *, long long, unsigned long long,
+                                                unsigned long long, int, int *);
 extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned short *);
 
 extern "C" int cpecan_systolic_max_width(void);
@@ -121,6 +133,15 @@ struct cpecan_ctx {
     DevBuf<double> models5; /* 5-state symbol models, nModels5 * CP_MODEL5_STRIDE */
     std::vector<double> hostModels5;
     int nModels5 = 0;
+    /* HDP models: descriptors on the device, their tables in buffers of their own */
+    struct HdpTables {
+        DevBuf<int> kmerRow;
+        DevBuf<double> grid, y, slope;
+    };
+    std::vector<HdpTables *> hdpTables;
+    std::vector<DevHdpModel> hostModelsH;
+    DevBuf<DevHdpModel> modelsH;
+    std::string hdpAlphabet;
     DevBuf<double> modelsV; /* vanilla signal models, nModelsV * CP_VMODEL_STRIDE */
     std::vector<double> hostModelsV;
     int nModelsV = 0;
@@ -137,8 +158,9 @@ struct cpecan_batch {
     DevBuf<long long> cellPrefix;
     DevBuf<char> chars, charsY; /* charsY: DNA batches (5-state machine) */
     bool dna = false;
-    bool vanilla = false;
+    bool vanilla = false, hdp = false;
     DevBuf<double> logNoise; /* vanilla batches: log(event noise), host libm */
+    DevBuf<int> kid;         /* HDP batches: k-mer id over the model's alphabet per X position */
     DevBuf<unsigned short> kidx;
     DevBuf<double> events;
     DevBuf<long long> anchors;
@@ -372,6 +394,56 @@ int cpecan_hip_modelsv_create(cpecan_ctx *c, const cpecan_vanilla_model *models,
     return CPECAN_OK;
 }
 
+int cpecan_hip_modelsh_create(cpecan_ctx *c, const cpecan_hdp_model *models, int32_t n, int32_t *ids) {
+    if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++) {
+        const cpecan_hdp_model &m = models[i];
+        if (!m.alphabet || m.alphabet_size < 1 || m.alphabet_size > 16 || m.grid_length < 2 || !m.grid ||
+            m.n_rows < 1 || !m.posterior_predictive || !m.spline_slopes || !m.kmer_row)
+            return fail(CPECAN_EINVAL, "HDP model %d is incomplete", i);
+        const std::string a(m.alphabet, (size_t) m.alphabet_size);
+        if (!c->hdpAlphabet.empty() && c->hdpAlphabet != a)
+            return fail(CPECAN_EINVAL, "all HDP models of a context must share one alphabet");
+        c->hdpAlphabet = a;
+        long long nK = 1;
+        for (int q = 0; q < 6; q++) nK *= m.alphabet_size;
+        for (long long k = 0; k < nK; k++)
+            if (m.kmer_row[k] < 0 || m.kmer_row[k] >= m.n_rows)
+                return fail(CPECAN_EINVAL, "HDP model %d: k-mer %lld points outside the tables", i, k);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++) {
+        const cpecan_hdp_model &m = models[i];
+        long long nK = 1;
+        for (int q = 0; q < 6; q++) nK *= m.alphabet_size;
+        auto *t = new cpecan_ctx::HdpTables();
+        c->hdpTables.push_back(t);
+        const size_t cells = (size_t) m.n_rows * (size_t) m.grid_length;
+        HIP_TRY(t->kmerRow.alloc((size_t) nK));
+        HIP_TRY(t->grid.alloc((size_t) m.grid_length));
+        HIP_TRY(t->y.alloc(cells));
+        HIP_TRY(t->slope.alloc(cells));
+        HIP_TRY(hipMemcpy(t->kmerRow.p, m.kmer_row, (size_t) nK * sizeof(int), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->grid.p, m.grid, (size_t) m.grid_length * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->y.p, m.posterior_predictive, cells * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(t->slope.p, m.spline_slopes, cells * sizeof(double), hipMemcpyHostToDevice));
+        DevHdpModel d;
+        for (int q = 0; q < 9; q++) d.t[q] = m.transitions[q];
+        d.gridLength = m.grid_length;
+        d.pad = 0;
+        d.kmerRow = t->kmerRow.p;
+        d.grid = t->grid.p;
+        d.y = t->y.p;
+        d.slope = t->slope.p;
+        ids[i] = (int32_t) c->hostModelsH.size();
+        c->hostModelsH.push_back(d);
+    }
+    HIP_TRY(c->modelsH.alloc(c->hostModelsH.size()));
+    HIP_TRY(hipMemcpy(c->modelsH.p, c->hostModelsH.data(), c->hostModelsH.size() * sizeof(DevHdpModel),
+                      hipMemcpyHostToDevice));
+    return CPECAN_OK;
+}
+
 int cpecan_hip_models5_create(cpecan_ctx *c, const cpecan_sm5_model *models, int32_t n, int32_t *ids) {
     if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -405,6 +477,11 @@ int cpecan_hip_models_clear(cpecan_ctx *c) {
     c->modelsV.release();
     c->hostModelsV.clear();
     c->nModelsV = 0;
+    for (auto *t : c->hdpTables) delete t;
+    c->hdpTables.clear();
+    c->hostModelsH.clear();
+    c->modelsH.release();
+    c->hdpAlphabet.clear();
     return CPECAN_OK;
 }
 
@@ -439,8 +516,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                              const char *xChars, int64_t nX, const double *events, const char *yChars,
                              int64_t nEvents, const int64_t *anchors, int64_t nAnchorPairs,
                              const cpecan_band_params *params, int32_t mode, int32_t kernel,
-                             int32_t flags, cpecan_batch **out, bool vanilla = false) {
+                             int32_t flags, cpecan_batch **out, bool vanilla = false, bool hdp = false) {
     const bool dna = yChars != nullptr;
+    if (hdp && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
+        return fail(CPECAN_EINVAL, "HDP batches: posterior decode only, no cell dumps");
     if (vanilla && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
         return fail(CPECAN_EINVAL, "vanilla batches: posterior decode only, no cell dumps");
     const int S = dna ? 5 : 3; /* states per cell */
@@ -476,7 +555,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             s.anchor_offset < 0 || s.x_offset + s.lX + (!dna && s.lX > 0 ? 5 : 0) > nX ||
             s.y_offset + s.lY > nEvents || s.anchor_offset + s.n_anchors > nAnchorPairs)
             return fail(CPECAN_EINVAL, "item %lld points outside the supplied buffers", (long long) i);
-        if (s.model_id < 0 || s.model_id >= (dna ? c->nModels5 : vanilla ? c->nModelsV : c->nModels))
+        if (s.model_id < 0 || s.model_id >= (dna ? c->nModels5 : vanilla ? c->nModelsV
+                                                      : hdp ? (int) c->hostModelsH.size() : c->nModels))
             return fail(CPECAN_EINVAL, "item %lld: unknown model id %d", (long long) i, s.model_id);
         if (s.lX + s.lY >= (1ll << 30)) return fail(CPECAN_EINVAL, "item %lld too long", (long long) i);
         DevItem &d = hItems[(size_t) i];
@@ -534,7 +614,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         d.cellBase = cellTotal;
         cellTotal += cells;
         d.pairBase = pairTotal;
-        d.pairCap = 4 * (s.lX + s.lY) + 64;
+        /* the HDP machine scores with linear densities (quirk Q6): its posteriors are flat and far more
+         * cells pass the threshold (2887 pairs for a ~800-event read in the reference's own test) */
+        d.pairCap = (hdp ? 16 : 4) * (s.lX + s.lY) + 64;
         pairTotal += d.pairCap;
         d.totBase = totTotal;
         d.totCap = (nDiag + 9) / 10 + nDiag / std::max<long long>(1, params->minDiagsBetweenTraceBack -
@@ -561,9 +643,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
-    int useKernel = dna || vanilla ? CPECAN_KERNEL_GENERAL : kernel;
+    int useKernel = dna || vanilla || hdp ? CPECAN_KERNEL_GENERAL : kernel;
     b->dna = dna;
     b->vanilla = vanilla;
+    b->hdp = hdp;
     if (useKernel == CPECAN_KERNEL_AUTO)
         useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && systolicOk && !b->P.debug && !unbanded)
                         ? CPECAN_KERNEL_SYSTOLIC : CPECAN_KERNEL_GENERAL;
@@ -681,8 +764,24 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     B_TRY(hipEventCreate(&b->ev1));
     B_TRY(hipEventCreate(&b->ev2));
 
+    if (hdp) { /* k-mer ids over the HDP's alphabet, once per batch like the k-mer indices below */
+        unsigned long long lo = 0, hi = 0;
+        for (size_t q = 0; q < c->hdpAlphabet.size(); q++) {
+            const unsigned long long ch = (unsigned char) c->hdpAlphabet[q];
+            if (q < 8) lo |= ch << (8 * q);
+            else hi |= ch << (8 * (q - 8));
+        }
+        B_TRY(b->kid.alloc((size_t) nX + 8));
+        const int blocks = (int) ((nX + 255) / 256);
+        if (blocks > 0)
+            hipLaunchKernelGGL(cpecan_k_hdp_kmer_id, dim3(blocks), dim3(256), 0, c->stream,
+                               (const char *) b->chars.p, (long long) nX, lo, hi, (int) c->hdpAlphabet.size(),
+                               b->kid.p);
+        B_TRY(hipGetLastError());
+        B_TRY(hipStreamSynchronize(c->stream));
+    }
     /* k-mer indices are part of input preparation (done once, like H2D) */
-    if (!dna) {
+    if (!dna && !hdp) {
         long long n = (long long) nX;
         int threads = 256;
         int blocks = (int) ((n + threads - 1) / threads);
@@ -715,6 +814,15 @@ int cpecan_hip_batch_create_vanilla(cpecan_ctx *c, const cpecan_item *items, int
                              params, CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out, true);
 }
 
+int cpecan_hip_batch_create_hdp(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
+                                const char *xChars, int64_t nX, const double *events, int64_t nEvents,
+                                const int64_t *anchors, int64_t nAnchorPairs,
+                                const cpecan_band_params *params, int32_t flags, cpecan_batch **out) {
+    if (!events) return fail(CPECAN_EINVAL, "bad argument");
+    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs,
+                             params, CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out, false, true);
+}
+
 int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
                                 const char *xChars, int64_t nX, const char *yChars, int64_t nY,
                                 const int64_t *anchors, int64_t nAnchorPairs,
@@ -741,6 +849,14 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            (const double *) c->models5.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
                            b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
                            (double *) nullptr);
+        HIP_TRY(hipGetLastError());
+    } else if (b->hdp) {
+        hipLaunchKernelGGL(cpecan_k_generalh, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
+                           (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
+                           (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
+                           (const int *) b->kid.p, (const double *) b->events.p,
+                           (const DevHdpModel *) c->modelsH.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
+                           b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p);
         HIP_TRY(hipGetLastError());
     } else if (b->vanilla) {
         hipLaunchKernelGGL(cpecan_k_generalv, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,

@@ -123,6 +123,9 @@ void *sequence_getKmer2(void *elements, int64_t index) {
     if (index < 0) return (char *) elements;
     return index > 0 ? (char *) elements + index - 1 : (char *) elements + index;
 }
+void *sequence_getKmer3(void *elements, int64_t index) {
+    return index >= 0 ? (char *) elements + index : (char *) elements;
+}
 void *sequence_getBase(void *elements, int64_t index) {
     return index >= 0 ? (void *) ((char *) elements + index) : (void *) "n";
 }
@@ -276,6 +279,146 @@ StateMachine *getStrawManStateMachine3(const char *modelFile) {
     return (StateMachine *) s;
 }
 
+/* ---- NanoporeHDP: the reader of serialized HDPs (impl/nanopore_hdp.c:845-870, impl/hdp.c:3009-3273) ---- */
+struct _nanopore_hdp {
+    char alphabet[32];
+    int64_t alphabetSize, kmerLength, numDps, gridLength, nRows;
+    double *grid, *y, *slope; /* y, slope: nRows x gridLength */
+    int32_t *kmerRow;         /* per k-mer id: row of the nearest observed ancestor (impl/hdp.c:2588-2590) */
+};
+static char *read_line(FILE *f) { /* one line of any length, without the newline; NULL at EOF */
+    size_t cap = 1 << 16, n = 0;
+    char *buf = malloc(cap);
+    int ch;
+    while ((ch = fgetc(f)) != EOF && ch != '\n') {
+        if (n + 2 > cap) buf = realloc(buf, cap *= 2);
+        buf[n++] = (char) ch;
+    }
+    if (ch == EOF && n == 0) { free(buf); return NULL; }
+    buf[n] = 0;
+    return buf;
+}
+static int64_t line_int(FILE *f, const char *what) {
+    char *l = read_line(f);
+    if (!l) die("cpecan: truncated .nhdp (%s)", what);
+    int64_t v = strtoll(l, NULL, 10);
+    free(l);
+    return v;
+}
+/* doubles of one line into dst (up to cap); returns how many the line holds */
+static int64_t line_doubles(FILE *f, double *dst, int64_t cap) {
+    char *l = read_line(f), *p = l, *e;
+    int64_t n = 0;
+    if (!l) die("cpecan: truncated .nhdp");
+    for (;;) {
+        double v = strtod(p, &e);
+        if (e == p) break;
+        if (n < cap && dst) dst[n] = v;
+        n++;
+        p = e;
+    }
+    free(l);
+    return n;
+}
+NanoporeHDP *deserialize_nhdp(const char *filepath) {
+    FILE *f = fopen(filepath, "r");
+    if (!f) die("cpecan: cannot open %s", filepath);
+    NanoporeHDP *h = calloc(1, sizeof *h);
+    h->alphabetSize = line_int(f, "alphabet size");
+    char *l = read_line(f);
+    if (!l || h->alphabetSize < 1 || h->alphabetSize > 16 || (int64_t) strlen(l) < h->alphabetSize)
+        die("cpecan: bad alphabet in %s", filepath);
+    memcpy(h->alphabet, l, (size_t) h->alphabetSize);
+    free(l);
+    h->kmerLength = line_int(f, "k-mer length");
+    if (h->kmerLength != KMER_LENGTH) die("cpecan: %s is not a 6-mer HDP", filepath);
+    const int64_t splines = line_int(f, "splines finalized"), hasData = line_int(f, "has data");
+    const int64_t sampleGamma = line_int(f, "sample gamma");
+    h->numDps = line_int(f, "number of Dirichlet processes");
+    if (!splines || !hasData) die("cpecan: %s does not hold a finalized HDP with data", filepath);
+    (void) line_doubles(f, NULL, 0); /* data */
+    (void) line_doubles(f, NULL, 0); /* Dirichlet process of each datum */
+    (void) line_doubles(f, NULL, 0); /* base parameters mu nu alpha beta */
+    double g[3];
+    if (line_doubles(f, g, 3) != 3) die("cpecan: bad sampling grid in %s", filepath);
+    h->gridLength = (int64_t) g[2];
+    if (h->gridLength < 2 || !(g[0] < g[1])) die("cpecan: bad sampling grid in %s", filepath);
+    h->grid = malloc(sizeof(double) * (size_t) h->gridLength);
+    {   /* linspace (impl/hdp_math_utils.c:497-510) */
+        const int64_t n = h->gridLength - 1;
+        const double dx = (g[1] - g[0]) / ((double) n);
+        for (int64_t i = 0; i < n; i++) h->grid[i] = g[0] + i * dx;
+        h->grid[n] = g[1];
+    }
+    (void) line_doubles(f, NULL, 0); /* gamma */
+    if (sampleGamma)
+        for (int q = 0; q < 4; q++) (void) line_doubles(f, NULL, 0); /* gamma alpha, beta, w, s */
+    int64_t *parent = malloc(sizeof(int64_t) * (size_t) h->numDps);
+    for (int64_t d = 0; d < h->numDps; d++) {
+        l = read_line(f);
+        if (!l) die("cpecan: truncated .nhdp (parents)");
+        parent[d] = l[0] == '-' ? -1 : strtoll(l, NULL, 10);
+        free(l);
+    }
+    /* posterior predictives: a line per process, empty unless observed */
+    int64_t *rowOf = malloc(sizeof(int64_t) * (size_t) h->numDps);
+    size_t cap = 256;
+    h->y = malloc(sizeof(double) * cap * (size_t) h->gridLength);
+    for (int64_t d = 0; d < h->numDps; d++) {
+        if ((size_t) h->nRows == cap) h->y = realloc(h->y, sizeof(double) * (cap *= 2) * (size_t) h->gridLength);
+        const int64_t n = line_doubles(f, h->y + h->nRows * h->gridLength, h->gridLength);
+        if (n != 0 && n != h->gridLength) die("cpecan: bad distribution for process %lld", (long long) d);
+        rowOf[d] = n ? h->nRows++ : -1;
+    }
+    h->slope = malloc(sizeof(double) * (size_t) h->nRows * (size_t) h->gridLength);
+    for (int64_t d = 0; d < h->numDps; d++) {
+        double *dst = rowOf[d] >= 0 ? h->slope + rowOf[d] * h->gridLength : NULL;
+        const int64_t n = line_doubles(f, dst, dst ? h->gridLength : 0);
+        if ((n != 0) != (rowOf[d] >= 0) || (n != 0 && n != h->gridLength))
+            die("cpecan: spline slopes of process %lld do not match its distribution", (long long) d);
+    }
+    fclose(f); /* the factor lines that follow are the sampler's state: not needed for densities */
+    int64_t nK = 1;
+    for (int q = 0; q < KMER_LENGTH; q++) nK *= h->alphabetSize;
+    if (nK > h->numDps) die("cpecan: %s has fewer Dirichlet processes than k-mers", filepath);
+    h->kmerRow = malloc(sizeof(int32_t) * (size_t) nK);
+    for (int64_t k = 0; k < nK; k++) {
+        int64_t d = k;
+        while (d >= 0 && rowOf[d] < 0) d = parent[d];
+        if (d < 0) die("cpecan: k-mer %lld has no observed ancestor", (long long) k);
+        h->kmerRow[k] = (int32_t) rowOf[d];
+    }
+    free(parent);
+    free(rowOf);
+    return h;
+}
+void destroy_nanopore_hdp(NanoporeHDP *h) {
+    if (!h) return;
+    free(h->grid); free(h->y); free(h->slope); free(h->kmerRow); free(h);
+}
+int64_t get_nanopore_hdp_alphabet_size(NanoporeHDP *h) { return h->alphabetSize; }
+char *get_nanopore_hdp_alphabet(NanoporeHDP *h) {
+    char *c = calloc((size_t) h->alphabetSize + 1, 1);
+    memcpy(c, h->alphabet, (size_t) h->alphabetSize);
+    return c;
+}
+double get_nanopore_kmer_density(NanoporeHDP *nhdp, void *kmer, void *x) {
+    (void) nhdp; (void) kmer; (void) x;
+    die("cpecan: get_nanopore_kmer_density is a marker; densities are evaluated on the device");
+    return 0.0;
+}
+StateMachine *getHdpStateMachine3(NanoporeHDP *hdp) {
+    StateMachine3_HDP *s = calloc(1, sizeof *s);
+    s->model.type = threeStateHdp;
+    s->model.stateNumber = 3;
+    s->model.matchState = match;
+    s->model.parameterSetSize = NUM_OF_KMERS;
+    s->hdpModel = hdp;
+    /* StateMachine3_HDP starts with the same nine transitions as StateMachine3 */
+    stateMachine3_setTransitionsToNanoporeDefaults((StateMachine *) s);
+    return (StateMachine *) s;
+}
+
 StateMachine *getSignalStateMachine3Vanilla(const char *modelFile) {
     StateMachine3Vanilla *s = calloc(1, sizeof(StateMachine3Vanilla));
     s->model.type = vanilla;
@@ -379,13 +522,20 @@ static cpecan_ctx *context(void) {
 }
 
 /* returns 1 for the DNA-against-DNA combination (5-state machine, sequence_getBase on both sides),
- * 2 for k-mers against events under the vanilla machine (sequence_getKmer2), 0 under the 3-state strawMan
- * machine (sequence_getKmer); anything else is not on the GPU path */
+ * 2 for k-mers against events under the vanilla machine (sequence_getKmer2), 3 under the HDP machine
+ * (sequence_getKmer3), 0 under the 3-state strawMan machine (sequence_getKmer); anything else is not on
+ * the GPU path */
 static int check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY) {
     if ((sM->type == fiveState || sM->type == fiveStateAsymmetric) && sM->stateNumber == 5) {
         if (sX->get != sequence_getBase || sY->get != sequence_getBase)
             die("cpecan: the 5-state machine needs sequence_getBase element getters on both sequences");
         return 1;
+    }
+    if (sM->type == threeStateHdp && sM->stateNumber == 3) {
+        if (sX->get != sequence_getKmer3 || sY->get != sequence_getEvent)
+            die("cpecan: the HDP machine needs sequence_getKmer3 / sequence_getEvent element getters");
+        if (!((StateMachine3_HDP *) sM)->hdpModel) die("cpecan: the HDP machine has no NanoporeHDP");
+        return 3;
     }
     if (sM->type == vanilla && sM->stateNumber == 3) {
         if (sX->get != sequence_getKmer2 || sY->get != sequence_getEvent)
@@ -413,7 +563,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     cpecan_ctx *ctx = context();
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
     const int kind = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
-    const int dna = kind == 1, van = kind == 2;
+    const int dna = kind == 1, van = kind == 2, hdp = kind == 3;
     if (kind != 0 && mode != 0) die("cpecan: expectations run on the GPU path for the strawMan machine only");
     const int64_t xPad = dna ? 0 : KMER_LENGTH - 1; /* a k-mer sequence of lX elements spans lX + 5 chars */
     for (int64_t i = 0; i < n; i++) {
@@ -474,6 +624,29 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         }
         modelOf[i] = found;
     }
+    cpecan_hdp_model *modelsH = malloc(sizeof(cpecan_hdp_model) * (size_t) (hdp ? n : 1));
+    for (int64_t i = 0; hdp && i < n; i++) { /* one model per distinct StateMachine3_HDP */
+        int32_t found = -1;
+        for (int32_t k = 0; k < nModels && found < 0; k++)
+            if (owner5[k] == sMs[i]) found = k;
+        if (found < 0) {
+            const StateMachine3_HDP *sh = (const StateMachine3_HDP *) sMs[i];
+            const NanoporeHDP *nh = sh->hdpModel;
+            cpecan_hdp_model *m = &modelsH[nModels];
+            memcpy(m->transitions, &sh->TRANSITION_MATCH_CONTINUE, sizeof m->transitions);
+            m->alphabet = nh->alphabet;
+            m->alphabet_size = (int32_t) nh->alphabetSize;
+            m->grid_length = (int32_t) nh->gridLength;
+            m->grid = nh->grid;
+            m->n_rows = nh->nRows;
+            m->posterior_predictive = nh->y;
+            m->spline_slopes = nh->slope;
+            m->kmer_row = nh->kmerRow;
+            owner5[nModels] = sMs[i];
+            found = nModels++;
+        }
+        modelOf[i] = found;
+    }
     for (int64_t i = 0; kind == 0 && i < n; i++) {
         StateMachine3 *s3 = (StateMachine3 *) sMs[i];
         const double t[9] = { s3->TRANSITION_MATCH_CONTINUE, s3->TRANSITION_MATCH_FROM_GAP_X,
@@ -502,6 +675,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     CHECK(cpecan_hip_models_clear(ctx));
     if (dna) CHECK(cpecan_hip_models5_create(ctx, models5, nModels, ids));
     else if (van) CHECK(cpecan_hip_modelsv_create(ctx, modelsV, nModels, 0, ids));
+    else if (hdp) CHECK(cpecan_hip_modelsh_create(ctx, modelsH, nModels, ids));
     else CHECK(cpecan_hip_models_create(ctx, models, nModels, 0, ids));
 
     int64_t xo = 0, yo = 0, ao = 0;
@@ -564,6 +738,9 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         if (dna)
             CHECK(cpecan_hip_batch_create_dna(ctx, items, nItems, chars, xo, ychars, yo, anchors, ao, &bp,
                                               unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+        else if (hdp)
+            CHECK(cpecan_hip_batch_create_hdp(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
+                                              unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
         else if (van)
             CHECK(cpecan_hip_batch_create_vanilla(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                                   unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
@@ -618,7 +795,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         for (int64_t i = 0; i < n; i++) lists[i] = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
     }
     free(chars); free(events); free(anchors); free(items); free(origin); free(firstItem);
-    free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars); free(modelsV);
+    free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars); free(modelsV); free(modelsH);
     pthread_mutex_unlock(&g_lock);
 }
 

@@ -64,6 +64,7 @@ void sequence_sequenceDestroy(Sequence *seq);
 void *sequence_getKmer(void *elements, int64_t index);
 void *sequence_getBase(void *elements, int64_t index); /* :308-312 */
 void *sequence_getKmer2(void *elements, int64_t index); /* :320-325: previous + current k-mer */
+void *sequence_getKmer3(void *elements, int64_t index); /* :327-331: index < 0 reads the first k-mer */
 Sequence *sequence_sliceNucleotideSequence(Sequence *inputSequence, int64_t start, int64_t sliceLength);
 void *sequence_getEvent(void *elements, int64_t index);
 int64_t sequence_correctSeqLength(int64_t length, SequenceType type);
@@ -169,6 +170,34 @@ typedef struct _StateMachine3vanilla {
  * skip bins of its second line stored as beta and alpha (:284-297) */
 StateMachine *getSignalStateMachine3Vanilla(const char *modelFile);
 void stateMachine3Vanilla_setStrandTransitionsToDefaults(StateMachine *sM, Strand strand); /* :1291 */
+
+/* ---- HDP signal machine (inc/nanopore_hdp.h, inc/stateMachine.h:197-216) ------------------------------
+ * NanoporeHDP is opaque, as in the reference.  deserialize_nhdp reads a file written by the reference's
+ * serialize_nhdp (impl/nanopore_hdp.c:820-905, impl/hdp.c:2880-3273) as far as density queries need it:
+ * alphabet, sampling grid, the tree of Dirichlet processes and the finalized distributions of the observed
+ * ones.  It must hold a finalized HDP with data (first two flags 1), which is what the reference's
+ * aligner loads; building or sampling HDPs is not part of this path. */
+typedef struct _nanopore_hdp NanoporeHDP;
+NanoporeHDP *deserialize_nhdp(const char *filepath);
+void destroy_nanopore_hdp(NanoporeHDP *nhdp);
+int64_t get_nanopore_hdp_alphabet_size(NanoporeHDP *nhdp);
+char *get_nanopore_hdp_alphabet(NanoporeHDP *nhdp); /* a copy, as in the reference; caller frees */
+double get_nanopore_kmer_density(NanoporeHDP *nhdp, void *kmer, void *x); /* marker: runs on the device */
+typedef struct _StateMachine3_HDP {
+    StateMachine model;
+    double TRANSITION_MATCH_CONTINUE;
+    double TRANSITION_MATCH_FROM_GAP_X;
+    double TRANSITION_MATCH_FROM_GAP_Y;
+    double TRANSITION_GAP_OPEN_X;
+    double TRANSITION_GAP_OPEN_Y;
+    double TRANSITION_GAP_EXTEND_X;
+    double TRANSITION_GAP_EXTEND_Y;
+    double TRANSITION_GAP_SWITCH_TO_X;
+    double TRANSITION_GAP_SWITCH_TO_Y;
+    double (*getXGapProbFcn)(const double *emissionXGapProbs, void *i); /* unused: kept for the layout */
+    NanoporeHDP *hdpModel;
+} StateMachine3_HDP;
+StateMachine *getHdpStateMachine3(NanoporeHDP *hdp); /* impl/stateMachine.c:1738 */
 
 /* getStrawManStateMachine3 (impl/stateMachine.c:1725): 3-state machine with nanopore default
  * transitions (:1278), log(0.1) k-mer gap table (:1506), emission tables from a 3-line .model file */

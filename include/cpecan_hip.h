@@ -94,6 +94,26 @@ typedef struct {
 int cpecan_hip_modelsv_create(cpecan_ctx *ctx, const cpecan_vanilla_model *models, int32_t n,
                               int32_t threads, int32_t *ids);
 
+/* The 3-state HDP signal machine: getHdpStateMachine3(NanoporeHDP *) (impl/stateMachine.c:1738) over a
+ * finalized NanoporeHDP (deserialize_nhdp impl/nanopore_hdp.c:845).  transitions as cpecan_sm3_model; the
+ * HDP as densities need it (dir_proc_density impl/hdp.c:2577-2601): the alphabet (sorted, as the k-mer ids
+ * are taken over it, impl/nanopore_hdp.c:348-380), the sampling grid, and per k-mer id the row -- in
+ * posterior_predictive / spline_slopes, rows x grid_length doubles -- of the Dirichlet process's nearest
+ * OBSERVED ancestor.  Ids live in their own space (used by cpecan_hip_batch_create_hdp only); all models of
+ * a context must share one alphabet. */
+typedef struct {
+    double transitions[9];
+    const char *alphabet;
+    int32_t alphabet_size;      /* <= 16 */
+    int32_t grid_length;
+    const double *grid;         /* [grid_length] */
+    int64_t n_rows;
+    const double *posterior_predictive; /* [n_rows * grid_length] */
+    const double *spline_slopes;        /* [n_rows * grid_length] */
+    const int32_t *kmer_row;    /* [alphabet_size ^ 6] */
+} cpecan_hdp_model;
+int cpecan_hip_modelsh_create(cpecan_ctx *ctx, const cpecan_hdp_model *models, int32_t n, int32_t *ids);
+
 /* ---- band / split geometry (host integer code, exported because the reference exports it) ----
  * cpecan_band_construct: band_construct (impl/pairwiseAligner.c:132); xmyL/xmyR hold lX+lY+1 entries.
  * cpecan_split_points: getSplitPoints (:1313); out holds up to cap 4-tuples; returns the count. */
@@ -166,6 +186,15 @@ int cpecan_hip_batch_create_vanilla(cpecan_ctx *ctx, const cpecan_item *items, i
                                     const char *x_chars, int64_t n_x, const double *events, int64_t n_events,
                                     const int64_t *anchors, int64_t n_anchor_pairs,
                                     const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
+
+/* k-mers against events with an HDP model (getAlignedPairsUsingAnchors with a StateMachine3_HDP,
+ * sequence_getKmer3 / sequence_getEvent): same buffers as cpecan_hip_batch_create (x characters over the
+ * model's alphabet), model_id is a cpecan_hip_modelsh_create id.  Posterior decode on the general kernel;
+ * flags: UNBANDED only. */
+int cpecan_hip_batch_create_hdp(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
+                                const char *x_chars, int64_t n_x, const double *events, int64_t n_events,
+                                const int64_t *anchors, int64_t n_anchor_pairs,
+                                const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
 
 int cpecan_hip_batch_run(cpecan_batch *batch);
 int cpecan_hip_batch_sync(cpecan_batch *batch);

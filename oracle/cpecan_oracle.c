@@ -122,6 +122,48 @@ static inline int64_t skip_bin(const double *matchModel, int64_t k_im1, int64_t 
     return bin >= 30 ? 29 : bin;
 }
 
+/* grid_spline_interp impl/hdp_math_utils.c:471-495 (evenly spaced grid) */
+double orc_grid_spline_interp(double query_x, const double *x, const double *y, const double *slope,
+                              int64_t length) {
+    if (query_x <= x[0]) return y[0] - slope[0] * (x[0] - query_x);
+    if (query_x >= x[length - 1]) {
+        int64_t n = length - 1;
+        return y[n] + slope[n] * (query_x - x[n]);
+    }
+    double dx = x[1] - x[0];
+    int64_t idx_left = (int64_t) ((query_x - x[0]) / dx);
+    int64_t idx_right = idx_left + 1;
+    double dy = y[idx_right] - y[idx_left];
+    double a = slope[idx_left] * dx - dy;
+    double b = dy - slope[idx_right] * dx;
+    double t_left = (query_x - x[idx_left]) / dx;
+    double t_right = 1.0 - t_left;
+    return t_right * y[idx_left] + t_left * y[idx_right] + t_left * t_right * (a * t_right + b * t_left);
+}
+
+/* kmer_id impl/nanopore_hdp.c:348-380: digits over the (sorted) alphabet, most significant first */
+int64_t orc_hdp_kmer_id(const orc_model *m, const char *kmer) {
+    int64_t id = 0;
+    for (int i = 0; i < ORC_KMER_LEN; i++) {
+        int j = 0;
+        while (j < m->alphabetSize && kmer[i] != m->alphabet[j]) j++;
+        if (j == m->alphabetSize) return -1; /* the reference exits here (:364-367) */
+        id = id * m->alphabetSize + j;
+    }
+    return id;
+}
+
+/* get_nanopore_kmer_density :390 -> dir_proc_density impl/hdp.c:2577-2601 (the walk to the nearest
+ * observed ancestor is folded into hdpRow) */
+double orc_hdp_density(const orc_model *m, const char *kmer, double x) {
+    int64_t id = orc_hdp_kmer_id(m, kmer);
+    if (id < 0) return NAN;
+    int64_t row = m->hdpRow[id];
+    double interp = orc_grid_spline_interp(x, m->hdpGrid, m->hdpY + row * m->gridLength,
+                                           m->hdpSlope + row * m->gridLength, m->gridLength);
+    return interp > 0.0 ? interp : 0.0;
+}
+
 /* emissions_kmer_getGapProb :175-187 */
 double orc_kmer_gap(const double *gapX, int64_t k) {
     return k > ORC_NUM_KMERS ? LOG_ZERO : gapX[k];
@@ -162,6 +204,12 @@ enum {
     T5_GAP_SHORT_OPEN_Y, T5_GAP_SHORT_EXTEND_Y, T5_GAP_SHORT_SWITCH_TO_Y, T5_GAP_LONG_OPEN_Y,
     T5_GAP_LONG_EXTEND_Y, T5_GAP_LONG_SWITCH_TO_Y
 };
+
+void orc_defaults_hdp(orc_model *m) {
+    orc_defaults_sm3_nanopore(m); /* getHdpStateMachine3 :1738: stateMachine3_setTransitionsToNanoporeDefaults */
+    m->kind = ORC_SM3_HDP;
+    m->stateNumber = 3;
+}
 
 void orc_defaults_vanilla(orc_model *m) {
     m->kind = ORC_SM3_VANILLA;
@@ -229,12 +277,20 @@ typedef struct {
     int64_t kx;        /* sm3: k-mer index of X element (>4096 invalid); sm5: base index */
     int64_t ky;        /* sm5: base index of Y */
     int64_t kp;        /* vanilla: index of the k-mer before kx (sequence_getKmer2) */
+    const char *kmer;  /* HDP: the k-mer's characters (sequence_getKmer3) */
     const double *ev;  /* sm3: event */
 } symbols_t;
 
 static inline void get_symbols(const seqs_t *s, int64_t ix, int64_t iy, symbols_t *o) {
     o->kp = 0;
-    if (s->m->kind == ORC_SM3_VANILLA) {
+    o->kmer = NULL;
+    if (s->m->kind == ORC_SM3_HDP) {
+        /* sequence_getKmer3 (:327-331): index < 0 reads the first k-mer */
+        o->kmer = s->x + (ix >= 0 ? ix : 0);
+        o->kx = 0;
+        o->ev = iy >= 0 ? ((const double *) s->y) + 3 * iy : NULLEVENT;
+        o->ky = 0;
+    } else if (s->m->kind == ORC_SM3_VANILLA) {
         /* sequence_getKmer2 (:320-325): a pointer to char max(ix-1, 0); the emission code reads the
          * k-mer at +1 and the skip-bin code the k-mers at +0 and +1 (so element 0 is scored as k-mer 1) */
         const char *p = s->x + (ix > 0 ? ix - 1 : 0);
@@ -313,6 +369,29 @@ static void cell_sm3(const orc_model *m, double *cur, double *lower, double *mid
     }
 }
 
+/* stateMachine3HDP_cellCalculate impl/stateMachine.c:1336-1366 */
+static void cell_hdp(const orc_model *m, double *cur, double *lower, double *middle, double *upper,
+                     const symbols_t *s, trans_fn fn, void *extra) {
+    const double *t = m->t;
+    if (lower != NULL) {
+        double eP = -2.3025850929940455; /* log(0.1) */
+        fn(lower, cur, ST_MATCH, ST_SHORT_GAP_X, eP, t[ORC_T3_GAP_OPEN_X], extra);
+        fn(lower, cur, ST_SHORT_GAP_X, ST_SHORT_GAP_X, eP, t[ORC_T3_GAP_EXTEND_X], extra);
+        fn(lower, cur, ST_SHORT_GAP_Y, ST_SHORT_GAP_X, eP, t[ORC_T3_GAP_SWITCH_TO_X], extra);
+    }
+    if (middle != NULL) {
+        double eP = orc_hdp_density(m, s->kmer, s->ev[0]);
+        fn(middle, cur, ST_MATCH, ST_MATCH, eP, t[ORC_T3_MATCH_CONTINUE], extra);
+        fn(middle, cur, ST_SHORT_GAP_X, ST_MATCH, eP, t[ORC_T3_MATCH_FROM_GAP_X], extra);
+        fn(middle, cur, ST_SHORT_GAP_Y, ST_MATCH, eP, t[ORC_T3_MATCH_FROM_GAP_Y], extra);
+    }
+    if (upper != NULL) {
+        double eP = orc_hdp_density(m, s->kmer, s->ev[0]);
+        fn(upper, cur, ST_MATCH, ST_SHORT_GAP_Y, eP, t[ORC_T3_GAP_OPEN_Y], extra);
+        fn(upper, cur, ST_SHORT_GAP_Y, ST_SHORT_GAP_Y, eP, t[ORC_T3_GAP_EXTEND_Y], extra);
+    }
+}
+
 /* stateMachine3Vanilla_cellCalculate impl/stateMachine.c:1368-1409 */
 static void cell_vanilla(const orc_model *m, double *cur, double *lower, double *middle, double *upper,
                          const symbols_t *s, trans_fn fn, void *extra) {
@@ -378,7 +457,8 @@ static void cell_sm5(const orc_model *m, double *cur, double *lower, double *mid
 
 static inline void cell_calc(const orc_model *m, double *cur, double *lower, double *middle,
                              double *upper, const symbols_t *s, trans_fn fn, void *extra) {
-    if (m->kind == ORC_SM3_VANILLA) cell_vanilla(m, cur, lower, middle, upper, s, fn, extra);
+    if (m->kind == ORC_SM3_HDP) cell_hdp(m, cur, lower, middle, upper, s, fn, extra);
+    else if (m->kind == ORC_SM3_VANILLA) cell_vanilla(m, cur, lower, middle, upper, s, fn, extra);
     else if (m->kind == ORC_SM3_STRAWMAN) cell_sm3(m, cur, lower, middle, upper, s, fn, extra);
     else cell_sm5(m, cur, lower, middle, upper, s, fn, extra);
 }
@@ -395,7 +475,7 @@ static double state_value(const orc_model *m, int which, int s) {
         default: return s == ST_MATCH ? (t[3] + t[4]) / 2.0 : s == ST_SHORT_GAP_X ? t[3] : t[4];
         }
     }
-    if (m->kind == ORC_SM3_STRAWMAN) {
+    if (m->kind == ORC_SM3_STRAWMAN || m->kind == ORC_SM3_HDP) {
         switch (which) {
         case 0: return s == ST_MATCH ? 0 : LOG_ZERO;
         case 1: return (s == ST_SHORT_GAP_X || s == ST_SHORT_GAP_Y) ? 0 : LOG_ZERO;

@@ -40,13 +40,25 @@ enum {
     ORC_T3_GAP_SWITCH_TO_X, ORC_T3_GAP_SWITCH_TO_Y, ORC_T3_COUNT
 };
 
+#define ORC_SM3_HDP 3      /* stateMachine3HDP_cellCalculate (impl/stateMachine.c:1336-1366): sm3 transitions,
+                              X-gap emission log(0.1), match and Y-gap emission = the HDP's posterior-predictive
+                              DENSITY at the event mean for the k-mer's Dirichlet process (a linear density used
+                              where a log is expected: quirk Q6); X elements read with sequence_getKmer3 */
 typedef struct {
-    int32_t kind;          /* ORC_SM3_STRAWMAN | ORC_SM5_SYMBOL */
+    int32_t kind;          /* ORC_SM3_STRAWMAN | ORC_SM5_SYMBOL | ORC_SM3_VANILLA | ORC_SM3_HDP */
     int32_t stateNumber;   /* 3 | 5 */
     double t[17];          /* transitions: sm3 uses ORC_T3_*, sm5 uses struct order of _StateMachine5 */
     const double *match;   /* sm3: [1+4096*5] EMISSION_MATCH_PROBS; sm5: [16] */
     const double *gapX;    /* sm3: [4096] EMISSION_GAP_X_PROBS;    sm5: [4]  */
     const double *gapY;    /* sm3: [1+4096*5] EMISSION_GAP_Y_PROBS; sm5: [4]  */
+    /* HDP (impl/nanopore_hdp.c, impl/hdp.c:2577-2601): per k-mer id (base-alphabetSize, most significant
+     * first, :348-380) the row of its nearest observed ancestor's tables; rows of gridLength values */
+    const int32_t *hdpRow; /* [alphabetSize^6] */
+    const double *hdpGrid; /* [gridLength] sampling grid (linspace, impl/hdp_math_utils.c:497-510) */
+    const double *hdpY;    /* [rows][gridLength] posterior predictive */
+    const double *hdpSlope;/* [rows][gridLength] spline slopes        */
+    int32_t gridLength, alphabetSize;
+    char alphabet[16];
 } orc_model;
 
 typedef struct {
@@ -78,6 +90,11 @@ typedef struct {
 void orc_defaults_sm3_nanopore(orc_model *m);   /* impl/stateMachine.c:1278-1289 */
 void orc_defaults_sm5(orc_model *m, double *match16, double *gap4x, double *gap4y); /* :60-82,:920-937 */
 void orc_defaults_vanilla(orc_model *m);       /* stateMachine3Vanilla_construct :1560-1600 */
+void orc_defaults_hdp(orc_model *m);           /* stateMachine3Hdp_construct + nanopore defaults */
+double orc_grid_spline_interp(double query_x, const double *x, const double *y, const double *slope,
+                              int64_t length); /* impl/hdp_math_utils.c:471-495 */
+int64_t orc_hdp_kmer_id(const orc_model *m, const char *kmer); /* impl/nanopore_hdp.c:348-380; -1: bad char */
+double orc_hdp_density(const orc_model *m, const char *kmer, double x); /* get_nanopore_kmer_density :390 */
 double orc_vanilla_match(const double *model, int64_t k, const double *event); /* :499-528 */
 void orc_params_default(orc_params *p);         /* impl/pairwiseAligner.c:1428-1441 */
 

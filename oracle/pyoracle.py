@@ -14,12 +14,15 @@ _LIB = None
 
 NUM_KMERS = 4096
 MODEL_LEN = 1 + NUM_KMERS * 5
-SM3, SM5, VANILLA = 0, 1, 2
+SM3, SM5, VANILLA, HDP = 0, 1, 2, 3
 
 
 class OrcModel(C.Structure):
     _fields_ = [("kind", C.c_int32), ("stateNumber", C.c_int32), ("t", C.c_double * 17),
-                ("match", C.c_void_p), ("gapX", C.c_void_p), ("gapY", C.c_void_p)]
+                ("match", C.c_void_p), ("gapX", C.c_void_p), ("gapY", C.c_void_p),
+                ("hdpRow", C.c_void_p), ("hdpGrid", C.c_void_p), ("hdpY", C.c_void_p),
+                ("hdpSlope", C.c_void_p), ("gridLength", C.c_int32), ("alphabetSize", C.c_int32),
+                ("alphabet", C.c_char * 16)]
 
 
 class OrcParams(C.Structure):
@@ -74,6 +77,11 @@ def lib():
         L.orc_defaults_sm3_nanopore.argtypes = [C.POINTER(OrcModel)]
         L.orc_defaults_sm5.argtypes = [C.POINTER(OrcModel), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_defaults_vanilla.argtypes = [C.POINTER(OrcModel)]
+        L.orc_defaults_hdp.argtypes = [C.POINTER(OrcModel)]
+        L.orc_hdp_density.restype = C.c_double
+        L.orc_hdp_density.argtypes = [C.POINTER(OrcModel), C.c_char_p, C.c_double]
+        L.orc_hdp_kmer_id.restype = C.c_int64
+        L.orc_hdp_kmer_id.argtypes = [C.POINTER(OrcModel), C.c_char_p]
         L.orc_params_default.argtypes = [C.POINTER(OrcParams)]
         L.orc_aligned_pairs_using_anchors.restype = C.c_int
         L.orc_aligned_pairs_using_anchors.argtypes = [
@@ -163,6 +171,91 @@ class VanillaModel:
         m = self.match.copy()
         lib().orc_scale_model(_ptr(m), scale, shift, var, scale_sd, var_sd)
         return VanillaModel(m, self.skip, self.gap_y, self.c.t[0], self.c.t[1])
+
+
+def load_nhdp(path):
+    """Parse a serialized NanoporeHDP (serialize_nhdp impl/nanopore_hdp.c:820-843 / serialize_hdp
+    impl/hdp.c:2880-3007; read back by deserialize_hdp :3009-3273) as far as densities need it: the
+    alphabet, the sampling grid, every Dirichlet process's parent and, for the observed ones, the
+    posterior-predictive values and spline slopes on the grid.  Returns a dict with, per k-mer id, the
+    table row of its nearest observed ancestor (the walk of dir_proc_density :2588-2590)."""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    alphabet_size, alphabet, kmer_length = int(lines[0]), lines[1].strip(), int(lines[2])
+    i = 3
+    splines, has_data, sample_gamma, num_dps = (bool(int(lines[i])), bool(int(lines[i + 1])),
+                                                bool(int(lines[i + 2])), int(lines[i + 3]))
+    i += 4
+    assert splines and has_data, "densities need a finalized HDP with data"
+    i += 2                      # data, dp ids
+    i += 1                      # base parameters mu nu alpha beta
+    g0, g1, gl = lines[i].split()
+    grid_start, grid_stop, grid_length = float(g0), float(g1), int(gl)
+    i += 1
+    i += 1                      # gamma
+    if sample_gamma:
+        i += 4                  # gamma alpha, gamma beta, w, s
+    parent = np.full(num_dps, -1, np.int64)
+    for d in range(num_dps):
+        tok = lines[i + d].split()
+        if tok[0] != "-":
+            parent[d] = int(tok[0])
+    i += num_dps
+    rows, row_of = [], np.full(num_dps, -1, np.int64)
+    for d in range(num_dps):
+        tok = lines[i + d].split()
+        if tok:
+            row_of[d] = len(rows)
+            rows.append(np.array(tok, dtype=np.float64))
+    i += num_dps
+    slopes = [None] * len(rows)
+    for d in range(num_dps):
+        tok = lines[i + d].split()
+        if tok:
+            slopes[row_of[d]] = np.array(tok, dtype=np.float64)
+    n_kmers = alphabet_size ** kmer_length
+    kmer_row = np.zeros(n_kmers, np.int32)
+    for k in range(n_kmers):
+        d = k
+        while row_of[d] < 0:
+            d = parent[d]
+        kmer_row[k] = row_of[d]
+    n = grid_length - 1
+    dx = (grid_stop - grid_start) / float(n)   # linspace, impl/hdp_math_utils.c:497-510
+    grid = np.array([grid_start + j * dx for j in range(n)] + [grid_stop])
+    return dict(alphabet=alphabet, alphabet_size=alphabet_size, kmer_length=kmer_length, grid=grid,
+                y=np.ascontiguousarray(np.stack(rows)), slope=np.ascontiguousarray(np.stack(slopes)),
+                kmer_row=kmer_row)
+
+
+class HdpModel:
+    """3-state HDP signal model (getHdpStateMachine3, stateMachine.c:1738) over a parsed .nhdp"""
+
+    def __init__(self, nhdp, transitions=None):
+        assert nhdp["kmer_length"] == 6
+        self.nhdp = nhdp
+        self.c = OrcModel()
+        lib().orc_defaults_hdp(C.byref(self.c))
+        if transitions is not None:
+            for i, v in enumerate(transitions):
+                self.c.t[i] = v
+        self.c.hdpRow = nhdp["kmer_row"].ctypes.data
+        self.c.hdpGrid = nhdp["grid"].ctypes.data
+        self.c.hdpY = nhdp["y"].ctypes.data
+        self.c.hdpSlope = nhdp["slope"].ctypes.data
+        self.c.gridLength = nhdp["grid"].size
+        self.c.alphabetSize = nhdp["alphabet_size"]
+        self.c.alphabet = nhdp["alphabet"].encode()
+
+    @property
+    def transitions(self):
+        return np.array([self.c.t[i] for i in range(9)])
+
+    def density(self, kmer, x):
+        return lib().orc_hdp_density(C.byref(self.c), kmer.encode(), x)
+
+    def kmer_id(self, kmer):
+        return lib().orc_hdp_kmer_id(C.byref(self.c), kmer.encode())
 
 
 class Sm5Model:

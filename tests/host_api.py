@@ -54,6 +54,8 @@ EXPORTS = [
     "stateMachine5_construct", "emissions_symbol_setEmissionsToDefaults", "emissions_symbol_getGapProb",
     "emissions_symbol_getMatchProb", "cell_updateExpectations", "sequence_getKmer2",
     "getSignalStateMachine3Vanilla", "stateMachine3Vanilla_setStrandTransitionsToDefaults",
+    "sequence_getKmer3", "deserialize_nhdp", "destroy_nanopore_hdp", "get_nanopore_hdp_alphabet_size",
+    "get_nanopore_hdp_alphabet", "get_nanopore_kmer_density", "getHdpStateMachine3",
 ]
 
 _LIB = None
@@ -92,6 +94,13 @@ def lib():
         L.getSignalStateMachine3Vanilla.restype = vp
         L.getSignalStateMachine3Vanilla.argtypes = [C.c_char_p]
         L.stateMachine3Vanilla_setStrandTransitionsToDefaults.argtypes = [vp, C.c_int]
+        L.deserialize_nhdp.restype = vp
+        L.deserialize_nhdp.argtypes = [C.c_char_p]
+        L.destroy_nanopore_hdp.argtypes = [vp]
+        L.get_nanopore_hdp_alphabet_size.restype = C.c_int64
+        L.get_nanopore_hdp_alphabet_size.argtypes = [vp]
+        L.getHdpStateMachine3.restype = vp
+        L.getHdpStateMachine3.argtypes = [vp]
         L.stateMachine5_construct.restype = vp
         L.stateMachine5_construct.argtypes = [C.c_int, C.c_int64, vp, vp, vp, vp, vp]
         L.getAlignedPairsUsingAnchors.restype = vp

@@ -307,3 +307,52 @@ def test_baum_welch_iterations_on_the_zymo_read(golden_dir, zymo_read, template_
     L.stList_destruct(lst)
     L.pairwiseAlignmentBandingParameters_destruct(p)
     L.stateMachine_destruct(sm)
+
+
+@pytest.mark.gpu
+def test_hdp_machine_through_host_api(golden_dir):
+    """deserialize_nhdp (the C reader of the host library) + getHdpStateMachine3 + sequence_getKmer3 +
+    getAlignedPairsUsingAnchors on the reference's serialized HDP, against the oracle fed by the
+    independent Python reader of the same file."""
+    L = h.lib()
+    path = os.path.join(golden_dir, "testTemplate.nhdp")
+    nh = L.deserialize_nhdp(path.encode())
+    assert L.get_nanopore_hdp_alphabet_size(nh) == 6
+    sm = L.getHdpStateMachine3(nh)
+    parsed = o.load_nhdp(path)
+    om = o.HdpModel(parsed)
+    rng = np.random.default_rng(71)
+    lX = 160
+    x = "".join(rng.choice(list("ACGT"), lX + 5))
+    ev, anchors = [], []
+    for k in range(lX):
+        row = parsed["kmer_row"][om.kmer_id(x[k:k + 6])]
+        mode = parsed["grid"][int(np.argmax(parsed["y"][row]))]
+        if k % 40 == 20:
+            anchors.append((k, len(ev)))
+        for _ in range(1 if rng.random() < 0.6 else 2):
+            ev.append((mode + rng.normal(0, 1.0), 1.0, 0.01))
+    ev = np.ascontiguousarray(np.array(ev).reshape(-1))
+    xbuf = C.create_string_buffer(x.encode())
+    sX = L.sequence_construct2(lX, C.cast(xbuf, C.c_void_p), h.fn_ptr("sequence_getKmer3"),
+                               h.fn_ptr("sequence_sliceNucleotideSequence2"))
+    sY = L.sequence_construct2(ev.size // 3, ev.ctypes.data_as(C.c_void_p), h.fn_ptr("sequence_getEvent"),
+                               h.fn_ptr("sequence_sliceEventSequence2"))
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    p.contents.minDiagsBetweenTraceBack = 100
+    lst = h.make_anchor_list(anchors)
+    pairs = L.getAlignedPairsUsingAnchors(sm, sX, sY, lst, p, h.fn_ptr("diagonalCalculationPosteriorMatchProbs"),
+                                          True, True)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    ref = o.aligned_pairs_using_anchors(om, x, lX, ev.reshape(-1, 3), anchors,
+                                        o.default_params(minDiagsBetweenTraceBack=100), True, True)
+    assert len(got) > lX // 2
+    assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
+    assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+    L.stList_destruct(lst)
+    L.sequence_sequenceDestroy(sX)
+    L.sequence_sequenceDestroy(sY)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)
+    L.destroy_nanopore_hdp(nh)

@@ -7,6 +7,8 @@ The reference itself cannot be built here (sonLib is absent), so these are what 
 """
 import math
 
+import os
+
 import numpy as np
 import pytest
 
@@ -164,3 +166,34 @@ def test_banded_matches_unbanded_on_real_read(template_model, zymo_read):
     assert len(banded["totals"]) == (lX + 799 + 9) // 10
     assert np.ptp(banded["totals"]) < 0.01
     assert banded["cells"] == full["cells"] == (lX + 1) * 800
+
+
+def test_hdp_kmer_id_known_answers(golden_dir):
+    # tests/nanoporeHdpTests.c:104-108 (kmer_id over an arbitrary sorted alphabet, most significant
+    # character first), restated for the 6-mers this path uses
+    import ctypes as C
+    def kid(kmer, alphabet):
+        m = o.OrcModel()
+        m.alphabetSize = len(alphabet)
+        m.alphabet = alphabet.encode()
+        return o.lib().orc_hdp_kmer_id(C.byref(m), kmer.encode())
+    assert kid("AAAAAC", "ACGT") == 1
+    assert kid("AAAAAT", "ACGT") == 3
+    assert kid("AAAAAT", "ACT") == 2
+    assert kid("GGGGGG", "ABCDEFG") == 7 ** 6 - 1
+    assert kid("AAACAA", "ACGT") == 16
+    assert kid("AAANAA", "ACGT") == -1  # the reference exits on a character outside the alphabet
+
+
+def test_hdp_fixture_parses_and_densities_are_sane(golden_dir):
+    # the reference's own serialized HDP (tests/test_hdp/testTemplate.nhdp): 6-letter alphabet, 46 657
+    # Dirichlet processes, 100-point grid on [0, 100]; densities are non-negative and integrate to ~1
+    n = o.load_nhdp(os.path.join(golden_dir, "testTemplate.nhdp"))
+    assert n["alphabet"] == "ACEGOT" and n["grid"].size == 100 and n["kmer_row"].size == 6 ** 6
+    assert n["grid"][0] == 0.0 and n["grid"][-1] == 100.0
+    m = o.HdpModel(n)
+    xs = np.linspace(0, 100, 2001)
+    for kmer in ("ACGTAC", "TTTTTT", "GATTAC"):
+        d = np.array([m.density(kmer, float(x)) for x in xs])
+        assert (d >= 0).all()
+        assert abs(float(np.sum((d[1:] + d[:-1]) * np.diff(xs)) / 2) - 1.0) < 0.05
