@@ -490,6 +490,120 @@ void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMat
     die("cpecan: diagonalCalculationPosteriorMatchProbs is a marker for the GPU path, not a host function");
 }
 
+/* ---- Diagonal / Band / BandIterator / logAdd / filterToRemoveOverlap (host integer utilities) ---------- */
+Diagonal diagonal_construct(int64_t xay, int64_t xmyL, int64_t xmyR) {
+    if ((xay + xmyL) % 2 != 0 || (xay + xmyR) % 2 != 0 || xmyL > xmyR)
+        die("PAIRWISE_ALIGNMENT_EXCEPTION: Attempt to create diagonal with invalid coordinates: xay %lld xmyL %lld "
+            "xmyR %lld", (long long) xay, (long long) xmyL, (long long) xmyR);
+    Diagonal d = { xay, xmyL, xmyR };
+    return d;
+}
+int64_t diagonal_getXay(Diagonal d) { return d.xay; }
+int64_t diagonal_getMinXmy(Diagonal d) { return d.xmyL; }
+int64_t diagonal_getMaxXmy(Diagonal d) { return d.xmyR; }
+int64_t diagonal_getWidth(Diagonal d) { return (d.xmyR - d.xmyL) / 2 + 1; }
+int64_t diagonal_getXCoordinate(int64_t xay, int64_t xmy) { return (xay + xmy) / 2; }
+int64_t diagonal_getYCoordinate(int64_t xay, int64_t xmy) { return (xay - xmy) / 2; }
+int64_t diagonal_equals(Diagonal a, Diagonal b) { return a.xay == b.xay && a.xmyL == b.xmyL && a.xmyR == b.xmyR; }
+
+struct _band {
+    Diagonal *diagonals;
+    int64_t lXalY;
+};
+Band *band_construct(stList *anchorPairs, int64_t lX, int64_t lY, int64_t expansion) {
+    const int64_t na = anchorPairs ? stList_length(anchorPairs) : 0, n = lX + lY + 1;
+    int64_t *a = malloc(sizeof(int64_t) * 2 * (size_t) (na + 1));
+    for (int64_t k = 0; k < na; k++) {
+        a[2 * k] = stIntTuple_get(stList_get(anchorPairs, k), 0);
+        a[2 * k + 1] = stIntTuple_get(stList_get(anchorPairs, k), 1);
+    }
+    int32_t *L = malloc(sizeof(int32_t) * (size_t) n), *R = malloc(sizeof(int32_t) * (size_t) n);
+    CHECK(cpecan_band_construct(a, na, lX, lY, expansion, L, R));
+    Band *b = malloc(sizeof *b);
+    b->lXalY = lX + lY;
+    b->diagonals = malloc(sizeof(Diagonal) * (size_t) n);
+    for (int64_t d = 0; d < n; d++) b->diagonals[d] = diagonal_construct(d, L[d], R[d]);
+    free(a); free(L); free(R);
+    return b;
+}
+void band_destruct(Band *band) {
+    free(band->diagonals);
+    free(band);
+}
+struct _bandIterator {
+    Band *band;
+    int64_t index;
+};
+BandIterator *bandIterator_construct(Band *band) {
+    BandIterator *it = malloc(sizeof *it);
+    it->band = band;
+    it->index = 0;
+    return it;
+}
+BandIterator *bandIterator_clone(BandIterator *it) {
+    BandIterator *c = malloc(sizeof *c);
+    *c = *it;
+    return c;
+}
+void bandIterator_destruct(BandIterator *it) { free(it); }
+/* past either end the iterator keeps returning the end diagonal (:213-227) */
+Diagonal bandIterator_getNext(BandIterator *it) {
+    const int64_t last = it->band->lXalY;
+    const Diagonal d = it->band->diagonals[it->index > last ? last : it->index];
+    if (it->index <= last) it->index++;
+    return d;
+}
+Diagonal bandIterator_getPrevious(BandIterator *it) {
+    if (it->index > 0) it->index--;
+    return it->band->diagonals[it->index];
+}
+
+/* lookup() / logAdd() :238-255: log(exp(x) + exp(y)) by a piecewise cubic of the gap, with float-suffixed
+ * coefficients promoted to double, the larger operand returned as is beyond a gap of 7.5 */
+static double logadd_lookup(double x) {
+    if (x <= 2.50f) {
+        if (x <= 1.00f)
+            return ((-0.009350833524763f * x + 0.130659527668286f) * x + 0.498799810682272f) * x + 0.693203116424741f;
+        return ((-0.014532321752540f * x + 0.139942324101744f) * x + 0.495635523139337f) * x + 0.692140569840976f;
+    }
+    if (x <= 4.50f)
+        return ((-0.004605031767994f * x + 0.063427417320019f) * x + 0.695956496475118f) * x + 0.514272634594009f;
+    return ((-0.000458661602210f * x + 0.009695946122598f) * x + 0.930734667215156f) * x + 0.168037164329057f;
+}
+double logAdd(double x, double y) {
+    if (x < y) return (x == LOG_ZERO || y - x >= 7.5) ? y : logadd_lookup(y - x) + x;
+    return (y == LOG_ZERO || x - y >= 7.5) ? x : logadd_lookup(x - y) + y;
+}
+
+stList *filterToRemoveOverlap(stList *pairs) {
+    const int64_t n = stList_length(pairs);
+    int64_t *x = malloc(sizeof(int64_t) * (size_t) (n + 1)), *y = malloc(sizeof(int64_t) * (size_t) (n + 1));
+    char *below = calloc((size_t) n + 1, 1); /* smaller in both coordinates than everything after it */
+    for (int64_t i = 0; i < n; i++) {
+        x[i] = stIntTuple_get(stList_get(pairs, i), 0);
+        y[i] = stIntTuple_get(stList_get(pairs, i), 1);
+    }
+    int64_t mx = INT64_MAX, my = INT64_MAX;
+    for (int64_t i = n - 1; i >= 0; i--) {
+        below[i] = x[i] < mx && y[i] < my;
+        if (x[i] < mx) mx = x[i];
+        if (y[i] < my) my = y[i];
+    }
+    /* the reference looks candidates up by VALUE: an equal pair earlier in the list counts as marked too */
+    for (int64_t i = n - 2; i >= 0; i--)
+        if (!below[i] && below[i + 1] && x[i] == x[i + 1] && y[i] == y[i + 1]) below[i] = 1;
+    stList *out = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    mx = INT64_MIN;
+    my = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        if (x[i] > mx && y[i] > my && below[i]) stList_append(out, stIntTuple_construct2(x[i], y[i]));
+        if (x[i] > mx) mx = x[i];
+        if (y[i] > my) my = y[i];
+    }
+    free(x); free(y); free(below);
+    return out;
+}
+
 stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize,
                        bool raggedL, bool raggedR) {
     int64_t n = stList_length(anchorPairs);
@@ -693,7 +807,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         /* getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps :1356-1422 */
         int64_t *sp = malloc(sizeof(int64_t) * 4 * (size_t) (na + 2));
         int64_t nSp;
-        if (unbanded) {
+        if (unbanded) { /* 1: getAlignedPairsWithoutBanding; 2: one getPosteriorProbsWithBanding call */
             nSp = 1; sp[0] = 0; sp[1] = 0; sp[2] = lX; sp[3] = lY;
         } else {
             nSp = cpecan_split_points(ra, na, lX, lY, p->splitMatrixBiggerThanThis, raggedL, raggedR, sp, na + 2);
@@ -737,17 +851,17 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         cpecan_batch *batch = NULL;
         if (dna)
             CHECK(cpecan_hip_batch_create_dna(ctx, items, nItems, chars, xo, ychars, yo, anchors, ao, &bp,
-                                              unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                              unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
         else if (hdp)
             CHECK(cpecan_hip_batch_create_hdp(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
-                                              unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                              unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
         else if (van)
             CHECK(cpecan_hip_batch_create_vanilla(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
-                                                  unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                                  unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
         else
             CHECK(cpecan_hip_batch_create(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                           mode ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
-                                          CPECAN_KERNEL_AUTO, unbanded ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                          CPECAN_KERNEL_AUTO, unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
         CHECK(cpecan_hip_batch_run(batch));
         CHECK(cpecan_hip_batch_sync(batch));
         if (mode == 0) {
@@ -758,7 +872,10 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                 for (int64_t k = firstItem[i]; k < firstItem[i + 1]; k++) {
                     int64_t *tri = malloc(sizeof(int64_t) * 3 * (size_t) (np[k] + 1));
                     CHECK(cpecan_hip_batch_fetch_pairs(batch, k, tri, NULL, np[k] + 1));
-                    if (unbanded) {
+                    if (unbanded == 2) { /* the order diagonalCalculationPosteriorMatchProbs appends in */
+                        for (int64_t q = 0; q < np[k]; q++)
+                            stList_append(lists[i], stIntTuple_construct3(tri[3 * q], tri[3 * q + 1], tri[3 * q + 2]));
+                    } else if (unbanded) {
                         /* getAlignedPairsWithoutBanding walks the diagonals upwards (:1560): groups of
                          * equal x+y in reverse group order, order inside a group kept */
                         int64_t e = np[k];
@@ -807,6 +924,20 @@ stList *getAlignedPairsUsingAnchors(StateMachine *sM, Sequence *SsX, Sequence *S
     stList *out = NULL;
     run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 0, 0, &out, NULL);
     return out;
+}
+
+void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, Sequence *sX, Sequence *sY,
+                                  PairwiseAlignmentParameters *p, bool raggedL, bool raggedR,
+                                  DiagonalPosteriorProbFn fn, void *extraArgs) {
+    if (fn != diagonalCalculationPosteriorMatchProbs)
+        die("cpecan: the GPU path implements diagonalCalculationPosteriorMatchProbs only");
+    stList *dest = ((void **) extraArgs)[0], *out = NULL;
+    run_reads(1, &sM, &sX, &sY, &anchorPairs, p, raggedL, raggedR, 0, 2, &out, NULL);
+    for (int64_t i = 0; i < stList_length(out); i++) {
+        stIntTuple *t = stList_get(out, i);
+        stList_append(dest, stIntTuple_construct3(stIntTuple_get(t, 0), stIntTuple_get(t, 1), stIntTuple_get(t, 2)));
+    }
+    stList_destruct(out);
 }
 
 stList **getAlignedPairsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **sYs,

@@ -232,6 +232,45 @@ stList *getAlignedPairsWithoutBanding(StateMachine *sM, void *cX, void *cY, int6
 stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize,
                        bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 
+/* one getPosteriorProbsWithBanding call (inc/pairwiseAligner.h:269): no splitting; the aligned triples are
+ * appended to the stList in ((void **) extraArgs)[0] in the reference's emission order (windows forward,
+ * diagonals descending inside a window), as diagonalCalculationPosteriorMatchProbs does */
+void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, Sequence *sX, Sequence *sY,
+                                  PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,
+                                  bool alignmentHasRaggedRightEnd,
+                                  DiagonalPosteriorProbFn diagonalPosteriorProbFn, void *extraArgs);
+/* filterToRemoveOverlap (:324, impl :1160-1200): from (x, y) pairs sorted by x then y, the pairs that are
+ * smaller in both coordinates than every later pair and larger in both than every earlier one */
+stList *filterToRemoveOverlap(stList *sortedOverlappingPairs);
+
+/* ---- geometry the reference exports and tests (inc/pairwiseAligner.h:139-188; host integer code) -------- */
+typedef struct _diagonal {
+    int64_t xay;  /* x + y */
+    int64_t xmyL; /* smallest x - y */
+    int64_t xmyR; /* largest x - y  */
+} Diagonal;
+/* invalid coordinates (parity of xay + xmy, xmyL > xmyR) end the program with a message: the reference
+ * throws a sonLib exception here, which has no counterpart without sonLib */
+Diagonal diagonal_construct(int64_t xay, int64_t xmyL, int64_t xmyR);
+int64_t diagonal_getXay(Diagonal diagonal);
+int64_t diagonal_getMinXmy(Diagonal diagonal);
+int64_t diagonal_getMaxXmy(Diagonal diagonal);
+int64_t diagonal_getWidth(Diagonal diagonal);
+int64_t diagonal_getXCoordinate(int64_t xay, int64_t xmy);
+int64_t diagonal_getYCoordinate(int64_t xay, int64_t xmy);
+int64_t diagonal_equals(Diagonal diagonal1, Diagonal diagonal2);
+typedef struct _band Band;
+Band *band_construct(stList *anchorPairs, int64_t lX, int64_t lY, int64_t expansion);
+void band_destruct(Band *band);
+typedef struct _bandIterator BandIterator;
+BandIterator *bandIterator_construct(Band *band);
+void bandIterator_destruct(BandIterator *bandIterator);
+BandIterator *bandIterator_clone(BandIterator *bandIterator);
+Diagonal bandIterator_getNext(BandIterator *bandIterator);
+Diagonal bandIterator_getPrevious(BandIterator *bandIterator);
+#define LOG_ZERO (-INFINITY)
+double logAdd(double x, double y); /* :235-255, host double arithmetic */
+
 /* ---- expectations for Baum-Welch (inc/continuousHmm.h:17-23, impl/continuousHmm.c:90-232) ------- */
 typedef struct _continuousPairHmmExpectations {
     double likelihood;

@@ -33,6 +33,10 @@ class StateMachine3(C.Structure):
         "TRANSITION_GAP_EXTEND_Y", "TRANSITION_GAP_SWITCH_TO_X", "TRANSITION_GAP_SWITCH_TO_Y")]
 
 
+class Diagonal(C.Structure):
+    _fields_ = [("xay", C.c_int64), ("xmyL", C.c_int64), ("xmyR", C.c_int64)]
+
+
 class Expectations(C.Structure):
     _fields_ = [("likelihood", C.c_double), ("transitions", C.c_double * 9),
                 ("individualKmerGapProbs", C.c_double * NUM_KMERS)]
@@ -56,6 +60,11 @@ EXPORTS = [
     "getSignalStateMachine3Vanilla", "stateMachine3Vanilla_setStrandTransitionsToDefaults",
     "sequence_getKmer3", "deserialize_nhdp", "destroy_nanopore_hdp", "get_nanopore_hdp_alphabet_size",
     "get_nanopore_hdp_alphabet", "get_nanopore_kmer_density", "getHdpStateMachine3",
+    "getPosteriorProbsWithBanding", "filterToRemoveOverlap", "diagonal_construct", "diagonal_getXay",
+    "diagonal_getMinXmy", "diagonal_getMaxXmy", "diagonal_getWidth", "diagonal_getXCoordinate",
+    "diagonal_getYCoordinate", "diagonal_equals", "band_construct", "band_destruct",
+    "bandIterator_construct", "bandIterator_destruct", "bandIterator_clone", "bandIterator_getNext",
+    "bandIterator_getPrevious", "logAdd",
 ]
 
 _LIB = None
@@ -94,6 +103,33 @@ def lib():
         L.getSignalStateMachine3Vanilla.restype = vp
         L.getSignalStateMachine3Vanilla.argtypes = [C.c_char_p]
         L.stateMachine3Vanilla_setStrandTransitionsToDefaults.argtypes = [vp, C.c_int]
+        L.diagonal_construct.restype = Diagonal
+        L.diagonal_construct.argtypes = [C.c_int64] * 3
+        for f in ("getXay", "getMinXmy", "getMaxXmy", "getWidth"):
+            getattr(L, "diagonal_" + f).restype = C.c_int64
+            getattr(L, "diagonal_" + f).argtypes = [Diagonal]
+        for f in ("getXCoordinate", "getYCoordinate"):
+            getattr(L, "diagonal_" + f).restype = C.c_int64
+            getattr(L, "diagonal_" + f).argtypes = [C.c_int64, C.c_int64]
+        L.diagonal_equals.restype = C.c_int64
+        L.diagonal_equals.argtypes = [Diagonal, Diagonal]
+        L.band_construct.restype = vp
+        L.band_construct.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64]
+        L.band_destruct.argtypes = [vp]
+        L.bandIterator_construct.restype = vp
+        L.bandIterator_construct.argtypes = [vp]
+        L.bandIterator_clone.restype = vp
+        L.bandIterator_clone.argtypes = [vp]
+        L.bandIterator_destruct.argtypes = [vp]
+        L.bandIterator_getNext.restype = Diagonal
+        L.bandIterator_getNext.argtypes = [vp]
+        L.bandIterator_getPrevious.restype = Diagonal
+        L.bandIterator_getPrevious.argtypes = [vp]
+        L.logAdd.restype = C.c_double
+        L.logAdd.argtypes = [C.c_double, C.c_double]
+        L.filterToRemoveOverlap.restype = vp
+        L.filterToRemoveOverlap.argtypes = [vp]
+        L.getPosteriorProbsWithBanding.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.c_bool, C.c_bool, vp, vp]
         L.deserialize_nhdp.restype = vp
         L.deserialize_nhdp.argtypes = [C.c_char_p]
         L.destroy_nanopore_hdp.argtypes = [vp]

@@ -356,3 +356,98 @@ def test_hdp_machine_through_host_api(golden_dir):
     L.pairwiseAlignmentBandingParameters_destruct(p)
     L.stateMachine_destruct(sm)
     L.destroy_nanopore_hdp(nh)
+
+
+def test_diagonal_band_iterator_logadd_and_overlap_filter():
+    """the geometry and utility functions the reference exports and tests (tests/pairwiseAlignerTest.c:
+    test_diagonal :22, test_bands :74, test_logAdd :139, test_filterToRemoveOverlap :515), host-only"""
+    L = h.lib()
+    xL, yL, xU, yU = 10, 20, 30, 0
+    d = L.diagonal_construct(xL + yL, xL - yL, xU - yU)
+    assert L.diagonal_getXay(d) == xL + yL and L.diagonal_getMinXmy(d) == xL - yL
+    assert L.diagonal_getMaxXmy(d) == xU - yU and L.diagonal_getWidth(d) == (xU - yU - (xL - yL)) // 2 + 1
+    assert L.diagonal_getXCoordinate(xL + yL, xL - yL) == xL and L.diagonal_getYCoordinate(xL + yL, xL - yL) == yL
+    assert L.diagonal_equals(d, d) and not L.diagonal_equals(d, L.diagonal_construct(0, 0, 0))
+
+    # test_bands: anchors (1,0) (2,1) (3,3), lX 7, lY 5, expansion 2, and the iterator's clamping at both ends
+    anchors = [(1, 0), (2, 1), (3, 3)]
+    lst = h.make_anchor_list(anchors)
+    band = L.band_construct(lst, 7, 5, 2)
+    lo, hi = o.band(anchors, 7, 5, 2)
+    it = L.bandIterator_construct(band)
+    for k in range(13):
+        dd = L.bandIterator_getNext(it)
+        assert (dd.xay, dd.xmyL, dd.xmyR) == (k, lo[k], hi[k])
+    for _ in range(3):  # past the end: the last diagonal again
+        dd = L.bandIterator_getNext(it)
+        assert (dd.xay, dd.xmyL, dd.xmyR) == (12, lo[12], hi[12])
+    clone = L.bandIterator_clone(it)
+    for k in range(12, -1, -1):
+        dd = L.bandIterator_getPrevious(it)
+        assert (dd.xay, dd.xmyL, dd.xmyR) == (k, lo[k], hi[k])
+    dd = L.bandIterator_getPrevious(it)
+    assert dd.xay == 0
+    assert L.bandIterator_getPrevious(clone).xay == 12
+    L.bandIterator_destruct(it)
+    L.bandIterator_destruct(clone)
+    L.band_destruct(band)
+    L.stList_destruct(lst)
+
+    rng = np.random.default_rng(3)
+    for _ in range(20000):
+        i, j = rng.random(), rng.random()
+        got = L.logAdd(np.log(i), np.log(j))
+        assert abs(np.exp(got) - (i + j)) < 0.001
+        assert got == o.lib().orc_logAdd(np.log(i), np.log(j))  # bit-identical to the oracle's
+    assert L.logAdd(-np.inf, -3.0) == -3.0 and L.logAdd(-3.0, -np.inf) == -3.0
+
+    for _ in range(10):
+        lX, lY, acc = rng.integers(0, 60), rng.integers(0, 60), rng.random()
+        pairs = [(x, y) for x in range(lX) for y in range(lY) if rng.random() > acc]
+        lst = h.make_anchor_list(pairs)
+        out = L.filterToRemoveOverlap(lst)
+        got = {tuple(r) for r in h.list_to_array(out, 2)}
+        arr = h.list_to_array(out, 2)
+        assert all(arr[k, 0] < arr[k + 1, 0] and arr[k, 1] < arr[k + 1, 1] for k in range(len(arr) - 1))
+        want = {(x, y) for (x, y) in pairs
+                if not any((x2 <= x and y2 >= y) or (x2 >= x and y2 <= y) for (x2, y2) in pairs if (x2, y2) != (x, y))}
+        assert got == want
+        L.stList_destruct(out)
+        L.stList_destruct(lst)
+
+
+@pytest.mark.gpu
+def test_single_banded_call_appends_in_emission_order(golden_dir):
+    """getPosteriorProbsWithBanding (one call, no splitting) appends the triples as the reference's
+    diagonal function does; getAlignedPairsUsingAnchors returns the same list tail first (:1447-1454)"""
+    L = h.lib()
+    rng = np.random.default_rng(9)
+    x = "".join(rng.choice(list("ACGT"), 150))
+    y = "".join(ch if rng.random() > 0.1 else rng.choice(list("ACGT")) for ch in x)
+    sm = L.stateMachine5_construct(0, 4, h.fn_ptr("emissions_symbol_setEmissionsToDefaults"),
+                                   h.fn_ptr("emissions_symbol_getGapProb"), h.fn_ptr("emissions_symbol_getGapProb"),
+                                   h.fn_ptr("emissions_symbol_getMatchProb"), h.fn_ptr("cell_updateExpectations"))
+    xb, yb = C.create_string_buffer(x.encode()), C.create_string_buffer(y.encode())
+    sX = L.sequence_construct2(len(x), C.cast(xb, C.c_void_p), h.fn_ptr("sequence_getBase"),
+                               h.fn_ptr("sequence_sliceNucleotideSequence"))
+    sY = L.sequence_construct2(len(y), C.cast(yb, C.c_void_p), h.fn_ptr("sequence_getBase"),
+                               h.fn_ptr("sequence_sliceNucleotideSequence"))
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    p.contents.minDiagsBetweenTraceBack = 60
+    p.contents.traceBackDiagonals = 10
+    lst = h.make_anchor_list([(30, 30), (90, 90)])
+    dest = L.stList_construct3(0, h.fn_ptr("stIntTuple_destruct"))
+    extra = (C.c_void_p * 1)(dest)
+    L.getPosteriorProbsWithBanding(sm, lst, sX, sY, p, False, False,
+                                   h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), C.cast(extra, C.c_void_p))
+    raw = h.list_to_array(dest)
+    pairs = L.getAlignedPairsUsingAnchors(sm, sX, sY, lst, p, h.fn_ptr("diagonalCalculationPosteriorMatchProbs"),
+                                          False, False)
+    got = h.list_to_array(pairs)
+    assert len(raw) > 100 and np.array_equal(raw[::-1], got)
+    for q in (dest, pairs, lst):
+        L.stList_destruct(q)
+    L.sequence_sequenceDestroy(sX)
+    L.sequence_sequenceDestroy(sY)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)
