@@ -407,6 +407,78 @@ double get_nanopore_kmer_density(NanoporeHDP *nhdp, void *kmer, void *x) {
     die("cpecan: get_nanopore_kmer_density is a marker; densities are evaluated on the device");
     return 0.0;
 }
+/* ---- NanoporeRead (impl/nanopore.c) ------------------------------------------------------------------ */
+static void line_int64s(FILE *f, int64_t *dst, int64_t n, const char *what) {
+    char *l = read_line(f), *p = l, *e;
+    if (!l) die("cpecan: truncated .npRead (%s)", what);
+    for (int64_t i = 0; i < n; i++) {
+        dst[i] = strtoll(p, &e, 10);
+        if (e == p) die("%s is not the correct length, should be %lld, got %lld", what, (long long) n, (long long) i);
+        p = e;
+    }
+    (void) strtoll(p, &e, 10);
+    if (e != p) die("%s is not the correct length, should be %lld", what, (long long) n);
+    free(l);
+}
+NanoporeRead *nanopore_loadNanoporeReadFromFile(const char *nanoporeReadFile) {
+    FILE *f = fopen(nanoporeReadFile, "r");
+    if (!f) die("cpecan: cannot open %s", nanoporeReadFile);
+    double hdr[13];
+    if (line_doubles(f, hdr, 13) != 13) die("error parsing the header line of %s", nanoporeReadFile);
+    NanoporeRead *r = calloc(1, sizeof *r);
+    r->readLength = (int64_t) hdr[0];
+    r->nbTemplateEvents = (int64_t) hdr[1];
+    r->nbComplementEvents = (int64_t) hdr[2];
+    const NanoporeReadAdjustmentParameters t = { hdr[3], hdr[4], hdr[5], hdr[6], hdr[7] };
+    const NanoporeReadAdjustmentParameters c = { hdr[8], hdr[9], hdr[10], hdr[11], hdr[12] };
+    r->templateParams = t;
+    r->complementParams = c;
+    r->twoDread = read_line(f);
+    if (!r->twoDread) die("error parsing read from npRead file");
+    for (char *q = r->twoDread; *q; q++) /* the reference reads it with %s: first token only */
+        if (*q == ' ' || *q == '\t' || *q == '\r') { *q = 0; break; }
+    r->templateEventMap = malloc(sizeof(int64_t) * (size_t) (r->readLength + 1));
+    line_int64s(f, r->templateEventMap, r->readLength, "template event map");
+    r->templateEvents = malloc(sizeof(double) * (size_t) (r->nbTemplateEvents * NB_EVENT_PARAMS + 1));
+    if (line_doubles(f, r->templateEvents, r->nbTemplateEvents * NB_EVENT_PARAMS) != r->nbTemplateEvents * NB_EVENT_PARAMS)
+        die("incorrect number of template events, should be %lld", (long long) r->nbTemplateEvents);
+    r->complementEventMap = malloc(sizeof(int64_t) * (size_t) (r->readLength + 1));
+    line_int64s(f, r->complementEventMap, r->readLength, "complement event map");
+    r->complementEvents = malloc(sizeof(double) * (size_t) (r->nbComplementEvents * NB_EVENT_PARAMS + 1));
+    if (line_doubles(f, r->complementEvents, r->nbComplementEvents * NB_EVENT_PARAMS) !=
+        r->nbComplementEvents * NB_EVENT_PARAMS)
+        die("incorrect number of complement events, should be %lld", (long long) r->nbComplementEvents);
+    r->scaled = true;
+    fclose(f);
+    return r;
+}
+stList *nanopore_remapAnchorPairs(stList *anchorPairs, int64_t *eventMap) {
+    return nanopore_remapAnchorPairsWithOffset(anchorPairs, eventMap, -1);
+}
+/* (x, y) in 2D-read coordinates -> (x, event index); mapOffset >= 0 re-bases on that position's event */
+stList *nanopore_remapAnchorPairsWithOffset(stList *unmappedPairs, int64_t *eventMap, int64_t mapOffset) {
+    stList *mapped = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    const int64_t base = mapOffset >= 0 ? eventMap[mapOffset] : 0;
+    for (int64_t i = 0; i < stList_length(unmappedPairs); i++) {
+        stIntTuple *p = stList_get(unmappedPairs, i);
+        stList_append(mapped, stIntTuple_construct2(stIntTuple_get(p, 0), eventMap[stIntTuple_get(p, 1)] - base));
+    }
+    return mapped;
+}
+void nanopore_descaleNanoporeRead(NanoporeRead *r) {
+    /* nanopore_descaleEvents (:34-38) walks i < nb_events in steps of NB_EVENT_PARAMS over the flat array,
+     * so only the means of the first third of the events are de-scaled: kept as is */
+    for (int64_t i = 0; i < r->nbTemplateEvents; i += NB_EVENT_PARAMS)
+        r->templateEvents[i] = (r->templateEvents[i] - r->templateParams.shift) / r->templateParams.scale;
+    for (int64_t i = 0; i < r->nbComplementEvents; i += NB_EVENT_PARAMS)
+        r->complementEvents[i] = (r->complementEvents[i] - r->complementParams.shift) / r->complementParams.scale;
+    r->scaled = false;
+}
+void nanopore_nanoporeReadDestruct(NanoporeRead *r) {
+    free(r->twoDread); free(r->templateEventMap); free(r->templateEvents);
+    free(r->complementEventMap); free(r->complementEvents); free(r);
+}
+
 StateMachine *getHdpStateMachine3(NanoporeHDP *hdp) {
     StateMachine3_HDP *s = calloc(1, sizeof *s);
     s->model.type = threeStateHdp;

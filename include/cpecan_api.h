@@ -171,6 +171,31 @@ typedef struct _StateMachine3vanilla {
 StateMachine *getSignalStateMachine3Vanilla(const char *modelFile);
 void stateMachine3Vanilla_setStrandTransitionsToDefaults(StateMachine *sM, Strand strand); /* :1291 */
 
+/* ---- nanopore reads (inc/nanopore.h; SURVEY section 8f N1: the data format either side of the path) ------- */
+typedef struct _nanoporeReadAdjustmentParameters {
+    double scale, shift, var, scale_sd, var_sd;
+} NanoporeReadAdjustmentParameters;
+typedef struct _nanoporeRead {
+    int64_t readLength;         /* 2D read length in nucleotides */
+    int64_t nbTemplateEvents;
+    int64_t nbComplementEvents;
+    NanoporeReadAdjustmentParameters templateParams;
+    NanoporeReadAdjustmentParameters complementParams;
+    char *twoDread;
+    int64_t *templateEventMap;  /* [readLength] */
+    double *templateEvents;     /* [nbTemplateEvents * NB_EVENT_PARAMS]: mean, noise, duration */
+    int64_t *complementEventMap;
+    double *complementEvents;
+    bool scaled;
+} NanoporeRead;
+/* the 6-line .npRead text format (impl/nanopore.c:40-200): 13 header tokens, the 2D read, template event
+ * map, template events, complement event map, complement events */
+NanoporeRead *nanopore_loadNanoporeReadFromFile(const char *nanoporeReadFile);
+stList *nanopore_remapAnchorPairs(stList *anchorPairs, int64_t *eventMap);                       /* :202 */
+stList *nanopore_remapAnchorPairsWithOffset(stList *unmappedPairs, int64_t *eventMap, int64_t mapOffset);
+void nanopore_descaleNanoporeRead(NanoporeRead *npRead); /* :228, with the reference's stride (quirk Q5) */
+void nanopore_nanoporeReadDestruct(NanoporeRead *npRead);
+
 /* ---- HDP signal machine (inc/nanopore_hdp.h, inc/stateMachine.h:197-216) ------------------------------
  * NanoporeHDP is opaque, as in the reference.  deserialize_nhdp reads a file written by the reference's
  * serialize_nhdp (impl/nanopore_hdp.c:820-905, impl/hdp.c:2880-3273) as far as density queries need it:

@@ -64,8 +64,21 @@ EXPORTS = [
     "diagonal_getMinXmy", "diagonal_getMaxXmy", "diagonal_getWidth", "diagonal_getXCoordinate",
     "diagonal_getYCoordinate", "diagonal_equals", "band_construct", "band_destruct",
     "bandIterator_construct", "bandIterator_destruct", "bandIterator_clone", "bandIterator_getNext",
-    "bandIterator_getPrevious", "logAdd",
+    "bandIterator_getPrevious", "logAdd", "nanopore_loadNanoporeReadFromFile", "nanopore_remapAnchorPairs",
+    "nanopore_remapAnchorPairsWithOffset", "nanopore_descaleNanoporeRead", "nanopore_nanoporeReadDestruct",
 ]
+
+
+class AdjustmentParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("scale", "shift", "var", "scale_sd", "var_sd")]
+
+
+class NanoporeRead(C.Structure):
+    _fields_ = [("readLength", C.c_int64), ("nbTemplateEvents", C.c_int64), ("nbComplementEvents", C.c_int64),
+                ("templateParams", AdjustmentParams), ("complementParams", AdjustmentParams),
+                ("twoDread", C.c_char_p), ("templateEventMap", C.POINTER(C.c_int64)),
+                ("templateEvents", C.POINTER(C.c_double)), ("complementEventMap", C.POINTER(C.c_int64)),
+                ("complementEvents", C.POINTER(C.c_double)), ("scaled", C.c_bool)]
 
 _LIB = None
 
@@ -127,6 +140,14 @@ def lib():
         L.bandIterator_getPrevious.argtypes = [vp]
         L.logAdd.restype = C.c_double
         L.logAdd.argtypes = [C.c_double, C.c_double]
+        L.nanopore_loadNanoporeReadFromFile.restype = C.POINTER(NanoporeRead)
+        L.nanopore_loadNanoporeReadFromFile.argtypes = [C.c_char_p]
+        L.nanopore_remapAnchorPairs.restype = vp
+        L.nanopore_remapAnchorPairs.argtypes = [vp, C.POINTER(C.c_int64)]
+        L.nanopore_remapAnchorPairsWithOffset.restype = vp
+        L.nanopore_remapAnchorPairsWithOffset.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64]
+        L.nanopore_descaleNanoporeRead.argtypes = [C.POINTER(NanoporeRead)]
+        L.nanopore_nanoporeReadDestruct.argtypes = [C.POINTER(NanoporeRead)]
         L.filterToRemoveOverlap.restype = vp
         L.filterToRemoveOverlap.argtypes = [vp]
         L.getPosteriorProbsWithBanding.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.c_bool, C.c_bool, vp, vp]

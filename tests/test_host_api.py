@@ -358,6 +358,44 @@ def test_hdp_machine_through_host_api(golden_dir):
     L.destroy_nanopore_hdp(nh)
 
 
+def test_npread_loader_remap_and_descale(golden_dir, zymo_read):
+    """the .npRead reader and anchor re-mapping the reference's signal tests start from
+    (tests/signalPairwiseTest.c:1007-1105, tests/nanoporeTest.c), on the reference's own read file"""
+    L = h.lib()
+    r = L.nanopore_loadNanoporeReadFromFile(os.path.join(golden_dir, "ZymoC_ch_1_file1.npRead").encode())
+    n = r.contents
+    assert (n.readLength, n.nbTemplateEvents, n.nbComplementEvents) == (
+        zymo_read["read_length"], zymo_read["n_template"], zymo_read["n_complement"])
+    assert n.readLength == len(n.twoDread) and n.twoDread.decode() == zymo_read["read"] and n.scaled
+    tp, cpar = n.templateParams, n.complementParams
+    assert [tp.scale, tp.shift, tp.var, tp.scale_sd, tp.var_sd] == zymo_read["template_params"]
+    assert [cpar.scale, cpar.shift, cpar.var, cpar.scale_sd, cpar.var_sd] == zymo_read["complement_params"]
+    tmap = np.ctypeslib.as_array(n.templateEventMap, shape=(n.readLength,))
+    cmap = np.ctypeslib.as_array(n.complementEventMap, shape=(n.readLength,))
+    tev = np.ctypeslib.as_array(n.templateEvents, shape=(3 * n.nbTemplateEvents,))
+    cev = np.ctypeslib.as_array(n.complementEvents, shape=(3 * n.nbComplementEvents,))
+    assert np.array_equal(tmap, zymo_read["template_map"]) and np.array_equal(cmap, zymo_read["complement_map"])
+    assert np.array_equal(tev, zymo_read["template_events"])
+    assert np.array_equal(cev, zymo_read["complement_events"])
+    # remapping: (x, y in read coordinates) -> (x, event index), optionally re-based
+    pairs = [(3, 0), (10, 7), (200, n.readLength - 1)]
+    lst = h.make_anchor_list(pairs)
+    m = L.nanopore_remapAnchorPairs(lst, n.templateEventMap)
+    assert h.list_to_array(m, 2).tolist() == [[x, int(tmap[y])] for x, y in pairs]
+    mo = L.nanopore_remapAnchorPairsWithOffset(lst, n.templateEventMap, 5)
+    assert h.list_to_array(mo, 2).tolist() == [[x, int(tmap[y] - tmap[5])] for x, y in pairs]
+    for q in (m, mo, lst):
+        L.stList_destruct(q)
+    # de-scaling keeps the reference's stride (SURVEY quirk Q5): every third slot below nbEvents
+    want_t, want_c = zymo_read["template_events"].copy(), zymo_read["complement_events"].copy()
+    it, ic = np.arange(0, n.nbTemplateEvents, 3), np.arange(0, n.nbComplementEvents, 3)
+    want_t[it] = (want_t[it] - tp.shift) / tp.scale
+    want_c[ic] = (want_c[ic] - cpar.shift) / cpar.scale
+    L.nanopore_descaleNanoporeRead(r)
+    assert not n.scaled and np.array_equal(tev, want_t) and np.array_equal(cev, want_c)
+    L.nanopore_nanoporeReadDestruct(r)
+
+
 def test_diagonal_band_iterator_logadd_and_overlap_filter():
     """the geometry and utility functions the reference exports and tests (tests/pairwiseAlignerTest.c:
     test_diagonal :22, test_bands :74, test_logAdd :139, test_filterToRemoveOverlap :515), host-only"""
