@@ -22,9 +22,11 @@ KERNEL_AUTO, KERNEL_GENERAL, KERNEL_SYSTOLIC = 0, 1, 2
 FLAG_DEBUG_DUMP = 1
 FLAG_UNBANDED = 2
 FLAG_SCAN_DECODE = 4
+FLAG_EXPECTATIONS = 8
 NUM_KMERS = 4096
 MODEL_TABLE_LEN = 1 + NUM_KMERS * 5
 EXPECTATION_LEN = 9 + NUM_KMERS + 1
+EXPECTATION5_LEN = 25 + 5 * 16 + 1
 
 # every symbol include/cpecan_hip.h declares
 EXPORTS = [
@@ -332,6 +334,7 @@ class Batch:
                                                  C.byref(params), mode, kernel, flags, C.byref(h)))
         self.h = h
         self.n = items.shape[0]
+        self.dna = y_chars is not None
 
     def run(self):
         _check(lib().cpecan_hip_batch_run(self.h))
@@ -375,7 +378,7 @@ class Batch:
         return xay[:n], tot[:n]
 
     def expectations(self, model_id):
-        out = np.zeros(EXPECTATION_LEN)
+        out = np.zeros(EXPECTATION5_LEN if self.dna else EXPECTATION_LEN)
         _check(lib().cpecan_hip_batch_fetch_expectations(self.h, int(model_id), _ptr(out)))
         return out
 

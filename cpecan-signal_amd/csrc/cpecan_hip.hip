@@ -29,7 +29,7 @@ extern "C" __global__ void cpecan_k_general(const DevItem *, DevParams, const in
 extern "C" __global__ void cpecan_k_general5(const DevItem *, DevParams, const int *, const int *,
                                              const long long *, const char *, const char *, const double *,
                                              double *, double *, long long *, double *, long long *,
-                                             long long *, double *, long long *, double *);
+                                             long long *, double *, long long *, double *, double *);
 extern "C" __global__ void cpecan_k_generalv(const DevItem *, DevParams, const int *, const int *,
                                              const long long *, const unsigned short *, const double *,
                                              const double *, const double *, double *, double *,
@@ -182,6 +182,7 @@ struct cpecan_batch {
     int ringD = 0, maxLX = 0;
     int nWorkers = 0, maxWidth = 0;
     int nModels = 0;
+    int expectLen = CPECAN_EXPECTATION_LEN; /* doubles per model in `expect` */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     /* systolic path: the batch runs as nGroups independent groups of alignments, each on a stream of
      * its own, so that the tail of one group's kernel overlaps the other groups' kernels (a launch
@@ -525,8 +526,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     const int S = dna ? 5 : 3; /* states per cell */
     if (!c || !items || nItems <= 0 || !xChars || (!events && !yChars) || !params || !out)
         return fail(CPECAN_EINVAL, "bad argument");
-    if (dna && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
-        return fail(CPECAN_EINVAL, "DNA batches: posterior decode only, no cell dumps");
+    if (dna && (flags & CPECAN_FLAG_DEBUG_DUMP)) return fail(CPECAN_EINVAL, "DNA batches: no cell dumps");
+    if (dna && mode == CPECAN_MODE_EXPECTATIONS && (flags & CPECAN_FLAG_UNBANDED))
+        return fail(CPECAN_EINVAL, "expectations run over the banded matrix only");
     if (nAnchorPairs > 0 && !anchors) return fail(CPECAN_EINVAL, "anchors is NULL");
     if (mode != CPECAN_MODE_POSTERIOR && mode != CPECAN_MODE_EXPECTATIONS)
         return fail(CPECAN_EINVAL, "unknown mode %d", mode);
@@ -632,7 +634,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->nItems = nItems;
     b->mode = mode;
     b->flags = flags;
-    b->nModels = c->nModels;
+    b->nModels = dna ? c->nModels5 : c->nModels;
+    b->expectLen = dna ? CPECAN_EXPECTATION5_LEN : CPECAN_EXPECTATION_LEN;
     b->P.threshold = params->threshold;
     b->P.minDiags = params->minDiagsBetweenTraceBack;
     b->P.tbDiags = params->traceBackDiagonals;
@@ -695,7 +698,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     B_TRY(b->nCells.alloc((size_t) nItems));
     B_TRY(b->totXay.alloc((size_t) totTotal));
     B_TRY(b->totVal.alloc((size_t) totTotal));
-    B_TRY(b->expect.alloc((size_t) b->nModels * CPECAN_EXPECTATION_LEN));
+    B_TRY(b->expect.alloc((size_t) std::max(b->nModels, 1) * b->expectLen));
     B_TRY(hipMemset(b->expect.p, 0, b->expect.n * sizeof(double)));
     b->hNCells.resize((size_t) nItems);
     for (int64_t i = 0; i < nItems; i++) b->hNCells[(size_t) i] = hItems[(size_t) i].nCells;
@@ -828,8 +831,9 @@ int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t
                                 const int64_t *anchors, int64_t nAnchorPairs,
                                 const cpecan_band_params *params, int32_t flags, cpecan_batch **out) {
     if (!yChars) return fail(CPECAN_EINVAL, "bad argument");
-    return batch_create_impl(c, items, nItems, xChars, nX, nullptr, yChars, nY, anchors, nAnchorPairs,
-                             params, CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out);
+    return batch_create_impl(c, items, nItems, xChars, nX, nullptr, yChars, nY, anchors, nAnchorPairs, params,
+                             (flags & CPECAN_FLAG_EXPECTATIONS) ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
+                             CPECAN_KERNEL_GENERAL, flags & ~CPECAN_FLAG_EXPECTATIONS, out);
 }
 
 int cpecan_hip_batch_run(cpecan_batch *b) {
@@ -848,7 +852,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            (const char *) b->chars.p, (const char *) b->charsY.p,
                            (const double *) c->models5.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
                            b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
-                           (double *) nullptr);
+                           (double *) nullptr, b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
     } else if (b->hdp) {
         hipLaunchKernelGGL(cpecan_k_generalh, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
@@ -1064,8 +1068,8 @@ int cpecan_hip_batch_fetch_expectations(cpecan_batch *b, int32_t modelId, double
     if (!b || !out || modelId < 0 || modelId >= b->nModels) return fail(CPECAN_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(b->ctx->device));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-    HIP_TRY(hipMemcpy(out, b->expect.p + (size_t) modelId * CPECAN_EXPECTATION_LEN,
-                      CPECAN_EXPECTATION_LEN * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, b->expect.p + (size_t) modelId * b->expectLen, (size_t) b->expectLen * sizeof(double),
+                      hipMemcpyDeviceToHost));
     return CPECAN_OK;
 }
 

@@ -39,13 +39,12 @@ struct Ctx5 {
     int maxWidth;
 };
 
-/* emissions_discrete_getBaseIndex impl/stateMachine.c:104-118: anything but ACGT (either case) is
- * "not a base" (4097 there); index < 0 is the "n" sentinel of sequence_getBase (:308-312) */
+/* emissions_discrete_getBaseIndex impl/stateMachine.c:104-118: anything but upper-case ACGT is "not a
+ * base" (4097 there); index < 0 is the "n" sentinel of sequence_getBase (:308-312) */
 __device__ __forceinline__ int base_of(const char *s, long long i) {
     if (i < 0) return 4;
     const char ch = s[i];
-    return ch == 'A' || ch == 'a' ? 0 : ch == 'C' || ch == 'c' ? 1 : ch == 'G' || ch == 'g' ? 2
-           : ch == 'T' || ch == 't' ? 3 : 4;
+    return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
 }
 /* emissions_symbol_getGapProb / getMatchProb :155-173 (N-free input is a precondition, quirk Q3) */
 __device__ __forceinline__ double e_gap(const double *g, int i) { return i < 4 ? g[i] : CP_NEG_INF; }
@@ -151,7 +150,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_general5(
     const DevItem *items, DevParams P, const int *bandL, const int *bandR,
     const long long *cellPrefix, const char *xChars, const char *yChars, const double *models,
     double *Fstore, double *Bstore, long long *pairs, double *pairLogp, long long *nPairs,
-    long long *totXay, double *totVal, long long *nTot, double *dbgB) {
+    long long *totXay, double *totVal, long long *nTot, double *dbgB, double *expect) {
     const DevItem it = items[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Ctx5 c;
@@ -171,6 +170,10 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_general5(
     const double *t = c.t;
 
     __shared__ double sTotal;
+    /* Baum-Welch sums of this alignment: 25 transitions [from*5+to], 80 emissions [state*16+x*4+y] and the
+     * likelihood, one copy per wave (LDS atomics), folded into the model's block of `expect` at the end */
+    __shared__ double sExp[4][CP_EXPECT5_LEN + 2];
+    for (int i = tid; i < 4 * (CP_EXPECT5_LEN + 2); i += 256) (&sExp[0][0])[i] = 0.0;
     const long long D = it.lX + it.lY;
     long long myPairs = 0, myTot = 0;
     if (D == 0) {
@@ -309,6 +312,60 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_general5(
                 for (int cc = tid; cc < w2 * S5; cc += 256) o[cc] = bdd[cc];
             }
 
+            if (P.mode == 1) {
+                /* diagonalCalculation_Expectations :841-863 over stateMachine5_cellCalculate with
+                 * cell_updateExpectations (:407-424): every transition into a cell of backward[d2] from its
+                 * forward neighbours adds p = exp(from + to + (eP + tP) - total) to its transition count and,
+                 * unless a base is not ACGT, to the emission count [to][x][y] */
+                double *acc = sExp[wave];
+                if (tid == 0) acc[CP_EXPECT5_LEN - 1] += total; /* likelihood, once per diagonal (quirk Q7) */
+                const bool haveMiddle = d2 - 2 >= tracedBackTo; /* forward[d2-2] is freed otherwise (:982) */
+                for (int cc = tid; cc < w2; cc += 256) {
+                    const int xmy = l2 + 2 * cc;
+                    const long long x = (d2 + xmy) / 2, y = (d2 - xmy) / 2;
+                    const int bx = base_of(c.cx, x - 1), by = base_of(c.cy, y - 1);
+                    const double *cur = bdd + cc * S5;
+                    const double *lower = fcell5(c, d2 - 1, xmy - 1);
+                    const double *middle = haveMiddle ? fcell5(c, d2 - 2, xmy) : nullptr;
+                    const double *upper = fcell5(c, d2 - 1, xmy + 1);
+                    double into[S5] = { 0.0, 0.0, 0.0, 0.0, 0.0 }; /* per to-state sums for the emission counts */
+                    auto tr = [&](const double *nb, int f, int to, double eP, int ti) {
+                        const double pr = exp(nb[f] + cur[to] + (eP + t[ti]) - total);
+                        atomicAdd(&acc[f * S5 + to], pr);
+                        into[to] += pr;
+                    };
+                    if (lower) {
+                        const double eP = e_gap(c.gx, bx);
+                        tr(lower, 0, 1, eP, T5_GAP_SHORT_OPEN_X);
+                        tr(lower, 1, 1, eP, T5_GAP_SHORT_EXTEND_X);
+                        tr(lower, 0, 3, eP, T5_GAP_LONG_OPEN_X);
+                        tr(lower, 3, 3, eP, T5_GAP_LONG_EXTEND_X);
+                    }
+                    if (middle) {
+                        const double eP = e_match(c.mm, bx, by);
+                        tr(middle, 0, 0, eP, T5_MATCH_CONTINUE);
+                        tr(middle, 1, 0, eP, T5_MATCH_FROM_SHORT_GAP_X);
+                        tr(middle, 2, 0, eP, T5_MATCH_FROM_SHORT_GAP_Y);
+                        tr(middle, 3, 0, eP, T5_MATCH_FROM_LONG_GAP_X);
+                        tr(middle, 4, 0, eP, T5_MATCH_FROM_LONG_GAP_Y);
+                    }
+                    if (upper) {
+                        const double eP = e_gap(c.gy, by);
+                        tr(upper, 0, 2, eP, T5_GAP_SHORT_OPEN_Y);
+                        tr(upper, 2, 2, eP, T5_GAP_SHORT_EXTEND_Y);
+                        tr(upper, 0, 4, eP, T5_GAP_LONG_OPEN_Y);
+                        tr(upper, 4, 4, eP, T5_GAP_LONG_EXTEND_Y);
+                    }
+                    if (bx < 4 && by < 4) {
+#pragma unroll
+                        for (int st = 0; st < S5; st++)
+                            if (into[st] != 0.0) atomicAdd(&acc[25 + st * 16 + bx * 4 + by], into[st]);
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+
             /* diagonalCalculationPosteriorMatchProbs :756-795, ordered emission by wave 0 */
             if (wave == 0) {
                 for (int base = 0; base < w2; base += 64) {
@@ -344,6 +401,14 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_general5(
             __syncthreads();
         }
         tracedBackTo = tracedBackFrom;
+    }
+    if (P.mode == 1 && expect) {
+        __syncthreads();
+        double *dst = expect + (long long) it.model * CP_EXPECT5_LEN;
+        for (int i = tid; i < CP_EXPECT5_LEN; i += 256) {
+            const double v = ((sExp[0][i] + sExp[1][i]) + sExp[2][i]) + sExp[3][i];
+            if (v != 0.0) atomicAdd(dst + i, v);
+        }
     }
     if (tid == 0) {
         nPairs[blockIdx.x] = myPairs;

@@ -744,13 +744,14 @@ typedef struct {
  * added into hmm (all reads must then share sMs[0]). */
 static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **sYs, stList **anchorLists,
                       PairwiseAlignmentParameters *p, bool raggedL, bool raggedR, int mode, int unbanded,
-                      stList **lists, ContinuousPairHmmExpectations *hmm) {
+                      stList **lists, void *hmmOut) {
     pthread_mutex_lock(&g_lock); /* one batch at a time per process; calls from several threads queue */
     cpecan_ctx *ctx = context();
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
     const int kind = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
     const int dna = kind == 1, van = kind == 2, hdp = kind == 3;
-    if (kind != 0 && mode != 0) die("cpecan: expectations run on the GPU path for the strawMan machine only");
+    if (kind > 1 && mode != 0)
+        die("cpecan: expectations run on the GPU path for the strawMan and the 5-state symbol machines only");
     const int64_t xPad = dna ? 0 : KMER_LENGTH - 1; /* a k-mer sequence of lX elements spans lX + 5 chars */
     for (int64_t i = 0; i < n; i++) {
         if (check_known_combination(sMs[i], sXs[i], sYs[i]) != kind)
@@ -923,7 +924,8 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         cpecan_batch *batch = NULL;
         if (dna)
             CHECK(cpecan_hip_batch_create_dna(ctx, items, nItems, chars, xo, ychars, yo, anchors, ao, &bp,
-                                              unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                              (unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0) |
+                                                  (mode ? CPECAN_FLAG_EXPECTATIONS : 0), &batch));
         else if (hdp)
             CHECK(cpecan_hip_batch_create_hdp(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                               unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
@@ -969,7 +971,25 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                 }
             }
             free(np);
+        } else if (dna) {
+            /* the device's per-model sums go through the Hmm's own add functions (cell_updateExpectations
+             * :407-424 calls them per transition) */
+            Hmm *hmm = hmmOut;
+            double e[CPECAN_EXPECTATION5_LEN];
+            for (int32_t k = 0; k < nModels; k++) {
+                CHECK(cpecan_hip_batch_fetch_expectations(batch, ids[k], e));
+                for (int64_t f = 0; f < 5; f++)
+                    for (int64_t t = 0; t < 5; t++)
+                        if (e[f * 5 + t] != 0.0) hmm->addToTransitionExpectationFcn(hmm, f, t, e[f * 5 + t]);
+                for (int64_t st = 0; st < 5; st++)
+                    for (int64_t x = 0; x < 4; x++)
+                        for (int64_t y = 0; y < 4; y++)
+                            if (e[25 + st * 16 + x * 4 + y] != 0.0)
+                                hmm->addToEmissionExpectationFcn(hmm, st, x, y, e[25 + st * 16 + x * 4 + y]);
+                hmm->likelihood += e[CPECAN_EXPECTATION5_LEN - 1];
+            }
         } else {
+            ContinuousPairHmmExpectations *hmm = hmmOut;
             double *e = malloc(sizeof(double) * CPECAN_EXPECTATION_LEN);
             for (int32_t k = 0; k < nModels; k++) {
                 CHECK(cpecan_hip_batch_fetch_expectations(batch, ids[k], e));
@@ -1064,4 +1084,314 @@ void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM, Continuo
     s->TRANSITION_GAP_EXTEND_Y = log(t[shortGapY * 3 + shortGapY]);
     s->TRANSITION_GAP_SWITCH_TO_X = log(t[shortGapY * 3 + shortGapX]);
     for (int64_t i = 0; i < NUM_OF_KMERS; i++) sM->EMISSION_GAP_X_PROBS[i] = log(hmm->individualKmerGapProbs[i]);
+}
+
+/* ---- .hmm files of the strawMan expectations (impl/continuousHmm.c:234-370) --------------------------- */
+void continuousPairHmm_writeToFile(ContinuousPairHmmExpectations *hmm, FILE *fh) {
+    fprintf(fh, "%i\t%lld\t%lld\t\n", (int) threeState, 3ll, (long long) NUM_OF_KMERS);
+    for (int i = 0; i < 9; i++)
+        if (isnan(hmm->transitions[i])) { /* hmmContinuous_checkTransitions :48-58: nothing more is written */
+            fprintf(stdout, "GOT NaN TRANS\n");
+            return;
+        }
+    for (int i = 0; i < 9; i++) fprintf(fh, "%f\t", hmm->transitions[i]);
+    fprintf(fh, "%f\n", hmm->likelihood);
+    for (int i = 0; i < NUM_OF_KMERS; i++) fprintf(fh, "%f\t", hmm->individualKmerGapProbs[i]);
+    fprintf(fh, "\n");
+}
+ContinuousPairHmmExpectations *continuousPairHmm_loadFromFile(const char *fileName) {
+    FILE *f = fopen(fileName, "r");
+    if (!f) die("cpecan: cannot open %s", fileName);
+    double hdr[3], line[10];
+    if (line_doubles(f, hdr, 3) != 3) die("Failed to parse the header line of %s", fileName);
+    if ((int) hdr[0] != (int) threeState || (int64_t) hdr[1] != 3 || (int64_t) hdr[2] != NUM_OF_KMERS)
+        die("cpecan: %s is not a 3-state k-mer HMM (type %d, %lld states, %lld symbols)", fileName, (int) hdr[0],
+            (long long) hdr[1], (long long) hdr[2]);
+    ContinuousPairHmmExpectations *hmm = calloc(1, sizeof *hmm);
+    const int64_t nT = line_doubles(f, line, 10);
+    if (nT != 10)
+        die("Incorrect number of transitions in the input HMM file %s, got %lld instead of %lld", fileName,
+            (long long) nT, 10ll);
+    memcpy(hmm->transitions, line, sizeof(double) * 9);
+    hmm->likelihood = line[9];
+    const int64_t nE = line_doubles(f, hmm->individualKmerGapProbs, NUM_OF_KMERS);
+    if (nE != NUM_OF_KMERS)
+        die("Incorrect number of emissions in the input HMM file %s, got %lld instead of %lld", fileName,
+            (long long) nE, (long long) NUM_OF_KMERS);
+    fclose(f);
+    return hmm;
+}
+
+/* ---- HmmDiscrete (impl/discreteHmm.c) ----------------------------------------------------------------- */
+Hmm *hmmDiscrete_constructEmpty(double pseudocount, int64_t stateNumber, int64_t symbolSetSize,
+                                StateMachineType type,
+                                void (*addToTransitionExpFcn)(Hmm *, int64_t, int64_t, double),
+                                void (*setTransitionFcn)(Hmm *, int64_t, int64_t, double),
+                                double (*getTransitionsExpFcn)(Hmm *, int64_t, int64_t),
+                                void (*addEmissionsExpFcn)(Hmm *, int64_t, int64_t, int64_t, double),
+                                void (*setEmissionExpFcn)(Hmm *, int64_t, int64_t, int64_t, double),
+                                double (*getEmissionExpFcn)(Hmm *, int64_t, int64_t, int64_t),
+                                int64_t (*getElementIndexFcn)(void *)) {
+    HmmDiscrete *h = calloc(1, sizeof *h);
+    h->baseHmm.stateNumber = stateNumber;
+    h->baseHmm.symbolSetSize = symbolSetSize;
+    h->baseHmm.matrixSize = symbolSetSize * symbolSetSize;
+    h->baseHmm.type = type;
+    const int64_t nT = stateNumber * stateNumber, nE = stateNumber * h->baseHmm.matrixSize;
+    h->transitions = malloc(sizeof(double) * (size_t) nT);
+    h->emissions = malloc(sizeof(double) * (size_t) nE);
+    for (int64_t i = 0; i < nT; i++) h->transitions[i] = pseudocount;
+    for (int64_t i = 0; i < nE; i++) h->emissions[i] = pseudocount;
+    h->baseHmm.likelihood = 0.0;
+    h->baseHmm.addToTransitionExpectationFcn = addToTransitionExpFcn;
+    h->baseHmm.setTransitionFcn = setTransitionFcn;
+    h->baseHmm.getTransitionsExpFcn = getTransitionsExpFcn;
+    h->baseHmm.addToEmissionExpectationFcn = addEmissionsExpFcn;
+    h->baseHmm.setEmissionExpectationFcn = setEmissionExpFcn;
+    h->baseHmm.getEmissionExpFcn = getEmissionExpFcn;
+    h->baseHmm.getElementIndexFcn = getElementIndexFcn;
+    return (Hmm *) h;
+}
+#define HD(hmm) ((HmmDiscrete *) (hmm))
+void hmmDiscrete_addToTransitionExpectation(Hmm *hmm, int64_t from, int64_t to, double p) {
+    HD(hmm)->transitions[from * hmm->stateNumber + to] += p;
+}
+void hmmDiscrete_setTransitionExpectation(Hmm *hmm, int64_t from, int64_t to, double p) {
+    HD(hmm)->transitions[from * hmm->stateNumber + to] = p;
+}
+double hmmDiscrete_getTransitionExpectation(Hmm *hmm, int64_t from, int64_t to) {
+    return HD(hmm)->transitions[from * hmm->stateNumber + to];
+}
+void hmmDiscrete_addToEmissionExpectation(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p) {
+    HD(hmm)->emissions[state * hmm->matrixSize + x * hmm->symbolSetSize + y] += p;
+}
+void hmmDiscrete_setEmissionExpectation(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p) {
+    HD(hmm)->emissions[state * hmm->matrixSize + x * hmm->symbolSetSize + y] = p;
+}
+double hmmDiscrete_getEmissionExpectation(Hmm *hmm, int64_t state, int64_t x, int64_t y) {
+    return HD(hmm)->emissions[state * hmm->matrixSize + x * hmm->symbolSetSize + y];
+}
+void hmmDiscrete_randomizeTransitions(Hmm *hmm) { /* st_random(): uniform on [0, 1) */
+    for (int64_t from = 0; from < hmm->stateNumber; from++)
+        for (int64_t to = 0; to < hmm->stateNumber; to++) hmm->setTransitionFcn(hmm, from, to, drand48());
+}
+void hmmDiscrete_randomizeEmissions(Hmm *hmm) {
+    if (hmm->symbolSetSize <= 0) die("hmmDiscrete_randomizeEmissions: got NULL for symbolSetSize");
+    for (int64_t s = 0; s < hmm->stateNumber; s++)
+        for (int64_t x = 0; x < hmm->symbolSetSize; x++)
+            for (int64_t y = 0; y < hmm->symbolSetSize; y++) hmm->setEmissionExpectationFcn(hmm, s, x, y, drand48());
+}
+void hmmDiscrete_randomize(Hmm *hmm) {
+    hmmDiscrete_randomizeTransitions(hmm);
+    hmmDiscrete_randomizeEmissions(hmm);
+    hmmDiscrete_normalize2(hmm, true);
+}
+void hmmDiscrete_normalize2(Hmm *hmm, bool normalizeEmissions) {
+    for (int64_t from = 0; from < hmm->stateNumber; from++) {
+        double total = 0.0;
+        for (int64_t to = 0; to < hmm->stateNumber; to++) total += hmm->getTransitionsExpFcn(hmm, from, to);
+        for (int64_t to = 0; to < hmm->stateNumber; to++)
+            hmm->setTransitionFcn(hmm, from, to, hmm->getTransitionsExpFcn(hmm, from, to) / total);
+    }
+    if (!normalizeEmissions) return;
+    for (int64_t s = 0; s < hmm->stateNumber; s++) {
+        double total = 0.0;
+        for (int64_t x = 0; x < hmm->symbolSetSize; x++)
+            for (int64_t y = 0; y < hmm->symbolSetSize; y++) total += hmm->getEmissionExpFcn(hmm, s, x, y);
+        for (int64_t x = 0; x < hmm->symbolSetSize; x++)
+            for (int64_t y = 0; y < hmm->symbolSetSize; y++)
+                hmm->setEmissionExpectationFcn(hmm, s, x, y, hmm->getEmissionExpFcn(hmm, s, x, y) / total);
+    }
+}
+void hmmDiscrete_write(Hmm *hmm, FILE *fh) {
+    HmmDiscrete *h = HD(hmm);
+    fprintf(fh, "%i\t%lld\t%lld\t\n", (int) hmm->type, (long long) hmm->stateNumber, (long long) hmm->symbolSetSize);
+    for (int64_t i = 0; i < hmm->stateNumber * hmm->stateNumber; i++) fprintf(fh, "%f\t", h->transitions[i]);
+    fprintf(fh, "%f\n", hmm->likelihood);
+    for (int64_t i = 0; i < hmm->stateNumber * hmm->matrixSize; i++) fprintf(fh, "%f\t", h->emissions[i]);
+    fprintf(fh, "\n");
+}
+Hmm *hmmDiscrete_loadFromFile(const char *fileName) {
+    FILE *f = fopen(fileName, "r");
+    if (!f) die("cpecan: cannot open %s", fileName);
+    double hdr[3];
+    if (line_doubles(f, hdr, 3) < 3) die("Got an empty line in the input state machine file %s", fileName);
+    Hmm *hmm = hmmDiscrete_constructEmpty(0.0, (int64_t) hdr[1], (int64_t) hdr[2], (StateMachineType) (int) hdr[0],
+                                          hmmDiscrete_addToTransitionExpectation,
+                                          hmmDiscrete_setTransitionExpectation,
+                                          hmmDiscrete_getTransitionExpectation,
+                                          hmmDiscrete_addToEmissionExpectation,
+                                          hmmDiscrete_setEmissionExpectation,
+                                          hmmDiscrete_getEmissionExpectation, emissions_discrete_getBaseIndex);
+    HmmDiscrete *h = HD(hmm);
+    const int64_t nT = hmm->stateNumber * hmm->stateNumber, nE = hmm->stateNumber * hmm->matrixSize;
+    double *line = malloc(sizeof(double) * (size_t) (nT + 1));
+    const int64_t gotT = line_doubles(f, line, nT + 1);
+    if (gotT != nT + 1) /* the likelihood ends the transition line */
+        die("Got the wrong number of transitions in the input state machine file %s, got %lld instead of %lld",
+            fileName, (long long) gotT, (long long) (nT + 1));
+    memcpy(h->transitions, line, sizeof(double) * (size_t) nT);
+    hmm->likelihood = line[nT];
+    free(line);
+    const int64_t gotE = line_doubles(f, h->emissions, nE);
+    if (gotE != nE)
+        die("Got the wrong number of emissions in the input state machine file %s, got %lld instead of %lld",
+            fileName, (long long) gotE, (long long) nE);
+    fclose(f);
+    return hmm;
+}
+void hmmDiscrete_destruct(Hmm *hmm) {
+    free(HD(hmm)->transitions);
+    free(HD(hmm)->emissions);
+    free(hmm);
+}
+int64_t emissions_discrete_getBaseIndex(void *base) {
+    switch (*(char *) base) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return NUM_OF_KMERS + 1;
+    }
+}
+StateMachineFunctions *stateMachineFunctions_construct(double (*gapXProbFcn)(const double *, void *),
+                                                       double (*gapYProbFcn)(const double *, void *),
+                                                       double (*matchProbFcn)(const double *, void *, void *)) {
+    StateMachineFunctions *f = malloc(sizeof *f);
+    f->gapXProbFcn = gapXProbFcn;
+    f->gapYProbFcn = gapYProbFcn;
+    f->matchProbFcn = matchProbFcn;
+    return f;
+}
+
+/* ---- the M-step for the 5-state machine (impl/stateMachine.c:679-732, 1051-1154, 1698-1723) ------------ */
+static void swap_doubles(double *a, double *b) { double t = *a; *a = *b; *b = t; }
+static void em_load_gap_probs(double *gap, Hmm *hmm, const int64_t *xStates, int nX, const int64_t *yStates, int nY) {
+    const int64_t n = hmm->symbolSetSize;
+    for (int64_t i = 0; i < n; i++) gap[i] = 0.0;
+    for (int k = 0; k < nX; k++) /* collapse [x][y] onto x */
+        for (int64_t x = 0; x < n; x++)
+            for (int64_t y = 0; y < n; y++) gap[x] += hmm->getEmissionExpFcn(hmm, xStates[k], x, y);
+    for (int k = 0; k < nY; k++) /* ... onto y */
+        for (int64_t x = 0; x < n; x++)
+            for (int64_t y = 0; y < n; y++) gap[y] += hmm->getEmissionExpFcn(hmm, yStates[k], x, y);
+    double total = 0.0;
+    for (int64_t i = 0; i < n; i++) total += gap[i];
+    for (int64_t i = 0; i < n; i++) gap[i] = log(gap[i] / total);
+}
+#define TR(f, t) hmm->getTransitionsExpFcn(hmm, f, t)
+static void swap_short_long_x(StateMachine5 *s) {
+    if (s->TRANSITION_GAP_SHORT_EXTEND_X > s->TRANSITION_GAP_LONG_EXTEND_X) {
+        /* a "long" state that extends less than the "short" one (can happen during training): trade places */
+        swap_doubles(&s->TRANSITION_GAP_SHORT_EXTEND_X, &s->TRANSITION_GAP_LONG_EXTEND_X);
+        swap_doubles(&s->TRANSITION_MATCH_FROM_SHORT_GAP_X, &s->TRANSITION_MATCH_FROM_LONG_GAP_X);
+        swap_doubles(&s->TRANSITION_GAP_SHORT_OPEN_X, &s->TRANSITION_GAP_LONG_OPEN_X);
+        swap_doubles(&s->TRANSITION_GAP_SHORT_SWITCH_TO_X, &s->TRANSITION_GAP_LONG_SWITCH_TO_X);
+    }
+}
+static void sm5_load_asymmetric(StateMachine5 *s, Hmm *hmm) {
+    const int64_t n = hmm->symbolSetSize;
+    s->TRANSITION_MATCH_CONTINUE = log(TR(match, match));
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_X = log(TR(shortGapX, match));
+    s->TRANSITION_MATCH_FROM_LONG_GAP_X = log(TR(longGapX, match));
+    s->TRANSITION_GAP_SHORT_OPEN_X = log(TR(match, shortGapX));
+    s->TRANSITION_GAP_SHORT_EXTEND_X = log(TR(shortGapX, shortGapX));
+    s->TRANSITION_GAP_SHORT_SWITCH_TO_X = log(TR(shortGapY, shortGapX));
+    s->TRANSITION_GAP_LONG_OPEN_X = log(TR(match, longGapX));
+    s->TRANSITION_GAP_LONG_EXTEND_X = log(TR(longGapX, longGapX));
+    s->TRANSITION_GAP_LONG_SWITCH_TO_X = log(TR(longGapY, longGapX));
+    swap_short_long_x(s);
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_Y = log(TR(shortGapY, match));
+    s->TRANSITION_MATCH_FROM_LONG_GAP_Y = log(TR(longGapY, match));
+    s->TRANSITION_GAP_SHORT_OPEN_Y = log(TR(match, shortGapY));
+    s->TRANSITION_GAP_SHORT_EXTEND_Y = log(TR(shortGapY, shortGapY));
+    s->TRANSITION_GAP_SHORT_SWITCH_TO_Y = log(TR(shortGapX, shortGapY));
+    s->TRANSITION_GAP_LONG_OPEN_Y = log(TR(match, longGapY));
+    s->TRANSITION_GAP_LONG_EXTEND_Y = log(TR(longGapY, longGapY));
+    s->TRANSITION_GAP_LONG_SWITCH_TO_Y = log(TR(longGapX, longGapY));
+    if (s->TRANSITION_GAP_SHORT_EXTEND_Y > s->TRANSITION_GAP_LONG_EXTEND_Y) {
+        swap_doubles(&s->TRANSITION_GAP_SHORT_EXTEND_Y, &s->TRANSITION_GAP_LONG_EXTEND_Y);
+        swap_doubles(&s->TRANSITION_MATCH_FROM_SHORT_GAP_Y, &s->TRANSITION_MATCH_FROM_LONG_GAP_Y);
+        swap_doubles(&s->TRANSITION_GAP_SHORT_OPEN_Y, &s->TRANSITION_GAP_LONG_OPEN_Y);
+        swap_doubles(&s->TRANSITION_GAP_SHORT_SWITCH_TO_Y, &s->TRANSITION_GAP_LONG_SWITCH_TO_Y);
+    }
+    for (int64_t x = 0; x < n; x++)
+        for (int64_t y = 0; y < n; y++)
+            s->model.EMISSION_MATCH_PROBS[x * n + y] = log(hmm->getEmissionExpFcn(hmm, match, x, y));
+    const int64_t xs[2] = { shortGapX, longGapX }, ys[2] = { shortGapY, longGapY };
+    em_load_gap_probs(s->model.EMISSION_GAP_X_PROBS, hmm, xs, 2, NULL, 0);
+    em_load_gap_probs(s->model.EMISSION_GAP_Y_PROBS, hmm, NULL, 0, ys, 2);
+}
+static void sm5_load_symmetric(StateMachine5 *s, Hmm *hmm) {
+    const int64_t n = hmm->symbolSetSize;
+    s->TRANSITION_MATCH_CONTINUE = log(TR(match, match));
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_X = log((TR(shortGapX, match) + TR(shortGapY, match)) / 2);
+    s->TRANSITION_MATCH_FROM_LONG_GAP_X = log((TR(longGapX, match) + TR(longGapY, match)) / 2);
+    s->TRANSITION_GAP_SHORT_OPEN_X = log((TR(match, shortGapX) + TR(match, shortGapY)) / 2);
+    s->TRANSITION_GAP_SHORT_EXTEND_X = log((TR(shortGapX, shortGapX) + TR(shortGapY, shortGapY)) / 2);
+    s->TRANSITION_GAP_SHORT_SWITCH_TO_X = log((TR(shortGapX, shortGapY) + TR(shortGapY, shortGapX)) / 2);
+    s->TRANSITION_GAP_LONG_OPEN_X = log((TR(match, longGapX) + TR(match, longGapY)) / 2);
+    s->TRANSITION_GAP_LONG_EXTEND_X = log((TR(longGapX, longGapX) + TR(longGapY, longGapY)) / 2);
+    s->TRANSITION_GAP_LONG_SWITCH_TO_X = log((TR(longGapX, longGapY) + TR(longGapY, longGapX)) / 2);
+    swap_short_long_x(s);
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_Y = s->TRANSITION_MATCH_FROM_SHORT_GAP_X;
+    s->TRANSITION_MATCH_FROM_LONG_GAP_Y = s->TRANSITION_MATCH_FROM_LONG_GAP_X;
+    s->TRANSITION_GAP_SHORT_OPEN_Y = s->TRANSITION_GAP_SHORT_OPEN_X;
+    s->TRANSITION_GAP_SHORT_EXTEND_Y = s->TRANSITION_GAP_SHORT_EXTEND_X;
+    s->TRANSITION_GAP_SHORT_SWITCH_TO_Y = s->TRANSITION_GAP_SHORT_SWITCH_TO_X;
+    s->TRANSITION_GAP_LONG_OPEN_Y = s->TRANSITION_GAP_LONG_OPEN_X;
+    s->TRANSITION_GAP_LONG_EXTEND_Y = s->TRANSITION_GAP_LONG_EXTEND_X;
+    s->TRANSITION_GAP_LONG_SWITCH_TO_Y = s->TRANSITION_GAP_LONG_SWITCH_TO_X;
+    for (int64_t x = 0; x < n; x++) {
+        s->model.EMISSION_MATCH_PROBS[x * n + x] = log(hmm->getEmissionExpFcn(hmm, match, x, x));
+        for (int64_t y = x + 1; y < n; y++) {
+            const double d = log((hmm->getEmissionExpFcn(hmm, match, x, y) + hmm->getEmissionExpFcn(hmm, match, y, x)) / 2.0);
+            s->model.EMISSION_MATCH_PROBS[x * n + y] = d;
+            s->model.EMISSION_MATCH_PROBS[y * n + x] = d;
+        }
+    }
+    const int64_t xs[2] = { shortGapX, longGapX }, ys[2] = { shortGapY, longGapY };
+    em_load_gap_probs(s->model.EMISSION_GAP_X_PROBS, hmm, xs, 2, ys, 2);
+    em_load_gap_probs(s->model.EMISSION_GAP_Y_PROBS, hmm, xs, 2, ys, 2);
+}
+#undef TR
+StateMachine *getStateMachine5(Hmm *hmmD, StateMachineFunctions *sMfs) {
+    if (hmmD->type != fiveState && hmmD->type != fiveStateAsymmetric) die("Wrong hmm type");
+    /* the reference constructs with type fiveState in both cases (:1700,:1710) and zeroed emissions */
+    StateMachine5 *s = (StateMachine5 *) stateMachine5_construct(fiveState, hmmD->symbolSetSize, NULL,
+                                                                 sMfs->gapXProbFcn, sMfs->gapYProbFcn,
+                                                                 sMfs->matchProbFcn, cell_updateExpectations);
+    if (hmmD->type == fiveState) sm5_load_symmetric(s, hmmD);
+    else sm5_load_asymmetric(s, hmmD);
+    return (StateMachine *) s;
+}
+
+void diagonalCalculation_Expectations(StateMachine *sM, int64_t xay, DpMatrix *f, DpMatrix *b, Sequence *sX,
+                                      Sequence *sY, double total, PairwiseAlignmentParameters *p, void *extra) {
+    (void) sM; (void) xay; (void) f; (void) b; (void) sX; (void) sY; (void) total; (void) p; (void) extra;
+    die("cpecan: diagonalCalculation_Expectations is a marker for the GPU path, not a host function");
+}
+void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, Sequence *SsX, Sequence *SsY,
+                                 stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                 DiagonalPosteriorProbFn fn, bool raggedL, bool raggedR) {
+    if (fn != diagonalCalculation_Expectations)
+        die("cpecan: the GPU path implements diagonalCalculation_Expectations only");
+    if ((sM->type != fiveState && sM->type != fiveStateAsymmetric) || hmmExpectations->stateNumber != 5 ||
+        hmmExpectations->symbolSetSize != SYMBOL_NUMBER_NO_N)
+        die("cpecan: getExpectationsUsingAnchors takes a 5-state machine and a 5-state, 4-symbol Hmm "
+            "(signal machines: getSignalExpectationsUsingAnchors)");
+    run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmmExpectations);
+}
+void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY, int64_t lX, int64_t lY,
+                     PairwiseAlignmentParameters *p, void *(*getFcn)(void *, int64_t),
+                     stList *(*getAnchorPairFcn)(void *, void *, PairwiseAlignmentParameters *),
+                     bool raggedL, bool raggedR) {
+    stList *anchorPairs = getAnchorPairFcn(sX, sY, p);
+    Sequence *SsX = sequence_construct2(lX, sX, getFcn, sequence_sliceNucleotideSequence2);
+    Sequence *SsY = sequence_construct2(lY, sY, getFcn, sequence_sliceNucleotideSequence2);
+    getExpectationsUsingAnchors(sM, hmmExpectations, SsX, SsY, anchorPairs, p, diagonalCalculation_Expectations,
+                                raggedL, raggedR);
+    sequence_sequenceDestroy(SsX);
+    sequence_sequenceDestroy(SsY);
+    stList_destruct(anchorPairs);
 }

@@ -18,6 +18,7 @@
 
 #include <stdbool.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -311,6 +312,81 @@ void getSignalExpectationsUsingAnchors(StateMachine *sM, ContinuousPairHmmExpect
 void continuousPairHmm_normalize(ContinuousPairHmmExpectations *hmm);                 /* :174-191 */
 void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM,
                                                       ContinuousPairHmmExpectations *hmm); /* :206-232 */
+
+void continuousPairHmm_writeToFile(ContinuousPairHmmExpectations *hmm, FILE *fileHandle);   /* :234-272 */
+ContinuousPairHmmExpectations *continuousPairHmm_loadFromFile(const char *fileName);         /* :274-370 */
+
+/* ---- Hmm / HmmDiscrete: Baum-Welch for the 5-state symbol machine (inc/stateMachine.h:47-74,
+ * inc/discreteHmm.h:9-52, impl/discreteHmm.c), the reference's own structs and signatures ---------- */
+typedef struct _hmm Hmm;
+struct _hmm {
+    double likelihood;
+    StateMachineType type;
+    int64_t stateNumber;
+    int64_t symbolSetSize;
+    int64_t matrixSize;
+    void (*addToTransitionExpectationFcn)(Hmm *hmm, int64_t from, int64_t to, double p);
+    void (*setTransitionFcn)(Hmm *hmm, int64_t from, int64_t to, double p);
+    double (*getTransitionsExpFcn)(Hmm *hmm, int64_t from, int64_t to);
+    void (*addToEmissionExpectationFcn)(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p);
+    void (*setEmissionExpectationFcn)(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p);
+    double (*getEmissionExpFcn)(Hmm *hmm, int64_t state, int64_t x, int64_t y);
+    int64_t (*getElementIndexFcn)(void *);
+};
+typedef struct _hmmDiscrete {
+    Hmm baseHmm;
+    double *transitions; /* [from * stateNumber + to] */
+    double *emissions;   /* [state * matrixSize + x * symbolSetSize + y] */
+} HmmDiscrete;
+Hmm *hmmDiscrete_constructEmpty(double pseudocount, int64_t stateNumber, int64_t symbolSetSize,
+                                StateMachineType type,
+                                void (*addToTransitionExpFcn)(Hmm *hmm, int64_t from, int64_t to, double p),
+                                void (*setTransitionFcn)(Hmm *hmm, int64_t from, int64_t to, double p),
+                                double (*getTransitionsExpFcn)(Hmm *hmm, int64_t from, int64_t to),
+                                void (*addEmissionsExpFcn)(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p),
+                                void (*setEmissionExpFcn)(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p),
+                                double (*getEmissionExpFcn)(Hmm *hmm, int64_t state, int64_t x, int64_t y),
+                                int64_t (*getElementIndexFcn)(void *));
+void hmmDiscrete_addToTransitionExpectation(Hmm *hmm, int64_t from, int64_t to, double p);
+void hmmDiscrete_setTransitionExpectation(Hmm *hmm, int64_t from, int64_t to, double p);
+double hmmDiscrete_getTransitionExpectation(Hmm *hmm, int64_t from, int64_t to);
+void hmmDiscrete_addToEmissionExpectation(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p);
+void hmmDiscrete_setEmissionExpectation(Hmm *hmm, int64_t state, int64_t x, int64_t y, double p);
+double hmmDiscrete_getEmissionExpectation(Hmm *hmm, int64_t state, int64_t x, int64_t y);
+void hmmDiscrete_randomizeTransitions(Hmm *hmm);
+void hmmDiscrete_randomizeEmissions(Hmm *hmm);
+void hmmDiscrete_randomize(Hmm *hmm);                          /* uniform draws, then normalize2(TRUE) */
+void hmmDiscrete_normalize2(Hmm *hmm, bool normalizeEmissions); /* :125-153 */
+void hmmDiscrete_write(Hmm *hmm, FILE *fileHandle);            /* :156-180: 3 lines, "%f" fields */
+Hmm *hmmDiscrete_loadFromFile(const char *fileName);           /* :183-273 */
+void hmmDiscrete_destruct(Hmm *hmm);
+int64_t emissions_discrete_getBaseIndex(void *base);           /* impl/stateMachine.c:104-118 */
+typedef struct _stateMachineFunctions {
+    double (*gapXProbFcn)(const double *, void *);
+    double (*gapYProbFcn)(const double *, void *);
+    double (*matchProbFcn)(const double *, void *, void *);
+} StateMachineFunctions;
+StateMachineFunctions *stateMachineFunctions_construct(double (*gapXProbFcn)(const double *, void *),
+                                                       double (*gapYProbFcn)(const double *, void *),
+                                                       double (*matchProbFcn)(const double *, void *, void *));
+/* the M-step: a 5-state machine from normalised expectations (impl/stateMachine.c:1698-1723 with
+ * stateMachine5_loadSymmetric :1100-1154 for type fiveState, _loadAsymmetric :1051-1098 otherwise) */
+StateMachine *getStateMachine5(Hmm *hmmD, StateMachineFunctions *sMfs);
+/* marker, like diagonalCalculationPosteriorMatchProbs: names the per-diagonal function of the E-step */
+void diagonalCalculation_Expectations(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,
+                                      DpMatrix *backwardDpMatrix, Sequence *sX, Sequence *sY,
+                                      double totalProbability, PairwiseAlignmentParameters *p, void *extraArgs);
+/* the E-step of one alignment (impl/pairwiseAligner.c:1571-1591): adds to hmmExpectations through its
+ * add functions.  GPU path: fiveState / fiveStateAsymmetric machines with an HmmDiscrete. */
+void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, Sequence *SsX, Sequence *SsY,
+                                 stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                 DiagonalPosteriorProbFn diagonalCalcExpectationFcn,
+                                 bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+/* (:1593-1617) with the caller's anchor generator; destroys the anchor list it obtained */
+void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY, int64_t lX, int64_t lY,
+                     PairwiseAlignmentParameters *p, void *(*getFcn)(void *, int64_t),
+                     stList *(*getAnchorPairFcn)(void *, void *, PairwiseAlignmentParameters *),
+                     bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 
 /* ---- additive batch entry (many reads, one call; SURVEY section 8b last row) ---------------------
  * Aligns n reads; read i uses state machine sMs[i] (already scaled for that read), sequences

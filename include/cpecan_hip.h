@@ -161,6 +161,10 @@ typedef struct {
                                     the band instead of the sweep's candidate lists (the path a window falls
                                     back to by itself when its totals drift or a list overflows) */
 
+#define CPECAN_FLAG_EXPECTATIONS 8 /* cpecan_hip_batch_create_dna only: run diagonalCalculation_Expectations
+                                      (:841) instead of the posterior decode, as CPECAN_MODE_EXPECTATIONS does
+                                      for the signal batches */
+
 /* Copies the inputs to HBM and builds per-item band tables.  All host pointers may be released
  * after the call returns. */
 int cpecan_hip_batch_create(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
@@ -172,8 +176,8 @@ int cpecan_hip_batch_create(cpecan_ctx *ctx, const cpecan_item *items, int64_t n
 /* DNA against DNA with a 5-state model (getAlignedPairsUsingAnchors with a stateMachine5 and
  * sequence_getBase on both sides, impl/pairwiseAligner.c:1456,:308): X and Y are nucleotide strings,
  * lX / lY count bases, x_offset / y_offset index x_chars / y_chars, model_id is a
- * cpecan_hip_models5_create id.  Posterior decode on the general kernel; flags: DEBUG_DUMP is not
- * available, UNBANDED is. */
+ * cpecan_hip_models5_create id.  General kernel; flags: DEBUG_DUMP is not available, UNBANDED and
+ * EXPECTATIONS are (the latter: hmmDiscrete sums through cpecan_hip_batch_fetch_expectations). */
 int cpecan_hip_batch_create_dna(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
                                 const char *x_chars, int64_t n_x, const char *y_chars, int64_t n_y,
                                 const int64_t *anchors, int64_t n_anchor_pairs,
@@ -222,6 +226,9 @@ int cpecan_hip_batch_fetch_totals(cpecan_batch *batch, int64_t item, int64_t *xa
  * + likelihood = 4106 doubles, summed over the items of the batch that use that model. The device
  * buffer pointer is exposed so that a caller can all-reduce it in place (RCCL) before fetching. */
 #define CPECAN_EXPECTATION_LEN (9 + CPECAN_NUM_KMERS + 1)
+/* DNA batches (HmmDiscrete, impl/discreteHmm.c:10-153): 25 transitions [from*5+to], 5 x 16 emissions
+ * [state*16 + x*4 + y] (cell_updateExpectations :407-424) + likelihood, per cpecan_hip_models5_create id */
+#define CPECAN_EXPECTATION5_LEN (25 + 5 * 16 + 1)
 int cpecan_hip_batch_expectations_device_ptr(cpecan_batch *batch, void **dev_ptr, int64_t *n_doubles);
 int cpecan_hip_batch_fetch_expectations(cpecan_batch *batch, int32_t model_id, double *out);
 /* Debug: forward cells and backward cells (as they stand when posteriors are taken) of an item,

@@ -315,8 +315,8 @@ static inline void get_symbols(const seqs_t *s, int64_t ix, int64_t iy, symbols_
 /* ------------------------------------------------------------------------------------------ */
 typedef struct {
     double total;           /* totalProbability of the enclosing diagonal */
-    orc_expectations *hmm;
-    int64_t kx;
+    orc_expectations *hmm;  /* an orc_expectations5 for the 5-state symbol machine */
+    int64_t kx, ky;
 } exp_args_t;
 
 typedef void (*trans_fn)(double *from, double *to, int f, int t, double eP, double tP, void *extra);
@@ -342,6 +342,16 @@ static void trans_expect_sm3(double *from, double *to, int f, int t, double eP, 
         if (a->kx >= 0 && a->kx < ORC_NUM_KMERS) /* reference writes out of bounds otherwise */
             a->hmm->kmerGap[a->kx] += p;
     }
+}
+
+/* cell_updateExpectations :407-424 (HmmDiscrete: transitions [from*5+to], emissions [to][x][y]) */
+static void trans_expect_sm5(double *from, double *to, int f, int t, double eP, double tP, void *e) {
+    exp_args_t *a = (exp_args_t *) e;
+    orc_expectations5 *h = (orc_expectations5 *) a->hmm;
+    double p = exp(from[f] + to[t] + (eP + tP) - a->total);
+    h->transitions[f * 5 + t] += p;
+    if (a->kx < 4 && a->ky < 4) /* ignore gaps involving Ns */
+        h->emissions[t * 16 + a->kx * 4 + a->ky] += p;
 }
 
 enum { ST_MATCH = 0, ST_SHORT_GAP_X = 1, ST_SHORT_GAP_Y = 2, ST_LONG_GAP_X = 3, ST_LONG_GAP_Y = 4 };
@@ -686,7 +696,7 @@ static void diag_calc(const seqs_t *sq, dpm_t *mc, dpm_t *m1, dpm_t *m2, int64_t
         double *lower = m1 ? dpm_cell(m1, xay - 1, xmy - 1) : NULL;
         double *middle = m2 ? dpm_cell(m2, xay - 2, xmy) : NULL;
         double *upper = m1 ? dpm_cell(m1, xay - 1, xmy + 1) : NULL;
-        if (ea) ea->kx = sy.kx;
+        if (ea) { ea->kx = sy.kx; ea->ky = sy.ky; }
         cell_calc(sq->m, cur, lower, middle, upper, &sy, fn, ea);
     }
 }
@@ -745,7 +755,12 @@ static void posterior_match_probs(dpm_t *F, dpm_t *B, int64_t xay, double total,
 /* diagonalCalculation_Expectations :841-863 */
 static void expectations_diag(const seqs_t *sq, dpm_t *F, dpm_t *B, int64_t xay, double total,
                               orc_expectations *hmm) {
-    exp_args_t ea = { total, hmm, 0 };
+    exp_args_t ea = { total, hmm, 0, 0 };
+    if (sq->m->kind == ORC_SM5_SYMBOL) {
+        ((orc_expectations5 *) hmm)->likelihood += total;
+        diag_calc(sq, B, F, F, xay, trans_expect_sm5, &ea);
+        return;
+    }
     hmm->likelihood += total;
     diag_calc(sq, B, F, F, xay, trans_expect_sm3, &ea);
 }
@@ -935,6 +950,30 @@ int orc_aligned_pairs_without_banding(const orc_model *m, const char *x, int64_t
     dpm_free(&B);
     free(L); free(R);
     return 0;
+}
+
+int orc_expectations5_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
+                                    const int64_t *anchors, int64_t nAnchors, const orc_params *p,
+                                    int raggedLeft, int raggedRight, orc_expectations5 *hmm) {
+    if (m->kind != ORC_SM5_SYMBOL) return -2;
+    orc_result *scratch = orc_result_new();
+    int rc = orc_aligned_pairs_using_anchors(m, x, lX, y, lY, anchors, nAnchors, p, raggedLeft, raggedRight,
+                                             (orc_expectations *) hmm, scratch);
+    orc_result_free(scratch);
+    return rc;
+}
+
+void orc_expectations5_normalize(orc_expectations5 *e) {
+    for (int from = 0; from < 5; from++) {
+        double total = 0.0;
+        for (int to = 0; to < 5; to++) total += e->transitions[from * 5 + to];
+        for (int to = 0; to < 5; to++) e->transitions[from * 5 + to] = e->transitions[from * 5 + to] / total;
+    }
+    for (int s = 0; s < 5; s++) {
+        double total = 0.0;
+        for (int i = 0; i < 16; i++) total += e->emissions[s * 16 + i];
+        for (int i = 0; i < 16; i++) e->emissions[s * 16 + i] = e->emissions[s * 16 + i] / total;
+    }
 }
 
 /* continuousPairHmm_normalize impl/continuousHmm.c:174-191 + hmmDiscrete_normalize2 :125-136 */

@@ -76,6 +76,14 @@ typedef struct {
     double likelihood;
 } orc_expectations;
 
+/* sufficient statistics of the 5-state symbol HMM (HmmDiscrete, impl/discreteHmm.c:10-153 with
+ * cell_updateExpectations impl/pairwiseAligner.c:407-424) */
+typedef struct {
+    double transitions[25]; /* [from*5+to] */
+    double emissions[80];   /* [state*16 + x*4 + y] */
+    double likelihood;
+} orc_expectations5;
+
 /* result container (growable) */
 typedef struct {
     int64_t n, cap;
@@ -147,6 +155,12 @@ int orc_banded_dump(const orc_model *m, const char *x, int64_t lX, const void *y
 
 /* continuousPairHmm_normalize, impl/continuousHmm.c:174-204 */
 void orc_expectations_normalize(orc_expectations *e);
+/* getExpectationsUsingAnchors (:1571) for an ORC_SM5_SYMBOL model: adds to *hmm */
+int orc_expectations5_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
+                                    const int64_t *anchors, int64_t nAnchors, const orc_params *p,
+                                    int raggedLeft, int raggedRight, orc_expectations5 *hmm);
+/* hmmDiscrete_normalize2(hmm, TRUE) impl/discreteHmm.c:125-153 */
+void orc_expectations5_normalize(orc_expectations5 *e);
 
 #ifdef __cplusplus
 }

@@ -66,7 +66,47 @@ EXPORTS = [
     "bandIterator_construct", "bandIterator_destruct", "bandIterator_clone", "bandIterator_getNext",
     "bandIterator_getPrevious", "logAdd", "nanopore_loadNanoporeReadFromFile", "nanopore_remapAnchorPairs",
     "nanopore_remapAnchorPairsWithOffset", "nanopore_descaleNanoporeRead", "nanopore_nanoporeReadDestruct",
+    "continuousPairHmm_writeToFile", "continuousPairHmm_loadFromFile", "hmmDiscrete_constructEmpty",
+    "hmmDiscrete_addToTransitionExpectation", "hmmDiscrete_setTransitionExpectation",
+    "hmmDiscrete_getTransitionExpectation", "hmmDiscrete_addToEmissionExpectation",
+    "hmmDiscrete_setEmissionExpectation", "hmmDiscrete_getEmissionExpectation",
+    "hmmDiscrete_randomizeTransitions", "hmmDiscrete_randomizeEmissions", "hmmDiscrete_randomize",
+    "hmmDiscrete_normalize2", "hmmDiscrete_write", "hmmDiscrete_loadFromFile", "hmmDiscrete_destruct",
+    "emissions_discrete_getBaseIndex", "stateMachineFunctions_construct", "getStateMachine5",
+    "diagonalCalculation_Expectations", "getExpectationsUsingAnchors", "getExpectations",
 ]
+
+
+class Hmm(C.Structure):
+    _fields_ = [("likelihood", C.c_double), ("type", C.c_int), ("stateNumber", C.c_int64),
+                ("symbolSetSize", C.c_int64), ("matrixSize", C.c_int64)] + [
+                    (n, C.c_void_p) for n in ("addToTransitionExpectationFcn", "setTransitionFcn",
+                                              "getTransitionsExpFcn", "addToEmissionExpectationFcn",
+                                              "setEmissionExpectationFcn", "getEmissionExpFcn",
+                                              "getElementIndexFcn")]
+
+
+class HmmDiscrete(C.Structure):
+    _fields_ = [("baseHmm", Hmm), ("transitions", C.POINTER(C.c_double)), ("emissions", C.POINTER(C.c_double))]
+
+
+class StateMachine5(C.Structure):
+    _fields_ = [("model", StateMachine)] + [(n, C.c_double) for n in (
+        "MATCH_CONTINUE", "MATCH_FROM_SHORT_GAP_X", "MATCH_FROM_LONG_GAP_X", "GAP_SHORT_OPEN_X",
+        "GAP_SHORT_EXTEND_X", "GAP_SHORT_SWITCH_TO_X", "GAP_LONG_OPEN_X", "GAP_LONG_EXTEND_X",
+        "GAP_LONG_SWITCH_TO_X", "MATCH_FROM_SHORT_GAP_Y", "MATCH_FROM_LONG_GAP_Y", "GAP_SHORT_OPEN_Y",
+        "GAP_SHORT_EXTEND_Y", "GAP_SHORT_SWITCH_TO_Y", "GAP_LONG_OPEN_Y", "GAP_LONG_EXTEND_Y",
+        "GAP_LONG_SWITCH_TO_Y")]
+
+
+def new_hmm_discrete(pseudocount, symbols=4, hmm_type=0):
+    """hmmDiscrete_constructEmpty with the reference's own accessor functions"""
+    L = lib()
+    return L.hmmDiscrete_constructEmpty(
+        pseudocount, 5, symbols, hmm_type, fn_ptr("hmmDiscrete_addToTransitionExpectation"),
+        fn_ptr("hmmDiscrete_setTransitionExpectation"), fn_ptr("hmmDiscrete_getTransitionExpectation"),
+        fn_ptr("hmmDiscrete_addToEmissionExpectation"), fn_ptr("hmmDiscrete_setEmissionExpectation"),
+        fn_ptr("hmmDiscrete_getEmissionExpectation"), fn_ptr("emissions_discrete_getBaseIndex"))
 
 
 class AdjustmentParams(C.Structure):
@@ -148,6 +188,31 @@ def lib():
         L.nanopore_remapAnchorPairsWithOffset.argtypes = [vp, C.POINTER(C.c_int64), C.c_int64]
         L.nanopore_descaleNanoporeRead.argtypes = [C.POINTER(NanoporeRead)]
         L.nanopore_nanoporeReadDestruct.argtypes = [C.POINTER(NanoporeRead)]
+        HP = C.POINTER(HmmDiscrete)
+        L.hmmDiscrete_constructEmpty.restype = HP
+        L.hmmDiscrete_constructEmpty.argtypes = [C.c_double, C.c_int64, C.c_int64, C.c_int] + [vp] * 7
+        for name in ("hmmDiscrete_addToTransitionExpectation", "hmmDiscrete_setTransitionExpectation"):
+            getattr(L, name).argtypes = [HP, C.c_int64, C.c_int64, C.c_double]
+        L.hmmDiscrete_getTransitionExpectation.restype = C.c_double
+        L.hmmDiscrete_getTransitionExpectation.argtypes = [HP, C.c_int64, C.c_int64]
+        for name in ("hmmDiscrete_addToEmissionExpectation", "hmmDiscrete_setEmissionExpectation"):
+            getattr(L, name).argtypes = [HP, C.c_int64, C.c_int64, C.c_int64, C.c_double]
+        L.hmmDiscrete_getEmissionExpectation.restype = C.c_double
+        L.hmmDiscrete_getEmissionExpectation.argtypes = [HP, C.c_int64, C.c_int64, C.c_int64]
+        for name in ("hmmDiscrete_randomize", "hmmDiscrete_destruct"):
+            getattr(L, name).argtypes = [HP]
+        L.hmmDiscrete_normalize2.argtypes = [HP, C.c_bool]
+        L.hmmDiscrete_loadFromFile.restype = HP
+        L.hmmDiscrete_loadFromFile.argtypes = [C.c_char_p]
+        L.continuousPairHmm_loadFromFile.restype = C.POINTER(Expectations)
+        L.continuousPairHmm_loadFromFile.argtypes = [C.c_char_p]
+        L.emissions_discrete_getBaseIndex.restype = C.c_int64
+        L.emissions_discrete_getBaseIndex.argtypes = [C.c_char_p]
+        L.stateMachineFunctions_construct.restype = vp
+        L.stateMachineFunctions_construct.argtypes = [vp, vp, vp]
+        L.getStateMachine5.restype = C.POINTER(StateMachine5)
+        L.getStateMachine5.argtypes = [HP, vp]
+        L.getExpectationsUsingAnchors.argtypes = [vp, HP, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
         L.filterToRemoveOverlap.restype = vp
         L.filterToRemoveOverlap.argtypes = [vp]
         L.getPosteriorProbsWithBanding.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.c_bool, C.c_bool, vp, vp]

@@ -108,3 +108,38 @@ def test_config1_two_1kb_sequences(ctx):
     x, y, _ = evolve(rng, 1000)
     bp = band_params(0.01, 1000, 40, 20)
     run_case(ctx, [(x, y, np.zeros((0, 2), np.int64))], bp, (0, 0))
+
+
+def test_discrete_expectations_match_oracle(ctx):
+    """Baum-Welch sums of the 5-state machine (getExpectationsUsingAnchors with
+    diagonalCalculation_Expectations and cell_updateExpectations, impl/pairwiseAligner.c:407-424,:841-863):
+    25 transitions, 5 x 16 emissions and the likelihood of a batch, summed per model.  The device adds
+    the per-cell terms in another order than the host loop: 1e-9 relative (north_star asks 1e-6)."""
+    rng = np.random.default_rng(77)
+    model = o.Sm5Model()
+    ctx.models_clear()
+    ids = ctx.models5_create([(list(model.c.t), model.match, model.gx, model.gy)])
+    bp = band_params(0.01, 60, 10, 12)
+    p = orc_params(bp, split=1 << 60)
+    xs, ys, an, seqs = "", "", [], []
+    items = np.zeros(4, cp.ITEM_DTYPE)
+    for i in range(4):
+        x, y, pairs = evolve(rng, 120 + 40 * i)
+        a = pairs[4::9]
+        items[i] = (len(xs), len(x), len(ys), len(y), sum(len(q) for q in an), len(a), ids[0], 0, 0, 0)
+        xs += x
+        ys += y
+        an.append(a)
+        seqs.append((x, y, a))
+    b = cp.Batch(ctx, items, xs, None, np.concatenate(an), bp, flags=cp.FLAG_EXPECTATIONS, y_chars=ys)
+    b.run()
+    b.sync()
+    got = b.expectations(ids[0])
+    hmm = o.OrcExpectations5()
+    for x, y, a in seqs:
+        o.expectations5_using_anchors(model, x, len(x), y, a, p, hmm)
+    ref = hmm.as_array()
+    assert ref[-1] < 0 and ref[0] > 10  # a real likelihood, many match->match transitions
+    assert np.count_nonzero(ref[:25]) == 13  # the transitions stateMachine5_cellCalculate takes
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
+    b.close()

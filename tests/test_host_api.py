@@ -396,6 +396,150 @@ def test_npread_loader_remap_and_descale(golden_dir, zymo_read):
     L.nanopore_nanoporeReadDestruct(r)
 
 
+def _c_file(path, mode):
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    return libc, libc.fopen(str(path).encode(), mode)
+
+
+@pytest.mark.parametrize("symbols,hmm_type", [(4, 0), (5, 1)])
+def test_hmm_discrete_file_round_trip_and_normalisation(tmp_path, symbols, hmm_type):
+    """tests/pairwiseAlignerTest.c:754-855 (test_hmmDiscrete for fiveState / fiveStateAsymmetric): counts in,
+    written, re-read identical; hmmDiscrete_normalize2's known answers"""
+    L = h.lib()
+    hmm = h.new_hmm_discrete(0.0, symbols, hmm_type)
+    for f in range(5):
+        for t in range(5):
+            L.hmmDiscrete_addToTransitionExpectation(hmm, f, t, float(f * 5 + t))
+    for st in range(5):
+        for x in range(symbols):
+            for y in range(symbols):
+                L.hmmDiscrete_addToEmissionExpectation(hmm, st, x, y, float(st * symbols * symbols + x * symbols + y))
+    path = tmp_path / "temp.hmm"
+    libc, fh = _c_file(path, b"w")
+    L.hmmDiscrete_write.argtypes = [C.POINTER(h.HmmDiscrete), C.c_void_p]
+    L.hmmDiscrete_write(hmm, fh)
+    libc.fclose(fh)
+    L.hmmDiscrete_destruct(hmm)
+    lines = open(path).read().split("\n")
+    assert lines[0].split() == [str(hmm_type), "5", str(symbols)]
+    assert len(lines[1].split()) == 26 and len(lines[2].split()) == 5 * symbols * symbols
+    assert lines[1].split()[7] == "7.000000"  # "%f" fields (quirk Q7)
+    hmm = L.hmmDiscrete_loadFromFile(str(path).encode())
+    b = hmm.contents.baseHmm
+    assert (b.type, b.stateNumber, b.symbolSetSize, b.matrixSize) == (hmm_type, 5, symbols, symbols * symbols)
+    for f in range(5):
+        for t in range(5):
+            assert L.hmmDiscrete_getTransitionExpectation(hmm, f, t) == f * 5 + t
+    for st in range(5):
+        for x in range(symbols):
+            for y in range(symbols):
+                assert L.hmmDiscrete_getEmissionExpectation(hmm, st, x, y) == st * symbols * symbols + x * symbols + y
+    L.hmmDiscrete_normalize2(hmm, True)
+    m = symbols * symbols
+    for f in range(5):
+        z = f * 25 + 10
+        for t in range(5):
+            assert L.hmmDiscrete_getTransitionExpectation(hmm, f, t) == (f * 5 + t) / z
+    for st in range(5):
+        total = m * m * st + (m * (m - 1)) // 2
+        for x in range(symbols):
+            for y in range(symbols):
+                assert L.hmmDiscrete_getEmissionExpectation(hmm, st, x, y) == (st * m + x * symbols + y) / total
+    L.hmmDiscrete_destruct(hmm)
+    assert L.emissions_discrete_getBaseIndex(b"G") == 2 and L.emissions_discrete_getBaseIndex(b"n") == 4097
+
+
+def test_continuous_pair_hmm_file_round_trip(tmp_path):
+    """tests/signalPairwiseTest.c:1461-1542: transitions, likelihood and k-mer gap counts through a .hmm file"""
+    L = h.lib()
+    e = h.Expectations()
+    for i in range(9):
+        e.transitions[i] = float(i)
+    for i in range(h.NUM_KMERS):
+        e.individualKmerGapProbs[i] = float(4096 * 3 + i)
+    e.likelihood = -1234.5
+    path = tmp_path / "temp.hmm"
+    libc, fh = _c_file(path, b"w")
+    L.continuousPairHmm_writeToFile.argtypes = [C.POINTER(h.Expectations), C.c_void_p]
+    L.continuousPairHmm_writeToFile(C.byref(e), fh)
+    libc.fclose(fh)
+    lines = open(path).read().split("\n")
+    assert lines[0].split() == ["2", "3", "4096"] and len(lines[1].split()) == 10 and len(lines[2].split()) == 4096
+    r = L.continuousPairHmm_loadFromFile(str(path).encode()).contents
+    assert list(r.transitions) == list(e.transitions) and r.likelihood == e.likelihood
+    assert list(r.individualKmerGapProbs) == list(e.individualKmerGapProbs)
+    L.continuousPairHmm_normalize(C.byref(r))
+    assert r.transitions[4] == 4.0 / 12.0 and abs(sum(r.individualKmerGapProbs) - 1.0) < 1e-12
+
+
+def _sm5_as_oracle_model(sm):
+    """an oracle 5-state model carrying the transitions and emissions of a host StateMachine5"""
+    m = o.Sm5Model()
+    s = sm.contents
+    for i, (name, _) in enumerate(h.StateMachine5._fields_[1:]):
+        m.c.t[i] = getattr(s, name)
+    m.match[:] = np.ctypeslib.as_array(s.model.EMISSION_MATCH_PROBS, shape=(16,))
+    m.gx[:] = np.ctypeslib.as_array(s.model.EMISSION_GAP_X_PROBS, shape=(4,))
+    m.gy[:] = np.ctypeslib.as_array(s.model.EMISSION_GAP_Y_PROBS, shape=(4,))
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hmm_type", [0, 1])
+def test_discrete_baum_welch_from_a_random_model(hmm_type):
+    """tests/pairwiseAlignerTest.c:857-945 (test_HmmDiscrete_em): start from hmmDiscrete_randomize, ten
+    rounds of E-step (getExpectationsUsingAnchors on the GPU) / hmmDiscrete_normalize2 / M-step
+    (getStateMachine5); the likelihood must not fall by more than the reference's 5 % allowance, and every
+    E-step is compared with the oracle run on the machine of that round."""
+    L = h.lib()
+    rng = np.random.default_rng(19 + hmm_type)
+    for trial in range(3):
+        x = "".join(rng.choice(list("ACGT"), int(rng.integers(30, 100))))
+        y = "".join(ch if rng.random() > 0.2 else rng.choice(list("ACGT")) for ch in x if rng.random() > 0.05)
+        xb, yb = C.create_string_buffer(x.encode()), C.create_string_buffer(y.encode())
+        sX = L.sequence_construct2(len(x), C.cast(xb, C.c_void_p), h.fn_ptr("sequence_getBase"),
+                                   h.fn_ptr("sequence_sliceNucleotideSequence2"))
+        sY = L.sequence_construct2(len(y), C.cast(yb, C.c_void_p), h.fn_ptr("sequence_getBase"),
+                                   h.fn_ptr("sequence_sliceNucleotideSequence2"))
+        p = L.pairwiseAlignmentBandingParameters_construct()
+        op = o.default_params()
+        fns = L.stateMachineFunctions_construct(h.fn_ptr("emissions_symbol_getGapProb"),
+                                                h.fn_ptr("emissions_symbol_getGapProb"),
+                                                h.fn_ptr("emissions_symbol_getMatchProb"))
+        hmm = h.new_hmm_discrete(0.0, 4, hmm_type)
+        L.hmmDiscrete_randomize(hmm)
+        sm = L.getStateMachine5(hmm, fns)
+        L.hmmDiscrete_destruct(hmm)
+        lst = h.make_anchor_list([])
+        previous = -np.inf
+        for it in range(10):
+            hmm = h.new_hmm_discrete(1e-12, 4, hmm_type)
+            L.getExpectationsUsingAnchors(sm, hmm, sX, sY, lst, p, h.fn_ptr("diagonalCalculation_Expectations"),
+                                          False, False)
+            ref = o.expectations5_using_anchors(_sm5_as_oracle_model(sm), x, len(x), y, np.zeros((0, 2), np.int64),
+                                                op, o.OrcExpectations5()).as_array()
+            got = np.concatenate([np.ctypeslib.as_array(hmm.contents.transitions, shape=(25,)),
+                                  np.ctypeslib.as_array(hmm.contents.emissions, shape=(80,)),
+                                  [hmm.contents.baseHmm.likelihood]])
+            assert np.allclose(got, ref + np.r_[np.full(105, 1e-12), 0.0], rtol=1e-9, atol=1e-12)
+            L.hmmDiscrete_normalize2(hmm, True)
+            like = hmm.contents.baseHmm.likelihood
+            assert previous <= like * 0.95
+            previous = like
+            L.stateMachine_destruct(sm)
+            sm = L.getStateMachine5(hmm, fns)
+            L.hmmDiscrete_destruct(hmm)
+        assert np.isfinite(previous)
+        L.stateMachine_destruct(sm)
+        L.stList_destruct(lst)
+        L.sequence_sequenceDestroy(sX)
+        L.sequence_sequenceDestroy(sY)
+        L.pairwiseAlignmentBandingParameters_destruct(p)
+
+
 def test_diagonal_band_iterator_logadd_and_overlap_filter():
     """the geometry and utility functions the reference exports and tests (tests/pairwiseAlignerTest.c:
     test_diagonal :22, test_bands :74, test_logAdd :139, test_filterToRemoveOverlap :515), host-only"""
