@@ -1395,3 +1395,45 @@ void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY,
     sequence_sequenceDestroy(SsY);
     stList_destruct(anchorPairs);
 }
+
+/* ---- re-weighting (impl/pairwiseAligner.c:1619-1667) -------------------------------------------------- */
+int64_t *getIndelProbabilities(stList *alignedPairs, int64_t seqLength, bool xIfTrueElseY) {
+    int64_t *gap = malloc(sizeof(int64_t) * (size_t) (seqLength > 0 ? seqLength : 1));
+    for (int64_t i = 0; i < seqLength; i++) gap[i] = PAIR_ALIGNMENT_PROB_1;
+    for (int64_t i = 0; i < stList_length(alignedPairs); i++) {
+        stIntTuple *t = stList_get(alignedPairs, i);
+        gap[stIntTuple_get(t, xIfTrueElseY ? 1 : 2)] -= stIntTuple_get(t, 0);
+    }
+    for (int64_t i = 0; i < seqLength; i++)
+        if (gap[i] < 0) gap[i] = 0;
+    return gap;
+}
+stList *reweightAlignedPairs(stList *alignedPairs, int64_t *indelProbsX, int64_t *indelProbsY, double gapGamma) {
+    stList *out = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    for (int64_t i = 0; i < stList_length(alignedPairs); i++) {
+        stIntTuple *t = stList_get(alignedPairs, i);
+        const int64_t x = stIntTuple_get(t, 1), y = stIntTuple_get(t, 2);
+        /* int64 - double, converted back on assignment, as the reference writes it */
+        const int64_t w = stIntTuple_get(t, 0) - gapGamma * (indelProbsX[x] + indelProbsY[y]);
+        stList_append(out, stIntTuple_construct3(w, x, y));
+    }
+    stList_destruct(alignedPairs);
+    return out;
+}
+stList *reweightAlignedPairs2(stList *alignedPairs, int64_t seqLengthX, int64_t seqLengthY, double gapGamma) {
+    if (gapGamma <= 0.0) return alignedPairs;
+    int64_t *gx = getIndelProbabilities(alignedPairs, seqLengthX, 1);
+    int64_t *gy = getIndelProbabilities(alignedPairs, seqLengthY, 0);
+    alignedPairs = reweightAlignedPairs(alignedPairs, gx, gy, gapGamma);
+    free(gx);
+    free(gy);
+    return alignedPairs;
+}
+void sequence_padSequence(Sequence *sequence) {
+    const char *pad = "nnnnnnnnnnnnnnnnnnnnnnnnnnnnnn";
+    const char *old = sequence->elements;
+    char *padded = malloc(strlen(old) + strlen(pad) + 1);
+    strcpy(padded, old);
+    strcat(padded, pad);
+    sequence->elements = padded;
+}

@@ -388,6 +388,13 @@ void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY,
                      stList *(*getAnchorPairFcn)(void *, void *, PairwiseAlignmentParameters *),
                      bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 
+/* ---- re-weighting aligned pairs by the chance of aligning to a gap (impl/pairwiseAligner.c:1619-1667) ----- */
+int64_t *getIndelProbabilities(stList *alignedPairs, int64_t seqLength, bool xIfTrueElseY);
+stList *reweightAlignedPairs(stList *alignedPairs, int64_t *indelProbsX, int64_t *indelProbsY,
+                             double gapGamma); /* consumes alignedPairs */
+stList *reweightAlignedPairs2(stList *alignedPairs, int64_t seqLengthX, int64_t seqLengthY, double gapGamma);
+void sequence_padSequence(Sequence *sequence); /* :282-285: elements become a padded copy (echelon callers) */
+
 /* ---- additive batch entry (many reads, one call; SURVEY section 8b last row) ---------------------
  * Aligns n reads; read i uses state machine sMs[i] (already scaled for that read), sequences
  * sXs[i] (sequence_getKmer) / sYs[i] (sequence_getEvent) and anchor list anchors[i].  Returns an

@@ -74,6 +74,7 @@ EXPORTS = [
     "hmmDiscrete_normalize2", "hmmDiscrete_write", "hmmDiscrete_loadFromFile", "hmmDiscrete_destruct",
     "emissions_discrete_getBaseIndex", "stateMachineFunctions_construct", "getStateMachine5",
     "diagonalCalculation_Expectations", "getExpectationsUsingAnchors", "getExpectations",
+    "getIndelProbabilities", "reweightAlignedPairs", "reweightAlignedPairs2", "sequence_padSequence",
 ]
 
 
@@ -213,6 +214,10 @@ def lib():
         L.getStateMachine5.restype = C.POINTER(StateMachine5)
         L.getStateMachine5.argtypes = [HP, vp]
         L.getExpectationsUsingAnchors.argtypes = [vp, HP, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
+        L.getIndelProbabilities.restype = C.POINTER(C.c_int64)
+        L.getIndelProbabilities.argtypes = [vp, C.c_int64, C.c_bool]
+        L.reweightAlignedPairs2.restype = vp
+        L.reweightAlignedPairs2.argtypes = [vp, C.c_int64, C.c_int64, C.c_double]
         L.filterToRemoveOverlap.restype = vp
         L.filterToRemoveOverlap.argtypes = [vp]
         L.getPosteriorProbsWithBanding.argtypes = [vp, vp, vp, vp, C.POINTER(Params), C.c_bool, C.c_bool, vp, vp]

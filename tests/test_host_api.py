@@ -540,6 +540,34 @@ def test_discrete_baum_welch_from_a_random_model(hmm_type):
         L.pairwiseAlignmentBandingParameters_destruct(p)
 
 
+def test_reweighting_by_gap_probability():
+    """getIndelProbabilities / reweightAlignedPairs2 (impl/pairwiseAligner.c:1619-1667) against their
+    definition: gap mass per position = 1e7 - sum of its pair weights (floored at 0); new weight =
+    weight - gapGamma * (gapX[x] + gapY[y]) with the reference's int64 - double -> int64 conversion"""
+    L = h.lib()
+    L.stIntTuple_construct3.restype = C.c_void_p
+    L.stIntTuple_construct3.argtypes = [C.c_int64] * 3
+    tri = [(9000000, 0, 0), (600000, 0, 1), (7000000, 1, 1), (5000000, 2, 3), (6000000, 2, 3), (123457, 3, 2)]
+    lst = L.stList_construct3(0, h.fn_ptr("stIntTuple_destruct"))
+    for t in tri:
+        L.stList_append(lst, L.stIntTuple_construct3(*t))
+    gx = L.getIndelProbabilities(lst, 4, True)
+    gy = L.getIndelProbabilities(lst, 4, False)
+    want_x, want_y = [10000000] * 4, [10000000] * 4
+    for w, x, y in tri:
+        want_x[x] -= w
+        want_y[y] -= w
+    want_x, want_y = [max(v, 0) for v in want_x], [max(v, 0) for v in want_y]
+    assert [gx[i] for i in range(4)] == want_x and [gy[i] for i in range(4)] == want_y
+    assert want_x[2] == 0  # over-full position is floored
+    assert L.reweightAlignedPairs2(lst, 4, 4, 0.0) == lst  # gapGamma <= 0: the list itself
+    out = L.reweightAlignedPairs2(lst, 4, 4, 0.3)
+    got = h.list_to_array(out)
+    want = [[int(w - 0.3 * (want_x[x] + want_y[y])), x, y] for w, x, y in tri]
+    assert got.tolist() == want
+    L.stList_destruct(out)
+
+
 def test_diagonal_band_iterator_logadd_and_overlap_filter():
     """the geometry and utility functions the reference exports and tests (tests/pairwiseAlignerTest.c:
     test_diagonal :22, test_bands :74, test_logAdd :139, test_filterToRemoveOverlap :515), host-only"""
