@@ -35,6 +35,7 @@
 #define CP_YK2 15
 #define CP_GAPX 16
 #define CP_MODEL5_STRIDE 48 /* 5-state symbol model: 17 transitions, pad to 24, 16 match, 4 gapX, 4 gapY */
+#define CP_EXPECTV_LEN 61   /* vanilla machine's Baum-Welch sums: 30 beta + 30 alpha skip bins, likelihood */
 #define CP_EXPECT5_LEN 106  /* its Baum-Welch sums: 25 transitions, 5 x 16 emissions, likelihood */
 /* vanilla signal model block: header (scalars, per-bin log transition probabilities), then one row per
  * k-mer (4096 + the "not a k-mer" row): the match table's six values, then the extra-event table's */

@@ -34,7 +34,7 @@ extern "C" __global__ void cpecan_k_generalv(const DevItem *, DevParams, const i
                                              const long long *, const unsigned short *, const double *,
                                              const double *, const double *, double *, double *,
                                              long long *, double *, long long *, long long *, double *,
-                                             long long *);
+                                             long long *, double *);
 struct DevHdpModel { /* as in cpecan_kernel_generalh.hip */
     double t[9];
     int gridLength, pad;
@@ -521,8 +521,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     const bool dna = yChars != nullptr;
     if (hdp && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
         return fail(CPECAN_EINVAL, "HDP batches: posterior decode only, no cell dumps");
-    if (vanilla && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
-        return fail(CPECAN_EINVAL, "vanilla batches: posterior decode only, no cell dumps");
+    if (vanilla && (flags & CPECAN_FLAG_DEBUG_DUMP)) return fail(CPECAN_EINVAL, "vanilla batches: no cell dumps");
+    if (vanilla && mode == CPECAN_MODE_EXPECTATIONS && (flags & CPECAN_FLAG_UNBANDED))
+        return fail(CPECAN_EINVAL, "expectations run over the banded matrix only");
     const int S = dna ? 5 : 3; /* states per cell */
     if (!c || !items || nItems <= 0 || !xChars || (!events && !yChars) || !params || !out)
         return fail(CPECAN_EINVAL, "bad argument");
@@ -634,8 +635,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->nItems = nItems;
     b->mode = mode;
     b->flags = flags;
-    b->nModels = dna ? c->nModels5 : c->nModels;
-    b->expectLen = dna ? CPECAN_EXPECTATION5_LEN : CPECAN_EXPECTATION_LEN;
+    b->nModels = dna ? c->nModels5 : vanilla ? c->nModelsV : c->nModels;
+    b->expectLen = dna ? CPECAN_EXPECTATION5_LEN : vanilla ? CPECAN_EXPECTATIONV_LEN : CPECAN_EXPECTATION_LEN;
     b->P.threshold = params->threshold;
     b->P.minDiags = params->minDiagsBetweenTraceBack;
     b->P.tbDiags = params->traceBackDiagonals;
@@ -813,8 +814,9 @@ int cpecan_hip_batch_create_vanilla(cpecan_ctx *c, const cpecan_item *items, int
                                     const int64_t *anchors, int64_t nAnchorPairs,
                                     const cpecan_band_params *params, int32_t flags, cpecan_batch **out) {
     if (!events) return fail(CPECAN_EINVAL, "bad argument");
-    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs,
-                             params, CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out, true);
+    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs, params,
+                             (flags & CPECAN_FLAG_EXPECTATIONS) ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
+                             CPECAN_KERNEL_GENERAL, flags & ~CPECAN_FLAG_EXPECTATIONS, out, true);
 }
 
 int cpecan_hip_batch_create_hdp(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
@@ -869,7 +871,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            (const unsigned short *) b->kidx.p, (const double *) b->events.p,
                            (const double *) b->logNoise.p, (const double *) c->modelsV.p, b->Fstore.p,
                            b->Bstore.p, b->pairs.p, b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p,
-                           b->nTot.p);
+                           b->nTot.p, b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
     } else if (b->kernel == CPECAN_KERNEL_GENERAL) {
         hipLaunchKernelGGL(cpecan_k_general, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,

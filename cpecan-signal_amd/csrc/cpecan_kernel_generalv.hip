@@ -152,7 +152,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalv(
     const DevItem *items, DevParams P, const int *bandL, const int *bandR,
     const long long *cellPrefix, const unsigned short *kidx, const double *events,
     const double *logNoise, const double *models, double *Fstore, double *Bstore, long long *pairs,
-    double *pairLogp, long long *nPairs, long long *totXay, double *totVal, long long *nTot) {
+    double *pairLogp, long long *nPairs, long long *totXay, double *totVal, long long *nTot, double *expect) {
     const DevItem it = items[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     CtxV c;
@@ -169,6 +169,10 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalv(
     c.maxWidth = it.maxWidth;
 
     __shared__ double sTotal;
+    /* Baum-Welch sums of this alignment (VanillaHmm): 30 beta + 30 alpha skip bins and the likelihood,
+     * one copy per wave, folded into the model's block of `expect` at the end */
+    __shared__ double sExp[4][CP_EXPECTV_LEN + 1];
+    for (int i = tid; i < 4 * (CP_EXPECTV_LEN + 1); i += 256) (&sExp[0][0])[i] = 0.0;
     const long long D = it.lX + it.lY;
     long long myPairs = 0, myTot = 0;
     if (D == 0) {
@@ -287,6 +291,29 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalv(
                 __syncthreads();
             }
 
+            if (P.mode == 1) {
+                /* diagonalCalculation_Expectations :841-863 with cell_signal_updateBetaAndAlphaProb :478-498:
+                 * of all transitions only match->gapX (into the cell's skip bin) and gapX->gapX (bin + 30)
+                 * are collected; both live in the lower block */
+                double *acc = sExp[wave];
+                if (tid == 0) acc[CP_EXPECTV_LEN - 1] += total;
+                for (int cc = tid; cc < w2; cc += 256) {
+                    const int xmy = l2 + 2 * cc;
+                    const long long x = (d2 + xmy) / 2;
+                    const double *lower = fcellv(c, d2 - 1, xmy - 1);
+                    if (!lower) continue;
+                    int kPrev, kCur;
+                    kmers_of(c, x - 1, kPrev, kCur);
+                    const double *bl = bin_logs(c, kPrev, kCur);
+                    const int bin = (int) ((bl - (c.hdr + CP_VHDR_BINS)) / 5);
+                    const double *cur = bdd + cc * 3;
+                    atomicAdd(&acc[bin], exp(lower[0] + cur[1] + (0 + bl[0]) - total));
+                    atomicAdd(&acc[bin + 30], exp(lower[1] + cur[1] + (0 + bl[1]) - total));
+                }
+                __syncthreads();
+                continue;
+            }
+
             /* diagonalCalculationPosteriorMatchProbs :756-795, ordered emission by wave 0 */
             if (wave == 0) {
                 for (int base = 0; base < w2; base += 64) {
@@ -322,6 +349,14 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalv(
             __syncthreads();
         }
         tracedBackTo = tracedBackFrom;
+    }
+    if (P.mode == 1 && expect) {
+        __syncthreads();
+        double *dst = expect + (long long) it.model * CP_EXPECTV_LEN;
+        for (int i = tid; i < CP_EXPECTV_LEN; i += 256) {
+            const double v = ((sExp[0][i] + sExp[1][i]) + sExp[2][i]) + sExp[3][i];
+            if (v != 0.0) atomicAdd(dst + i, v);
+        }
     }
     if (tid == 0) {
         nPairs[blockIdx.x] = myPairs;

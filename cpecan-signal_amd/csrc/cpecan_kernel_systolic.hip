@@ -446,6 +446,9 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         x[0] = Fm; x[1] = Fx; x[2] = Fy; x[3] = em; x[4] = en;
     }
 
+    const long long tbFromL = tracedBackTo + P.minDiags;
+    const int tbFrom = uni((int) (tbFromL < 0x7fffffff ? tbFromL : 0x7fffffff));
+    const int tbWidth = uni((int) (widthLimit < 0x7fffffff ? widthLimit : 0x7fffffff));
     PROF_DECL
     /* blocks of SY_FEED diagonals: the loads sit between the blocks, the inner loop has none */
 #pragma unroll 1
@@ -567,7 +570,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         PROF(8)
 
         const bool atEnd = d == D;
-        const bool tb = d >= tracedBackTo + P.minDiags && (xmax - xmin + 1) <= P.expansion * 2 + 1;
+        const bool tb = d >= tbFrom && xmax - xmin < tbWidth; /* both wave-uniform 32-bit: scalar compares */
         if (atEnd || tb) { /* traceback point (:917-921): hand the window to the backward kernel */
             if (threadIdx.x == 0) {
                 const int from = d - (atEnd ? 0 : (int) P.tbDiags + 1);

@@ -750,8 +750,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
     const int kind = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
     const int dna = kind == 1, van = kind == 2, hdp = kind == 3;
-    if (kind > 1 && mode != 0)
-        die("cpecan: expectations run on the GPU path for the strawMan and the 5-state symbol machines only");
+    if (kind == 3 && mode != 0) die("cpecan: expectations do not run on the GPU path for the HDP machine");
     const int64_t xPad = dna ? 0 : KMER_LENGTH - 1; /* a k-mer sequence of lX elements spans lX + 5 chars */
     for (int64_t i = 0; i < n; i++) {
         if (check_known_combination(sMs[i], sXs[i], sYs[i]) != kind)
@@ -931,7 +930,8 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                                               unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
         else if (van)
             CHECK(cpecan_hip_batch_create_vanilla(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
-                                                  unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                                  (unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0) |
+                                                      (mode ? CPECAN_FLAG_EXPECTATIONS : 0), &batch));
         else
             CHECK(cpecan_hip_batch_create(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                           mode ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
@@ -987,6 +987,14 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                             if (e[25 + st * 16 + x * 4 + y] != 0.0)
                                 hmm->addToEmissionExpectationFcn(hmm, st, x, y, e[25 + st * 16 + x * 4 + y]);
                 hmm->likelihood += e[CPECAN_EXPECTATION5_LEN - 1];
+            }
+        } else if (van) {
+            VanillaHmmExpectations *hmm = hmmOut;
+            double e[CPECAN_EXPECTATIONV_LEN];
+            for (int32_t k = 0; k < nModels; k++) {
+                CHECK(cpecan_hip_batch_fetch_expectations(batch, ids[k], e));
+                for (int q = 0; q < 60; q++) hmm->kmerSkipBins[q] += e[q];
+                hmm->likelihood += e[60];
             }
         } else {
             ContinuousPairHmmExpectations *hmm = hmmOut;
@@ -1436,4 +1444,21 @@ void sequence_padSequence(Sequence *sequence) {
     strcpy(padded, old);
     strcat(padded, pad);
     sequence->elements = padded;
+}
+
+/* ---- vanilla machine: E-step entry and the M-step of its skip bins (impl/continuousHmm.c:420-462) ------- */
+void getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations *hmm, Sequence *SsX,
+                                        Sequence *SsY, stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                        bool raggedL, bool raggedR) {
+    if (sM->type != vanilla) die("cpecan: getVanillaExpectationsUsingAnchors takes a StateMachine3Vanilla");
+    run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmm);
+}
+void vanillaHmm_normalizeKmerSkipBins(VanillaHmmExpectations *hmm) {
+    double total = 0.0; /* alpha and beta bins together, as the reference does */
+    for (int i = 0; i < 60; i++) total += hmm->kmerSkipBins[i];
+    for (int i = 0; i < 60; i++) hmm->kmerSkipBins[i] = hmm->kmerSkipBins[i] / total;
+}
+void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, VanillaHmmExpectations *hmm) {
+    if (sM->type != vanilla) die("you gave me the wrong type of HMM");
+    for (int i = 0; i < 60; i++) sM->EMISSION_GAP_X_PROBS[i] = hmm->kmerSkipBins[i];
 }

@@ -316,6 +316,19 @@ void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM,
 void continuousPairHmm_writeToFile(ContinuousPairHmmExpectations *hmm, FILE *fileHandle);   /* :234-272 */
 ContinuousPairHmmExpectations *continuousPairHmm_loadFromFile(const char *fileName);         /* :274-370 */
 
+/* ---- expectations of the vanilla machine (VanillaHmm, impl/continuousHmm.c:373-466) ------------------- */
+typedef struct _vanillaHmmExpectations {
+    double likelihood;
+    double kmerSkipBins[60]; /* 0..29 beta (match -> gapX), 30..59 alpha (gapX -> gapX) */
+} VanillaHmmExpectations;
+/* getExpectationsUsingAnchors (:1571) with diagonalCalculation_Expectations for a StateMachine3Vanilla
+ * (cell_signal_updateBetaAndAlphaProb :478-498): adds this alignment's expectations to *hmm */
+void getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations *hmm, Sequence *SsX,
+                                        Sequence *SsY, stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                        bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+void vanillaHmm_normalizeKmerSkipBins(VanillaHmmExpectations *hmm);                        /* :420-429 */
+void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, VanillaHmmExpectations *hmm); /* :452-462 */
+
 /* ---- Hmm / HmmDiscrete: Baum-Welch for the 5-state symbol machine (inc/stateMachine.h:47-74,
  * inc/discreteHmm.h:9-52, impl/discreteHmm.c), the reference's own structs and signatures ---------- */
 typedef struct _hmm Hmm;

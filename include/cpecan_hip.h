@@ -161,7 +161,7 @@ typedef struct {
                                     the band instead of the sweep's candidate lists (the path a window falls
                                     back to by itself when its totals drift or a list overflows) */
 
-#define CPECAN_FLAG_EXPECTATIONS 8 /* cpecan_hip_batch_create_dna only: run diagonalCalculation_Expectations
+#define CPECAN_FLAG_EXPECTATIONS 8 /* cpecan_hip_batch_create_dna / _vanilla: run diagonalCalculation_Expectations
                                       (:841) instead of the posterior decode, as CPECAN_MODE_EXPECTATIONS does
                                       for the signal batches */
 
@@ -185,7 +185,7 @@ int cpecan_hip_batch_create_dna(cpecan_ctx *ctx, const cpecan_item *items, int64
 
 /* k-mers against events with a vanilla model (getAlignedPairsUsingAnchors with a StateMachine3Vanilla,
  * sequence_getKmer2 / sequence_getEvent): same buffers as cpecan_hip_batch_create, model_id is a
- * cpecan_hip_modelsv_create id.  Posterior decode on the general kernel; flags: UNBANDED only. */
+ * cpecan_hip_modelsv_create id.  General kernel; flags: UNBANDED or EXPECTATIONS. */
 int cpecan_hip_batch_create_vanilla(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
                                     const char *x_chars, int64_t n_x, const double *events, int64_t n_events,
                                     const int64_t *anchors, int64_t n_anchor_pairs,
@@ -229,6 +229,9 @@ int cpecan_hip_batch_fetch_totals(cpecan_batch *batch, int64_t item, int64_t *xa
 /* DNA batches (HmmDiscrete, impl/discreteHmm.c:10-153): 25 transitions [from*5+to], 5 x 16 emissions
  * [state*16 + x*4 + y] (cell_updateExpectations :407-424) + likelihood, per cpecan_hip_models5_create id */
 #define CPECAN_EXPECTATION5_LEN (25 + 5 * 16 + 1)
+/* vanilla batches (VanillaHmm, impl/continuousHmm.c:373-466): skip bins 0..29 beta (match -> gapX), 30..59
+ * alpha (gapX -> gapX) (cell_signal_updateBetaAndAlphaProb :478-498) + likelihood, per modelsv_create id */
+#define CPECAN_EXPECTATIONV_LEN (60 + 1)
 int cpecan_hip_batch_expectations_device_ptr(cpecan_batch *batch, void **dev_ptr, int64_t *n_doubles);
 int cpecan_hip_batch_fetch_expectations(cpecan_batch *batch, int32_t model_id, double *out);
 /* Debug: forward cells and backward cells (as they stand when posteriors are taken) of an item,

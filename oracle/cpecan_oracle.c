@@ -316,7 +316,7 @@ static inline void get_symbols(const seqs_t *s, int64_t ix, int64_t iy, symbols_
 typedef struct {
     double total;           /* totalProbability of the enclosing diagonal */
     orc_expectations *hmm;  /* an orc_expectations5 for the 5-state symbol machine */
-    int64_t kx, ky;
+    int64_t kx, ky, kp;
 } exp_args_t;
 
 typedef void (*trans_fn)(double *from, double *to, int f, int t, double eP, double tP, void *extra);
@@ -342,6 +342,19 @@ static void trans_expect_sm3(double *from, double *to, int f, int t, double eP, 
         if (a->kx >= 0 && a->kx < ORC_NUM_KMERS) /* reference writes out of bounds otherwise */
             a->hmm->kmerGap[a->kx] += p;
     }
+}
+
+/* cell_signal_updateBetaAndAlphaProb :478-498: the skip bin of the cell's k-mer pair (taken on the hmm's
+ * copy of the match model, vanillaHmm_implantMatchModelsintoHmm) collects match->gapX in bin and
+ * gapX->gapX in bin + 30 */
+static const double *g_vanilla_match; /* the running model's match table (test infrastructure: one thread) */
+static void trans_expect_vanilla(double *from, double *to, int f, int t, double eP, double tP, void *e) {
+    exp_args_t *a = (exp_args_t *) e;
+    orc_expectations_v *h = (orc_expectations_v *) a->hmm;
+    const int64_t bin = skip_bin(g_vanilla_match, a->kp, a->kx);
+    double p = exp(from[f] + to[t] + (eP + tP) - a->total);
+    if (f == 0 && t == 1) h->kmerSkipBins[bin] += p;
+    if (f == 1 && t == 1) h->kmerSkipBins[bin + 30] += p;
 }
 
 /* cell_updateExpectations :407-424 (HmmDiscrete: transitions [from*5+to], emissions [to][x][y]) */
@@ -696,7 +709,7 @@ static void diag_calc(const seqs_t *sq, dpm_t *mc, dpm_t *m1, dpm_t *m2, int64_t
         double *lower = m1 ? dpm_cell(m1, xay - 1, xmy - 1) : NULL;
         double *middle = m2 ? dpm_cell(m2, xay - 2, xmy) : NULL;
         double *upper = m1 ? dpm_cell(m1, xay - 1, xmy + 1) : NULL;
-        if (ea) { ea->kx = sy.kx; ea->ky = sy.ky; }
+        if (ea) { ea->kx = sy.kx; ea->ky = sy.ky; ea->kp = sy.kp; }
         cell_calc(sq->m, cur, lower, middle, upper, &sy, fn, ea);
     }
 }
@@ -755,7 +768,13 @@ static void posterior_match_probs(dpm_t *F, dpm_t *B, int64_t xay, double total,
 /* diagonalCalculation_Expectations :841-863 */
 static void expectations_diag(const seqs_t *sq, dpm_t *F, dpm_t *B, int64_t xay, double total,
                               orc_expectations *hmm) {
-    exp_args_t ea = { total, hmm, 0, 0 };
+    exp_args_t ea = { total, hmm, 0, 0, 0 };
+    if (sq->m->kind == ORC_SM3_VANILLA) {
+        g_vanilla_match = sq->m->match;
+        ((orc_expectations_v *) hmm)->likelihood += total;
+        diag_calc(sq, B, F, F, xay, trans_expect_vanilla, &ea);
+        return;
+    }
     if (sq->m->kind == ORC_SM5_SYMBOL) {
         ((orc_expectations5 *) hmm)->likelihood += total;
         diag_calc(sq, B, F, F, xay, trans_expect_sm5, &ea);
@@ -950,6 +969,17 @@ int orc_aligned_pairs_without_banding(const orc_model *m, const char *x, int64_t
     dpm_free(&B);
     free(L); free(R);
     return 0;
+}
+
+int orc_expectations_v_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
+                                     const int64_t *anchors, int64_t nAnchors, const orc_params *p,
+                                     int raggedLeft, int raggedRight, orc_expectations_v *hmm) {
+    if (m->kind != ORC_SM3_VANILLA) return -2;
+    orc_result *scratch = orc_result_new();
+    int rc = orc_aligned_pairs_using_anchors(m, x, lX, y, lY, anchors, nAnchors, p, raggedLeft, raggedRight,
+                                             (orc_expectations *) hmm, scratch);
+    orc_result_free(scratch);
+    return rc;
 }
 
 int orc_expectations5_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,

@@ -155,6 +155,16 @@ int orc_banded_dump(const orc_model *m, const char *x, int64_t lX, const void *y
 
 /* continuousPairHmm_normalize, impl/continuousHmm.c:174-204 */
 void orc_expectations_normalize(orc_expectations *e);
+/* sufficient statistics of the vanilla signal HMM (VanillaHmm, impl/continuousHmm.c:373-466 with
+ * cell_signal_updateBetaAndAlphaProb impl/pairwiseAligner.c:478-498): bins 0..29 beta (match -> gapX),
+ * 30..59 alpha (gapX -> gapX) */
+typedef struct {
+    double kmerSkipBins[60];
+    double likelihood;
+} orc_expectations_v;
+int orc_expectations_v_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
+                                     const int64_t *anchors, int64_t nAnchors, const orc_params *p,
+                                     int raggedLeft, int raggedRight, orc_expectations_v *hmm);
 /* getExpectationsUsingAnchors (:1571) for an ORC_SM5_SYMBOL model: adds to *hmm */
 int orc_expectations5_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
                                     const int64_t *anchors, int64_t nAnchors, const orc_params *p,

@@ -43,6 +43,13 @@ class OrcExpectations5(C.Structure):
         return np.concatenate([np.array(self.transitions), np.array(self.emissions), [self.likelihood]])
 
 
+class OrcExpectationsV(C.Structure):
+    _fields_ = [("kmerSkipBins", C.c_double * 60), ("likelihood", C.c_double)]
+
+    def as_array(self):
+        return np.concatenate([np.array(self.kmerSkipBins), [self.likelihood]])
+
+
 class OrcResult(C.Structure):
     _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("triples", C.POINTER(C.c_int64)),
                 ("logp", C.POINTER(C.c_double)), ("nTotals", C.c_int64), ("capTotals", C.c_int64),
@@ -105,6 +112,10 @@ def lib():
             C.POINTER(OrcResult)]
         L.orc_expectations_normalize.argtypes = [C.POINTER(OrcExpectations)]
         L.orc_expectations5_normalize.argtypes = [C.POINTER(OrcExpectations5)]
+        L.orc_expectations_v_using_anchors.restype = C.c_int
+        L.orc_expectations_v_using_anchors.argtypes = [
+            C.POINTER(OrcModel), C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.POINTER(OrcParams), C.c_int, C.c_int, C.POINTER(OrcExpectationsV)]
         L.orc_expectations5_using_anchors.restype = C.c_int
         L.orc_expectations5_using_anchors.argtypes = [
             C.POINTER(OrcModel), C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -316,6 +327,18 @@ def aligned_pairs_using_anchors(model, x, lX, y, anchors, params, ragged_left=Fa
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
     return out
+
+
+def expectations_v_using_anchors(model, x, lX, y, anchors, params, hmm, ragged_left=False, ragged_right=False):
+    """getExpectationsUsingAnchors for the vanilla signal machine: adds this alignment to hmm."""
+    xb, keep, yptr, lY = _xy(model, x, y)
+    a = np.ascontiguousarray(anchors, dtype=np.int64).reshape(-1, 2)
+    rc = lib().orc_expectations_v_using_anchors(C.byref(model.c), xb, lX, yptr, lY, _ptr(a), a.shape[0],
+                                                C.byref(params), int(ragged_left), int(ragged_right),
+                                                C.byref(hmm))
+    if rc != 0:
+        raise RuntimeError("oracle failed rc=%d" % rc)
+    return hmm
 
 
 def expectations5_using_anchors(model, x, lX, y, anchors, params, hmm, ragged_left=False, ragged_right=False):

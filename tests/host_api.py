@@ -75,7 +75,13 @@ EXPORTS = [
     "emissions_discrete_getBaseIndex", "stateMachineFunctions_construct", "getStateMachine5",
     "diagonalCalculation_Expectations", "getExpectationsUsingAnchors", "getExpectations",
     "getIndelProbabilities", "reweightAlignedPairs", "reweightAlignedPairs2", "sequence_padSequence",
+    "getVanillaExpectationsUsingAnchors", "vanillaHmm_normalizeKmerSkipBins",
+    "vanillaHmm_loadKmerSkipBinExpectations",
 ]
+
+
+class VanillaExpectations(C.Structure):
+    _fields_ = [("likelihood", C.c_double), ("kmerSkipBins", C.c_double * 60)]
 
 
 class Hmm(C.Structure):
@@ -214,6 +220,10 @@ def lib():
         L.getStateMachine5.restype = C.POINTER(StateMachine5)
         L.getStateMachine5.argtypes = [HP, vp]
         L.getExpectationsUsingAnchors.argtypes = [vp, HP, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
+        L.getVanillaExpectationsUsingAnchors.argtypes = [vp, C.POINTER(VanillaExpectations), vp, vp, vp,
+                                                         C.POINTER(Params), C.c_bool, C.c_bool]
+        L.vanillaHmm_normalizeKmerSkipBins.argtypes = [C.POINTER(VanillaExpectations)]
+        L.vanillaHmm_loadKmerSkipBinExpectations.argtypes = [vp, C.POINTER(VanillaExpectations)]
         L.getIndelProbabilities.restype = C.POINTER(C.c_int64)
         L.getIndelProbabilities.argtypes = [vp, C.c_int64, C.c_bool]
         L.reweightAlignedPairs2.restype = vp

@@ -255,6 +255,19 @@ def test_vanilla_zymo_read_through_host_api(golden_dir, zymo_read, template_mode
     ref = o.aligned_pairs_using_anchors(om, ref_seq, lX, zymo_read["template_events"], anchors, op, True, True)
     assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
     assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+
+    # the E-step of the same alignment (split sub-alignments included), then the M-step of the skip bins
+    hmm = h.VanillaExpectations()
+    L.getVanillaExpectationsUsingAnchors(sm, C.byref(hmm), sX, sY, lst, p, True, True)
+    want = o.expectations_v_using_anchors(om, ref_seq, lX, zymo_read["template_events"], anchors, op,
+                                          o.OrcExpectationsV(), True, True)
+    assert np.allclose(list(hmm.kmerSkipBins), list(want.kmerSkipBins), rtol=1e-9, atol=1e-12)
+    assert np.isclose(hmm.likelihood, want.likelihood, rtol=1e-12) and hmm.likelihood < 0
+    assert np.count_nonzero(list(hmm.kmerSkipBins)) > 30
+    L.vanillaHmm_normalizeKmerSkipBins(C.byref(hmm))
+    assert abs(sum(hmm.kmerSkipBins) - 1.0) < 1e-12
+    L.vanillaHmm_loadKmerSkipBinExpectations(sm, C.byref(hmm))
+    assert C.cast(sm, C.POINTER(h.StateMachine)).contents.EMISSION_GAP_X_PROBS[31] == hmm.kmerSkipBins[31]
     L.stList_destruct(lst)
     L.sequence_sequenceDestroy(sX)
     L.sequence_sequenceDestroy(sY)

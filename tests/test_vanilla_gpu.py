@@ -91,3 +91,34 @@ def test_vanilla_matches_oracle(ctx, case):
         strand = (np.float32(0.17), np.float32(0.55)) if i % 2 == 0 else (np.float32(0.14), np.float32(0.49))
         models.append(o.VanillaModel(match, skip_bins(i), gapy, float(strand[0]), float(strand[1])))
     run(ctx, batch, models, band_params(0.01, case["md"], case["tb"], case["e"]), case["ragged"])
+
+
+def test_vanilla_expectations_match_oracle(ctx):
+    """Baum-Welch sums of the vanilla machine (diagonalCalculation_Expectations with
+    cell_signal_updateBetaAndAlphaProb, impl/pairwiseAligner.c:478-498): 30 beta + 30 alpha skip bins and the
+    likelihood, per model.  Per-cell terms are added in another order than the host loop: 1e-9 relative."""
+    batch = synth.make_batch(57, 4, 150, 310, anchor_every=30)
+    models = [o.VanillaModel(match, skip_bins(i), gapy) for i, (match, _, gapy) in enumerate(batch["models"])]
+    bp = band_params(0.01, 60, 10, 20)
+    ctx.models_clear()
+    ids = ctx.modelsv_create([(m.scalars, m.match, m.skip, m.gap_y) for m in models])
+    b = cp.Batch(ctx, make_items(batch, (1, 1)), batch["x_chars"], batch["events"], batch["anchors"], bp,
+                 flags=cp.FLAG_EXPECTATIONS, vanilla=True)
+    b.run()
+    b.sync()
+    p = orc_params(bp, split=1 << 60)
+    hmms = [o.OrcExpectationsV() for _ in models]
+    for it in batch["items"]:
+        x = batch["x_chars"][it["x_offset"]: it["x_offset"] + it["lX"] + 5]
+        ev = batch["events"][it["y_offset"]: it["y_offset"] + it["lY"]]
+        an = batch["anchors"][it["anchor_offset"]: it["anchor_offset"] + it["n_anchors"]]
+        o.expectations_v_using_anchors(models[it["model"]], x, it["lX"], ev, an, p, hmms[it["model"]], True, True)
+    seen = 0
+    for mid, hmm in zip(ids, hmms):
+        ref = hmm.as_array()
+        got = b.expectations(mid)
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
+        seen += np.count_nonzero(ref[:60])
+        assert ref[-1] < 0
+    assert seen > 20  # several beta and alpha bins were hit
+    b.close()
