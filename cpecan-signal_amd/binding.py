@@ -28,6 +28,7 @@ MODEL_TABLE_LEN = 1 + NUM_KMERS * 5
 EXPECTATION_LEN = 9 + NUM_KMERS + 1
 EXPECTATION5_LEN = 25 + 5 * 16 + 1
 EXPECTATIONV_LEN = 60 + 1
+EXPECTATIONH_LEN = 9 + 1
 
 # every symbol include/cpecan_hip.h declares
 EXPORTS = [
@@ -337,6 +338,7 @@ class Batch:
         self.n = items.shape[0]
         self.dna = y_chars is not None
         self.vanilla = bool(vanilla) and not self.dna
+        self.hdp = bool(hdp) and not self.dna
 
     def run(self):
         _check(lib().cpecan_hip_batch_run(self.h))
@@ -380,7 +382,8 @@ class Batch:
         return xay[:n], tot[:n]
 
     def expectations(self, model_id):
-        out = np.zeros(EXPECTATION5_LEN if self.dna else EXPECTATIONV_LEN if self.vanilla else EXPECTATION_LEN)
+        out = np.zeros(EXPECTATION5_LEN if self.dna else EXPECTATIONV_LEN if self.vanilla
+                       else EXPECTATIONH_LEN if self.hdp else EXPECTATION_LEN)
         _check(lib().cpecan_hip_batch_fetch_expectations(self.h, int(model_id), _ptr(out)))
         return out
 

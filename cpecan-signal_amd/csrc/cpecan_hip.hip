@@ -44,7 +44,7 @@ struct DevHdpModel { /* as in cpecan_kernel_generalh.hip */
 extern "C" __global__ void cpecan_k_generalh(const DevItem *, DevParams, const int *, const int *,
                                              const long long *, const int *, const double *,
                                              const DevHdpModel *, double *, double *, long long *, double *,
-                                             long long *, long long *, double *, long long *);
+                                             long long *, long long *, double *, long long *, double *);
 extern "C" __global__ void cpecan_k_hdp_kmer_id(const char *, long long, unsigned long long,
                                                 unsigned long long, int, int *);
 extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned short *);
@@ -519,8 +519,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                              const cpecan_band_params *params, int32_t mode, int32_t kernel,
                              int32_t flags, cpecan_batch **out, bool vanilla = false, bool hdp = false) {
     const bool dna = yChars != nullptr;
-    if (hdp && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
-        return fail(CPECAN_EINVAL, "HDP batches: posterior decode only, no cell dumps");
+    if (hdp && (flags & CPECAN_FLAG_DEBUG_DUMP)) return fail(CPECAN_EINVAL, "HDP batches: no cell dumps");
+    if (hdp && mode == CPECAN_MODE_EXPECTATIONS && (flags & CPECAN_FLAG_UNBANDED))
+        return fail(CPECAN_EINVAL, "expectations run over the banded matrix only");
     if (vanilla && (flags & CPECAN_FLAG_DEBUG_DUMP)) return fail(CPECAN_EINVAL, "vanilla batches: no cell dumps");
     if (vanilla && mode == CPECAN_MODE_EXPECTATIONS && (flags & CPECAN_FLAG_UNBANDED))
         return fail(CPECAN_EINVAL, "expectations run over the banded matrix only");
@@ -635,8 +636,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->nItems = nItems;
     b->mode = mode;
     b->flags = flags;
-    b->nModels = dna ? c->nModels5 : vanilla ? c->nModelsV : c->nModels;
-    b->expectLen = dna ? CPECAN_EXPECTATION5_LEN : vanilla ? CPECAN_EXPECTATIONV_LEN : CPECAN_EXPECTATION_LEN;
+    b->nModels = dna ? c->nModels5 : vanilla ? c->nModelsV : hdp ? (int) c->hostModelsH.size() : c->nModels;
+    b->expectLen = dna ? CPECAN_EXPECTATION5_LEN : vanilla ? CPECAN_EXPECTATIONV_LEN
+                   : hdp ? CPECAN_EXPECTATIONH_LEN : CPECAN_EXPECTATION_LEN;
     b->P.threshold = params->threshold;
     b->P.minDiags = params->minDiagsBetweenTraceBack;
     b->P.tbDiags = params->traceBackDiagonals;
@@ -824,8 +826,9 @@ int cpecan_hip_batch_create_hdp(cpecan_ctx *c, const cpecan_item *items, int64_t
                                 const int64_t *anchors, int64_t nAnchorPairs,
                                 const cpecan_band_params *params, int32_t flags, cpecan_batch **out) {
     if (!events) return fail(CPECAN_EINVAL, "bad argument");
-    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs,
-                             params, CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out, false, true);
+    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs, params,
+                             (flags & CPECAN_FLAG_EXPECTATIONS) ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
+                             CPECAN_KERNEL_GENERAL, flags & ~CPECAN_FLAG_EXPECTATIONS, out, false, true);
 }
 
 int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t nItems,
@@ -862,7 +865,8 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
                            (const int *) b->kid.p, (const double *) b->events.p,
                            (const DevHdpModel *) c->modelsH.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
-                           b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p);
+                           b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
+                           b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
     } else if (b->vanilla) {
         hipLaunchKernelGGL(cpecan_k_generalv, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,

@@ -140,7 +140,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalh(
     const DevItem *items, DevParams P, const int *bandL, const int *bandR,
     const long long *cellPrefix, const int *kid, const double *events,
     const DevHdpModel *models, double *Fstore, double *Bstore, long long *pairs,
-    double *pairLogp, long long *nPairs, long long *totXay, double *totVal, long long *nTot) {
+    double *pairLogp, long long *nPairs, long long *totXay, double *totVal, long long *nTot, double *expect) {
     const DevItem it = items[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     CtxH c;
@@ -156,6 +156,9 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalh(
     c.maxWidth = it.maxWidth;
 
     __shared__ double sTotal;
+    __shared__ double sExp[16];
+    double expAcc[10]; /* per-thread partial expectations: 9 transitions + likelihood */
+    for (int i = 0; i < 10; i++) expAcc[i] = 0.0;
     const long long D = it.lX + it.lY;
     long long myPairs = 0, myTot = 0;
     if (D == 0) {
@@ -279,6 +282,80 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalh(
                 __syncthreads();
             }
 
+            if (P.mode == 1) {
+                /* diagonalCalculation_Expectations :841-863 with
+                 * cell_signal_updateTransAndKmerSkipExpectations2 :445-476: every transition adds its posterior
+                 * to the transition counts; one INTO match with posterior >= the HdpHmm's threshold (carried in
+                 * P.threshold) also assigns the cell's event to its k-mer.  Assignments come out in the host
+                 * loop's order (cells by x-y, per cell from match, gapX, gapY) as (from, x-1, y-1) triples. */
+                if (tid == 0) expAcc[9] += total;
+                const bool haveMiddle = d2 - 2 >= tracedBackTo; /* forward[d2-2] is freed otherwise (:982) */
+                for (int cc = tid; cc < w2; cc += 256) {
+                    const int xmy = l2 + 2 * cc;
+                    const long long x = (d2 + xmy) / 2, y = (d2 - xmy) / 2;
+                    const double *cur = bdd + cc * 3;
+                    const double *lower = fcellh(c, d2 - 1, xmy - 1);
+                    const double *middle = haveMiddle ? fcellh(c, d2 - 2, xmy) : nullptr;
+                    const double *upper = fcellh(c, d2 - 1, xmy + 1);
+                    if (lower) {
+                        expAcc[0 * 3 + 1] += exp(lower[0] + cur[1] + (GAPX_EP + t[T_GAP_OPEN_X]) - total);
+                        expAcc[1 * 3 + 1] += exp(lower[1] + cur[1] + (GAPX_EP + t[T_GAP_EXTEND_X]) - total);
+                        expAcc[2 * 3 + 1] += exp(lower[2] + cur[1] + (GAPX_EP + t[T_GAP_SWITCH_TO_X]) - total);
+                    }
+                    if (middle) {
+                        const double eP = density(c, x - 1, y - 1);
+                        expAcc[0 * 3 + 0] += exp(middle[0] + cur[0] + (eP + t[T_MATCH_CONTINUE]) - total);
+                        expAcc[1 * 3 + 0] += exp(middle[1] + cur[0] + (eP + t[T_MATCH_FROM_GAP_X]) - total);
+                        expAcc[2 * 3 + 0] += exp(middle[2] + cur[0] + (eP + t[T_MATCH_FROM_GAP_Y]) - total);
+                    }
+                    if (upper) {
+                        const double eP = density(c, x - 1, y - 1);
+                        expAcc[0 * 3 + 2] += exp(upper[0] + cur[2] + (eP + t[T_GAP_OPEN_Y]) - total);
+                        expAcc[2 * 3 + 2] += exp(upper[2] + cur[2] + (eP + t[T_GAP_EXTEND_Y]) - total);
+                    }
+                }
+                if (wave == 0 && haveMiddle) {
+                    for (int base = 0; base < w2; base += 64) {
+                        const int cc = base + lane;
+                        double e[3] = { 0.0, 0.0, 0.0 };
+                        bool hit[3] = { false, false, false };
+                        long long x = 0, y = 0;
+                        if (cc < w2) {
+                            const int xmy = l2 + 2 * cc;
+                            x = (d2 + xmy) / 2;
+                            y = (d2 - xmy) / 2;
+                            const double *middle = fcellh(c, d2 - 2, xmy);
+                            if (middle) {
+                                const double eP = density(c, x - 1, y - 1), cm = bdd[cc * 3];
+                                e[0] = middle[0] + cm + (eP + t[T_MATCH_CONTINUE]) - total;
+                                e[1] = middle[1] + cm + (eP + t[T_MATCH_FROM_GAP_X]) - total;
+                                e[2] = middle[2] + cm + (eP + t[T_MATCH_FROM_GAP_Y]) - total;
+#pragma unroll
+                                for (int f = 0; f < 3; f++) hit[f] = exp(e[f]) >= P.threshold;
+                            }
+                        }
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]), m2 = __ballot(hit[2]);
+                        long long idx = myPairs + __popcll(m0 & below) + __popcll(m1 & below) + __popcll(m2 & below);
+#pragma unroll
+                        for (int f = 0; f < 3; f++) {
+                            if (!hit[f]) continue;
+                            if (idx < it.pairCap) {
+                                long long *o = pairs + (it.pairBase + idx) * 3;
+                                o[0] = f;
+                                o[1] = x - 1;
+                                o[2] = y - 1;
+                                pairLogp[it.pairBase + idx] = e[f];
+                            }
+                            idx++;
+                        }
+                        myPairs += __popcll(m0) + __popcll(m1) + __popcll(m2);
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+
             /* diagonalCalculationPosteriorMatchProbs :756-795, ordered emission by wave 0 */
             if (wave == 0) {
                 for (int base = 0; base < w2; base += 64) {
@@ -314,6 +391,18 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_generalh(
             __syncthreads();
         }
         tracedBackTo = tracedBackFrom;
+    }
+    if (P.mode == 1 && expect) {
+        /* block reduction of the per-thread partial sums, then one atomic per value */
+        if (tid < 16) sExp[tid] = 0.0;
+        __syncthreads();
+        for (int i = 0; i < 10; i++) {
+            double v = expAcc[i];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0) atomicAdd(&sExp[i], v);
+        }
+        __syncthreads();
+        if (tid < 10) atomicAdd(expect + (long long) it.model * 10 + tid, sExp[tid]);
     }
     if (tid == 0) {
         nPairs[blockIdx.x] = myPairs;

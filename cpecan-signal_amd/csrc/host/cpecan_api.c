@@ -750,7 +750,6 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
     const int kind = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
     const int dna = kind == 1, van = kind == 2, hdp = kind == 3;
-    if (kind == 3 && mode != 0) die("cpecan: expectations do not run on the GPU path for the HDP machine");
     const int64_t xPad = dna ? 0 : KMER_LENGTH - 1; /* a k-mer sequence of lX elements spans lX + 5 chars */
     for (int64_t i = 0; i < n; i++) {
         if (check_known_combination(sMs[i], sXs[i], sYs[i]) != kind)
@@ -920,6 +919,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     if (nItems > 0) {
         cpecan_band_params bp = { p->threshold, p->minDiagsBetweenTraceBack, p->traceBackDiagonals,
                                   p->diagonalExpansion };
+        if (hdp && mode) bp.threshold = ((HdpHmmExpectations *) hmmOut)->threshold; /* the assignment bar */
         cpecan_batch *batch = NULL;
         if (dna)
             CHECK(cpecan_hip_batch_create_dna(ctx, items, nItems, chars, xo, ychars, yo, anchors, ao, &bp,
@@ -927,7 +927,8 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                                                   (mode ? CPECAN_FLAG_EXPECTATIONS : 0), &batch));
         else if (hdp)
             CHECK(cpecan_hip_batch_create_hdp(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
-                                              unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                              (unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0) |
+                                                  (mode ? CPECAN_FLAG_EXPECTATIONS : 0), &batch));
         else if (van)
             CHECK(cpecan_hip_batch_create_vanilla(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                                   (unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0) |
@@ -988,6 +989,36 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                                 hmm->addToEmissionExpectationFcn(hmm, st, x, y, e[25 + st * 16 + x * 4 + y]);
                 hmm->likelihood += e[CPECAN_EXPECTATION5_LEN - 1];
             }
+        } else if (hdp) {
+            HdpHmmExpectations *hmm = hmmOut;
+            double e[CPECAN_EXPECTATIONH_LEN];
+            for (int32_t k = 0; k < nModels; k++) {
+                CHECK(cpecan_hip_batch_fetch_expectations(batch, ids[k], e));
+                for (int q = 0; q < 9; q++) hmm->transitions[q] += e[q];
+                hmm->likelihood += e[9];
+            }
+            /* assignments, sub-alignment after sub-alignment as the reference walks them: (k-mer, event mean) */
+            int64_t *np = malloc(sizeof(int64_t) * (size_t) nItems);
+            CHECK(cpecan_hip_batch_counts(batch, np, NULL, NULL));
+            for (int64_t i = 0; i < n; i++)
+                for (int64_t k = firstItem[i]; k < firstItem[i + 1]; k++) {
+                    int64_t *tri = malloc(sizeof(int64_t) * 3 * (size_t) (np[k] + 1));
+                    CHECK(cpecan_hip_batch_fetch_pairs(batch, k, tri, NULL, np[k] + 1));
+                    for (int64_t q = 0; q < np[k]; q++) {
+                        const int64_t x = tri[3 * q + 1] + origin[k].x1, y = tri[3 * q + 2] + origin[k].y1;
+                        if (hmm->numberOfAssignments == hmm->capacity) {
+                            hmm->capacity = hmm->capacity ? 2 * hmm->capacity : 1024;
+                            hmm->eventAssignments = realloc(hmm->eventAssignments, sizeof(double) * (size_t) hmm->capacity);
+                            hmm->kmerAssignments = realloc(hmm->kmerAssignments, (size_t) hmm->capacity * (KMER_LENGTH + 1));
+                        }
+                        char *dst = hmm->kmerAssignments + hmm->numberOfAssignments * (KMER_LENGTH + 1);
+                        memcpy(dst, (const char *) sXs[i]->elements + (x >= 0 ? x : 0), KMER_LENGTH);
+                        dst[KMER_LENGTH] = 0;
+                        hmm->eventAssignments[hmm->numberOfAssignments++] = ((const double *) sYs[i]->elements)[3 * y];
+                    }
+                    free(tri);
+                }
+            free(np);
         } else if (van) {
             VanillaHmmExpectations *hmm = hmmOut;
             double e[CPECAN_EXPECTATIONV_LEN];
@@ -1461,4 +1492,51 @@ void vanillaHmm_normalizeKmerSkipBins(VanillaHmmExpectations *hmm) {
 void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, VanillaHmmExpectations *hmm) {
     if (sM->type != vanilla) die("you gave me the wrong type of HMM");
     for (int i = 0; i < 60; i++) sM->EMISSION_GAP_X_PROBS[i] = hmm->kmerSkipBins[i];
+}
+
+/* ---- HDP machine: E-step entry, transition M-step and the .expectations file (impl/continuousHmm.c:631-753) -- */
+HdpHmmExpectations *hdpHmm_constructEmpty(double pseudocount, double threshold) {
+    HdpHmmExpectations *h = calloc(1, sizeof *h);
+    for (int i = 0; i < 9; i++) h->transitions[i] = pseudocount;
+    h->threshold = threshold;
+    return h;
+}
+void hdpHmm_destruct(HdpHmmExpectations *hmm) {
+    free(hmm->eventAssignments);
+    free(hmm->kmerAssignments);
+    free(hmm);
+}
+void getHdpExpectationsUsingAnchors(StateMachine *sM, HdpHmmExpectations *hmm, Sequence *SsX, Sequence *SsY,
+                                    stList *anchorPairs, PairwiseAlignmentParameters *p, bool raggedL, bool raggedR) {
+    if (sM->type != threeStateHdp) die("cpecan: getHdpExpectationsUsingAnchors takes a StateMachine3_HDP");
+    run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmm);
+}
+void hdpHmm_loadTransitions(StateMachine *sM, HdpHmmExpectations *hmm) {
+    StateMachine3_HDP *s = (StateMachine3_HDP *) sM;
+    const double *t = hmm->transitions;
+    s->TRANSITION_MATCH_CONTINUE = log(t[match * 3 + match]);
+    s->TRANSITION_GAP_OPEN_X = log(t[match * 3 + shortGapX]);
+    s->TRANSITION_GAP_OPEN_Y = log(t[match * 3 + shortGapY]);
+    s->TRANSITION_MATCH_FROM_GAP_X = log(t[shortGapX * 3 + match]);
+    s->TRANSITION_GAP_EXTEND_X = log(1 - t[shortGapX * 3 + match]); /* tied to the line above */
+    s->TRANSITION_GAP_SWITCH_TO_Y = LOG_ZERO;                       /* no skip -> extra event */
+    s->TRANSITION_MATCH_FROM_GAP_Y = log(t[shortGapY * 3 + match]);
+    s->TRANSITION_GAP_EXTEND_Y = log(t[shortGapY * 3 + shortGapY]);
+    s->TRANSITION_GAP_SWITCH_TO_X = log(t[shortGapY * 3 + shortGapX]);
+}
+void hdpHmm_writeToFile(HdpHmmExpectations *hmm, FILE *fh) {
+    fprintf(fh, "%i\t%lld\t%lf\t%lld\t\n", (int) threeStateHdp, 3ll, hmm->threshold,
+            (long long) hmm->numberOfAssignments);
+    for (int i = 0; i < 9; i++)
+        if (isnan(hmm->transitions[i])) {
+            fprintf(stdout, "GOT NaN TRANS\n");
+            return;
+        }
+    for (int i = 0; i < 9; i++) fprintf(fh, "%f\t", hmm->transitions[i]);
+    fprintf(fh, "%f\n", hmm->likelihood);
+    for (int64_t i = 0; i < hmm->numberOfAssignments; i++) fprintf(fh, "%lf\t", hmm->eventAssignments[i]);
+    fprintf(fh, "\n");
+    for (int64_t i = 0; i < hmm->numberOfAssignments; i++)
+        fprintf(fh, "%.*s\t", KMER_LENGTH, hmm->kmerAssignments + i * (KMER_LENGTH + 1));
+    fprintf(fh, "\n");
 }

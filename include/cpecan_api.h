@@ -329,6 +329,26 @@ void getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations
 void vanillaHmm_normalizeKmerSkipBins(VanillaHmmExpectations *hmm);                        /* :420-429 */
 void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, VanillaHmmExpectations *hmm); /* :452-462 */
 
+/* ---- expectations of the HDP machine (HdpHmm, inc/continuousHmm.h:26-36, impl/continuousHmm.c:631-790) ----- */
+typedef struct _hdpHmmExpectations {
+    double likelihood;
+    double transitions[9];     /* [from * 3 + to] */
+    double threshold;          /* a transition into match with posterior >= threshold assigns event to k-mer */
+    int64_t numberOfAssignments;
+    int64_t capacity;
+    double *eventAssignments;  /* [numberOfAssignments] event means */
+    char *kmerAssignments;     /* [numberOfAssignments][KMER_LENGTH + 1], NUL-terminated copies */
+} HdpHmmExpectations;
+HdpHmmExpectations *hdpHmm_constructEmpty(double pseudocount, double threshold);
+void hdpHmm_destruct(HdpHmmExpectations *hmm);
+/* getExpectationsUsingAnchors (:1571) with diagonalCalculation_Expectations for a StateMachine3_HDP
+ * (cell_signal_updateTransAndKmerSkipExpectations2 :445-476): adds this alignment to *hmm */
+void getHdpExpectationsUsingAnchors(StateMachine *sM, HdpHmmExpectations *hmm, Sequence *SsX, Sequence *SsY,
+                                    stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                    bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+void hdpHmm_loadTransitions(StateMachine *sM, HdpHmmExpectations *hmm);      /* :681-699 */
+void hdpHmm_writeToFile(HdpHmmExpectations *hmm, FILE *fileHandle);          /* :701-753, the .expectations file */
+
 /* ---- Hmm / HmmDiscrete: Baum-Welch for the 5-state symbol machine (inc/stateMachine.h:47-74,
  * inc/discreteHmm.h:9-52, impl/discreteHmm.c), the reference's own structs and signatures ---------- */
 typedef struct _hmm Hmm;

@@ -161,7 +161,7 @@ typedef struct {
                                     the band instead of the sweep's candidate lists (the path a window falls
                                     back to by itself when its totals drift or a list overflows) */
 
-#define CPECAN_FLAG_EXPECTATIONS 8 /* cpecan_hip_batch_create_dna / _vanilla: run diagonalCalculation_Expectations
+#define CPECAN_FLAG_EXPECTATIONS 8 /* cpecan_hip_batch_create_dna / _vanilla / _hdp: run diagonalCalculation_Expectations
                                       (:841) instead of the posterior decode, as CPECAN_MODE_EXPECTATIONS does
                                       for the signal batches */
 
@@ -193,8 +193,8 @@ int cpecan_hip_batch_create_vanilla(cpecan_ctx *ctx, const cpecan_item *items, i
 
 /* k-mers against events with an HDP model (getAlignedPairsUsingAnchors with a StateMachine3_HDP,
  * sequence_getKmer3 / sequence_getEvent): same buffers as cpecan_hip_batch_create (x characters over the
- * model's alphabet), model_id is a cpecan_hip_modelsh_create id.  Posterior decode on the general kernel;
- * flags: UNBANDED only. */
+ * model's alphabet), model_id is a cpecan_hip_modelsh_create id.  General kernel; flags: UNBANDED or
+ * EXPECTATIONS. */
 int cpecan_hip_batch_create_hdp(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
                                 const char *x_chars, int64_t n_x, const double *events, int64_t n_events,
                                 const int64_t *anchors, int64_t n_anchor_pairs,
@@ -232,6 +232,12 @@ int cpecan_hip_batch_fetch_totals(cpecan_batch *batch, int64_t item, int64_t *xa
 /* vanilla batches (VanillaHmm, impl/continuousHmm.c:373-466): skip bins 0..29 beta (match -> gapX), 30..59
  * alpha (gapX -> gapX) (cell_signal_updateBetaAndAlphaProb :478-498) + likelihood, per modelsv_create id */
 #define CPECAN_EXPECTATIONV_LEN (60 + 1)
+/* HDP batches (HdpHmm, impl/continuousHmm.c:631-697): 9 transitions [from*3+to] + likelihood per
+ * cpecan_hip_modelsh_create id; params->threshold is the HdpHmm's assignment threshold, and the event-to-k-mer
+ * assignments of an item (cell_signal_updateTransAndKmerSkipExpectations2 impl/pairwiseAligner.c:445-476) come
+ * back through cpecan_hip_batch_fetch_pairs as (from state, x, y) triples in the reference's order, logp = the
+ * transition's log posterior */
+#define CPECAN_EXPECTATIONH_LEN (9 + 1)
 int cpecan_hip_batch_expectations_device_ptr(cpecan_batch *batch, void **dev_ptr, int64_t *n_doubles);
 int cpecan_hip_batch_fetch_expectations(cpecan_batch *batch, int32_t model_id, double *out);
 /* Debug: forward cells and backward cells (as they stand when posteriors are taken) of an item,

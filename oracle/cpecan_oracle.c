@@ -317,6 +317,7 @@ typedef struct {
     double total;           /* totalProbability of the enclosing diagonal */
     orc_expectations *hmm;  /* an orc_expectations5 for the 5-state symbol machine */
     int64_t kx, ky, kp;
+    int64_t ix, iy;         /* sequence indices of the cell's elements */
 } exp_args_t;
 
 typedef void (*trans_fn)(double *from, double *to, int f, int t, double eP, double tP, void *extra);
@@ -355,6 +356,26 @@ static void trans_expect_vanilla(double *from, double *to, int f, int t, double 
     double p = exp(from[f] + to[t] + (eP + tP) - a->total);
     if (f == 0 && t == 1) h->kmerSkipBins[bin] += p;
     if (f == 1 && t == 1) h->kmerSkipBins[bin + 30] += p;
+}
+
+/* cell_signal_updateTransAndKmerSkipExpectations2 :445-476 */
+static void trans_expect_hdp(double *from, double *to, int f, int t, double eP, double tP, void *e) {
+    exp_args_t *a = (exp_args_t *) e;
+    orc_expectations_h *h = (orc_expectations_h *) a->hmm;
+    const double lp = from[f] + to[t] + (eP + tP) - a->total;
+    const double p = exp(lp);
+    h->transitions[f * 3 + t] += p;
+    if (t == 0 && p >= h->threshold) {
+        if (h->n == h->cap) {
+            h->cap = h->cap ? 2 * h->cap : 256;
+            h->assign = realloc(h->assign, sizeof(int64_t) * 3 * (size_t) h->cap);
+            h->logp = realloc(h->logp, sizeof(double) * (size_t) h->cap);
+        }
+        h->assign[3 * h->n] = f;
+        h->assign[3 * h->n + 1] = a->ix;
+        h->assign[3 * h->n + 2] = a->iy;
+        h->logp[h->n++] = lp;
+    }
 }
 
 /* cell_updateExpectations :407-424 (HmmDiscrete: transitions [from*5+to], emissions [to][x][y]) */
@@ -709,7 +730,10 @@ static void diag_calc(const seqs_t *sq, dpm_t *mc, dpm_t *m1, dpm_t *m2, int64_t
         double *lower = m1 ? dpm_cell(m1, xay - 1, xmy - 1) : NULL;
         double *middle = m2 ? dpm_cell(m2, xay - 2, xmy) : NULL;
         double *upper = m1 ? dpm_cell(m1, xay - 1, xmy + 1) : NULL;
-        if (ea) { ea->kx = sy.kx; ea->ky = sy.ky; ea->kp = sy.kp; }
+        if (ea) {
+            ea->kx = sy.kx; ea->ky = sy.ky; ea->kp = sy.kp;
+            ea->ix = diag_x(xay, xmy) - 1; ea->iy = diag_y(xay, xmy) - 1;
+        }
         cell_calc(sq->m, cur, lower, middle, upper, &sy, fn, ea);
     }
 }
@@ -768,7 +792,12 @@ static void posterior_match_probs(dpm_t *F, dpm_t *B, int64_t xay, double total,
 /* diagonalCalculation_Expectations :841-863 */
 static void expectations_diag(const seqs_t *sq, dpm_t *F, dpm_t *B, int64_t xay, double total,
                               orc_expectations *hmm) {
-    exp_args_t ea = { total, hmm, 0, 0, 0 };
+    exp_args_t ea = { total, hmm, 0, 0, 0, 0, 0 };
+    if (sq->m->kind == ORC_SM3_HDP) {
+        ((orc_expectations_h *) hmm)->likelihood += total;
+        diag_calc(sq, B, F, F, xay, trans_expect_hdp, &ea);
+        return;
+    }
     if (sq->m->kind == ORC_SM3_VANILLA) {
         g_vanilla_match = sq->m->match;
         ((orc_expectations_v *) hmm)->likelihood += total;
@@ -917,8 +946,14 @@ int orc_aligned_pairs_using_anchors(const orc_model *m, const char *x, int64_t l
         seqs_t sq;
         make_seqs(&sq, m, x + x1, x2 - x1, slice_y(m, y, y1), y2 - y1);
         orc_result *part = orc_result_new();
+        orc_expectations_h *hh = (hmm && m->kind == ORC_SM3_HDP) ? (orc_expectations_h *) hmm : NULL;
+        const int64_t nAssign0 = hh ? hh->n : 0;
         rc = banded(&sq, sub, nSub, p, raggedLeft || i > 0, raggedRight || i < nSp - 1, hmm, part,
                     NULL);
+        for (int64_t k = nAssign0; hh && k < hh->n; k++) { /* sub-alignment coordinates -> the read's */
+            hh->assign[3 * k + 1] += x1;
+            hh->assign[3 * k + 2] += y1;
+        }
         for (int64_t k = part->n - 1; k >= 0; k--)
             result_push(out, part->triples[3 * k], part->triples[3 * k + 1] + x1,
                         part->triples[3 * k + 2] + y1, part->logp[k]);
@@ -969,6 +1004,27 @@ int orc_aligned_pairs_without_banding(const orc_model *m, const char *x, int64_t
     dpm_free(&B);
     free(L); free(R);
     return 0;
+}
+
+orc_expectations_h *orc_expectations_h_new(double threshold) {
+    orc_expectations_h *h = calloc(1, sizeof *h);
+    h->threshold = threshold;
+    return h;
+}
+void orc_expectations_h_free(orc_expectations_h *h) {
+    free(h->assign);
+    free(h->logp);
+    free(h);
+}
+int orc_expectations_h_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
+                                     const int64_t *anchors, int64_t nAnchors, const orc_params *p,
+                                     int raggedLeft, int raggedRight, orc_expectations_h *hmm) {
+    if (m->kind != ORC_SM3_HDP) return -2;
+    orc_result *scratch = orc_result_new();
+    int rc = orc_aligned_pairs_using_anchors(m, x, lX, y, lY, anchors, nAnchors, p, raggedLeft, raggedRight,
+                                             (orc_expectations *) hmm, scratch);
+    orc_result_free(scratch);
+    return rc;
 }
 
 int orc_expectations_v_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,

@@ -165,6 +165,23 @@ typedef struct {
 int orc_expectations_v_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
                                      const int64_t *anchors, int64_t nAnchors, const orc_params *p,
                                      int raggedLeft, int raggedRight, orc_expectations_v *hmm);
+/* sufficient statistics of the HDP signal HMM (HdpHmm, impl/continuousHmm.c:631-697 with
+ * cell_signal_updateTransAndKmerSkipExpectations2 impl/pairwiseAligner.c:445-476): transitions, and for every
+ * transition into match with posterior >= threshold an assignment of the cell's event to its k-mer, recorded as
+ * (from state, X index, Y index) in the order the reference appends them */
+typedef struct {
+    double transitions[9];
+    double likelihood;
+    double threshold;
+    int64_t n, cap;
+    int64_t *assign; /* 3 per assignment */
+    double *logp;    /* the transition's log posterior */
+} orc_expectations_h;
+orc_expectations_h *orc_expectations_h_new(double threshold);
+void orc_expectations_h_free(orc_expectations_h *h);
+int orc_expectations_h_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
+                                     const int64_t *anchors, int64_t nAnchors, const orc_params *p,
+                                     int raggedLeft, int raggedRight, orc_expectations_h *hmm);
 /* getExpectationsUsingAnchors (:1571) for an ORC_SM5_SYMBOL model: adds to *hmm */
 int orc_expectations5_using_anchors(const orc_model *m, const char *x, int64_t lX, const void *y, int64_t lY,
                                     const int64_t *anchors, int64_t nAnchors, const orc_params *p,

@@ -50,6 +50,12 @@ class OrcExpectationsV(C.Structure):
         return np.concatenate([np.array(self.kmerSkipBins), [self.likelihood]])
 
 
+class OrcExpectationsH(C.Structure):
+    _fields_ = [("transitions", C.c_double * 9), ("likelihood", C.c_double), ("threshold", C.c_double),
+                ("n", C.c_int64), ("cap", C.c_int64), ("assign", C.POINTER(C.c_int64)),
+                ("logp", C.POINTER(C.c_double))]
+
+
 class OrcResult(C.Structure):
     _fields_ = [("n", C.c_int64), ("cap", C.c_int64), ("triples", C.POINTER(C.c_int64)),
                 ("logp", C.POINTER(C.c_double)), ("nTotals", C.c_int64), ("capTotals", C.c_int64),
@@ -112,6 +118,13 @@ def lib():
             C.POINTER(OrcResult)]
         L.orc_expectations_normalize.argtypes = [C.POINTER(OrcExpectations)]
         L.orc_expectations5_normalize.argtypes = [C.POINTER(OrcExpectations5)]
+        L.orc_expectations_h_new.restype = C.POINTER(OrcExpectationsH)
+        L.orc_expectations_h_new.argtypes = [C.c_double]
+        L.orc_expectations_h_free.argtypes = [C.POINTER(OrcExpectationsH)]
+        L.orc_expectations_h_using_anchors.restype = C.c_int
+        L.orc_expectations_h_using_anchors.argtypes = [
+            C.POINTER(OrcModel), C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.POINTER(OrcParams), C.c_int, C.c_int, C.POINTER(OrcExpectationsH)]
         L.orc_expectations_v_using_anchors.restype = C.c_int
         L.orc_expectations_v_using_anchors.argtypes = [
             C.POINTER(OrcModel), C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -327,6 +340,27 @@ def aligned_pairs_using_anchors(model, x, lX, y, anchors, params, ragged_left=Fa
     if rc != 0:
         raise RuntimeError("oracle failed rc=%d" % rc)
     return out
+
+
+def expectations_h_using_anchors(model, reads, params, threshold, ragged_left=False, ragged_right=False):
+    """getExpectationsUsingAnchors for the HDP signal machine over reads = [(x, lX, events, anchors), ...]:
+    dict(transitions[9], likelihood, assign[n][3] = (from, X index, Y index), logp[n])."""
+    h = lib().orc_expectations_h_new(threshold)
+    try:
+        for x, lX, y, anchors in reads:
+            xb, keep, yptr, lY = _xy(model, x, y)
+            a = np.ascontiguousarray(anchors, dtype=np.int64).reshape(-1, 2)
+            rc = lib().orc_expectations_h_using_anchors(C.byref(model.c), xb, lX, yptr, lY, _ptr(a), a.shape[0],
+                                                        C.byref(params), int(ragged_left), int(ragged_right), h)
+            if rc != 0:
+                raise RuntimeError("oracle failed rc=%d" % rc)
+        c = h.contents
+        n = c.n
+        return dict(transitions=np.array(c.transitions), likelihood=c.likelihood,
+                    assign=np.ctypeslib.as_array(c.assign, shape=(n, 3)).copy() if n else np.zeros((0, 3), np.int64),
+                    logp=np.ctypeslib.as_array(c.logp, shape=(n,)).copy() if n else np.zeros(0))
+    finally:
+        lib().orc_expectations_h_free(h)
 
 
 def expectations_v_using_anchors(model, x, lX, y, anchors, params, hmm, ragged_left=False, ragged_right=False):

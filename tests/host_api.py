@@ -76,8 +76,15 @@ EXPORTS = [
     "diagonalCalculation_Expectations", "getExpectationsUsingAnchors", "getExpectations",
     "getIndelProbabilities", "reweightAlignedPairs", "reweightAlignedPairs2", "sequence_padSequence",
     "getVanillaExpectationsUsingAnchors", "vanillaHmm_normalizeKmerSkipBins",
-    "vanillaHmm_loadKmerSkipBinExpectations",
+    "vanillaHmm_loadKmerSkipBinExpectations", "hdpHmm_constructEmpty", "hdpHmm_destruct",
+    "getHdpExpectationsUsingAnchors", "hdpHmm_loadTransitions", "hdpHmm_writeToFile",
 ]
+
+
+class HdpExpectations(C.Structure):
+    _fields_ = [("likelihood", C.c_double), ("transitions", C.c_double * 9), ("threshold", C.c_double),
+                ("numberOfAssignments", C.c_int64), ("capacity", C.c_int64),
+                ("eventAssignments", C.POINTER(C.c_double)), ("kmerAssignments", C.POINTER(C.c_char))]
 
 
 class VanillaExpectations(C.Structure):
@@ -224,6 +231,13 @@ def lib():
                                                          C.POINTER(Params), C.c_bool, C.c_bool]
         L.vanillaHmm_normalizeKmerSkipBins.argtypes = [C.POINTER(VanillaExpectations)]
         L.vanillaHmm_loadKmerSkipBinExpectations.argtypes = [vp, C.POINTER(VanillaExpectations)]
+        L.hdpHmm_constructEmpty.restype = C.POINTER(HdpExpectations)
+        L.hdpHmm_constructEmpty.argtypes = [C.c_double, C.c_double]
+        L.hdpHmm_destruct.argtypes = [C.POINTER(HdpExpectations)]
+        L.getHdpExpectationsUsingAnchors.argtypes = [vp, C.POINTER(HdpExpectations), vp, vp, vp, C.POINTER(Params),
+                                                     C.c_bool, C.c_bool]
+        L.hdpHmm_loadTransitions.argtypes = [vp, C.POINTER(HdpExpectations)]
+        L.hdpHmm_writeToFile.argtypes = [C.POINTER(HdpExpectations), vp]
         L.getIndelProbabilities.restype = C.POINTER(C.c_int64)
         L.getIndelProbabilities.argtypes = [vp, C.c_int64, C.c_bool]
         L.reweightAlignedPairs2.restype = vp

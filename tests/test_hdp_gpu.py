@@ -86,3 +86,42 @@ def test_hdp_matches_oracle(ctx, nhdp, case):
         assert_same_pairs(dict(triples=tri, logp=lp), ref)
         assert len(tri) > it["lX"] // 4
     b.close()
+
+
+def test_hdp_expectations_and_assignments_match_oracle(ctx, nhdp):
+    """Baum-Welch sums of the HDP machine (diagonalCalculation_Expectations with
+    cell_signal_updateTransAndKmerSkipExpectations2, impl/pairwiseAligner.c:445-476): 9 transitions and the
+    likelihood per model (another summation order than the host loop: 1e-9 relative), and per alignment the
+    event-to-k-mer assignments -- one per transition INTO match whose posterior reaches the HdpHmm's
+    threshold -- bit-identical and in the reference's order."""
+    batch, model = hdp_batch(67, 3, 120, 25, nhdp)
+    ctx.models_clear()
+    ids = ctx.modelsh_create([(cp.NANOPORE_TRANSITIONS, nhdp["alphabet"], nhdp["grid"], nhdp["y"],
+                               nhdp["slope"], nhdp["kmer_row"])])
+    threshold = 0.05  # the machine's posteriors are flat (quirk Q6): a low bar gives a few hundred assignments
+    bp = band_params(threshold, 60, 10, 20)
+    b = cp.Batch(ctx, make_items(batch, (1, 1)), batch["x_chars"], batch["events"], batch["anchors"], bp,
+                 flags=cp.FLAG_EXPECTATIONS, hdp=True)
+    b.run()
+    b.sync()
+    npairs, _, _ = b.counts()
+    p = orc_params(bp, split=1 << 60)
+    reads = []
+    for it in batch["items"]:
+        x = batch["x_chars"][it["x_offset"]: it["x_offset"] + it["lX"] + 5]
+        ev = batch["events"][it["y_offset"]: it["y_offset"] + it["lY"]]
+        an = batch["anchors"][it["anchor_offset"]: it["anchor_offset"] + it["n_anchors"]]
+        reads.append((x, it["lX"], ev, an))
+    total = o.expectations_h_using_anchors(model, reads, p, threshold, True, True)
+    got = b.expectations(ids[0])
+    assert np.allclose(got[:9], total["transitions"], rtol=1e-9, atol=1e-12)
+    assert np.isclose(got[9], total["likelihood"], rtol=1e-12) and total["likelihood"] != 0.0
+    n_assign = 0
+    for i, rd in enumerate(reads):
+        ref = o.expectations_h_using_anchors(model, [rd], p, threshold, True, True)
+        tri, lp = b.pairs(i, npairs[i])
+        assert np.array_equal(tri, ref["assign"])
+        assert np.array_equal(lp, ref["logp"])
+        n_assign += len(tri)
+    assert n_assign > 50 and n_assign == len(total["assign"])
+    b.close()

@@ -323,7 +323,7 @@ def test_baum_welch_iterations_on_the_zymo_read(golden_dir, zymo_read, template_
 
 
 @pytest.mark.gpu
-def test_hdp_machine_through_host_api(golden_dir):
+def test_hdp_machine_through_host_api(golden_dir, tmp_path):
     """deserialize_nhdp (the C reader of the host library) + getHdpStateMachine3 + sequence_getKmer3 +
     getAlignedPairsUsingAnchors on the reference's serialized HDP, against the oracle fed by the
     independent Python reader of the same file."""
@@ -363,6 +363,31 @@ def test_hdp_machine_through_host_api(golden_dir):
     assert len(got) > lX // 2
     assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
     assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+
+    # the E-step of the same alignment: transitions, likelihood, assignments; then the .expectations file
+    hmm = L.hdpHmm_constructEmpty(0.0, 0.05)
+    L.getHdpExpectationsUsingAnchors(sm, hmm, sX, sY, lst, p, True, True)
+    want = o.expectations_h_using_anchors(om, [(x, lX, ev.reshape(-1, 3), anchors)],
+                                          o.default_params(minDiagsBetweenTraceBack=100), 0.05, True, True)
+    e = hmm.contents
+    assert np.allclose(list(e.transitions), want["transitions"], rtol=1e-9, atol=1e-12)
+    assert np.isclose(e.likelihood, want["likelihood"], rtol=1e-12)
+    n = e.numberOfAssignments
+    assert n == len(want["assign"]) and n > 20
+    kmers = [e.kmerAssignments[i * 7:i * 7 + 6].decode() for i in range(n)]
+    assert kmers == [x[int(ix):int(ix) + 6] for _, ix, _ in want["assign"]]
+    assert [e.eventAssignments[i] for i in range(n)] == [ev[3 * int(iy)] for _, _, iy in want["assign"]]
+    path = os.path.join(str(tmp_path), "t.expectations")
+    libc, fh = _c_file(path, b"w")
+    L.hdpHmm_writeToFile(hmm, fh)
+    libc.fclose(fh)
+    lines = open(path).read().split("\n")
+    assert lines[0].split() == ["7", "3", "0.050000", str(n)]  # type threeStateHdp, states, threshold, count
+    assert len(lines[1].split()) == 10 and len(lines[2].split()) == n and lines[3].split() == kmers
+    L.hdpHmm_loadTransitions(sm, hmm)  # un-normalised counts here: only the wiring is checked
+    s3 = C.cast(sm, C.POINTER(h.StateMachine3)).contents
+    assert s3.TRANSITION_MATCH_CONTINUE == np.log(e.transitions[0]) and s3.TRANSITION_GAP_SWITCH_TO_Y == -np.inf
+    L.hdpHmm_destruct(hmm)
     L.stList_destruct(lst)
     L.sequence_sequenceDestroy(sX)
     L.sequence_sequenceDestroy(sY)
