@@ -769,12 +769,16 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                      * phase T: v = cell_dotProduct(forward[t], backward[t]) (:391-397) ... */
                     const bool second = t + 1 <= dTop;
                     double v = CP_NEG_INF, w = CP_NEG_INF;
-                    if (tvalid) {
+                    /* all five loads of a refresh go out together (one HBM round trip, not two: the store of
+                     * v below would otherwise fence the second group behind the first); masked when used */
+                    const bool below = second && activeN && xsN - 1 >= pxmin && xsN - 1 <= pxmax;
 #ifdef SY_ABLATE_TOTLOADS
-                        const double fx = fMc, fy = fMc;
+                    const double fx = fMc, fy = fMc, r0 = fMc, r1 = fMc, r2 = fMc;
 #else
-                        const double fx = *g.rp(t, 1), fy = *g.rp(t, 2);
+                    const double *pa = tvalid ? g.rp(t, 1) : g.rw, *pb = below ? g.rpb(t - 1, 0) : g.rw;
+                    const double fx = pa[0], fy = pa[64], r0 = pb[0], r1 = pb[64], r2 = pb[128];
 #endif
+                    if (tvalid) {
                         v = fb;
                         v = ladd(v, fx + Bx, cf);
                         v = ladd(v, fy + By, cf);
@@ -784,16 +788,8 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                         /* ... and w = matches stepping over t: forward[t-1] --match--> the cells of
                          * t+1, dotted with backward[t+1] (only the match state of that clone is
                          * ever above -inf) */
-                        double s0 = CP_NEG_INF, s1 = CP_NEG_INF, s2 = CP_NEG_INF;
-                        if (xsN - 1 >= pxmin && xsN - 1 <= pxmax) {
-#ifdef SY_ABLATE_TOTLOADS
-                            s0 = s1 = s2 = fMc;
-#else
-                            s0 = *g.rpb(t - 1, 0);
-                            s1 = *g.rpb(t - 1, 1);
-                            s2 = *g.rpb(t - 1, 2);
-#endif
-                        }
+                        const double s0 = below ? r0 : CP_NEG_INF, s1 = below ? r1 : CP_NEG_INF,
+                                     s2 = below ? r2 : CP_NEG_INF;
                         double mm = s0 + (pmPrev + T[T_MATCH_CONTINUE]);
                         mm = ladd(mm, s1 + (pmPrev + T[T_MATCH_FROM_GAP_X]), cf);
                         mm = ladd(mm, s2 + (pmPrev + T[T_MATCH_FROM_GAP_Y]), cf);
