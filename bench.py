@@ -40,7 +40,8 @@ def main():
     ap.add_argument("--kmers", type=int, default=5000)
     ap.add_argument("--band", type=int, default=100)
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 systolic")
-    ap.add_argument("--cpu-reads", type=int, default=20, help="reads timed on the CPU oracle (0: skip)")
+    ap.add_argument("--cpu-reads", type=int, default=60,
+                    help="reads timed on the CPU oracle, ~0.3 s each on one core (0: skip)")
     ap.add_argument("--check", type=int, default=2, help="reads compared with the oracle after the run")
     args = ap.parse_args()
 

@@ -491,21 +491,35 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         PROF(1)
         lds_barrier(); /* also orders the band/event/k-mer staging above before the reads below */
         int xmin, xmax;
+#ifdef SY_ABLATE_BAND
+        xmin = d / 3; xmax = xmin + 132;
+#else
         band_get(bf, d, xmin, xmax);
+#endif
         cells += xmax - xmin + 1;
         const bool full = ((fullMask >> (d - db)) & 1u) != 0u;
         PROF_ACTIVE(row_active(wave, xmin, xmax))
         PROF(2)
+#ifdef SY_ABLATE_XCH
+        const double rm = shr1(Fm, Fm), rx = shr1(Fx, Fx), ry = shr1(Fy, Fy);
+        em = shr1(em, em);
+        en = shr1(en, en);
+#else
         const double *xb = sh.xch[(d - 1) & 1][g.waveBelow];
         const double rm = shr1(xb[0], Fm), rx = shr1(xb[1], Fx), ry = shr1(xb[2], Fy);
         em = shr1(xb[3], em);
         en = shr1(xb[4], en);
+#endif
         PROF_FENCE(em) PROF_FENCE(en)
         PROF(3)
         if (xs < xmin) xs += SY_P;
         const bool valid = xs <= xmax;
         while (xin <= xmax) { /* the entering k-mer's constants (at most one k-mer per step) */
+#ifdef SY_ABLATE_INSTALL
+            if (d == -1) {
+#else
             if (((xin >> 6) & (SY_R - 1)) == wave && lane == (xin & 63)) {
+#endif
                 const double *r = fd.row + (xin & (SY_FEED_ROW - 1)) * CP_ROW;
 #pragma unroll
                 for (int j = 0; j < SY_NPRM; j++) prm[j] = r[j];
@@ -524,10 +538,14 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         double nmv = CP_NEG_INF, nxv = CP_NEG_INF, nyv = CP_NEG_INF;
         if (row_active(wave, xmin, xmax)) {
             const double px = prm[CP_GAPX];
+#ifdef SY_ABLATE_EMIT
+            double pm = em + prm[CP_K1], py = en + prm[CP_YK1];
+#else
             double pm = lgauss(em, prm[CP_MU], prm[CP_SD], prm[CP_RSD], prm[CP_K1])
                             + lgauss(en, prm[CP_NMU], prm[CP_NSD], prm[CP_RNSD], prm[CP_K2]);
             double py = lgauss(em, prm[CP_YMU], prm[CP_YSD], prm[CP_RYSD], prm[CP_YK1])
                             + lgauss(en, prm[CP_YNMU], prm[CP_YNSD], prm[CP_RYNSD], prm[CP_YK2]);
+#endif
             PROF_FENCE(pm) PROF_FENCE(py)
             PROF(5)
             /* cell_calculateForward: to[t] = logAdd(to[t], from[f] + (eP + tP)) (:365-376) in the

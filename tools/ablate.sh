@@ -1,6 +1,8 @@
 #!/bin/bash
 # Timing ablations of the systolic kernels (results are WRONG by construction; timing only).
-# usage (on the GPU box): bash tools/ablate.sh BARRIER LADD COEF STORE INSTALL
+# usage (on the GPU box): bash tools/ablate.sh BARRIER LADD COEF STORE INSTALL EMIT BAND XCH PMPY ...
+# (an argument may carry further -D flags: "LADD -DSY_ABLATE_EMIT"); columns: ms per pass, backward and
+# forward launch averages with the whole batch in one stream group
 set -e
 cd "$(dirname "$0")/../cpecan-signal_amd"
 out=../gpurun_out/ablate.txt
