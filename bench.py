@@ -149,8 +149,10 @@ def main():
                 "kernel_ms": round(1e3 * avg_kernel_s, 3), "bytes_per_cell": bytes_per_cell,
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
                 "fp64_valu_busy": valu,
-                "note": "fp64 log-space recurrence: the kernels are bound by fp64 vector issue (fraction of SIMD "
-                        "time with a VALU instruction executing, from the committed PMC profile), not by HBM"}
+                "note": "fp64 log-space recurrence, not HBM-bound: fp64_valu_busy is the fraction of SIMD time "
+                        "with a VALU instruction executing (committed PMC profile); the rest is the dependency "
+                        "chain of an anti-diagonal (barrier, LDS exchange, serial log-adds) at 4 workgroups per "
+                        "CU -- DESIGN.md section 5"}
     if stage:
         f_ms = float(np.mean([x[0] for x in stage]))
         k_ms = float(np.mean([x[1] for x in stage]))
