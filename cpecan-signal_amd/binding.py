@@ -9,6 +9,7 @@ The directory name contains a hyphen, so load this module by path:
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -108,6 +109,15 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise CpecanError(ENODEVICE, "libcpecan_hip.so is not built (run __graft_entry__.build())")
+        if "torch" not in sys.modules and not os.environ.get("CPECAN_NO_TORCH_PRELOAD"):
+            # PyTorch-ROCm ships its own HIP/HSA runtime.  A process that loads this library first and torch
+            # later ends up with two HSA runtimes and torch sees no GPU (measured on the MI355X box); loaded
+            # after torch, this library binds to the runtime torch brought.  Callers that never use torch.cuda
+            # (plain C programs, CPECAN_NO_TORCH_PRELOAD=1) run on the system runtime.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.cpecan_hip_last_error.restype = C.c_char_p
         L.cpecan_hip_version.restype = C.c_char_p

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:  # torch brings its own HIP/HSA runtime: it has to be the first one loaded in a process that also uses
+    import torch  # noqa: F401  torch.cuda (the EM driver, bench.py); see binding.lib()
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:

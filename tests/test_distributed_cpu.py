@@ -66,6 +66,56 @@ def test_two_rank_shard_and_allreduce(tmp_path):
     assert np.isneginf(trans[8]) and np.all(trans[:7] <= 0)
 
 
+def _loop_worker(rank, world, port, out_dir):
+    for p in (os.path.dirname(os.path.abspath(__file__)),
+              os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = synth.make_batch(43, 5, 100, 210, anchor_every=25, distinct_models=False)
+    bp = band_params(0.01, 80, 20, 40)
+    mine = dist_em.shard([it["lX"] + it["lY"] for it in batch["items"]], rank, world)
+    _, gap0, _ = batch["models"][0]
+
+    def e_step(transitions, gap_x):  # the oracle stands in for the GPU op (tests only)
+        hmm = o.OrcExpectations()
+        saved = batch["models"][0]
+        batch["models"][0] = (saved[0], gap_x, saved[2])
+        for i in mine:
+            run_oracle_item(batch, i, bp, (1, 1), transitions=list(transitions), expectations=hmm)
+        batch["models"][0] = saved
+        v = np.full(dist_em.EXP_LEN, 1e-9)
+        v[:9] += hmm.transitions[:]
+        v[9:9 + 4096] += hmm.kmerGap[:]
+        v[-1] = hmm.likelihood
+        t = torch.from_numpy(v)
+        dist_em.allreduce_expectations(t, dist)
+        return t.numpy()
+
+    import harness
+    lines = []
+    r = dist_em.train(e_step, harness.cp.NANOPORE_TRANSITIONS, gap0, 3, log=lines.append)
+    np.save(os.path.join(out_dir, "loop%d.npy" % rank),
+            np.concatenate([r["transitions"], r["gap_x"], r["running_likelihoods"]]))
+    assert len(lines) == 3 and lines[0].startswith("0| ")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_baum_welch_loop(tmp_path):
+    """the EM loop driver (cpecan-signal_amd/em.py) on two gloo ranks: the same model and the same running
+    likelihoods on every rank, and a likelihood that rises"""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "loop0.npy"), np.load(tmp_path / "loop1.npy")
+    assert np.array_equal(r0, r1)
+    like = r0[-3:]
+    assert like[0] < like[1] < like[2] < 0
+    assert np.isneginf(r0[8]) and np.all(np.isfinite(r0[9:9 + 4096]))  # SWITCH_TO_Y; pseudocounts keep logs finite
+
+
 def test_shard_is_balanced_and_complete():
     sizes = [100, 900, 300, 300, 50, 700, 10, 400]
     parts = [dist_em.shard(sizes, r, 4) for r in range(4)]
