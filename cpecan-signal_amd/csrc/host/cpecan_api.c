@@ -1540,3 +1540,44 @@ void hdpHmm_writeToFile(HdpHmmExpectations *hmm, FILE *fh) {
         fprintf(fh, "%.*s\t", KMER_LENGTH, hmm->kmerAssignments + i * (KMER_LENGTH + 1));
     fprintf(fh, "\n");
 }
+
+/* ---- the TSV of aligned pairs (vanillaAlign.c:26-96) -------------------------------------------------- */
+static char complement_base(char c) { /* as stString_reverseComplementString does for nucleotides */
+    switch (c) {
+    case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+    case 'a': return 't'; case 't': return 'a'; case 'c': return 'g'; case 'g': return 'c';
+    default: return c;
+    }
+}
+void writePosteriorProbs(char *posteriorProbsFile, char *readFile, double *matchModel, double scale, double shift,
+                         double *events, char *target, bool forward, char *contig, int64_t eventSequenceOffset,
+                         int64_t referenceSequenceOffset, stList *alignedPairs, Strand strand) {
+    const char *strandLabel = strand == template ? "t" : "c";
+    /* template read forward or complement read backward: the pairs index the reference as given */
+    const bool sameSense = (strand == template && forward) || (strand == complement && !forward);
+    FILE *fh = fopen(posteriorProbsFile, "a");
+    if (!fh) die("cpecan: cannot open %s", posteriorProbsFile);
+    const int64_t refLength = (int64_t) strlen(target);
+    for (int64_t i = 0; i < stList_length(alignedPairs); i++) {
+        stIntTuple *pair = stList_get(alignedPairs, i);
+        const int64_t x = stIntTuple_get(pair, 1);
+        const int64_t xAdj = sameSense ? x + referenceSequenceOffset
+                                       : (refLength - KMER_LENGTH) - (x + (refLength - referenceSequenceOffset));
+        const int64_t y = stIntTuple_get(pair, 2) + eventSequenceOffset;
+        const double p = ((double) stIntTuple_get(pair, 0)) / PAIR_ALIGNMENT_PROB_1;
+        const double mean = events[y * NB_EVENT_PARAMS], noise = events[y * NB_EVENT_PARAMS + 1],
+                     duration = events[y * NB_EVENT_PARAMS + 2];
+        char kmer[KMER_LENGTH + 1], refKmer[KMER_LENGTH + 1];
+        memcpy(kmer, target + x, KMER_LENGTH);
+        kmer[KMER_LENGTH] = 0;
+        for (int k = 0; k < KMER_LENGTH; k++)
+            refKmer[k] = sameSense ? kmer[k] : complement_base(kmer[KMER_LENGTH - 1 - k]);
+        refKmer[KMER_LENGTH] = 0;
+        const int64_t ki = emissions_discrete_getKmerIndex(kmer);
+        const double levelMean = matchModel[1 + ki * MODEL_PARAMS], noiseMean = matchModel[1 + ki * MODEL_PARAMS + 2];
+        fprintf(fh, "%s\t%lld\t%s\t%s\t%s\t%lld\t%f\t%f\t%f\t%s\t%f\t%f\t%f\t%f\t%f\n", contig,
+                (long long) xAdj, refKmer, readFile, strandLabel, (long long) y, mean, noise, duration, kmer,
+                levelMean, noiseMean, p, (mean - shift) / scale, (levelMean - shift) / scale);
+    }
+    fclose(fh);
+}

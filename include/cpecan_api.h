@@ -428,6 +428,15 @@ stList *reweightAlignedPairs(stList *alignedPairs, int64_t *indelProbsX, int64_t
 stList *reweightAlignedPairs2(stList *alignedPairs, int64_t seqLengthX, int64_t seqLengthY, double gapGamma);
 void sequence_padSequence(Sequence *sequence); /* :282-285: elements become a padded copy (echelon callers) */
 
+/* ---- aligned pairs -> the 15-column TSV of signalAlign (vanillaAlign.c:26-96) ---------
+ * contig, reference position, reference k-mer, read file, strand (t/c), event index, event mean / noise /
+ * duration, aligned k-mer, model level mean / noise mean of that k-mer, posterior, de-scaled event mean,
+ * de-scaled model mean.  Appends to posteriorProbsFile.  matchModel is the (scaled) match table of the strand's
+ * state machine, events the strand's [mean, noise, duration] triples, target the sequence the pairs' x indexes. */
+void writePosteriorProbs(char *posteriorProbsFile, char *readFile, double *matchModel, double scale, double shift,
+                         double *events, char *target, bool forward, char *contig, int64_t eventSequenceOffset,
+                         int64_t referenceSequenceOffset, stList *alignedPairs, Strand strand);
+
 /* ---- additive batch entry (many reads, one call; SURVEY section 8b last row) ---------------------
  * Aligns n reads; read i uses state machine sMs[i] (already scaled for that read), sequences
  * sXs[i] (sequence_getKmer) / sYs[i] (sequence_getEvent) and anchor list anchors[i].  Returns an

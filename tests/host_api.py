@@ -77,7 +77,7 @@ EXPORTS = [
     "getIndelProbabilities", "reweightAlignedPairs", "reweightAlignedPairs2", "sequence_padSequence",
     "getVanillaExpectationsUsingAnchors", "vanillaHmm_normalizeKmerSkipBins",
     "vanillaHmm_loadKmerSkipBinExpectations", "hdpHmm_constructEmpty", "hdpHmm_destruct",
-    "getHdpExpectationsUsingAnchors", "hdpHmm_loadTransitions", "hdpHmm_writeToFile",
+    "getHdpExpectationsUsingAnchors", "hdpHmm_loadTransitions", "hdpHmm_writeToFile", "writePosteriorProbs",
 ]
 
 
@@ -238,6 +238,9 @@ def lib():
                                                      C.c_bool, C.c_bool]
         L.hdpHmm_loadTransitions.argtypes = [vp, C.POINTER(HdpExpectations)]
         L.hdpHmm_writeToFile.argtypes = [C.POINTER(HdpExpectations), vp]
+        L.writePosteriorProbs.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_double, C.c_double,
+                                          C.POINTER(C.c_double), C.c_char_p, C.c_bool, C.c_char_p, C.c_int64,
+                                          C.c_int64, vp, C.c_int]
         L.getIndelProbabilities.restype = C.POINTER(C.c_int64)
         L.getIndelProbabilities.argtypes = [vp, C.c_int64, C.c_bool]
         L.reweightAlignedPairs2.restype = vp

@@ -606,6 +606,45 @@ def test_reweighting_by_gap_probability():
     L.stList_destruct(out)
 
 
+def test_tsv_writer_reproduces_the_references_own_output(golden_dir, zymo_read, tmp_path):
+    """writePosteriorProbs (vanillaAlign.c:26-96) against tests/test_alignments/simple_alignment.tsv, the
+    reference's own output for the shipped Zymo read (template and complement strands): the aligned pairs,
+    event indices and posteriors are read back from that file, everything else -- reference positions, both
+    k-mer columns, event observations, scaled model levels, de-scaled means, the number formats -- is produced
+    here from the read, the two pore models and the reference sequence, and must match byte for byte."""
+    L = h.lib()
+    want = open(os.path.join(golden_dir, "simple_alignment.tsv")).read().split("\n")
+    want = [w for w in want if w]
+    ref = zymo_read["reference"]
+    rc = "".join({"A": "T", "C": "G", "G": "C", "T": "A"}[c] for c in reversed(ref))
+    out = tmp_path / "out.tsv"
+    L.stIntTuple_construct3.restype = C.c_void_p
+    L.stIntTuple_construct3.argtypes = [C.c_int64] * 3
+    read_file = want[0].split("\t")[3]
+    for strand, label, model_file, params, events, target, ref_offset in (
+            (0, "t", "template_median68pA.model", zymo_read["template_params"], zymo_read["template_events"], ref, 0),
+            (1, "c", "complement_median68pA_pop2.model", zymo_read["complement_params"],
+             zymo_read["complement_events"], rc, len(ref))):
+        sm = L.getStrawManStateMachine3(os.path.join(golden_dir, model_file).encode())
+        L.emissions_signal_scaleModel(sm, *params)
+        rows = [w.split("\t") for w in want if w.split("\t")[4] == label]
+        lst = L.stList_construct3(0, h.fn_ptr("stIntTuple_destruct"))
+        for r in rows:
+            x_adj, y, p = int(r[1]), int(r[5]), float(r[12])
+            x = x_adj if strand == 0 else (len(ref) - 6) - x_adj - (len(ref) - ref_offset)
+            L.stList_append(lst, L.stIntTuple_construct3(int(round(p * 1e7)), x, y))
+        ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+        L.writePosteriorProbs(str(out).encode(), read_file.encode(), sm.contents.model.EMISSION_MATCH_PROBS,
+                              params[0], params[1], ev.ctypes.data_as(C.POINTER(C.c_double)), target.encode(), True,
+                              b"ZYMO", 0, ref_offset, lst, strand)
+        L.stList_destruct(lst)
+        L.stateMachine_destruct(sm)
+    got = [g for g in open(out).read().split("\n") if g]
+    # the reference interleaves nothing: template rows then complement rows, as vanillaAlign writes them
+    assert len(got) == len(want) == 1907
+    assert got == [w for w in want if w.split("\t")[4] == "t"] + [w for w in want if w.split("\t")[4] == "c"]
+
+
 def test_diagonal_band_iterator_logadd_and_overlap_filter():
     """the geometry and utility functions the reference exports and tests (tests/pairwiseAlignerTest.c:
     test_diagonal :22, test_bands :74, test_logAdd :139, test_filterToRemoveOverlap :515), host-only"""
