@@ -1060,8 +1060,15 @@ stList *getAlignedPairsUsingAnchors(StateMachine *sM, Sequence *SsX, Sequence *S
 void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, Sequence *sX, Sequence *sY,
                                   PairwiseAlignmentParameters *p, bool raggedL, bool raggedR,
                                   DiagonalPosteriorProbFn fn, void *extraArgs) {
+    if (fn == diagonalCalculation_Expectations) { /* extraArgs is the Hmm (:850) */
+        if (sM->type != fiveState && sM->type != fiveStateAsymmetric)
+            die("cpecan: expectations through this entry point take a 5-state machine and its Hmm");
+        run_reads(1, &sM, &sX, &sY, &anchorPairs, p, raggedL, raggedR, 1, 2, NULL, extraArgs);
+        return;
+    }
     if (fn != diagonalCalculationPosteriorMatchProbs)
-        die("cpecan: the GPU path implements diagonalCalculationPosteriorMatchProbs only");
+        die("cpecan: the GPU path implements diagonalCalculationPosteriorMatchProbs and "
+            "diagonalCalculation_Expectations only");
     stList *dest = ((void **) extraArgs)[0], *out = NULL;
     run_reads(1, &sM, &sX, &sY, &anchorPairs, p, raggedL, raggedR, 0, 2, &out, NULL);
     for (int64_t i = 0; i < stList_length(out); i++) {
@@ -1580,4 +1587,49 @@ void writePosteriorProbs(char *posteriorProbsFile, char *readFile, double *match
                 levelMean, noiseMean, p, (mean - shift) / scale, (levelMean - shift) / scale);
     }
     fclose(fh);
+}
+
+/* ---- the split driver and getAlignedPairs, as the reference composes them (:1356-1422, :1486-1510) ---------- */
+void getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(
+    StateMachine *sM, stList *anchorPairs, Sequence *SsX, Sequence *SsY, PairwiseAlignmentParameters *p, bool raggedL,
+    bool raggedR, DiagonalPosteriorProbFn fn, void (*coordinateCorrectionFn)(int64_t, int64_t, void *),
+    void *extraArgs) {
+    stList *splitPoints = getSplitPoints(anchorPairs, SsX->length, SsY->length, p->splitMatrixBiggerThanThis,
+                                         raggedL, raggedR);
+    int64_t j = 0;
+    const int64_t n = stList_length(splitPoints);
+    for (int64_t i = 0; i < n; i++) {
+        stIntTuple *r = stList_get(splitPoints, i);
+        const int64_t x1 = stIntTuple_get(r, 0), y1 = stIntTuple_get(r, 1), x2 = stIntTuple_get(r, 2),
+                      y2 = stIntTuple_get(r, 3);
+        Sequence *sX3 = SsX->sliceFcn(SsX, x1, x2 - x1), *sY3 = SsY->sliceFcn(SsY, y1, y2 - y1);
+        stList *sub = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+        while (j < stList_length(anchorPairs)) {
+            stIntTuple *a = stList_get(anchorPairs, j);
+            const int64_t x = stIntTuple_get(a, 0), y = stIntTuple_get(a, 1);
+            if (x + y >= x2 + y2) break;
+            stList_append(sub, stIntTuple_construct2(x - x1, y - y1));
+            j++;
+        }
+        getPosteriorProbsWithBanding(sM, sub, sX3, sY3, p, raggedL || i > 0, raggedR || i < n - 1, fn, extraArgs);
+        if (coordinateCorrectionFn) coordinateCorrectionFn(x1, y1, extraArgs);
+        stList_destruct(sub);
+        sequence_sequenceDestroy(sX3);
+        sequence_sequenceDestroy(sY3);
+    }
+    stList_destruct(splitPoints);
+}
+stList *getAlignedPairs(StateMachine *sM, void *cX, void *cY, int64_t lX, int64_t lY, PairwiseAlignmentParameters *p,
+                        void *(*getXFcn)(void *, int64_t), void *(*getYFcn)(void *, int64_t),
+                        stList *(*getAnchorPairFcn)(void *, void *, PairwiseAlignmentParameters *), bool raggedL,
+                        bool raggedR) {
+    stList *anchorPairs = getAnchorPairFcn(cX, cY, p);
+    Sequence *SsX = sequence_construct2(lX, cX, getXFcn, sequence_sliceNucleotideSequence2);
+    Sequence *SsY = sequence_construct2(lY, cY, getYFcn, sequence_sliceNucleotideSequence2);
+    stList *pairs = getAlignedPairsUsingAnchors(sM, SsX, SsY, anchorPairs, p, diagonalCalculationPosteriorMatchProbs,
+                                                raggedL, raggedR);
+    sequence_sequenceDestroy(SsX);
+    sequence_sequenceDestroy(SsY);
+    stList_destruct(anchorPairs);
+    return pairs;
 }

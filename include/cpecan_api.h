@@ -265,6 +265,20 @@ void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, Sequenc
                                   PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,
                                   bool alignmentHasRaggedRightEnd,
                                   DiagonalPosteriorProbFn diagonalPosteriorProbFn, void *extraArgs);
+/* the split driver itself (:331, impl :1356-1422): one getPosteriorProbsWithBanding per sub-region of
+ * getSplitPoints, anchors re-based, ragged flags (left || i > 0, right || i < last), then
+ * coordinateCorrectionFn(x1, y1, extraArgs) if given.  diagonalPosteriorProbFn is one of the two markers
+ * (posterior decode: extraArgs[0] is the stList the triples go to; expectations: extraArgs is the Hmm). */
+void getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(
+    StateMachine *sM, stList *anchorPairs, Sequence *SsX, Sequence *SsY, PairwiseAlignmentParameters *p,
+    bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd, DiagonalPosteriorProbFn diagonalPosteriorProbFn,
+    void (*coordinateCorrectionFn)(int64_t offsetX, int64_t offsetY, void *extraArgs), void *extraArgs);
+/* getAlignedPairs (:100, impl :1486-1510): anchors from the caller's function (the reference passes its lastz
+ * wrapper), nucleotide-sliced Sequences, getAlignedPairsUsingAnchors; destroys the anchor list it obtained */
+stList *getAlignedPairs(StateMachine *sM, void *cX, void *cY, int64_t lX, int64_t lY, PairwiseAlignmentParameters *p,
+                        void *(*getXFcn)(void *, int64_t), void *(*getYFcn)(void *, int64_t),
+                        stList *(*getAnchorPairFcn)(void *, void *, PairwiseAlignmentParameters *),
+                        bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 /* filterToRemoveOverlap (:324, impl :1160-1200): from (x, y) pairs sorted by x then y, the pairs that are
  * smaller in both coordinates than every later pair and larger in both than every earlier one */
 stList *filterToRemoveOverlap(stList *sortedOverlappingPairs);

@@ -78,6 +78,7 @@ EXPORTS = [
     "getVanillaExpectationsUsingAnchors", "vanillaHmm_normalizeKmerSkipBins",
     "vanillaHmm_loadKmerSkipBinExpectations", "hdpHmm_constructEmpty", "hdpHmm_destruct",
     "getHdpExpectationsUsingAnchors", "hdpHmm_loadTransitions", "hdpHmm_writeToFile", "writePosteriorProbs",
+    "getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps", "getAlignedPairs",
 ]
 
 
@@ -241,6 +242,11 @@ def lib():
         L.writePosteriorProbs.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_double, C.c_double,
                                           C.POINTER(C.c_double), C.c_char_p, C.c_bool, C.c_char_p, C.c_int64,
                                           C.c_int64, vp, C.c_int]
+        L.getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps.argtypes = [
+            vp, vp, vp, vp, C.POINTER(Params), C.c_bool, C.c_bool, vp, vp, vp]
+        L.getAlignedPairs.restype = vp
+        L.getAlignedPairs.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.POINTER(Params), vp, vp, vp, C.c_bool,
+                                      C.c_bool]
         L.getIndelProbabilities.restype = C.POINTER(C.c_int64)
         L.getIndelProbabilities.argtypes = [vp, C.c_int64, C.c_bool]
         L.reweightAlignedPairs2.restype = vp

@@ -191,6 +191,35 @@ def test_five_state_dna_through_host_api():
     assert len(got) > 100
     assert np.array_equal(got[:, 1:], ref["triples"][:, 1:])
     assert np.abs(got[:, 0] - ref["triples"][:, 0]).max() <= 1
+
+    # getAlignedPairs with the caller's anchor function (the reference passes its lastz wrapper there), and the
+    # split driver called directly with a coordinate-correction callback, as getAlignedPairsUsingAnchors does
+    anchor_fn = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)(lambda cx, cy, pp: h.make_anchor_list(anchors))
+    pairs = L.getAlignedPairs(sm, C.cast(xb, C.c_void_p), C.cast(yb, C.c_void_p), len(x), len(y), p,
+                              h.fn_ptr("sequence_getBase"), h.fn_ptr("sequence_getBase"), anchor_fn, False, False)
+    assert np.array_equal(h.list_to_array(pairs), got)
+    L.stList_destruct(pairs)
+    p.contents.splitMatrixBiggerThanThis = 30 * 30
+    whole = L.getAlignedPairsUsingAnchors(sm, sX, sY, lst, p, h.fn_ptr("diagonalCalculationPosteriorMatchProbs"),
+                                          False, False)
+    sub_list, offsets = L.stList_construct3(0, h.fn_ptr("stIntTuple_destruct")), []
+    corr = C.CFUNCTYPE(None, C.c_int64, C.c_int64, C.c_void_p)(lambda ox, oy, extra: offsets.append(
+        (ox, oy, L.stList_length(sub_list))))
+    extra = (C.c_void_p * 2)(sub_list, None)
+    L.getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(
+        sm, lst, sX, sY, p, False, False, h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), corr, extra)
+    assert len(offsets) == len(o.split_points(anchors, len(x), len(y), 30 * 30, 0, 0)) > 1
+    raw = h.list_to_array(sub_list)  # sub-alignment coordinates, emission order, region after region
+    rebuilt, start = [], 0
+    for ox, oy, end in offsets:  # what alignedPairCoordinateCorrectionFn does: shift, then pop from the tail
+        part = raw[start:end].copy()
+        part[:, 1] += ox
+        part[:, 2] += oy
+        rebuilt.append(part[::-1])
+        start = end
+    assert np.array_equal(np.concatenate(rebuilt), h.list_to_array(whole))
+    L.stList_destruct(sub_list)
+    L.stList_destruct(whole)
     L.stList_destruct(lst)
     L.sequence_sequenceDestroy(sX)
     L.sequence_sequenceDestroy(sY)
