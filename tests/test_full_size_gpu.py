@@ -149,3 +149,57 @@ def test_expectation_sums_are_linear_in_the_batch(ctx, batch):
     assert whole[-1] < 0 and t[0, 0] > t[0, 1] > 0 and t[0, 2] > 0 and t[1, 2] == 0  # no gapX -> gapY (SWITCH_TO_Y)
     # every diagonal contributes the likelihood once (quirk Q7): ~15 000 diagonals per read
     assert whole[9:9 + 4096].sum() > 0
+
+
+def test_config5_hdp_long_read_against_the_oracle(ctx, golden_dir):
+    """BASELINE configs[4] at its per-read size: one 50 000-event read (41 500 k-mers at this generator's 1.2
+    events per k-mer) under the HDP machine (the reference's serialized test HDP), band 100, default
+    checkpointing -- 1.2 x 10^7 cells, ~90 windows, 7 x 10^5 aligned pairs (the machine's posteriors are flat,
+    quirk Q6); totals and posterior exponents bit-identical to the oracle."""
+    import os
+    import test_hdp_gpu as th
+    nhdp = o.load_nhdp(os.path.join(golden_dir, "testTemplate.nhdp"))
+    batch, model = th.hdp_batch(83, 1, 41500, 50, nhdp)
+    it = batch["items"][0]
+    assert 45000 <= it["lY"] <= 60000
+    ctx.models_clear()
+    ctx.modelsh_create([(cp.NANOPORE_TRANSITIONS, nhdp["alphabet"], nhdp["grid"], nhdp["y"], nhdp["slope"],
+                         nhdp["kmer_row"])])
+    bp = band_params(0.01, 1000, 40, 100)
+    b = cp.Batch(ctx, make_items(batch, (1, 1)), batch["x_chars"], batch["events"], batch["anchors"], bp, hdp=True)
+    b.run()
+    b.sync()
+    npairs, ntot, ncells = b.counts()
+    tri, lp = b.pairs(0, npairs[0])
+    xay, tot = b.totals(0, ntot[0])
+    from harness import orc_params
+    ref = o.aligned_pairs_using_anchors(model, batch["x_chars"], it["lX"], batch["events"], batch["anchors"],
+                                        orc_params(bp, split=1 << 60), True, True)
+    ref["triples"], ref["logp"] = ref["triples"][::-1], ref["logp"][::-1]
+    assert int(ncells[0]) == ref["cells"] > 9 * 10 ** 6
+    assert np.array_equal(xay, ref["totals_xay"]) and np.array_equal(tot, ref["totals"])
+    assert_same_pairs(dict(triples=tri, logp=lp), ref)
+    b.close()
+
+
+def test_config4_ragged_batch_expectations_against_the_oracle(ctx):
+    """BASELINE configs[3] shape: reads of log-normal length (median 8 000 events, sigma 0.5) in one batch, the
+    Baum-Welch sums of the systolic path against the oracle (8 reads here)."""
+    rb = synth.make_batch(4, 8, 4000, 8000, anchor_every=50, distinct_models=False, length_sigma=0.5)
+    lens = [it["lY"] for it in rb["items"]]
+    assert max(lens) > 2 * min(lens)
+    bp = band_params(0.01, 1000, 40, 100)
+    ctx.models_clear()
+    ctx.models_create([(cp.NANOPORE_TRANSITIONS,) + rb["models"][0]])
+    b = cp.Batch(ctx, make_items(rb, (1, 1)), rb["x_chars"], rb["events"], rb["anchors"], bp, cp.MODE_EXPECTATIONS,
+                 cp.KERNEL_AUTO, 0)
+    assert b.info()["kernel"] == "systolic"
+    b.run()
+    b.sync()
+    got = b.expectations(0)
+    b.close()
+    hmm = o.OrcExpectations()
+    for i in range(len(rb["items"])):
+        run_oracle_item(rb, i, bp, (1, 1), expectations=hmm)
+    ref = np.concatenate([np.array(hmm.transitions), np.array(hmm.kmerGap), [hmm.likelihood]])
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
