@@ -7,7 +7,10 @@ A step is one pass of the hot path (forward, checkpointed backward, posterior de
 synthetic batch per GPU: BASELINE.json configs[2], 1024 reads x (10k events x 5k k-mers), band
 (diagonalExpansion) 100, per-read scaled pore models.  Inputs are resident in HBM before the timed
 region.  Reads shard across ranks with no data-path collective (weak scaling: every GPU gets its
-own 1024 reads).  Rank 0 prints ONE JSON line.
+own 1024 reads).  Consecutive steps are pipelined (--inflight 2): step s+1 works on another batch of 1024
+reads on a stream of its own and is issued before step s is waited for, so two passes overlap on the GPU the
+way queued batches do in service; the timed region still covers exactly K complete steps.  Rank 0 prints ONE
+JSON line.
 
 value      = in-band cells (each counted once) of all ranks / max-over-ranks wall time, Gcells/s
 roofline   = algorithmic bytes (48 B per cell: one fp64 write + one re-read of 3 states,
@@ -43,6 +46,10 @@ def main():
     ap.add_argument("--cpu-reads", type=int, default=60,
                     help="reads timed on the CPU oracle, ~0.3 s each on one core (0: skip)")
     ap.add_argument("--check", type=int, default=2, help="reads compared with the oracle after the run")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="batches in flight: step s+1 (another batch, its own stream) is issued before step s is "
+                         "waited for, as a server with queued batches would; every step is still one pass over "
+                         "one batch and all K steps complete inside the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -63,23 +70,35 @@ def main():
     cp = binding()
 
     # ---- inputs: this rank's reads, uploaded before the timed region -------------------------
-    t0 = time.time()
-    config_id = 3 + 100 * rank  # distinct read seeds per rank
-    batch = synth.make_batch(config_id, args.reads, args.kmers, args.events, anchor_every=50)
-    t_gen = time.time() - t0
-    ctx = cp.Context(local_rank)
-    t0 = time.time()
-    ctx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in batch["models"]])
-    t_models = time.time() - t0
+    # `inflight` batches of distinct reads, each with a context (stream) of its own.  With two in flight every
+    # batch runs as ONE stream group (two kernels of 1024 workgroups overlap); alone, a batch is split into two
+    # groups so that its own forward and backward kernels overlap.
+    inflight = max(1, min(args.inflight, args.steps))
+    if inflight > 1 and "CPECAN_SYSTOLIC_GROUPS" not in os.environ:
+        os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"
     bp = cp.BandParams(0.01, 1000, 40, args.band)
-    items = np.zeros(len(batch["items"]), cp.ITEM_DTYPE)
-    for i, it in enumerate(batch["items"]):
-        items[i] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"],
-                    it["n_anchors"], it["model"], 1, 1, 0)  # ragged ends, as vanillaAlign.c:203
-    t0 = time.time()
-    b = cp.Batch(ctx, items, batch["x_chars"], batch["events"], batch["anchors"], bp,
-                 cp.MODE_POSTERIOR, args.kernel, 0)
-    t_upload = time.time() - t0
+    t_gen = t_models = t_upload = 0.0
+    batches, ctxs, bs = [], [], []
+    for j in range(inflight):
+        t0 = time.time()
+        config_id = 3 + 100 * rank + 10 * j  # distinct read seeds per rank and per batch in flight
+        bt = synth.make_batch(config_id, args.reads, args.kmers, args.events, anchor_every=50)
+        t_gen += time.time() - t0
+        cx = cp.Context(local_rank)
+        t0 = time.time()
+        cx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in bt["models"]])
+        t_models += time.time() - t0
+        items = np.zeros(len(bt["items"]), cp.ITEM_DTYPE)
+        for i, it in enumerate(bt["items"]):
+            items[i] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"],
+                        it["n_anchors"], it["model"], 1, 1, 0)  # ragged ends, as vanillaAlign.c:203
+        t0 = time.time()
+        bs.append(cp.Batch(cx, items, bt["x_chars"], bt["events"], bt["anchors"], bp,
+                           cp.MODE_POSTERIOR, args.kernel, 0))
+        t_upload += time.time() - t0
+        batches.append(bt)
+        ctxs.append(cx)
+    batch, b = batches[0], bs[0]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -87,18 +106,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        b.run()
-        b.sync()
-    sync_all()
     kernel_ms, stage = [], []
+
+    def run_steps(n, record):
+        """n steps, step s on batch s % inflight; a batch is waited for only when it is needed again"""
+        pending = [False] * inflight
+        for s_ in range(n):
+            j = s_ % inflight
+            if pending[j]:
+                bs[j].sync()
+                if record:
+                    kernel_ms.append(bs[j].elapsed_ms()[1])
+                    if bs[j].info()["kernel"] == "systolic":
+                        stage.append(bs[j].stage_ms())
+            bs[j].run()
+            pending[j] = True
+        for j in range(inflight):
+            if pending[j]:
+                bs[j].sync()
+                if record:
+                    kernel_ms.append(bs[j].elapsed_ms()[1])
+                    if bs[j].info()["kernel"] == "systolic":
+                        stage.append(bs[j].stage_ms())
+
+    run_steps(max(args.warmup, inflight if args.warmup > 0 else 0), False)
+    sync_all()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        b.run()
-        b.sync()
-        kernel_ms.append(b.elapsed_ms()[1])
-        if b.info()["kernel"] == "systolic":
-            stage.append(b.stage_ms())
+    run_steps(args.steps, True)
     sync_all()
     elapsed = time.perf_counter() - t_start
     if world > 1:
@@ -107,7 +141,8 @@ def main():
         elapsed = float(tt.item())
 
     npairs, ntot, ncells = b.counts()
-    cells = int(ncells.sum())
+    cells_of = [int(x.counts()[2].sum()) for x in bs]
+    cells = int(round(sum(cells_of[s_ % inflight] for s_ in range(args.steps)) / args.steps))  # per step
     if world > 1:
         ct = torch.tensor([cells], dtype=torch.int64, device="cuda")
         dist.all_reduce(ct, op=dist.ReduceOp.SUM)
@@ -124,7 +159,9 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     gcells = total_cells * args.steps / elapsed / 1e9
     reads_per_s = args.reads * world * args.steps / elapsed
-    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    # per-step time of this rank: with batches in flight the steps overlap, so it is the rank's wall time over
+    # its steps (HIP-event times of single runs overlap one another)
+    avg_kernel_s = elapsed / args.steps if inflight > 1 else float(np.mean(kernel_ms)) / 1e3
     bytes_per_cell = 48.0
     achieved = cells * bytes_per_cell / avg_kernel_s / 1e9
     # HBM traffic of one pass from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
@@ -157,18 +194,19 @@ def main():
         f_ms = float(np.mean([x[0] for x in stage]))
         k_ms = float(np.mean([x[1] for x in stage]))
         n_l = stage[0][2]
+        sfx = "_r3" if b.info().get("waves_per_workgroup") == 3 else ""  # the three-wave build of the kernels
         # dominant kernel: the backward-window kernel re-reads the 3 forward states of every cell
         # once (24 B per cell); the forward-window kernel writes them once (24 B per cell)
         roofline["dominant_kernel"] = {
-            "name": "cpecan_k_sy_backward", "launches_per_pass": n_l,
-            "note": "the batch runs as groups on separate streams: launches of different groups overlap, so the "
-                    "sum of launch durations exceeds the pass time",
+            "name": "cpecan_k_sy_backward" + sfx, "launches_per_pass": n_l,
+            "note": "launches of the batches in flight (and of a batch's stream groups) overlap, so the sum of "
+                    "launch durations exceeds the pass time",
             "avg_launch_ms": round(k_ms / n_l, 4),
             "algorithmic_bytes_per_launch": round(cells * 24.0 / n_l),
             "achieved": round(cells * 24.0 / (k_ms / 1e3) / 1e9, 2),
             "frac": round(cells * 24.0 / (k_ms / 1e3) / 1e9 / 8000.0, 5)}
         roofline["forward_kernel"] = {
-            "name": "cpecan_k_sy_forward", "launches_per_pass": n_l,
+            "name": "cpecan_k_sy_forward" + sfx, "launches_per_pass": n_l,
             "avg_launch_ms": round(f_ms / n_l, 4),
             "achieved": round(cells * 24.0 / (f_ms / 1e3) / 1e9, 2),
             "frac": round(cells * 24.0 / (f_ms / 1e3) / 1e9 / 8000.0, 5)}
@@ -223,6 +261,8 @@ def main():
                                "models, posterior decode" % (args.reads, args.events, args.kmers, args.band),
                    "cells_per_gpu": cells, "pairs_per_gpu": int(npairs.sum()),
                    "kernel": b.info(),
+                   "batches_in_flight": inflight,
+                   "step_latency_ms": round(float(np.mean(kernel_ms)), 3),
                    "parallelism": "reads sharded over %d GPU(s), no collective" % world},
         "roofline": roofline,
         "cpu_baseline": cpu,

@@ -41,6 +41,7 @@ EXPORTS = [
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
+    "cpecan_hip_batch_systolic_rows",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
     "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
     "cpecan_hip_modelsh_create", "cpecan_hip_batch_create_hdp",
@@ -151,6 +152,7 @@ def lib():
         for name in ("run", "sync", "destroy"):
             getattr(L, "cpecan_hip_batch_" + name).argtypes = [C.c_void_p]
         L.cpecan_hip_batch_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.cpecan_hip_batch_systolic_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.cpecan_hip_batch_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.cpecan_hip_batch_stage_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.cpecan_hip_batch_counts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -369,8 +371,13 @@ class Batch:
     def info(self):
         k, w, m = C.c_int32(), C.c_int32(), C.c_int32()
         _check(lib().cpecan_hip_batch_info(self.h, C.byref(k), C.byref(w), C.byref(m)))
-        return dict(kernel={1: "general", 2: "systolic"}.get(k.value, str(k.value)), workgroups=w.value,
-                    max_band_width=m.value)
+        out = dict(kernel={1: "general", 2: "systolic"}.get(k.value, str(k.value)), workgroups=w.value,
+                   max_band_width=m.value)
+        if k.value == KERNEL_SYSTOLIC:
+            r = C.c_int32()
+            _check(lib().cpecan_hip_batch_systolic_rows(self.h, C.byref(r)))
+            out["waves_per_workgroup"] = r.value
+        return out
 
     def counts(self):
         p = np.zeros(self.n, np.int64)

@@ -82,6 +82,32 @@ extern "C" int cpecan_systolic_launch_expect(hipStream_t stream, const DevItem *
 extern "C" int cpecan_systolic_bring_row_doubles(void);
 extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
                                              long long *nPairs, long long *nTot, long long *nCells);
+/* the same kernels built with three waves per workgroup (bands up to 184 k-mers, five workgroups per CU) */
+extern "C" int cpecan_systolic_max_width_r3(void);
+extern "C" int cpecan_systolic_rows_r3(void);
+extern "C" int cpecan_systolic_ring_row_doubles_r3(void);
+extern "C" long long cpecan_systolic_scratch_bytes_r3(int ringD);
+extern "C" int cpecan_systolic_launch_forward_r3(hipStream_t stream, const DevItem *items, long long nItems,
+                                              DevParams P, const void *bandTab, const double *track,
+                                              const long long *trackBase, const double *events,
+                                              const double *models, double *Fring,
+                                              long long ringDoubles, int ringD, void *states);
+extern "C" int cpecan_systolic_launch_backward_r3(hipStream_t stream, const DevItem *items, long long nItems,
+                                               DevParams P, const void *bandTab, const double *track,
+                                               const long long *trackBase, const double *models,
+                                               double *Fring, long long ringDoubles, int ringD,
+                                               void *states, long long *pairs, double *pairLogp,
+                                               long long *totXay, double *totVal, char *scratch,
+                                               long long scratchBytes, double *Bring);
+extern "C" int cpecan_systolic_launch_expect_r3(hipStream_t stream, const DevItem *items, long long nItems,
+                                             DevParams P, const void *bandTab, const double *track,
+                                             const long long *trackBase, const unsigned short *kidx,
+                                             const double *models, const double *Fring,
+                                             long long ringDoubles, const double *Bring, int ringD,
+                                             void *states, const char *scratch, long long scratchBytes,
+                                             double *expect);
+extern "C" int cpecan_systolic_bring_row_doubles_r3(void);
+
 
 namespace {
 
@@ -181,6 +207,7 @@ struct cpecan_batch {
     long long ringDoubles = 0;
     int ringD = 0, maxLX = 0;
     int nWorkers = 0, maxWidth = 0;
+    bool syR3 = false; /* systolic path: the three-wave build of the kernels */
     int nModels = 0;
     int expectLen = CPECAN_EXPECTATION_LEN; /* doubles per model in `expect` */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -668,6 +695,12 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     }
     b->kernel = useKernel;
     b->maxWidth = globalMaxWidth;
+    /* three waves per workgroup where the band fits their 192 slots: five workgroups per CU instead of four
+     * (CPECAN_SYSTOLIC_ROWS=4 forces the four-wave build, for tests and timing studies) */
+    {
+        const char *rows = getenv("CPECAN_SYSTOLIC_ROWS");
+        b->syR3 = globalMaxWidth <= cpecan_systolic_max_width_r3() && !(rows && atoi(rows) == 4);
+    }
     b->hItems = hItems;
 
     B_TRY(b->items.alloc((size_t) nItems));
@@ -726,7 +759,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         b->nWindows = maxWindows;
         b->ringD = 64;
         while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernels mask with ringD-1 */
-        b->ringDoubles = (long long) b->ringD * cpecan_systolic_ring_row_doubles();
+        b->ringDoubles = (long long) b->ringD * (b->syR3 ? cpecan_systolic_ring_row_doubles_r3() : cpecan_systolic_ring_row_doubles());
         if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
@@ -757,9 +790,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             B_TRY(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         }
         if (mode == CPECAN_MODE_EXPECTATIONS)
-            B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) cpecan_systolic_bring_row_doubles()));
+            B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) cpecan_systolic_bring_row_doubles()));  /* sized for four waves */
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
-        b->scratchBytes = (cpecan_systolic_scratch_bytes(b->ringD) + 63) / 64 * 64;
+        b->scratchBytes = ((b->syR3 ? cpecan_systolic_scratch_bytes_r3(b->ringD) : cpecan_systolic_scratch_bytes(b->ringD)) + 63) / 64 * 64;
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
         B_TRY(b->track.alloc((size_t) trackTotal * CP_ROW));
         B_TRY(b->trackBase.alloc((size_t) nItems));
@@ -907,32 +940,32 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
             hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup;
             HIP_TRY(hipStreamWaitEvent(st, b->evFork, 0));
             HIP_TRY(hipEventRecord(ev[0], st));
+            const long long bringRow = b->syR3 ? cpecan_systolic_bring_row_doubles_r3()
+                                               : cpecan_systolic_bring_row_doubles();
             for (int w = 0; w < b->nWindows && rc == 0; w++) {
                 /* the kernels index everything per alignment by blockIdx: shift the bases */
                 if (n > 0)
-                    rc = cpecan_systolic_launch_forward(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                    rc = (b->syR3 ? cpecan_systolic_launch_forward_r3 : cpecan_systolic_launch_forward)(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                         b->trackBase.p + i0, b->events.p, c->models.p,
                                                         b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                                         b->ringD,
                                                         b->syStates.p + i0 * cpecan_systolic_state_bytes());
                 HIP_TRY(hipEventRecord(ev[2 * w + 1], st));
                 if (rc == 0 && n > 0)
-                    rc = cpecan_systolic_launch_backward(st, b->items.p + i0, n, b->P, b->bandTab.p,
+                    rc = (b->syR3 ? cpecan_systolic_launch_backward_r3 : cpecan_systolic_launch_backward)(st, b->items.p + i0, n, b->P, b->bandTab.p,
                                                          b->track.p, b->trackBase.p + i0, c->models.p,
                                                          b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                                          b->ringD,
                                                          b->syStates.p + i0 * cpecan_systolic_state_bytes(),
                                                          b->pairs.p, b->pairLogp.p, b->totXay.p, b->totVal.p,
                                                          b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
-                                                         b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD *
-                                                                          cpecan_systolic_bring_row_doubles()
+                                                         b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD * bringRow
                                                                     : nullptr);
                 if (rc == 0 && n > 0 && b->mode == CPECAN_MODE_EXPECTATIONS)
-                    rc = cpecan_systolic_launch_expect(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                    rc = (b->syR3 ? cpecan_systolic_launch_expect_r3 : cpecan_systolic_launch_expect)(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                        b->trackBase.p + i0, b->kidx.p, c->models.p,
                                                        b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
-                                                       b->Bring.p + i0 * (long long) b->ringD *
-                                                           cpecan_systolic_bring_row_doubles(),
+                                                       b->Bring.p + i0 * (long long) b->ringD * bringRow,
                                                        b->ringD, b->syStates.p + i0 * cpecan_systolic_state_bytes(),
                                                        b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
                                                        b->expect.p);
@@ -949,6 +982,13 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
     }
     HIP_TRY(hipEventRecord(b->ev2, c->stream));
     b->ran = true;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_systolic_rows(cpecan_batch *b, int32_t *rows) {
+    if (!b || !rows) return fail(CPECAN_EINVAL, "bad argument");
+    if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "not a systolic batch");
+    *rows = b->syR3 ? 3 : 4;
     return CPECAN_OK;
 }
 

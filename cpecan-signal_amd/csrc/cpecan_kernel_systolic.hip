@@ -33,8 +33,26 @@
  */
 #include "cpecan_device.h"
 
-#define SY_R 4
+#ifndef SY_R
+#define SY_R 4 /* waves per workgroup: 4 (bands up to 248 k-mers) or 3 (up to 184; five workgroups fit a CU) */
+#endif
 #define SY_P (64 * SY_R)
+/* this file is compiled once per SY_R; the three-wave build's symbols carry _r3, and the pieces that do not depend
+ * on SY_R (track, counts, division self-test) exist in the four-wave build only */
+#if SY_R == 3
+#define SY_SYM(n) n##_r3
+#else
+#define SY_SYM(n) n
+#endif
+#if SY_R == 4
+#define SY_WAVE_OF(x) (((x) >> 6) & 3) /* the wave that owns k-mer x (x >= 0) */
+#define SY_WMOD(v) ((v) & 3)           /* a difference of wave indices, any sign, into 0..SY_R-1 */
+#define SY_SLOT(x) ((x) & (SY_P - 1))
+#else
+#define SY_WAVE_OF(x) (((x) >> 6) % SY_R)
+#define SY_WMOD(v) ((((v) % SY_R) + SY_R) % SY_R)
+#define SY_SLOT(x) ((x) % SY_P)
+#endif
 #define SY_NPRM 17
 #define SY_PREFETCH 4     /* diagonals the backward sweep fetches ahead (== its unroll factor) */
 #define SY_CAND_SLACK 0.25 /* candidates: cells within this (log units) below the posterior threshold */
@@ -44,14 +62,15 @@
 
 #ifdef SY_PROFILE
 /* timing build only: cycles per section of the forward step, summed over all waves */
-__device__ unsigned long long sy_prof[80];
+__device__ unsigned long long SY_SYM(sy_prof)[80];
+#define sy_prof SY_SYM(sy_prof)
 #define PROF_DECL unsigned long long prof_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, tprev_ = __builtin_readcyclecounter(); bool pact_ = false;
 #define PROF(k) { const unsigned long long now_ = __builtin_readcyclecounter(); if (pact_) prof_[k] += now_ - tprev_; else prof_[9] += now_ - tprev_; tprev_ = now_; }
 #define PROF_ACTIVE(a) { pact_ = (a); if (pact_) prof_[10]++; else prof_[11]++; }
 #define PROF_FENCE(x) asm volatile("" : "+v"(x));
 #define BPROF_DECL unsigned long long bt_[9]; for (int k_ = 0; k_ < 9; k_++) bt_[k_] = 0; bt_[0] = __builtin_readcyclecounter(); const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
 #define BPROF(k) bt_[k] = __builtin_readcyclecounter();
-#define BPROF_FLUSH if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&sy_prof[64 + k_], bt_[k_ + 1] - bt_[k_]); atomicMax(&sy_prof[75], bt_[8] - bt_[0]); { const unsigned long long rd_ = __builtin_amdgcn_s_memrealtime() - rt0_; atomicAdd(&sy_prof[76], rd_); atomicMax(&sy_prof[77], rd_); } atomicAdd(&sy_prof[72], 1ull); atomicAdd(&sy_prof[73], (unsigned long long) (sh.scan != 0)); atomicAdd(&sy_prof[74], (unsigned long long) (sh.cnt[1][0][0] + sh.cnt[1][1][0] + sh.cnt[1][2][0] + sh.cnt[1][3][0])); }
+#define BPROF_FLUSH if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) atomicAdd(&sy_prof[64 + k_], bt_[k_ + 1] - bt_[k_]); atomicMax(&sy_prof[75], bt_[8] - bt_[0]); { const unsigned long long rd_ = __builtin_amdgcn_s_memrealtime() - rt0_; atomicAdd(&sy_prof[76], rd_); atomicMax(&sy_prof[77], rd_); } atomicAdd(&sy_prof[72], 1ull); atomicAdd(&sy_prof[73], (unsigned long long) (sh.scan != 0)); atomicAdd(&sy_prof[74], (unsigned long long) (sh.cnt[1][0][0] + sh.cnt[1][1][0] + sh.cnt[1][2][0] + sh.cnt[1][SY_R - 1][0])); }
 #define PROF_FLUSH(wave) if ((threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 12; k_++) atomicAdd(&sy_prof[(wave) * 16 + k_], prof_[k_]); }
 #else
 #define PROF_DECL
@@ -196,7 +215,7 @@ struct BandFeed {
 };
 /* entries of diagonals lo..hi (clipped to 0..D) into the ring; all 256 threads */
 __device__ __forceinline__ void band_stage(BandFeed &bf, const int2 *__restrict__ tab, int D, int lo, int hi) {
-    for (int d = lo + (int) threadIdx.x; d <= hi; d += 256)
+    for (int d = lo + (int) threadIdx.x; d <= hi; d += SY_P)
         if (d >= 0 && d <= D) bf.e[d & (SY_BAND_RING - 1)] = tab[d];
 }
 __device__ __forceinline__ void band_get(const BandFeed &bf, int d, int &xmin, int &xmax) {
@@ -214,7 +233,7 @@ __device__ __forceinline__ void band_load(const int2 *__restrict__ tab, int d, i
 /* does wave w hold an in-band slot: waves (xmin>>6) .. (xmax>>6), modulo R */
 __device__ __forceinline__ bool row_active(int w, int xmin, int xmax) {
     int first = xmin >> 6, n = (xmax >> 6) - first;
-    return ((w - first) & (SY_R - 1)) <= n;
+    return SY_WMOD(w - first) <= n;
 }
 
 /* logAdd-fold of one value per lane into acc (wave-uniform in and out), lanes in ascending order;
@@ -301,8 +320,8 @@ __device__ __forceinline__ Geometry make_geometry(double *ring, int ringD) {
     Geometry g;
     g.lane = threadIdx.x & 63;
     g.wave = uni(threadIdx.x >> 6);
-    g.waveBelow = (g.wave + SY_R - 1) & (SY_R - 1);
-    g.waveAbove = (g.wave + 1) & (SY_R - 1);
+    g.waveBelow = (g.wave + SY_R - 1) % SY_R;
+    g.waveAbove = (g.wave + 1) % SY_R;
     /* ring of forward diagonals: [diagonal & (ringD-1)][wave][Fm,Fx,Fy,pm,py][lane] */
     g.rw = ring + g.wave * (SY_RING_VALUES * 64) + g.lane;
     g.rwb = ring + (g.lane == 0 ? g.waveBelow : g.wave) * (SY_RING_VALUES * 64) + ((g.lane + 63) & 63);
@@ -330,7 +349,7 @@ __device__ int next_traceback_point(const int2 *__restrict__ tab, int D, int dAf
         __syncthreads();
         const int r = uni(sh.item);
         if (r != 0x7fffffff) return r;
-        base += 256;
+        base += SY_P;
     }
 }
 
@@ -461,12 +480,12 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
             band_stage(bf, bandTab, D, db, db + 2 * SY_FEED - 1);
             const int evTo = db - fxmin - 1 + 3 * SY_FEED, rowTo = xin + 2 * SY_FEED;
 #pragma unroll 1
-            for (int i = evHi * 2 + (int) threadIdx.x; i < evTo * 2; i += 256) {
+            for (int i = evHi * 2 + (int) threadIdx.x; i < evTo * 2; i += SY_P) {
                 const int e = i >> 1;
                 fd.ev[(i & (2 * SY_FEED_EV - 1))] = e >= 0 && e < lY ? ev[3 * (long long) e + (i & 1)] : 0.0;
             }
 #pragma unroll 1
-            for (int i = rowHi * CP_ROW + (int) threadIdx.x; i < rowTo * CP_ROW; i += 256) {
+            for (int i = rowHi * CP_ROW + (int) threadIdx.x; i < rowTo * CP_ROW; i += SY_P) {
                 const int x = i / CP_ROW, j = i - x * CP_ROW;
                 fd.row[(x & (SY_FEED_ROW - 1)) * CP_ROW + j] = track[(long long) (x <= lX ? x : lX) * CP_ROW + j];
             }
@@ -518,7 +537,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
 #ifdef SY_ABLATE_INSTALL
             if (d == -1) {
 #else
-            if (((xin >> 6) & (SY_R - 1)) == wave && lane == (xin & 63)) {
+            if (SY_WAVE_OF(xin) == wave && lane == (xin & 63)) {
 #endif
                 const double *r = fd.row + (xin & (SY_FEED_ROW - 1)) * CP_ROW;
 #pragma unroll
@@ -526,7 +545,7 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
             }
             xin++;
         }
-        if (xmin == xminP && ((xmin >> 6) & (SY_R - 1)) == wave && lane == (xmin & 63)) {
+        if (xmin == xminP && SY_WAVE_OF(xmin) == wave && lane == (xmin & 63)) {
             /* the top cell's event is new.  Index -1 is NULLEVENT (:261): its emissions only ever
              * meet -inf cells, the staged 0.0 keeps NaN out */
             const double *e = fd.ev + ((2 * (d - xmin - 1)) & (2 * SY_FEED_EV - 1));
@@ -743,7 +762,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                         pxChunk = track[(long long) min(pxBase + lane, lX) * CP_ROW + CP_GAPX];
                     }
                     const double v = bcast(pxChunk, xinB - pxBase);
-                    if (((xinB >> 6) & (SY_R - 1)) == wave) pxReg = set_lane(pxReg, xinB & 63, v);
+                    if (SY_WAVE_OF(xinB) == wave) pxReg = set_lane(pxReg, xinB & 63, v);
                     xinB--;
                 }
                 BmPrev = Bm;
@@ -905,7 +924,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
     BPROF(1)
     /* ------------------------------ phase T: the totals ------------------------------ */
 #pragma unroll 1
-    for (int k = threadIdx.x; k < 2 * nTotWin; k += 256) {
+    for (int k = threadIdx.x; k < 2 * nTotWin; k += SY_P) {
         const WinTotal w = wtot[k >> 1];
         const int f = k & 1;
         double acc = CP_NEG_INF;
@@ -914,12 +933,12 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             const double *src = vw + ((long long) (k >> 1) * 2 + f) * SY_P;
             double v[8], nv[8]; /* the next eight terms are in flight while these eight are folded */
 #pragma unroll
-            for (int j = 0; j < 8; j++) v[j] = lo + j <= hi ? src[(lo + j) & (SY_P - 1)] : CP_NEG_INF;
+            for (int j = 0; j < 8; j++) v[j] = lo + j <= hi ? src[SY_SLOT(lo + j)] : CP_NEG_INF;
 #pragma unroll 1
             for (int x0 = lo; x0 <= hi; x0 += 8) {
 #pragma unroll
                 for (int j = 0; j < 8; j++)
-                    nv[j] = x0 + 8 + j <= hi ? src[(x0 + 8 + j) & (SY_P - 1)] : CP_NEG_INF;
+                    nv[j] = x0 + 8 + j <= hi ? src[SY_SLOT(x0 + 8 + j)] : CP_NEG_INF;
 #pragma unroll
                 for (int j = 0; j < 8; j++) acc = ladd(acc, v[j], cf); /* dpDiagonal_dotProduct :587-597 */
 #pragma unroll
@@ -967,15 +986,17 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             return __hip_atomic_load(msk + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto hits_of = [&](const int k) __attribute__((always_inline)) {
-            return __popcll(ld_msk(k * 4ll)) + __popcll(ld_msk(k * 4ll + 1)) + __popcll(ld_msk(k * 4ll + 2))
-                   + __popcll(ld_msk(k * 4ll + 3));
+            int n = 0; /* masks are kept four to a diagonal whatever SY_R is */
+#pragma unroll
+            for (int w2 = 0; w2 < SY_R; w2++) n += __popcll(ld_msk(k * 4ll + w2));
+            return n;
         };
         auto prefix = [&]() __attribute__((always_inline)) {
                 /* hits per diagonal from the masks; exclusive prefix in emission order */
                 int *part = (int *) sh.wbuf;
                 int carry = 0; /* hits of the rounds before this one */
 #pragma unroll 1
-                for (int base = 0; base < nPost; base += 8 * 256) { /* 2048 diagonals per round */
+                for (int base = 0; base < nPost; base += 8 * SY_P) { /* eight diagonals per thread and round */
                     const int b0 = base + (int) threadIdx.x * 8;
                     int h[8];
                     int sum = 0;
@@ -1000,7 +1021,8 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                         const int c = part[w2];
                         if (w2 < wave) o += c;
                     }
-                    carry += part[0] + part[1] + part[2] + part[3];
+#pragma unroll
+                    for (int w2 = 0; w2 < SY_R; w2++) carry += part[w2];
 #pragma unroll
                     for (int j = 0; j < 8; j++)
                         if (b0 + j < nPost) {
@@ -1021,7 +1043,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
              * with the per-diagonal offsets known, each hit is ranked inside its diagonal and written.
              */
             const int nC = sh.cnt[1][wave][0];
-            for (int i = threadIdx.x; i < nPost * 4; i += 256) msk[i] = 0ull;
+            for (int i = threadIdx.x; i < nPost * 4; i += SY_P) msk[i] = 0ull;
             __syncthreads();
             for (int pass = 0; pass < 2; pass++) {
 #pragma unroll 1
@@ -1038,14 +1060,14 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                     }
                     /* rank inside the diagonal, as in the scan below */
                     const int xmin = bandTab[t].x;
-                    const int W0 = (xmin >> 6) & (SY_R - 1), s0 = xmin & 63, c = (wave - W0) & (SY_R - 1);
+                    const int W0 = SY_WAVE_OF(xmin), s0 = xmin & 63, c = SY_WMOD(wave - W0);
                     const unsigned long long fromS0 = ~0ull << s0, below = (1ull << lane) - 1ull;
                     const unsigned long long own = ld_msk(k * 4ll + wave);
                     int first = 0, beforeMine = 0, others = 0;
 #pragma unroll
                     for (int w2 = 0; w2 < SY_R; w2++) {
                         const unsigned long long m2 = ld_msk(k * 4ll + w2);
-                        const int c2 = (w2 - W0) & (SY_R - 1);
+                        const int c2 = SY_WMOD(w2 - W0);
                         if (c2 == 0) first = __popcll(m2 & fromS0);
                         else {
                             others += __popcll(m2);
@@ -1153,14 +1175,14 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                     } else if (own[j] != 0ull) {
                         /* hits of this diagonal with a smaller k-mer index: the band starts in wave W0 at
                          * lane s0 and wraps around the four waves, possibly back into W0's low lanes */
-                        const int W0 = (xminA[j] >> 6) & (SY_R - 1), s0 = xminA[j] & 63;
+                        const int W0 = SY_WAVE_OF(xminA[j]), s0 = xminA[j] & 63;
                         const unsigned long long fromS0 = ~0ull << s0;
-                        const int c = (wave - W0) & (SY_R - 1);
+                        const int c = SY_WMOD(wave - W0);
                         int first = 0, beforeMine = 0, others = 0;
 #pragma unroll
                         for (int w2 = 0; w2 < SY_R; w2++) {
                             const unsigned long long m2 = lane64(mv, j * 4 + w2);
-                            const int c2 = (w2 - W0) & (SY_R - 1);
+                            const int c2 = SY_WMOD(w2 - W0);
                             if (c2 == 0) first = __popcll(m2 & fromS0);
                             else {
                                 others += __popcll(m2);
@@ -1205,7 +1227,7 @@ static __host__ __device__ long long scratch_cand_offset(int ringD) {
 }
 
 /* One workgroup per alignment: forward sweep up to its next traceback point. */
-extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
+extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_forward)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
@@ -1227,7 +1249,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_forward(
 }
 
 /* One workgroup per alignment: backward sweep + posterior decode of the window just described. */
-extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
+extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_backward)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
@@ -1283,7 +1305,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_backward(
  * The match block is skipped on the window's two lowest diagonals' worth of reach, as in the
  * reference, where forward[t-2] has been freed by then (quirk kept by the general kernel too).
  */
-extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_expect(
+extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_expect)(
     const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,
     const double *__restrict__ track, const long long *__restrict__ trackBase,
     const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
@@ -1395,6 +1417,7 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_sy_expect(
     }
 }
 
+#if SY_R == 4
 /* results of the per-alignment states into the batch's count arrays */
 extern "C" __global__ void cpecan_k_sy_counts(const SyState *states, long long nItems,
                                               long long *nPairs, long long *nTot, long long *nCells) {
@@ -1461,29 +1484,33 @@ extern "C" int cpecan_systolic_divtest(hipStream_t stream, long long n, unsigned
     hipLaunchKernelGGL(cpecan_k_divtest, dim3(1024), dim3(256), 0, stream, n, seed, bad);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+#endif /* SY_R == 4 */
 
 #ifdef SY_PROFILE
-extern "C" int cpecan_systolic_prof_fetch(unsigned long long *dst) {
+extern "C" int SY_SYM(cpecan_systolic_prof_fetch)(unsigned long long *dst) {
     unsigned long long zero[80] = {0};
     if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(sy_prof), sizeof(zero)) != hipSuccess) return -1;
     return hipMemcpyToSymbol(HIP_SYMBOL(sy_prof), zero, sizeof(zero)) == hipSuccess ? 0 : -1;
 }
 #endif
-extern "C" int cpecan_systolic_max_width(void) { return SY_P - 2 * SY_PREFETCH; }
-extern "C" int cpecan_systolic_rows(void) { return SY_R; }
-extern "C" int cpecan_systolic_ring_row_doubles(void) { return SY_R * SY_RING_VALUES * 64; }
+extern "C" int SY_SYM(cpecan_systolic_max_width)(void) { return SY_P - 2 * SY_PREFETCH; }
+extern "C" int SY_SYM(cpecan_systolic_rows)(void) { return SY_R; }
+extern "C" int SY_SYM(cpecan_systolic_ring_row_doubles)(void) { return SY_R * SY_RING_VALUES * 64; }
 
-extern "C" int cpecan_systolic_bring_row_doubles(void) { return SY_R * 3 * 64; }
+extern "C" int SY_SYM(cpecan_systolic_bring_row_doubles)(void) { return SY_R * 3 * 64; }
+#if SY_R == 4
 extern "C" int cpecan_systolic_state_bytes(void) { return (int) sizeof(SyState); }
+#endif
 /* HBM scratch per alignment: a hit count and an output offset per ring diagonal, and per refresh of the window one
  * WinTotal and the two rows of per-cell terms */
-extern "C" long long cpecan_systolic_scratch_bytes(int ringD) {
+extern "C" long long SY_SYM(cpecan_systolic_scratch_bytes)(int ringD) {
     return scratch_cand_offset(ringD)
            + (long long) SY_R * SY_CAND_PER_DIAG * ringD * (sizeof(int2) + sizeof(double));
 }
 
 /* Launchers of the four stages of one pass over a batch (the C-ABI layer sequences them:
  * track, then per window {forward, backward}, then counts). */
+#if SY_R == 4
 extern "C" int cpecan_systolic_launch_track(hipStream_t stream, const DevItem *items, long long nItems,
                                             const double *track, const long long *trackBase,
                                             const unsigned short *kidx, const double *models,
@@ -1495,50 +1522,53 @@ extern "C" int cpecan_systolic_launch_track(hipStream_t stream, const DevItem *i
     if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(SyState), stream) != hipSuccess) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-extern "C" int cpecan_systolic_launch_forward(hipStream_t stream, const DevItem *items, long long nItems,
+#endif
+extern "C" int SY_SYM(cpecan_systolic_launch_forward)(hipStream_t stream, const DevItem *items, long long nItems,
                                               DevParams P, const void *bandTab, const double *track,
                                               const long long *trackBase, const double *events,
                                               const double *models, double *Fring,
                                               long long ringDoubles, int ringD, void *states) {
-    hipLaunchKernelGGL(cpecan_k_sy_forward, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems,
+    hipLaunchKernelGGL(SY_SYM(cpecan_k_sy_forward), dim3((unsigned) nItems), dim3(SY_P), 0, stream, items, nItems,
                        P, (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
                        (SyState *) states);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem *items, long long nItems,
+extern "C" int SY_SYM(cpecan_systolic_launch_backward)(hipStream_t stream, const DevItem *items, long long nItems,
                                                DevParams P, const void *bandTab, const double *track,
                                                const long long *trackBase, const double *models,
                                                double *Fring, long long ringDoubles, int ringD,
                                                void *states, long long *pairs, double *pairLogp,
                                                long long *totXay, double *totVal, char *scratch,
                                                long long scratchBytes, double *Bring) {
-    hipLaunchKernelGGL(cpecan_k_sy_backward, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems,
+    hipLaunchKernelGGL(SY_SYM(cpecan_k_sy_backward), dim3((unsigned) nItems), dim3(SY_P), 0, stream, items, nItems,
                        P, (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
                        (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
-extern "C" int cpecan_systolic_launch_expect(hipStream_t stream, const DevItem *items, long long nItems,
+extern "C" int SY_SYM(cpecan_systolic_launch_expect)(hipStream_t stream, const DevItem *items, long long nItems,
                                              DevParams P, const void *bandTab, const double *track,
                                              const long long *trackBase, const unsigned short *kidx,
                                              const double *models, const double *Fring,
                                              long long ringDoubles, const double *Bring, int ringD,
                                              void *states, const char *scratch, long long scratchBytes,
                                              double *expect) {
-    hipLaunchKernelGGL(cpecan_k_sy_expect, dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems, P,
+    hipLaunchKernelGGL(SY_SYM(cpecan_k_sy_expect), dim3((unsigned) nItems), dim3(SY_P), 0, stream, items, nItems, P,
                        (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles, Bring, ringD,
                        (SyState *) states, scratch, scratchBytes, expect);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+#if SY_R == 4
 extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
                                              long long *nPairs, long long *nTot, long long *nCells) {
     hipLaunchKernelGGL(cpecan_k_sy_counts, dim3((unsigned) ((nItems + 255) / 256)), dim3(256), 0, stream,
                        (const SyState *) states, nItems, nPairs, nTot, nCells);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+#endif
 
-extern "C" int cpecan_systolic_occupancy(int *workgroupsPerCU) {
+extern "C" int SY_SYM(cpecan_systolic_occupancy)(int *workgroupsPerCU) {
     int n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cpecan_k_sy_backward, 256, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, SY_SYM(cpecan_k_sy_backward), SY_P, 0);
     if (e != hipSuccess) return -1;
     *workgroupsPerCU = n;
     return 0;

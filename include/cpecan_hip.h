@@ -207,6 +207,9 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *batch, float *ms_total, float *ms_
 /* Which kernel the batch uses (CPECAN_KERNEL_GENERAL / _SYSTOLIC after AUTO is resolved), how many
  * workgroups it launches and the widest band (cells) among its items. */
 int cpecan_hip_batch_info(cpecan_batch *batch, int32_t *kernel, int32_t *workgroups, int32_t *max_width);
+/* Systolic path only: waves per workgroup of the kernel build the batch runs on -- 3 where the widest band fits
+ * 184 k-mers (five workgroups per CU), else 4 (bands up to 248). */
+int cpecan_hip_batch_systolic_rows(cpecan_batch *batch, int32_t *rows);
 /* Systolic path only: HIP-event time of the last run spent in the forward-window kernels and in
  * the backward-window kernels (each launched `launches_each` times, once per traceback window). */
 int cpecan_hip_batch_stage_ms(cpecan_batch *batch, float *ms_forward, float *ms_backward,

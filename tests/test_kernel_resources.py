@@ -16,15 +16,17 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-def test_systolic_kernels_fit_four_waves_per_simd(tmp_path):
+@pytest.mark.parametrize("rows,suffix", [(4, ""), (3, "_r3")])
+def test_systolic_kernels_fit_four_waves_per_simd(tmp_path, rows, suffix):
     src = os.path.join(ROOT, "cpecan-signal_amd", "csrc", "cpecan_kernel_systolic.hip")
     out = str(tmp_path / "sy.s")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                           "-fno-fast-math", "-Wno-unused-function", "-I" + os.path.join(ROOT, "include"),
+                           "-fno-fast-math", "-Wno-unused-function", "-DSY_R=%d" % rows,
+                           "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-o", out, src],
                           stderr=subprocess.DEVNULL)
     text = open(out).read()
-    for name in ("cpecan_k_sy_forward", "cpecan_k_sy_backward"):
+    for name in ("cpecan_k_sy_forward" + suffix, "cpecan_k_sy_backward" + suffix):
         meta = text[text.index(".name:           " + name):]
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))

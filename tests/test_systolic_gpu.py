@@ -38,11 +38,22 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 4], ids=["rows-auto", "rows-4"])
+def rows(request, monkeypatch):
+    """both builds of the kernels: three waves per workgroup where the band fits 184 k-mers (picked by
+    itself), and the four-wave build forced"""
+    if request.param:
+        monkeypatch.setenv("CPECAN_SYSTOLIC_ROWS", str(request.param))
+    return request.param
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_systolic_matches_oracle(ctx, case):
+def test_systolic_matches_oracle(ctx, case, rows):
     batch = synth.make_batch(21, case["n"], case["lX"], case["lY"], anchor_every=case["every"])
     bp = band_params(0.01, case["md"], case["tb"], case["e"])
     res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=case["ragged"])
+    width = b.info()["max_band_width"]
+    assert b.info()["waves_per_workgroup"] == (4 if rows == 4 or width > 184 else 3)
     for i in range(case["n"]):
         ref = run_oracle_item(batch, i, bp, case["ragged"])
         assert res[i]["cells"] == ref["cells"]
@@ -52,7 +63,7 @@ def test_systolic_matches_oracle(ctx, case):
 
 
 @pytest.mark.parametrize("threshold", [0.01, 1e-4, 1e-7])
-def test_systolic_decode_paths_agree(ctx, threshold):
+def test_systolic_decode_paths_agree(ctx, threshold, rows):
     # the candidate-list decode (default) and the full-scan decode (CPECAN_FLAG_SCAN_DECODE, also the
     # path a window falls back to by itself; a tiny threshold makes long candidate lists)
     batch = synth.make_batch(25, 3, 300, 620, anchor_every=50)
@@ -106,7 +117,7 @@ def test_too_wide_band_is_refused_by_systolic_and_routed_by_auto(ctx):
     dict(n=3, lX=400, lY=800, e=100, md=200, tb=40, every=50, ragged=(0, 0)),
     dict(n=2, lX=200, lY=410, e=30, md=12, tb=10, every=40, ragged=(1, 0)),
 ])
-def test_systolic_expectations_match_oracle(ctx, case):
+def test_systolic_expectations_match_oracle(ctx, case, rows):
     # Baum-Welch sufficient statistics from the systolic kernels (forward, backward with the B ring,
     # element-wise expectation kernel) against the oracle and against the general kernel
     import pyoracle as o

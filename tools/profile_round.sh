@@ -5,8 +5,10 @@
 tag=${1:-r01}
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-B="python3 $root/bench.py --steps 2 --warmup 1 --check 0 --cpu-reads 0"
-timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/${tag}_stats -o run --output-format csv -- $B > $root/gpurun_out/${tag}_stats.log 2>&1 || exit 1
+# kernel durations: the bench's own default pipelining (two batches in flight); counters: one batch at a time,
+# so that a pass (--steps 2 --warmup 1 = 3 passes) is the unit the byte counts are divided by
+timeout -k 5 200 rocprofv3 --kernel-trace --stats -d $root/gpurun_out/${tag}_stats -o run --output-format csv -- python3 $root/bench.py --steps 4 --warmup 1 --check 0 --cpu-reads 0 > $root/gpurun_out/${tag}_stats.log 2>&1 || exit 1
+B="python3 $root/bench.py --steps 2 --warmup 1 --check 0 --cpu-reads 0 --inflight 1"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c -d $root/gpurun_out/${tag}_pmc_$c -o run --output-format csv -- $B > $root/gpurun_out/${tag}_pmc_$c.log 2>&1 || exit 1
 done
