@@ -46,8 +46,11 @@ for (k, c), v in tot.items():
         sq[k]["launches"] = n[(k, c)]
 for k, d in sq.items():
     if "SQ_WAVE_CYCLES" in d:
-        # 4 waves of four different workgroups share a SIMD in these kernels (1024 x 256 threads on 256 CUs)
-        d["valu_busy_fraction_of_simd_time"] = d["SQ_ACTIVE_INST_VALU"] / (d["SQ_WAVE_CYCLES"] / 4.0)
+        # the SQ pass runs one batch in one stream group: 1024 workgroups on 256 CUs, 4 workgroups per CU for the
+        # whole launch, i.e. as many waves per SIMD as a workgroup has waves (3 in the _r3 build, else 4)
+        per_simd = 3.0 if k.endswith("_r3") else 4.0
+        d["waves_per_simd"] = per_simd
+        d["valu_busy_fraction_of_simd_time"] = d["SQ_ACTIVE_INST_VALU"] / (d["SQ_WAVE_CYCLES"] / per_simd)
 out["SQ"] = sq
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", "%s_rocprofv3_pmc_summary.json" % tag), "w"), indent=1)
