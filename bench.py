@@ -36,7 +36,7 @@ import numpy as np  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=1024)
     ap.add_argument("--events", type=int, default=10000)
