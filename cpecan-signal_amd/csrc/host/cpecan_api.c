@@ -1633,3 +1633,83 @@ stList *getAlignedPairs(StateMachine *sM, void *cX, void *cY, int64_t lX, int64_
     stList_destruct(anchorPairs);
     return pairs;
 }
+
+/* ---- .hmm of the vanilla machine, .expectations reader of the HDP machine (impl/continuousHmm.c:477-900) ----- */
+void vanillaHmm_writeToFile(VanillaHmmExpectations *hmm, StateMachine *sM, FILE *fh) {
+    if (sM->type != vanilla) die("you gave me the wrong type of HMM");
+    fprintf(fh, "%i\t%lld\t%lld\t\n", (int) vanilla, 3ll, (long long) NUM_OF_KMERS);
+    for (int i = 0; i < 60; i++)
+        if (isnan(hmm->kmerSkipBins[i])) {
+            fprintf(stdout, "GOT NaN TRANS\n");
+            return;
+        }
+    for (int i = 0; i < 60; i++) fprintf(fh, "%f\t", hmm->kmerSkipBins[i]);
+    fprintf(fh, "%f\n", hmm->likelihood);
+    const int64_t n = 1 + (int64_t) NUM_OF_KMERS * MODEL_PARAMS;
+    for (int64_t i = 0; i < n; i++) fprintf(fh, "%f\t", sM->EMISSION_MATCH_PROBS[i]);
+    fprintf(fh, "\n");
+    for (int64_t i = 0; i < n; i++) fprintf(fh, "%f\t", sM->EMISSION_GAP_Y_PROBS[i]);
+    fprintf(fh, "\n");
+}
+VanillaHmmExpectations *vanillaHmm_loadFromFile(const char *fileName, StateMachine *sM) {
+    FILE *f = fopen(fileName, "r");
+    if (!f) die("cpecan: cannot open %s", fileName);
+    double hdr[3], line[61];
+    if (line_doubles(f, hdr, 3) != 3 || (int) hdr[0] != (int) vanilla)
+        die("Vanilla HMM construct: Wrong HMM type for this function got: %i", (int) hdr[0]);
+    if ((int64_t) hdr[2] != NUM_OF_KMERS) die("cpecan: %s: symbol set size %lld", fileName, (long long) hdr[2]);
+    const int64_t got = line_doubles(f, line, 61);
+    if (got != 61) die("incorrect number of kmer skip bins in HMM %s got %lld instead of 61", fileName, (long long) got);
+    VanillaHmmExpectations *hmm = calloc(1, sizeof *hmm);
+    memcpy(hmm->kmerSkipBins, line, sizeof(double) * 60);
+    hmm->likelihood = line[60];
+    const int64_t n = 1 + (int64_t) NUM_OF_KMERS * MODEL_PARAMS;
+    double *table = malloc(sizeof(double) * (size_t) n);
+    for (int which = 0; which < 2; which++) {
+        const int64_t m = line_doubles(f, table, n);
+        if (m != n)
+            die("incorrect number of members for %s in HMM %s got %lld instead of %lld",
+                which ? "extra event match model" : "match model", fileName, (long long) m, (long long) n);
+        if (sM) memcpy(which ? sM->EMISSION_GAP_Y_PROBS : sM->EMISSION_MATCH_PROBS, table, sizeof(double) * (size_t) n);
+    }
+    free(table);
+    fclose(f);
+    return hmm;
+}
+HdpHmmExpectations *hdpHmm_loadFromFile(const char *fileName) {
+    FILE *f = fopen(fileName, "r");
+    if (!f) die("cpecan: cannot open %s", fileName);
+    double hdr[4], line[10];
+    const int64_t nh = line_doubles(f, hdr, 4);
+    if (nh != 4) die("ERROR loading hdpHmm, got %lld tokens should get 4", (long long) nh);
+    if ((int64_t) hdr[1] != 3) die("cpecan: %s: %lld states", fileName, (long long) hdr[1]);
+    HdpHmmExpectations *hmm = hdpHmm_constructEmpty(0.0, hdr[2]);
+    const int64_t n = (int64_t) hdr[3];
+    const int64_t nt = line_doubles(f, line, 10);
+    if (nt != 10)
+        die("Incorrect number of transitions in the input HMM file %s, got %lld instead of %lld", fileName,
+            (long long) nt, 10ll);
+    memcpy(hmm->transitions, line, sizeof(double) * 9);
+    hmm->likelihood = line[9];
+    hmm->capacity = n > 0 ? n : 1;
+    hmm->eventAssignments = malloc(sizeof(double) * (size_t) hmm->capacity);
+    hmm->kmerAssignments = calloc((size_t) hmm->capacity, KMER_LENGTH + 1);
+    const int64_t ne = line_doubles(f, hmm->eventAssignments, n);
+    if (ne != n) die("Incorrect number of events got %lld, should be %lld", (long long) ne, (long long) n);
+    char *l = read_line(f), *p = l;
+    int64_t nk = 0;
+    while (p && *p) { /* tab-separated k-mers */
+        while (*p == '\t' || *p == ' ') p++;
+        if (!*p) break;
+        const char *start = p;
+        while (*p && *p != '\t' && *p != ' ') p++;
+        if (p - start != KMER_LENGTH) die("cpecan: %s: k-mer of length %lld", fileName, (long long) (p - start));
+        if (nk < n) memcpy(hmm->kmerAssignments + nk * (KMER_LENGTH + 1), start, KMER_LENGTH);
+        nk++;
+    }
+    free(l);
+    if (nk != n) die("Incorrect number of kmers got %lld, should be %lld", (long long) nk, (long long) n);
+    hmm->numberOfAssignments = n;
+    fclose(f);
+    return hmm;
+}

@@ -342,6 +342,11 @@ void getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations
                                         bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 void vanillaHmm_normalizeKmerSkipBins(VanillaHmmExpectations *hmm);                        /* :420-429 */
 void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, VanillaHmmExpectations *hmm); /* :452-462 */
+/* the vanilla .hmm file (:477-626): header, 60 skip bins + likelihood, then the match table and the extra-event
+ * table of the state machine the expectations were taken with (vanillaHmm_implantMatchModelsintoHmm :431-443).
+ * The loader fills *hmm and, if sM is given, copies the two tables into it. */
+void vanillaHmm_writeToFile(VanillaHmmExpectations *hmm, StateMachine *sM, FILE *fileHandle);
+VanillaHmmExpectations *vanillaHmm_loadFromFile(const char *fileName, StateMachine *sM);
 
 /* ---- expectations of the HDP machine (HdpHmm, inc/continuousHmm.h:26-36, impl/continuousHmm.c:631-790) ----- */
 typedef struct _hdpHmmExpectations {
@@ -362,6 +367,7 @@ void getHdpExpectationsUsingAnchors(StateMachine *sM, HdpHmmExpectations *hmm, S
                                     bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 void hdpHmm_loadTransitions(StateMachine *sM, HdpHmmExpectations *hmm);      /* :681-699 */
 void hdpHmm_writeToFile(HdpHmmExpectations *hmm, FILE *fileHandle);          /* :701-753, the .expectations file */
+HdpHmmExpectations *hdpHmm_loadFromFile(const char *fileName);               /* :755-900, without the HDP update */
 
 /* ---- Hmm / HmmDiscrete: Baum-Welch for the 5-state symbol machine (inc/stateMachine.h:47-74,
  * inc/discreteHmm.h:9-52, impl/discreteHmm.c), the reference's own structs and signatures ---------- */

@@ -79,6 +79,7 @@ EXPORTS = [
     "vanillaHmm_loadKmerSkipBinExpectations", "hdpHmm_constructEmpty", "hdpHmm_destruct",
     "getHdpExpectationsUsingAnchors", "hdpHmm_loadTransitions", "hdpHmm_writeToFile", "writePosteriorProbs",
     "getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps", "getAlignedPairs",
+    "vanillaHmm_writeToFile", "vanillaHmm_loadFromFile", "hdpHmm_loadFromFile",
 ]
 
 
@@ -247,6 +248,11 @@ def lib():
         L.getAlignedPairs.restype = vp
         L.getAlignedPairs.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.POINTER(Params), vp, vp, vp, C.c_bool,
                                       C.c_bool]
+        L.vanillaHmm_writeToFile.argtypes = [C.POINTER(VanillaExpectations), vp, vp]
+        L.vanillaHmm_loadFromFile.restype = C.POINTER(VanillaExpectations)
+        L.vanillaHmm_loadFromFile.argtypes = [C.c_char_p, vp]
+        L.hdpHmm_loadFromFile.restype = C.POINTER(HdpExpectations)
+        L.hdpHmm_loadFromFile.argtypes = [C.c_char_p]
         L.getIndelProbabilities.restype = C.POINTER(C.c_int64)
         L.getIndelProbabilities.argtypes = [vp, C.c_int64, C.c_bool]
         L.reweightAlignedPairs2.restype = vp

@@ -413,6 +413,12 @@ def test_hdp_machine_through_host_api(golden_dir, tmp_path):
     lines = open(path).read().split("\n")
     assert lines[0].split() == ["7", "3", "0.050000", str(n)]  # type threeStateHdp, states, threshold, count
     assert len(lines[1].split()) == 10 and len(lines[2].split()) == n and lines[3].split() == kmers
+    back = L.hdpHmm_loadFromFile(path.encode()).contents  # the reader of the same file
+    assert back.numberOfAssignments == n and back.threshold == 0.05
+    assert [back.kmerAssignments[i * 7:i * 7 + 6].decode() for i in range(n)] == kmers
+    assert np.allclose([back.eventAssignments[i] for i in range(n)], [e.eventAssignments[i] for i in range(n)],
+                       atol=1e-6)  # "%lf" keeps six decimals
+    assert np.allclose(list(back.transitions), list(e.transitions), atol=1e-6)
     L.hdpHmm_loadTransitions(sm, hmm)  # un-normalised counts here: only the wiring is checked
     s3 = C.cast(sm, C.POINTER(h.StateMachine3)).contents
     assert s3.TRANSITION_MATCH_CONTINUE == np.log(e.transitions[0]) and s3.TRANSITION_GAP_SWITCH_TO_Y == -np.inf
@@ -540,6 +546,42 @@ def test_continuous_pair_hmm_file_round_trip(tmp_path):
     assert list(r.individualKmerGapProbs) == list(e.individualKmerGapProbs)
     L.continuousPairHmm_normalize(C.byref(r))
     assert r.transitions[4] == 4.0 / 12.0 and abs(sum(r.individualKmerGapProbs) - 1.0) < 1e-12
+
+
+def test_vanilla_hmm_file_round_trip(golden_dir, tmp_path):
+    """tests/signalPairwiseTest.c:1544-1602 (test_vanillaHmm): skip-bin counts and the two emission tables of the
+    state machine through a .hmm file (tables to the file's "%f" precision, as the reference checks: 1e-3), then
+    vanillaHmm_normalizeKmerSkipBins' known answer"""
+    L = h.lib()
+    model = os.path.join(golden_dir, "template_median68pA.model").encode()
+    sm = L.getSignalStateMachine3Vanilla(model)
+    hmm = h.VanillaExpectations()
+    for i in range(60):
+        hmm.kmerSkipBins[i] = float(4096 * 3 + i)
+    hmm.likelihood = -77.25
+    path = tmp_path / "v.hmm"
+    libc, fh = _c_file(path, b"w")
+    L.vanillaHmm_writeToFile(C.byref(hmm), sm, fh)
+    libc.fclose(fh)
+    lines = open(path).read().split("\n")
+    assert lines[0].split() == ["4", "3", "4096"] and len(lines[1].split()) == 61
+    assert len(lines[2].split()) == len(lines[3].split()) == 1 + 4096 * 5
+    blank = L.getSignalStateMachine3Vanilla(model)
+    b = C.cast(blank, C.POINTER(h.StateMachine)).contents
+    a = C.cast(sm, C.POINTER(h.StateMachine)).contents
+    n = 1 + 4096 * 5
+    np.ctypeslib.as_array(b.EMISSION_MATCH_PROBS, shape=(n,))[:] = 0.0
+    np.ctypeslib.as_array(b.EMISSION_GAP_Y_PROBS, shape=(n,))[:] = 0.0
+    back = L.vanillaHmm_loadFromFile(str(path).encode(), blank).contents
+    assert list(back.kmerSkipBins) == list(hmm.kmerSkipBins) and back.likelihood == hmm.likelihood
+    for t in ("EMISSION_MATCH_PROBS", "EMISSION_GAP_Y_PROBS"):
+        assert np.allclose(np.ctypeslib.as_array(getattr(b, t), shape=(n,)),
+                           np.ctypeslib.as_array(getattr(a, t), shape=(n,)), atol=1e-3)
+    L.vanillaHmm_normalizeKmerSkipBins(C.byref(back))
+    total = sum(4096 * 3 + i for i in range(60))
+    assert all(back.kmerSkipBins[i] == (4096 * 3 + i) / total for i in range(60))
+    L.stateMachine_destruct(sm)
+    L.stateMachine_destruct(blank)
 
 
 def _sm5_as_oracle_model(sm):
