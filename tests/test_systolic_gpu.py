@@ -35,6 +35,8 @@ CASES = [
     # more ahead, so the forward kernel keeps every state everywhere
     dict(n=2, lX=200, lY=410, e=30, md=12, tb=10, every=40, ragged=(1, 1)),
     dict(n=2, lX=200, lY=410, e=30, md=25, tb=10, every=40, ragged=(0, 0)),
+    # bands of 181..231 k-mers: too wide for the three-wave build, the four-wave build is picked
+    dict(n=2, lX=600, lY=1200, e=180, md=400, tb=40, every=50, ragged=(1, 1)),
 ]
 
 
