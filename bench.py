@@ -275,9 +275,10 @@ def main():
     # ---- parity spot check + CPU baseline (oracle = checker / baseline only) -------------------
     check = {"reads": 0}
     cpu = None
-    if args.check > 0 or args.cpu_reads > 0:
+    cpu_reads = args.cpu_reads if world == 1 else 0  # the CPU baseline is a one-GPU (N=1) figure
+    if args.check > 0 or cpu_reads > 0:
         from harness import assert_same_pairs, run_oracle_item
-        n_cpu = max(args.check, args.cpu_reads)
+        n_cpu = max(args.check, cpu_reads)
         t_cpu, cpu_cells = 0.0, 0
         for i in range(min(n_cpu, args.reads)):
             t0 = time.perf_counter()
@@ -290,7 +291,7 @@ def main():
                 assert_same_pairs(dict(triples=tri, logp=lp), ref)
                 assert np.array_equal(tot, ref["totals"])
                 check["reads"] += 1
-        if args.cpu_reads > 0:
+        if cpu_reads > 0:
             one = {"value": round(cpu_cells / t_cpu / 1e9, 6), "unit": "Gcells/s", "cores": 1,
                    "kind": "port", "seconds": round(t_cpu, 2),
                    "sample": "first %d reads of the same batch, one thread, oracle/cpecan_oracle.c"
