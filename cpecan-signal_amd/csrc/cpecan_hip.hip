@@ -82,31 +82,45 @@ extern "C" int cpecan_systolic_launch_expect(hipStream_t stream, const DevItem *
 extern "C" int cpecan_systolic_bring_row_doubles(void);
 extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
                                              long long *nPairs, long long *nTot, long long *nCells);
-/* the same kernels built with three waves per workgroup (bands up to 184 k-mers, five workgroups per CU) */
-extern "C" int cpecan_systolic_max_width_r3(void);
-extern "C" int cpecan_systolic_rows_r3(void);
-extern "C" int cpecan_systolic_ring_row_doubles_r3(void);
-extern "C" long long cpecan_systolic_scratch_bytes_r3(int ringD);
-extern "C" int cpecan_systolic_launch_forward_r3(hipStream_t stream, const DevItem *items, long long nItems,
-                                              DevParams P, const void *bandTab, const double *track,
-                                              const long long *trackBase, const double *events,
-                                              const double *models, double *Fring,
-                                              long long ringDoubles, int ringD, void *states);
-extern "C" int cpecan_systolic_launch_backward_r3(hipStream_t stream, const DevItem *items, long long nItems,
-                                               DevParams P, const void *bandTab, const double *track,
-                                               const long long *trackBase, const double *models,
-                                               double *Fring, long long ringDoubles, int ringD,
-                                               void *states, long long *pairs, double *pairLogp,
-                                               long long *totXay, double *totVal, char *scratch,
-                                               long long scratchBytes, double *Bring);
-extern "C" int cpecan_systolic_launch_expect_r3(hipStream_t stream, const DevItem *items, long long nItems,
-                                             DevParams P, const void *bandTab, const double *track,
-                                             const long long *trackBase, const unsigned short *kidx,
-                                             const double *models, const double *Fring,
-                                             long long ringDoubles, const double *Bring, int ringD,
-                                             void *states, const char *scratch, long long scratchBytes,
-                                             double *expect);
-extern "C" int cpecan_systolic_bring_row_doubles_r3(void);
+/* the same kernels built with fewer waves per workgroup (symbols suffixed _r1.._r3): bands up to 56, 120, 184
+ * k-mers; the narrower the band, the more alignments are resident per CU */
+#define SY_DECLARE(sfx)                                                                                         \
+    extern "C" int cpecan_systolic_max_width##sfx(void);                                                          \
+    extern "C" int cpecan_systolic_ring_row_doubles##sfx(void);                                                   \
+    extern "C" int cpecan_systolic_bring_row_doubles##sfx(void);                                                  \
+    extern "C" long long cpecan_systolic_scratch_bytes##sfx(int ringD);                                           \
+    extern "C" int cpecan_systolic_launch_forward##sfx(hipStream_t, const DevItem *, long long, DevParams,        \
+                                                       const void *, const double *, const long long *,           \
+                                                       const double *, const double *, double *, long long, int, \
+                                                       void *);                                                   \
+    extern "C" int cpecan_systolic_launch_backward##sfx(hipStream_t, const DevItem *, long long, DevParams,       \
+                                                        const void *, const double *, const long long *,          \
+                                                        const double *, double *, long long, int, void *,         \
+                                                        long long *, double *, long long *, double *, char *,     \
+                                                        long long, double *);                                     \
+    extern "C" int cpecan_systolic_launch_expect##sfx(hipStream_t, const DevItem *, long long, DevParams,         \
+                                                      const void *, const double *, const long long *,            \
+                                                      const unsigned short *, const double *, const double *,     \
+                                                      long long, const double *, int, void *, const char *,       \
+                                                      long long, double *);
+SY_DECLARE(_r1)
+SY_DECLARE(_r2)
+SY_DECLARE(_r3)
+struct SyBuild { /* one build of the systolic kernels */
+    int rows;
+    int (*max_width)(void);
+    int (*ring_row_doubles)(void);
+    int (*bring_row_doubles)(void);
+    long long (*scratch_bytes)(int);
+    decltype(&cpecan_systolic_launch_forward) launch_forward;
+    decltype(&cpecan_systolic_launch_backward) launch_backward;
+    decltype(&cpecan_systolic_launch_expect) launch_expect;
+};
+#define SY_BUILD(r, sfx)                                                                                          \
+    { r, cpecan_systolic_max_width##sfx, cpecan_systolic_ring_row_doubles##sfx,                                   \
+      cpecan_systolic_bring_row_doubles##sfx, cpecan_systolic_scratch_bytes##sfx,                                 \
+      cpecan_systolic_launch_forward##sfx, cpecan_systolic_launch_backward##sfx, cpecan_systolic_launch_expect##sfx }
+static const SyBuild SY_BUILDS[4] = { SY_BUILD(1, _r1), SY_BUILD(2, _r2), SY_BUILD(3, _r3), SY_BUILD(4, ) };
 
 
 namespace {
@@ -207,7 +221,7 @@ struct cpecan_batch {
     long long ringDoubles = 0;
     int ringD = 0, maxLX = 0;
     int nWorkers = 0, maxWidth = 0;
-    bool syR3 = false; /* systolic path: the three-wave build of the kernels */
+    const SyBuild *sy = &SY_BUILDS[3]; /* systolic path: the build of the kernels the batch runs on */
     int nModels = 0;
     int expectLen = CPECAN_EXPECTATION_LEN; /* doubles per model in `expect` */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -695,11 +709,14 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     }
     b->kernel = useKernel;
     b->maxWidth = globalMaxWidth;
-    /* three waves per workgroup where the band fits their 192 slots: five workgroups per CU instead of four
-     * (CPECAN_SYSTOLIC_ROWS=4 forces the four-wave build, for tests and timing studies) */
+    /* the build with the fewest waves per workgroup whose slots hold the widest band: the fewer waves an alignment
+     * takes, the more alignments a CU holds (CPECAN_SYSTOLIC_ROWS=N asks for at least N waves: tests, timing) */
     {
         const char *rows = getenv("CPECAN_SYSTOLIC_ROWS");
-        b->syR3 = globalMaxWidth <= cpecan_systolic_max_width_r3() && !(rows && atoi(rows) == 4);
+        int r = rows ? atoi(rows) : 1;
+        r = r < 1 ? 1 : r > 4 ? 4 : r;
+        while (r < 4 && globalMaxWidth > SY_BUILDS[r - 1].max_width()) r++;
+        b->sy = &SY_BUILDS[r - 1];
     }
     b->hItems = hItems;
 
@@ -759,7 +776,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         b->nWindows = maxWindows;
         b->ringD = 64;
         while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernels mask with ringD-1 */
-        b->ringDoubles = (long long) b->ringD * (b->syR3 ? cpecan_systolic_ring_row_doubles_r3() : cpecan_systolic_ring_row_doubles());
+        b->ringDoubles = (long long) b->ringD * b->sy->ring_row_doubles();
         if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
@@ -792,7 +809,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         if (mode == CPECAN_MODE_EXPECTATIONS)
             B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) cpecan_systolic_bring_row_doubles()));  /* sized for four waves */
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
-        b->scratchBytes = ((b->syR3 ? cpecan_systolic_scratch_bytes_r3(b->ringD) : cpecan_systolic_scratch_bytes(b->ringD)) + 63) / 64 * 64;
+        b->scratchBytes = (b->sy->scratch_bytes(b->ringD) + 63) / 64 * 64;
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
         B_TRY(b->track.alloc((size_t) trackTotal * CP_ROW));
         B_TRY(b->trackBase.alloc((size_t) nItems));
@@ -940,19 +957,18 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
             hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup;
             HIP_TRY(hipStreamWaitEvent(st, b->evFork, 0));
             HIP_TRY(hipEventRecord(ev[0], st));
-            const long long bringRow = b->syR3 ? cpecan_systolic_bring_row_doubles_r3()
-                                               : cpecan_systolic_bring_row_doubles();
+            const long long bringRow = b->sy->bring_row_doubles();
             for (int w = 0; w < b->nWindows && rc == 0; w++) {
                 /* the kernels index everything per alignment by blockIdx: shift the bases */
                 if (n > 0)
-                    rc = (b->syR3 ? cpecan_systolic_launch_forward_r3 : cpecan_systolic_launch_forward)(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                    rc = b->sy->launch_forward(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                         b->trackBase.p + i0, b->events.p, c->models.p,
                                                         b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                                         b->ringD,
                                                         b->syStates.p + i0 * cpecan_systolic_state_bytes());
                 HIP_TRY(hipEventRecord(ev[2 * w + 1], st));
                 if (rc == 0 && n > 0)
-                    rc = (b->syR3 ? cpecan_systolic_launch_backward_r3 : cpecan_systolic_launch_backward)(st, b->items.p + i0, n, b->P, b->bandTab.p,
+                    rc = b->sy->launch_backward(st, b->items.p + i0, n, b->P, b->bandTab.p,
                                                          b->track.p, b->trackBase.p + i0, c->models.p,
                                                          b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                                          b->ringD,
@@ -962,7 +978,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                                          b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD * bringRow
                                                                     : nullptr);
                 if (rc == 0 && n > 0 && b->mode == CPECAN_MODE_EXPECTATIONS)
-                    rc = (b->syR3 ? cpecan_systolic_launch_expect_r3 : cpecan_systolic_launch_expect)(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                    rc = b->sy->launch_expect(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                        b->trackBase.p + i0, b->kidx.p, c->models.p,
                                                        b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                                        b->Bring.p + i0 * (long long) b->ringD * bringRow,
@@ -988,7 +1004,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
 int cpecan_hip_batch_systolic_rows(cpecan_batch *b, int32_t *rows) {
     if (!b || !rows) return fail(CPECAN_EINVAL, "bad argument");
     if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "not a systolic batch");
-    *rows = b->syR3 ? 3 : 4;
+    *rows = b->sy->rows;
     return CPECAN_OK;
 }
 

@@ -37,12 +37,22 @@
 #define SY_R 4 /* waves per workgroup: 4 (bands up to 248 k-mers) or 3 (up to 184; five workgroups fit a CU) */
 #endif
 #define SY_P (64 * SY_R)
-/* this file is compiled once per SY_R; the three-wave build's symbols carry _r3, and the pieces that do not depend
- * on SY_R (track, counts, division self-test) exist in the four-wave build only */
-#if SY_R == 3
-#define SY_SYM(n) n##_r3
-#else
+/* this file is compiled once per SY_R (1..4 waves per workgroup: bands up to 56, 120, 184, 248 k-mers); the symbols
+ * of the builds below four carry _r1.._r3, and the pieces that do not depend on SY_R (track, counts, division
+ * self-test) exist in the four-wave build only */
+#if SY_R == 4
 #define SY_SYM(n) n
+#elif SY_R == 3
+#define SY_SYM(n) n##_r3
+#elif SY_R == 2
+#define SY_SYM(n) n##_r2
+#else
+#define SY_SYM(n) n##_r1
+#endif
+#if SY_R == 1 /* the one-wave backward kernel lands on 129 VGPRs by itself: hold it to four waves per SIMD */
+#define SY_BACKWARD_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define SY_BACKWARD_ATTR
 #endif
 #if SY_R == 4
 #define SY_WAVE_OF(x) (((x) >> 6) & 3) /* the wave that owns k-mer x (x >= 0) */
@@ -1249,7 +1259,7 @@ extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_forward)(
 }
 
 /* One workgroup per alignment: backward sweep + posterior decode of the window just described. */
-extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_backward)(
+extern "C" __global__ __launch_bounds__(SY_P) SY_BACKWARD_ATTR void SY_SYM(cpecan_k_sy_backward)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,

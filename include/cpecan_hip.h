@@ -207,8 +207,9 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *batch, float *ms_total, float *ms_
 /* Which kernel the batch uses (CPECAN_KERNEL_GENERAL / _SYSTOLIC after AUTO is resolved), how many
  * workgroups it launches and the widest band (cells) among its items. */
 int cpecan_hip_batch_info(cpecan_batch *batch, int32_t *kernel, int32_t *workgroups, int32_t *max_width);
-/* Systolic path only: waves per workgroup of the kernel build the batch runs on -- 3 where the widest band fits
- * 184 k-mers (five workgroups per CU), else 4 (bands up to 248). */
+/* Systolic path only: waves per workgroup of the kernel build the batch runs on -- the fewest whose 64 slots each
+ * hold the widest band of the batch: 1 (bands up to 56 k-mers), 2 (120), 3 (184) or 4 (248).  The fewer waves an
+ * alignment takes, the more alignments a CU holds (16, 8, 5, 4). */
 int cpecan_hip_batch_systolic_rows(cpecan_batch *batch, int32_t *rows);
 /* Systolic path only: HIP-event time of the last run spent in the forward-window kernels and in
  * the backward-window kernels (each launched `launches_each` times, once per traceback window). */

@@ -16,7 +16,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("rows,suffix", [(4, ""), (3, "_r3")])
+@pytest.mark.parametrize("rows,suffix", [(4, ""), (3, "_r3"), (2, "_r2"), (1, "_r1")])
 def test_systolic_kernels_fit_four_waves_per_simd(tmp_path, rows, suffix):
     src = os.path.join(ROOT, "cpecan-signal_amd", "csrc", "cpecan_kernel_systolic.hip")
     out = str(tmp_path / "sy.s")

@@ -42,8 +42,8 @@ CASES = [
 
 @pytest.fixture(params=[0, 4], ids=["rows-auto", "rows-4"])
 def rows(request, monkeypatch):
-    """both builds of the kernels: three waves per workgroup where the band fits 184 k-mers (picked by
-    itself), and the four-wave build forced"""
+    """the builds of the kernels: the one with the fewest waves per workgroup that holds the band (1, 2, 3 or 4
+    waves for bands up to 56, 120, 184, 248 k-mers; picked by itself), and the four-wave build forced"""
     if request.param:
         monkeypatch.setenv("CPECAN_SYSTOLIC_ROWS", str(request.param))
     return request.param
@@ -55,7 +55,7 @@ def test_systolic_matches_oracle(ctx, case, rows):
     bp = band_params(0.01, case["md"], case["tb"], case["e"])
     res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=case["ragged"])
     width = b.info()["max_band_width"]
-    assert b.info()["waves_per_workgroup"] == (4 if rows == 4 or width > 184 else 3)
+    assert b.info()["waves_per_workgroup"] == (4 if rows == 4 else 1 + (width > 56) + (width > 120) + (width > 184))
     for i in range(case["n"]):
         ref = run_oracle_item(batch, i, bp, case["ragged"])
         assert res[i]["cells"] == ref["cells"]
