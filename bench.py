@@ -64,7 +64,7 @@ def cpu_all_cores(batch, band, per_core, cores):
         cells = sum(pool.map(_cpu_read, range(n), chunksize=1))
         dt = time.perf_counter() - t0
     return {"value": round(cells / dt / 1e9, 6), "unit": "Gcells/s", "cores": cores, "kind": "port",
-            "seconds": round(dt, 2),
+            "seconds": round(dt, 2), "cells": int(cells),
             "sample": "first %d reads of the same batch, %d worker processes, oracle/cpecan_oracle.c" % (n, cores)}
 
 
