@@ -18,6 +18,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <sched.h>
 #include <thread>
 #include <vector>
 
@@ -126,6 +127,19 @@ static const SyBuild SY_BUILDS[4] = { SY_BUILD(1, _r1), SY_BUILD(2, _r2), SY_BUI
 namespace {
 
 thread_local std::string g_err;
+
+/* worker threads for host-side table derivation: the CPUs this process may run on (its affinity mask, which is
+ * what a job's CPU share shows up as), at most 32 -- a node's hardware_concurrency() is the whole machine, and
+ * eight ranks of a multi-GPU job each spawning that many threads would run into the host's task limits */
+int host_threads() {
+    int n = (int) std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0 && c < n) n = c;
+    }
+    return n < 1 ? 1 : n > 32 ? 32 : n;
+}
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -328,7 +342,7 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
     HIP_TRY(hipSetDevice(c->device));
     const size_t old = c->hostModels.size();
     c->hostModels.resize(old + (size_t) n * CP_MODEL_STRIDE);
-    int nt = threads > 0 ? threads : (int) std::thread::hardware_concurrency();
+    int nt = threads > 0 ? threads : host_threads();
     nt = std::max(1, std::min(nt, (int) n));
     std::vector<std::thread> pool;
     for (int w = 0; w < nt; w++)
@@ -418,7 +432,7 @@ int cpecan_hip_modelsv_create(cpecan_ctx *c, const cpecan_vanilla_model *models,
     HIP_TRY(hipSetDevice(c->device));
     const size_t old = c->hostModelsV.size();
     c->hostModelsV.resize(old + (size_t) n * CP_VMODEL_STRIDE);
-    int nt = threads > 0 ? threads : (int) std::thread::hardware_concurrency();
+    int nt = threads > 0 ? threads : host_threads();
     nt = std::max(1, std::min(nt, (int) n));
     std::vector<std::thread> pool;
     for (int w = 0; w < nt; w++)
