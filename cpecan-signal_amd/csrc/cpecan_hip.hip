@@ -72,14 +72,14 @@ extern "C" int cpecan_systolic_launch_backward(hipStream_t stream, const DevItem
                                                double *Fring, long long ringDoubles, int ringD,
                                                void *states, long long *pairs, double *pairLogp,
                                                long long *totXay, double *totVal, char *scratch,
-                                               long long scratchBytes, double *Bring);
+                                               long long scratchBytes, double *Bring, int window);
 extern "C" int cpecan_systolic_launch_expect(hipStream_t stream, const DevItem *items, long long nItems,
                                              DevParams P, const void *bandTab, const double *track,
                                              const long long *trackBase, const unsigned short *kidx,
                                              const double *models, const double *Fring,
                                              long long ringDoubles, const double *Bring, int ringD,
                                              void *states, const char *scratch, long long scratchBytes,
-                                             double *expect);
+                                             double *expect, int window);
 extern "C" int cpecan_systolic_bring_row_doubles(void);
 extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
                                              long long *nPairs, long long *nTot, long long *nCells);
@@ -98,12 +98,12 @@ extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *sta
                                                         const void *, const double *, const long long *,          \
                                                         const double *, double *, long long, int, void *,         \
                                                         long long *, double *, long long *, double *, char *,     \
-                                                        long long, double *);                                     \
+                                                        long long, double *, int);                                \
     extern "C" int cpecan_systolic_launch_expect##sfx(hipStream_t, const DevItem *, long long, DevParams,         \
                                                       const void *, const double *, const long long *,            \
                                                       const unsigned short *, const double *, const double *,     \
                                                       long long, const double *, int, void *, const char *,       \
-                                                      long long, double *);
+                                                      long long, double *, int);
 SY_DECLARE(_r1)
 SY_DECLARE(_r2)
 SY_DECLARE(_r3)
@@ -990,7 +990,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                                          b->pairs.p, b->pairLogp.p, b->totXay.p, b->totVal.p,
                                                          b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
                                                          b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD * bringRow
-                                                                    : nullptr);
+                                                                    : nullptr, w);
                 if (rc == 0 && n > 0 && b->mode == CPECAN_MODE_EXPECTATIONS)
                     rc = b->sy->launch_expect(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                        b->trackBase.p + i0, b->kidx.p, c->models.p,
@@ -998,7 +998,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                                        b->Bring.p + i0 * (long long) b->ringD * bringRow,
                                                        b->ringD, b->syStates.p + i0 * cpecan_systolic_state_bytes(),
                                                        b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
-                                                       b->expect.p);
+                                                       b->expect.p, w);
                 HIP_TRY(hipEventRecord(ev[2 * w + 2], st));
             }
             HIP_TRY(hipEventRecord(b->evJoin[(size_t) gi], st));

@@ -68,6 +68,7 @@
 #define SY_CAND_SLACK 0.25 /* candidates: cells within this (log units) below the posterior threshold */
 #define SY_CAND_PER_DIAG 4 /* candidate capacity per wave, in records per ring diagonal */
 #define SY_DECODE_U 2     /* diagonals per batch of the posterior decode */
+#define SY_EXPECT_CHUNKS 8 /* workgroups that share one window's diagonals in the expectation pass */
 #define SY_RING_VALUES 5 /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
 
 #ifdef SY_PROFILE
@@ -1264,7 +1265,7 @@ extern "C" __global__ __launch_bounds__(SY_P) SY_BACKWARD_ATTR void SY_SYM(cpeca
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
     long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
-    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring) {
+    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window) {
     __shared__ Shared sh;
     __shared__ BandFeed bf;
     const long long idx = blockIdx.x;
@@ -1300,7 +1301,7 @@ extern "C" __global__ __launch_bounds__(SY_P) SY_BACKWARD_ATTR void SY_SYM(cpeca
         state->nPairs = out.nPairs;
         state->nTot = out.nTot;
         state->winValid = 0;
-        state->expectPending = P.mode != 0 ? 1 : 0;
+        state->expectPending = P.mode != 0 ? window + 1 : 0; /* which launch's window the B ring holds */
     }
 }
 
@@ -1320,12 +1321,14 @@ extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_expect)(
     const double *__restrict__ track, const long long *__restrict__ trackBase,
     const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
     long long ringDoubles, const double *Bring, int ringD, SyState *states, const char *scratch,
-    long long scratchBytes, double *expect) {
+    long long scratchBytes, double *expect, int window) {
     __shared__ double sExp[16];
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
-    SyState *state = states + idx;
-    if (!state->expectPending) return;
+    const SyState *state = states + idx;
+    /* the pass has no recurrence: gridDim.y workgroups share a window's diagonals, a contiguous run each; the
+     * state record is only read here (the backward kernel stamps it with the launch it belongs to) */
+    if (state->expectPending != window + 1) return;
     const DevItem it = uniform_item(items[idx]);
     const double *model = models + (long long) it.model * CP_MODEL_STRIDE;
     double T[9];
@@ -1348,14 +1351,18 @@ extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_expect)(
     double lik = 0.0, gapSum = 0.0;
     int gapX = -1; /* matrix column whose gap-X expectations gapSum holds */
 
+    const int perChunk = (tPost0 - to + (int) gridDim.y - 1) / (int) gridDim.y;
+    const int tHi = tPost0 - (int) blockIdx.y * perChunk;             /* this workgroup: diagonals tHi .. tLo+1 */
+    const int tLo = tHi - perChunk > to ? tHi - perChunk : to;
+    if (tHi <= to) return;
     int xs = wave * 64 + lane; /* this slot's k-mer: the one in (xmax-P, xmax] */
     int b0min, b0max, b1min, b1max, b2min, b2max;
-    band_load(tab, tPost0, b0min, b0max);
-    band_load(tab, tPost0 - 1, b1min, b1max);
+    band_load(tab, tHi, b0min, b0max);
+    band_load(tab, tHi - 1, b1min, b1max);
     xs += ((b0min - xs + SY_P - 1) / SY_P) * SY_P;
     if (xs > b0max) xs -= SY_P;
 #pragma unroll 1
-    for (int t = tPost0; t > to; t--) {
+    for (int t = tHi; t > tLo; t--) {
         band_load(tab, t - 2, b2min, b2max);
         if (xs > b0max) xs -= SY_P;
         const int x = xs;
@@ -1421,10 +1428,7 @@ extern "C" __global__ __launch_bounds__(SY_P) void SY_SYM(cpecan_k_sy_expect)(
     }
     __syncthreads();
     if (threadIdx.x < 9) atomicAdd(dst + threadIdx.x, sExp[threadIdx.x]);
-    if (threadIdx.x == 0) {
-        atomicAdd(dst + 9 + 4096, lik);
-        state->expectPending = 0;
-    }
+    if (threadIdx.x == 0) atomicAdd(dst + 9 + 4096, lik);
 }
 
 #if SY_R == 4
@@ -1549,10 +1553,10 @@ extern "C" int SY_SYM(cpecan_systolic_launch_backward)(hipStream_t stream, const
                                                double *Fring, long long ringDoubles, int ringD,
                                                void *states, long long *pairs, double *pairLogp,
                                                long long *totXay, double *totVal, char *scratch,
-                                               long long scratchBytes, double *Bring) {
+                                               long long scratchBytes, double *Bring, int window) {
     hipLaunchKernelGGL(SY_SYM(cpecan_k_sy_backward), dim3((unsigned) nItems), dim3(SY_P), 0, stream, items, nItems,
                        P, (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
-                       (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring);
+                       (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int SY_SYM(cpecan_systolic_launch_expect)(hipStream_t stream, const DevItem *items, long long nItems,
@@ -1561,10 +1565,10 @@ extern "C" int SY_SYM(cpecan_systolic_launch_expect)(hipStream_t stream, const D
                                              const double *models, const double *Fring,
                                              long long ringDoubles, const double *Bring, int ringD,
                                              void *states, const char *scratch, long long scratchBytes,
-                                             double *expect) {
-    hipLaunchKernelGGL(SY_SYM(cpecan_k_sy_expect), dim3((unsigned) nItems), dim3(SY_P), 0, stream, items, nItems, P,
-                       (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles, Bring, ringD,
-                       (SyState *) states, scratch, scratchBytes, expect);
+                                             double *expect, int window) {
+    hipLaunchKernelGGL(SY_SYM(cpecan_k_sy_expect), dim3((unsigned) nItems, SY_EXPECT_CHUNKS), dim3(SY_P), 0, stream,
+                       items, nItems, P, (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles,
+                       Bring, ringD, (SyState *) states, scratch, scratchBytes, expect, window);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 #if SY_R == 4
