@@ -10,6 +10,7 @@ The directory name contains a hyphen, so load this module by path:
 import ctypes as C
 import os
 import sys
+import weakref
 import subprocess
 
 import numpy as np
@@ -203,9 +204,12 @@ class Context:
         _check(lib().cpecan_hip_ctx_create(device, C.byref(h)))
         self.h = h
         self.device = device
+        self._batches = weakref.WeakSet()  # closed before the context is (a batch must not outlive its streams)
 
     def close(self):
         if self.h:
+            for b in list(self._batches):
+                b.close()
             lib().cpecan_hip_ctx_destroy(self.h)
             self.h = None
 
@@ -347,6 +351,7 @@ class Batch:
                                                  _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
                                                  C.byref(params), mode, kernel, flags, C.byref(h)))
         self.h = h
+        ctx._batches.add(self)
         self.n = items.shape[0]
         self.dna = y_chars is not None
         self.vanilla = bool(vanilla) and not self.dna

@@ -236,6 +236,7 @@ struct cpecan_batch {
     int ringD = 0, maxLX = 0;
     int nWorkers = 0, maxWidth = 0;
     const SyBuild *sy = &SY_BUILDS[3]; /* systolic path: the build of the kernels the batch runs on */
+    int device = 0;                    /* the context's device, kept for the destructor */
     int nModels = 0;
     int expectLen = CPECAN_EXPECTATION_LEN; /* doubles per model in `expect` */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -292,6 +293,7 @@ int cpecan_hip_ctx_destroy(cpecan_ctx *c) {
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
+    (void) hipGetLastError();
     return CPECAN_OK;
 }
 
@@ -543,7 +545,9 @@ int cpecan_hip_models_clear(cpecan_ctx *c) {
 
 int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (!b) return CPECAN_OK;
-    (void) hipSetDevice(b->ctx->device);
+    /* the batch keeps its own device id: a caller (a garbage collector, say) may destroy the context first, and
+     * nothing here may depend on it then */
+    (void) hipSetDevice(b->device);
     if (b->ev0) (void) hipEventDestroy(b->ev0);
     if (b->ev1) (void) hipEventDestroy(b->ev1);
     if (b->ev2) (void) hipEventDestroy(b->ev2);
@@ -552,6 +556,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (b->evFork) (void) hipEventDestroy(b->evFork);
     for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     delete b;
+    (void) hipGetLastError(); /* a failed clean-up call must not surface as the "last error" of a later launch */
     return CPECAN_OK;
 }
 
@@ -688,6 +693,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     cpecan_batch *b = new (std::nothrow) cpecan_batch();
     if (!b) return fail(CPECAN_EINVAL, "out of host memory");
     b->ctx = c;
+    b->device = c->device;
     b->nItems = nItems;
     b->mode = mode;
     b->flags = flags;

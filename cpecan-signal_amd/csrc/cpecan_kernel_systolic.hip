@@ -52,7 +52,11 @@
 #if SY_R == 1 /* the one-wave backward kernel lands on 129 VGPRs by itself: hold it to four waves per SIMD */
 #define SY_BACKWARD_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #else
+#ifdef SY_FORCE_WAVES
+#define SY_BACKWARD_ATTR __attribute__((amdgpu_waves_per_eu(SY_FORCE_WAVES, SY_FORCE_WAVES)))
+#else
 #define SY_BACKWARD_ATTR
+#endif
 #endif
 #if SY_R == 4
 #define SY_WAVE_OF(x) (((x) >> 6) & 3) /* the wave that owns k-mer x (x >= 0) */
@@ -704,10 +708,12 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
         if (xs > bxmax) xs -= SY_P;
         bool tvalid = xs >= bxmin;        /* slot in band on diagonal t */
         double Bm, Bx, By;                                        /* backward cell on diagonal t        */
-        double Hm = CP_NEG_INF, Hx = CP_NEG_INF, Hy = CP_NEG_INF; /* middle-block msgs from t+2 (moved) */
-        double Mm = CP_NEG_INF, Mx = CP_NEG_INF, My = CP_NEG_INF; /* middle-block msgs made on t+1      */
-        double Um = CP_NEG_INF, Uy = CP_NEG_INF;                  /* upper-block msgs from t+1 (same slot) */
-        double Gm = CP_NEG_INF, Gx = CP_NEG_INF, Gy = CP_NEG_INF; /* lower-block msgs made on t+1       */
+        /* What a cell hands to the diagonals below are sums B + (eP + tP) of its own backward value, its own
+         * emission and a transition.  The slot above sends the two ingredients (B.match with its match emission,
+         * B.gapX with its gap-X emission) down the lanes and the receiver forms the sums: four values to shift and
+         * to hold instead of eight; the sums are the same expressions, so the doubles are the same. */
+        double hB = CP_NEG_INF, hP = 0.0;        /* B.match and match emission of slot+1 on t+2 (middle block) */
+        double Um = CP_NEG_INF, Uy = CP_NEG_INF; /* upper-block sums from t+1 (same slot)                       */
         double pmPrev = 0.0, BmPrev = CP_NEG_INF;                 /* match emission / backward match of t+1 */
         {
             double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
@@ -764,8 +770,10 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             if (t < dTop) {
                 lds_barrier();
                 const double *xa = sh.xch[(t + 1) & 1][g.waveAbove];
-                const double gm = shl1(xa[0], Gm), gx_ = shl1(xa[1], Gx), gy_ = shl1(xa[2], Gy);
-                const double hm = shl1(xa[3], Mm), hx = shl1(xa[4], Mx), hy = shl1(xa[5], My);
+                /* of slot+1 on t+1: B.gapX with its k-mer's gap-X emission (lower block of t+1), B.match with its
+                 * match emission (middle block, used one diagonal further down) */
+                const double rBx = shl1(xa[0], Bx), rPx = shl1(xa[1], pxReg);
+                const double rBm = shl1(xa[2], Bm), rPm = shl1(xa[3], pmPrev);
                 const bool bvalid = xs >= bxmin;
                 while (xinB >= bxmin) {
                     if (xinB < pxBase) {
@@ -782,32 +790,24 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 if (active) {
                     /* gather form of cell_calculateBackward: (t+2) middle block, then (t+1, smaller
                      * x-y) upper block, then (t+1, larger x-y) lower block */
-                    bm = ladd(ladd(Hm, Um, cf), gm, cf);
-                    bx = ladd(Hx, gx_, cf);
-                    by = ladd(Hy, Uy, cf);
-                    if (hasSwitchX) by = ladd(by, gy_, cf);
+                    bm = ladd(ladd(hB + (hP + T[T_MATCH_CONTINUE]), Um, cf), rBx + (rPx + T[T_GAP_OPEN_X]), cf);
+                    bx = ladd(hB + (hP + T[T_MATCH_FROM_GAP_X]), rBx + (rPx + T[T_GAP_EXTEND_X]), cf);
+                    by = ladd(hB + (hP + T[T_MATCH_FROM_GAP_Y]), Uy, cf);
+                    if (hasSwitchX) by = ladd(by, rBx + (rPx + T[T_GAP_SWITCH_TO_X]), cf);
                     bm = bvalid ? bm : CP_NEG_INF;
                     bx = bvalid ? bx : CP_NEG_INF;
                     by = bvalid ? by : CP_NEG_INF;
                 }
                 Bm = bm; Bx = bx; By = by;
-                Hm = hm; Hx = hx; Hy = hy;
+                hB = rBm; hP = rPm;
             }
-            /* messages this diagonal sends to t-1 and t-2 */
-            Mm = Mx = My = Um = Uy = Gm = Gx = Gy = CP_NEG_INF;
-            if (active) {
-                Mm = Bm + (pmc + T[T_MATCH_CONTINUE]);
-                Mx = Bm + (pmc + T[T_MATCH_FROM_GAP_X]);
-                My = Bm + (pmc + T[T_MATCH_FROM_GAP_Y]);
-                Um = By + (pyc + T[T_GAP_OPEN_Y]);
-                Uy = By + (pyc + T[T_GAP_EXTEND_Y]);
-                Gm = Bx + (pxReg + T[T_GAP_OPEN_X]);
-                Gx = Bx + (pxReg + T[T_GAP_EXTEND_X]);
-                Gy = Bx + (pxReg + T[T_GAP_SWITCH_TO_X]);
-            }
+            /* what this diagonal hands down: the upper-block sums stay in the slot (a cell outside the band has
+             * B = -inf and a zero emission: the sums are -inf by themselves); the rest leaves as B and emission */
+            Um = By + (pyc + T[T_GAP_OPEN_Y]);
+            Uy = By + (pyc + T[T_GAP_EXTEND_Y]);
             if (lane == 0) {
                 double *x = sh.xch[t & 1][wave];
-                x[0] = Gm; x[1] = Gx; x[2] = Gy; x[3] = Mm; x[4] = Mx; x[5] = My;
+                x[0] = Bx; x[1] = pxReg; x[2] = Bm; x[3] = pmc;
             }
 
             if (t <= tracedBackFrom) {
