@@ -7,7 +7,7 @@ import numpy as np
 
 from cpecan_load import ROOT
 
-LIB_PATH = os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_host.so")
+LIB_PATH = os.environ.get("CPECAN_HOST_LIB") or os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_host.so")
 NUM_KMERS = 4096
 
 
