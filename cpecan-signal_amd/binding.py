@@ -42,7 +42,7 @@ EXPORTS = [
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
-    "cpecan_hip_batch_systolic_rows",
+    "cpecan_hip_batch_systolic_rows", "cpecan_hip_models_set_transitions",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
     "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
     "cpecan_hip_modelsh_create", "cpecan_hip_batch_create_hdp",
@@ -133,6 +133,7 @@ def lib():
         L.cpecan_hip_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.cpecan_hip_models_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.cpecan_hip_models_clear.argtypes = [C.c_void_p]
+        L.cpecan_hip_models_set_transitions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cpecan_hip_selftest_division.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]
         L.cpecan_hip_batch_create.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -223,6 +224,14 @@ class Context:
         s = C.c_void_p()
         _check(lib().cpecan_hip_ctx_stream(self.h, C.byref(s)))
         return s.value
+
+    def models_set_transitions(self, transitions, gap_x=None):
+        """the M-step's update of every strawMan model of the context, in place on the device"""
+        t = np.ascontiguousarray(transitions, dtype=np.float64)
+        assert t.size == 9
+        g = None if gap_x is None else np.ascontiguousarray(gap_x, dtype=np.float64)
+        assert g is None or g.size == NUM_KMERS
+        _check(lib().cpecan_hip_models_set_transitions(self.h, _ptr(t), _ptr(g) if g is not None else None))
 
     def models_create(self, models, threads=0):
         """models: list of (transitions[9], match[20481], gap_x[4096], gap_y[20481]) -> ids"""

@@ -362,6 +362,39 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
     return CPECAN_OK;
 }
 
+extern "C" __global__ void cpecan_k_set_transitions(double *models, int nModels, const double *values /* 9 + 4096 */,
+                                                    int withGap) {
+    const int m = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nModels) return;
+    double *blk = models + (long long) m * CP_MODEL_STRIDE;
+    if (i < 9) blk[i] = values[i];
+    else if (withGap && i < 9 + CPECAN_NUM_KMERS)
+        blk[CP_MODEL_HEADER + (long long) (i - 9) * CP_ROW + CP_GAPX] = values[i];
+}
+
+int cpecan_hip_models_set_transitions(cpecan_ctx *c, const double *transitions, const double *gapX) {
+    if (!c || !transitions) return fail(CPECAN_EINVAL, "bad argument");
+    if (c->nModels <= 0) return fail(CPECAN_EINVAL, "the context holds no strawMan models");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<double> v(9 + CPECAN_NUM_KMERS, 0.0);
+    for (int i = 0; i < 9; i++) v[(size_t) i] = transitions[i];
+    if (gapX) std::copy(gapX, gapX + CPECAN_NUM_KMERS, v.begin() + 9);
+    for (int m = 0; m < c->nModels; m++) { /* the host copy stays the truth for later appends */
+        double *blk = c->hostModels.data() + (size_t) m * CP_MODEL_STRIDE;
+        for (int i = 0; i < 9; i++) blk[i] = transitions[i];
+        if (gapX)
+            for (int k = 0; k < CPECAN_NUM_KMERS; k++) blk[CP_MODEL_HEADER + (size_t) k * CP_ROW + CP_GAPX] = gapX[k];
+    }
+    DevBuf<double> dv;
+    HIP_TRY(dv.alloc(v.size()));
+    HIP_TRY(hipMemcpyAsync(dv.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(cpecan_k_set_transitions, dim3((9 + CPECAN_NUM_KMERS + 255) / 256, (unsigned) c->nModels),
+                       dim3(256), 0, c->stream, c->models.p, c->nModels, (const double *) dv.p, gapX ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream)); /* dv is released on return */
+    return CPECAN_OK;
+}
+
 int cpecan_hip_selftest_division(cpecan_ctx *c, int64_t n, uint64_t seed, int64_t *mismatches) {
     if (!c || n <= 0 || !mismatches) return fail(CPECAN_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));

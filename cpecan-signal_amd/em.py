@@ -63,36 +63,116 @@ class _DeviceDoubles:
                                          "version": 2}
 
 
-def gpu_e_step(cp, ctx, batch, bp, read_idx, transitions, gap_x, dist=None, pseudocount=0.0):
+def gpu_e_step(cp, ctx, batch, bp, read_idx, transitions, gap_x, dist=None, pseudocount=0.0, ctx2=None):
     """Expectations of reads `read_idx` of `batch` (tests/synth.make_batch layout: per-read scaled match tables)
-    under (transitions, gap_x): one Batch in MODE_EXPECTATIONS, the per-model sums added on the device, one
-    all-reduce over the ranks, one copy to the host.  Returns the EXP_LEN vector (identical on every rank)."""
+    under (transitions, gap_x): expectation batches in MODE_EXPECTATIONS, the per-model sums added on the device,
+    one all-reduce over the ranks, one copy to the host.  Returns the EXP_LEN vector (identical on every rank).
+
+    With a second context (`ctx2`, same device) the reads are dealt into two batches that run at the same time on
+    the two contexts' streams, each as one stream group: the kernels of one batch fill the workgroup slots the
+    other leaves idle (the same overlap bench.py uses between consecutive steps)."""
+    import os
     import torch
 
-    items = np.zeros(len(read_idx), cp.ITEM_DTYPE)
-    models = []
-    for k, i in enumerate(read_idx):
-        it = batch["items"][i]
-        match, _, gap_y = batch["models"][it["model"]]
-        models.append((list(transitions), match, gap_x, gap_y))
-        items[k] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"], it["n_anchors"], k,
-                    1, 1, 0)
+    ctxs = [ctx] if ctx2 is None else [ctx, ctx2]
     dev = torch.device("cuda", ctx.device)
     total = torch.full((EXP_LEN,), float(pseudocount), dtype=torch.float64, device=dev)
     total[-1] = 0.0
-    if len(read_idx) > 0:
-        ctx.models_clear()
-        ctx.models_create(models)
-        b = cp.Batch(ctx, items, batch["x_chars"], batch["events"], batch["anchors"], bp, cp.MODE_EXPECTATIONS,
-                     cp.KERNEL_AUTO, 0)
-        b.run()
-        b.sync()
-        ptr, n = b.expectations_device_ptr()
-        total += torch.as_tensor(_DeviceDoubles(ptr, n), device=dev).view(-1, EXP_LEN).sum(0)
+    parts = [list(read_idx)[k::len(ctxs)] for k in range(len(ctxs))]
+    saved = os.environ.get("CPECAN_SYSTOLIC_GROUPS")
+    if len(ctxs) > 1 and saved is None:
+        os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"
+    running = []
+    try:
+        for cx, part in zip(ctxs, parts):
+            if not part:
+                continue
+            items = np.zeros(len(part), cp.ITEM_DTYPE)
+            models = []
+            for k, i in enumerate(part):
+                it = batch["items"][i]
+                match, _, gap_y = batch["models"][it["model"]]
+                models.append((list(transitions), match, gap_x, gap_y))
+                items[k] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"],
+                            it["n_anchors"], k, 1, 1, 0)
+            cx.models_clear()
+            cx.models_create(models)
+            b = cp.Batch(cx, items, batch["x_chars"], batch["events"], batch["anchors"], bp, cp.MODE_EXPECTATIONS,
+                         cp.KERNEL_AUTO, 0)
+            b.run()  # asynchronous on this context's streams: the next batch is issued before this one is waited for
+            running.append(b)
+        for b in running:
+            b.sync()
+            ptr, n = b.expectations_device_ptr()
+            total += torch.as_tensor(_DeviceDoubles(ptr, n), device=dev).view(-1, EXP_LEN).sum(0)
         torch.cuda.synchronize(dev)
-        b.close()
+    finally:
+        for b in running:
+            b.close()
+        if len(ctxs) > 1 and saved is None:
+            os.environ.pop("CPECAN_SYSTOLIC_GROUPS", None)
     allreduce_expectations(total, dist)
     return total.cpu().numpy()
+
+
+class PersistentEStep:
+    """The E-step of a Baum-Welch run whose reads stay the same from iteration to iteration (the usual case): the
+    inputs, band tables, rings and the per-read scaled emission tables are set up ONCE; an iteration rewrites the
+    nine transitions and the 4096 k-mer gap probabilities in place on the device
+    (cpecan_hip_models_set_transitions) and runs the batches again.  Calling the object is the `e_step` of train().
+
+    contexts: one or two binding.Context on the same device; with two, the reads are dealt into two batches that
+    run concurrently, each as one stream group."""
+
+    def __init__(self, cp, contexts, batch, bp, read_idx, transitions, gap_x, dist=None, pseudocount=0.0):
+        import os
+        import torch
+        self.cp, self.ctxs, self.dist, self.pseudocount = cp, list(contexts), dist, float(pseudocount)
+        self.dev = torch.device("cuda", self.ctxs[0].device)
+        saved = os.environ.get("CPECAN_SYSTOLIC_GROUPS")
+        if len(self.ctxs) > 1 and saved is None:
+            os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"
+        self.batches = []
+        try:
+            for k, cx in enumerate(self.ctxs):
+                part = list(read_idx)[k::len(self.ctxs)]
+                if not part:
+                    continue
+                items = np.zeros(len(part), cp.ITEM_DTYPE)
+                models = []
+                for j, i in enumerate(part):
+                    it = batch["items"][i]
+                    match, _, gap_y = batch["models"][it["model"]]
+                    models.append((list(transitions), match, gap_x, gap_y))
+                    items[j] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"],
+                                it["n_anchors"], j, 1, 1, 0)
+                cx.models_clear()
+                cx.models_create(models)
+                self.batches.append((cx, cp.Batch(cx, items, batch["x_chars"], batch["events"], batch["anchors"], bp,
+                                                  cp.MODE_EXPECTATIONS, cp.KERNEL_AUTO, 0)))
+        finally:
+            if len(self.ctxs) > 1 and saved is None:
+                os.environ.pop("CPECAN_SYSTOLIC_GROUPS", None)
+
+    def __call__(self, transitions, gap_x):
+        import torch
+        total = torch.full((EXP_LEN,), self.pseudocount, dtype=torch.float64, device=self.dev)
+        total[-1] = 0.0
+        for cx, b in self.batches:
+            cx.models_set_transitions(transitions, gap_x)
+            b.run()
+        for _, b in self.batches:
+            b.sync()
+            ptr, n = b.expectations_device_ptr()
+            total += torch.as_tensor(_DeviceDoubles(ptr, n), device=self.dev).view(-1, EXP_LEN).sum(0)
+        torch.cuda.synchronize(self.dev)
+        allreduce_expectations(total, self.dist)
+        return total.cpu().numpy()
+
+    def close(self):
+        for _, b in self.batches:
+            b.close()
+        self.batches = []
 
 
 def train(e_step, transitions, gap_x, iterations, log=None):

@@ -61,6 +61,13 @@ typedef struct {
 int cpecan_hip_models_create(cpecan_ctx *ctx, const cpecan_sm3_model *models, int32_t n,
                              int32_t threads, int32_t *ids);
 int cpecan_hip_models_clear(cpecan_ctx *ctx);
+/* The M-step of Baum-Welch changes the nine transitions and the k-mer gap probabilities only
+ * (continuousPairHmm_loadTransitionsAndKmerGapProbs impl/continuousHmm.c:206-232); the per-read scaled emission
+ * tables stay.  Rewrites those 9 + 4096 values in every strawMan model of the context in place (gap_x_probs may be
+ * NULL: transitions only), so that batches created on the context can simply be run again for the next
+ * iteration -- no table derivation, no upload. */
+int cpecan_hip_models_set_transitions(cpecan_ctx *ctx, const double *transitions /*[9]*/,
+                                      const double *gap_x_probs /*[CPECAN_NUM_KMERS] or NULL*/);
 
 /* The 5-state symbol machine of DNA-against-DNA alignment: stateMachine5_construct(fiveState)
  * (impl/stateMachine.c:896-965; BASELINE configs[0]).  transitions in the order of struct

@@ -8,3 +8,4 @@ allreduce_expectations = _m.allreduce_expectations
 m_step = _m.m_step
 train = _m.train
 gpu_e_step = _m.gpu_e_step
+PersistentEStep = _m.PersistentEStep

@@ -25,6 +25,25 @@ def test_gpu_e_step_and_loop():
     ref = np.concatenate([np.array(hmm.transitions), np.array(hmm.kmerGap), [hmm.likelihood]])
     assert np.allclose(got, ref, rtol=1e-9, atol=1e-12) and got[-1] < 0
 
+    # two contexts: the reads run as two concurrent batches; same sums up to the order of addition
+    ctx2 = cp.Context(0)
+    both = dist_em.gpu_e_step(cp, ctx, batch, bp, reads, cp.NANOPORE_TRANSITIONS, gap0, ctx2=ctx2)
+    assert np.allclose(both, got, rtol=1e-12, atol=1e-300)
+    ctx2.close()
+
+    # the persistent E-step: inputs and emission tables set up once, transitions and gap probabilities rewritten in
+    # place per iteration; identical to the one-shot E-step for the same model, also after the model has changed
+    ctx3, ctx4 = cp.Context(0), cp.Context(0)
+    keep = dist_em.PersistentEStep(cp, [ctx3, ctx4], batch, bp, reads, cp.NANOPORE_TRANSITIONS, gap0)
+    assert np.allclose(keep(cp.NANOPORE_TRANSITIONS, gap0), got, rtol=1e-12, atol=1e-300)
+    t1, g1 = dist_em.m_step(got + np.r_[np.full(dist_em.EXP_LEN - 1, 1e-9), 0.0])
+    again = keep(t1, g1)
+    assert np.allclose(again, dist_em.gpu_e_step(cp, ctx, batch, bp, reads, t1, g1), rtol=1e-12, atol=1e-300)
+    assert again[-1] > got[-1]  # one EM step raises the likelihood
+    keep.close()
+    ctx3.close()
+    ctx4.close()
+
     lines = []
     r = dist_em.train(lambda t, g: dist_em.gpu_e_step(cp, ctx, batch, bp, reads, t, g, pseudocount=1e-9),
                       cp.NANOPORE_TRANSITIONS, gap0, 3, log=lines.append)
