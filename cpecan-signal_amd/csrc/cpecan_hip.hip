@@ -107,21 +107,74 @@ extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *sta
 SY_DECLARE(_r1)
 SY_DECLARE(_r2)
 SY_DECLARE(_r3)
-struct SyBuild { /* one build of the systolic kernels */
-    int rows;
+/* the wave-per-alignment kernels (cpecan_kernel_wave.hip), built for 1..4 cells per lane (symbols _l1.._l4) */
+#define WV_DECLARE(sfx)                                                                                         \
+    extern "C" int cpecan_wave_max_width##sfx(void);                                                              \
+    extern "C" int cpecan_wave_ring_row_doubles##sfx(void);                                                       \
+    extern "C" int cpecan_wave_bring_row_doubles##sfx(void);                                                      \
+    extern "C" long long cpecan_wave_scratch_bytes##sfx(int ringD);                                               \
+    extern "C" int cpecan_wave_launch_forward##sfx(hipStream_t, const DevItem *, long long, DevParams,            \
+                                                   const void *, const double *, const long long *,               \
+                                                   const double *, const double *, double *, long long, int,     \
+                                                   void *, int);                                                  \
+    extern "C" int cpecan_wave_launch_backward##sfx(hipStream_t, const DevItem *, long long, DevParams,           \
+                                                    const void *, const double *, const long long *,              \
+                                                    const double *, double *, long long, int, void *,             \
+                                                    long long *, double *, long long *, double *, char *,         \
+                                                    long long, double *, int, int);                               \
+    extern "C" int cpecan_wave_launch_expect##sfx(hipStream_t, const DevItem *, long long, DevParams,             \
+                                                  const void *, const double *, const long long *,                \
+                                                  const unsigned short *, const double *, const double *,         \
+                                                  long long, const double *, int, void *, const char *,           \
+                                                  long long, double *, int);
+WV_DECLARE(_l2)
+WV_DECLARE(_l3)
+WV_DECLARE(_l4)
+extern "C" int cpecan_wave_launch_track(hipStream_t stream, const DevItem *items, long long nItems,
+                                        const double *track, const long long *trackBase,
+                                        const unsigned short *kidx, const double *models, void *states, int maxLX);
+extern "C" int cpecan_wave_track_row_doubles(void);
+
+struct SyBuild { /* one build of the throughput kernels */
+    int rows;  /* waves per workgroup (systolic) or cells per lane (wave) */
+    bool wave; /* one wave per alignment (cpecan_kernel_wave.hip) */
     int (*max_width)(void);
     int (*ring_row_doubles)(void);
     int (*bring_row_doubles)(void);
     long long (*scratch_bytes)(int);
-    decltype(&cpecan_systolic_launch_forward) launch_forward;
-    decltype(&cpecan_systolic_launch_backward) launch_backward;
+    int (*launch_forward)(hipStream_t, const DevItem *, long long, DevParams, const void *, const double *,
+                          const long long *, const double *, const double *, double *, long long, int, void *, int);
+    int (*launch_backward)(hipStream_t, const DevItem *, long long, DevParams, const void *, const double *,
+                           const long long *, const double *, double *, long long, int, void *, long long *, double *,
+                           long long *, double *, char *, long long, double *, int, int);
     decltype(&cpecan_systolic_launch_expect) launch_expect;
 };
 #define SY_BUILD(r, sfx)                                                                                          \
-    { r, cpecan_systolic_max_width##sfx, cpecan_systolic_ring_row_doubles##sfx,                                   \
+    { r, false, cpecan_systolic_max_width##sfx, cpecan_systolic_ring_row_doubles##sfx,                            \
       cpecan_systolic_bring_row_doubles##sfx, cpecan_systolic_scratch_bytes##sfx,                                 \
-      cpecan_systolic_launch_forward##sfx, cpecan_systolic_launch_backward##sfx, cpecan_systolic_launch_expect##sfx }
+      [](hipStream_t st, const DevItem *it, long long n, DevParams P, const void *bt, const double *tr,           \
+         const long long *tb, const double *ev, const double *mo, double *F, long long rd, int D, void *S, int) { \
+          return cpecan_systolic_launch_forward##sfx(st, it, n, P, bt, tr, tb, ev, mo, F, rd, D, S);              \
+      },                                                                                                          \
+      [](hipStream_t st, const DevItem *it, long long n, DevParams P, const void *bt, const double *tr,           \
+         const long long *tb, const double *mo, double *F, long long rd, int D, void *S, long long *pa,           \
+         double *pl, long long *tx, double *tv, char *sc, long long sb, double *B, int w, int) {                  \
+          return cpecan_systolic_launch_backward##sfx(st, it, n, P, bt, tr, tb, mo, F, rd, D, S, pa, pl, tx, tv,  \
+                                                      sc, sb, B, w);                                              \
+      },                                                                                                          \
+      cpecan_systolic_launch_expect##sfx }
+#define WV_BUILD(r, sfx)                                                                                          \
+    { r, true, cpecan_wave_max_width##sfx, cpecan_wave_ring_row_doubles##sfx, cpecan_wave_bring_row_doubles##sfx, \
+      cpecan_wave_scratch_bytes##sfx, cpecan_wave_launch_forward##sfx, cpecan_wave_launch_backward##sfx,          \
+      cpecan_wave_launch_expect##sfx }
 static const SyBuild SY_BUILDS[4] = { SY_BUILD(1, _r1), SY_BUILD(2, _r2), SY_BUILD(3, _r3), SY_BUILD(4, ) };
+/* (a one-cell-per-lane build would only serve bands below 57 k-mers; the two-cell build takes those too) */
+static const SyBuild WV_BUILDS[4] = { WV_BUILD(2, _l2), WV_BUILD(2, _l2), WV_BUILD(3, _l3), WV_BUILD(4, _l4) };
+/* which family a batch runs on: the wave kernels unless CPECAN_KERNELS=systolic asks for the workgroup-per-alignment ones */
+static bool use_wave_kernels() {
+    const char *k = getenv("CPECAN_KERNELS");
+    return !(k && strcmp(k, "systolic") == 0);
+}
 
 
 namespace {
@@ -248,6 +301,12 @@ struct cpecan_batch {
     std::vector<hipEvent_t> evStage, evJoin;
     hipEvent_t evFork = nullptr;
     std::vector<long long> hNPairs, hNTot, hNCells;
+    /* aligned pairs as the callers get them: the device selects by the exponent with a margin, the host finishes
+     * exp(), the threshold test and floor(p * 1e7) with the reference's libm (impl/pairwiseAligner.c:776-786) */
+    std::vector<long long> hPairs; /* triples, packed per item at hPairBase */
+    std::vector<double> hLogp;
+    std::vector<long long> hPairBase;
+    int trackRow = CP_ROW; /* doubles per column of the track */
     bool countsValid = false, ran = false;
 };
 
@@ -768,8 +827,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         const char *rows = getenv("CPECAN_SYSTOLIC_ROWS");
         int r = rows ? atoi(rows) : 1;
         r = r < 1 ? 1 : r > 4 ? 4 : r;
-        while (r < 4 && globalMaxWidth > SY_BUILDS[r - 1].max_width()) r++;
-        b->sy = &SY_BUILDS[r - 1];
+        const SyBuild *fam = use_wave_kernels() ? WV_BUILDS : SY_BUILDS;
+        while (r < 4 && globalMaxWidth > fam[r - 1].max_width()) r++;
+        b->sy = &fam[r - 1];
+        b->trackRow = b->sy->wave ? cpecan_wave_track_row_doubles() : CP_ROW;
     }
     b->hItems = hItems;
 
@@ -829,7 +890,12 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         b->nWindows = maxWindows;
         b->ringD = 64;
         while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernels mask with ringD-1 */
-        b->ringDoubles = (long long) b->ringD * b->sy->ring_row_doubles();
+        /* the wave kernels keep one more row behind the ring: the -inf row lanes without a cell read */
+        b->ringDoubles = (long long) (b->ringD + (b->sy->wave ? 1 : 0)) * b->sy->ring_row_doubles();
+        if (b->sy->wave && b->ringD > 8192) {
+            delete b;
+            return fail(CPECAN_EINVAL, "traceback windows of %d diagonals: the throughput kernels hold at most 8192", maxSpan);
+        }
         if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
@@ -860,11 +926,11 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             B_TRY(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         }
         if (mode == CPECAN_MODE_EXPECTATIONS)
-            B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) cpecan_systolic_bring_row_doubles()));  /* sized for four waves */
+            B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) b->sy->bring_row_doubles()));
         B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
         b->scratchBytes = (b->sy->scratch_bytes(b->ringD) + 63) / 64 * 64;
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
-        B_TRY(b->track.alloc((size_t) trackTotal * CP_ROW));
+        B_TRY(b->track.alloc((size_t) trackTotal * (size_t) b->trackRow));
         B_TRY(b->trackBase.alloc((size_t) nItems));
         B_TRY(hipMemcpy(b->trackBase.p, hTrackBase.data(), (size_t) nItems * sizeof(long long),
                         hipMemcpyHostToDevice));
@@ -999,9 +1065,14 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
             b->evStage.assign((size_t) (G * perGroup), nullptr);
             for (auto &e : b->evStage) HIP_TRY(hipEventCreate(&e));
         }
-        int rc = cpecan_systolic_launch_track(c->stream, b->items.p, b->nItems, b->track.p,
-                                              b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
-                                              b->maxLX);
+        /* does any model let gap Y switch to gap X?  (the nanopore default does not, stateMachine.c:1287: the
+         * kernels then run the build without that term) */
+        int withSwitch = 0;
+        for (int m = 0; m < c->nModels; m++)
+            if (c->hostModels[(size_t) m * CP_MODEL_STRIDE + T_GAP_SWITCH_TO_X] > -INFINITY) withSwitch = 1;
+        int rc = (b->sy->wave ? cpecan_wave_launch_track : cpecan_systolic_launch_track)(
+            c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
+            b->maxLX);
         HIP_TRY(hipEventRecord(b->evFork, c->stream));
         const long long per = (b->nItems + G - 1) / G;
         for (int gi = 0; gi < G && rc == 0; gi++) {
@@ -1018,7 +1089,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                                         b->trackBase.p + i0, b->events.p, c->models.p,
                                                         b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                                         b->ringD,
-                                                        b->syStates.p + i0 * cpecan_systolic_state_bytes());
+                                                        b->syStates.p + i0 * cpecan_systolic_state_bytes(), withSwitch);
                 HIP_TRY(hipEventRecord(ev[2 * w + 1], st));
                 if (rc == 0 && n > 0)
                     rc = b->sy->launch_backward(st, b->items.p + i0, n, b->P, b->bandTab.p,
@@ -1029,7 +1100,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                                          b->pairs.p, b->pairLogp.p, b->totXay.p, b->totVal.p,
                                                          b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
                                                          b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD * bringRow
-                                                                    : nullptr, w);
+                                                                    : nullptr, w, withSwitch);
                 if (rc == 0 && n > 0 && b->mode == CPECAN_MODE_EXPECTATIONS)
                     rc = b->sy->launch_expect(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                        b->trackBase.p + i0, b->kidx.p, c->models.p,
@@ -1110,15 +1181,74 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *b, float *msTotal, float *msKernel
     return CPECAN_OK;
 }
 
+/* Counts and aligned pairs of a finished run.  If an alignment produced more pairs than its share of the pair buffer
+ * holds (flat posteriors: a tiny threshold, the HDP machine's linear densities), the buffer is re-laid-out to the
+ * reported counts and the batch is run once more -- the reference returns the list whatever its length.  The device
+ * selects pairs by the exponent (F+B)-total with a margin below log(threshold); exp(), the exact threshold test and
+ * floor(p * 1e7) are finished here with the host libm, the one the reference calls
+ * (diagonalCalculationPosteriorMatchProbs, impl/pairwiseAligner.c:776-786). */
 static int ensure_counts(cpecan_batch *b) {
     if (!b->ran) return fail(CPECAN_EINVAL, "batch has not run");
     if (b->countsValid) return CPECAN_OK;
     HIP_TRY(hipSetDevice(b->ctx->device));
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     b->hNPairs.resize((size_t) b->nItems);
     b->hNTot.resize((size_t) b->nItems);
-    HIP_TRY(hipMemcpy(b->hNPairs.data(), b->nPairs.p, (size_t) b->nItems * sizeof(long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(b->hNTot.data(), b->nTot.p, (size_t) b->nItems * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int attempt = 0;; attempt++) {
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        HIP_TRY(hipMemcpy(b->hNPairs.data(), b->nPairs.p, (size_t) b->nItems * sizeof(long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(b->hNTot.data(), b->nTot.p, (size_t) b->nItems * sizeof(long long), hipMemcpyDeviceToHost));
+        bool over = false;
+        for (int64_t i = 0; i < b->nItems; i++)
+            if (b->hNPairs[(size_t) i] > b->hItems[(size_t) i].pairCap) over = true;
+        if (!over) break;
+        if (attempt == 2) return fail(CPECAN_EOVERFLOW, "aligned-pair counts keep growing between identical runs");
+        long long total = 0;
+        for (int64_t i = 0; i < b->nItems; i++) {
+            DevItem &d = b->hItems[(size_t) i];
+            d.pairCap = std::max(d.pairCap, b->hNPairs[(size_t) i] + 64);
+            d.pairBase = total;
+            total += d.pairCap;
+        }
+        HIP_TRY(b->pairs.alloc((size_t) total * 3));
+        HIP_TRY(b->pairLogp.alloc((size_t) total));
+        HIP_TRY(hipMemcpy(b->items.p, b->hItems.data(), (size_t) b->nItems * sizeof(DevItem), hipMemcpyHostToDevice));
+        int rc = cpecan_hip_batch_run(b);
+        if (rc != CPECAN_OK) return rc;
+    }
+    b->hPairBase.assign((size_t) b->nItems + 1, 0);
+    for (int64_t i = 0; i < b->nItems; i++)
+        b->hPairBase[(size_t) i + 1] = b->hPairBase[(size_t) i] + std::min(b->hNPairs[(size_t) i], b->hItems[(size_t) i].pairCap);
+    const long long all = b->hPairBase[(size_t) b->nItems];
+    b->hPairs.resize((size_t) all * 3);
+    b->hLogp.resize((size_t) all);
+    for (int64_t i = 0; i < b->nItems; i++) {
+        const DevItem &d = b->hItems[(size_t) i];
+        const long long n = b->hPairBase[(size_t) i + 1] - b->hPairBase[(size_t) i], o = b->hPairBase[(size_t) i];
+        if (n == 0) continue;
+        HIP_TRY(hipMemcpyAsync(b->hPairs.data() + o * 3, b->pairs.p + d.pairBase * 3, (size_t) n * 3 * sizeof(long long),
+                               hipMemcpyDeviceToHost, b->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->hLogp.data() + o, b->pairLogp.p + d.pairBase, (size_t) n * sizeof(double),
+                               hipMemcpyDeviceToHost, b->ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    const double threshold = b->P.threshold;
+    for (int64_t i = 0; i < b->nItems; i++) {
+        const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
+        long long *t = b->hPairs.data() + o * 3;
+        double *lp = b->hLogp.data() + o;
+        long long kept = 0;
+        for (long long k = 0; k < n; k++) {
+            double p = exp(lp[k]);
+            if (!(p >= threshold)) continue;
+            if (p > 1.0) p = 1.0;
+            t[kept * 3] = (long long) floor(p * 10000000.0);
+            t[kept * 3 + 1] = t[k * 3 + 1];
+            t[kept * 3 + 2] = t[k * 3 + 2];
+            lp[kept] = lp[k];
+            kept++;
+        }
+        b->hNPairs[(size_t) i] = kept;
+    }
     b->countsValid = true;
     return CPECAN_OK;
 }
@@ -1140,18 +1270,11 @@ int cpecan_hip_batch_fetch_pairs(cpecan_batch *b, int64_t item, int64_t *triples
     if (!b || item < 0 || item >= b->nItems || !triples) return fail(CPECAN_EINVAL, "bad argument");
     int rc = ensure_counts(b);
     if (rc) return rc;
-    const DevItem &d = b->hItems[(size_t) item];
-    long long n = b->hNPairs[(size_t) item];
-    if (n > d.pairCap)
-        return fail(CPECAN_EOVERFLOW, "item %lld produced %lld pairs, device capacity %lld",
-                    (long long) item, n, d.pairCap);
+    const long long n = b->hNPairs[(size_t) item], o = b->hPairBase[(size_t) item];
     if (n > cap) return fail(CPECAN_EOVERFLOW, "need room for %lld triples", n);
     if (n == 0) return CPECAN_OK;
-    HIP_TRY(hipMemcpy(triples, b->pairs.p + d.pairBase * 3, (size_t) n * 3 * sizeof(long long),
-                      hipMemcpyDeviceToHost));
-    if (logp)
-        HIP_TRY(hipMemcpy(logp, b->pairLogp.p + d.pairBase, (size_t) n * sizeof(double),
-                          hipMemcpyDeviceToHost));
+    memcpy(triples, b->hPairs.data() + o * 3, (size_t) n * 3 * sizeof(long long));
+    if (logp) memcpy(logp, b->hLogp.data() + o, (size_t) n * sizeof(double));
     return CPECAN_OK;
 }
 

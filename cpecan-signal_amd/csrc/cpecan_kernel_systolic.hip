@@ -32,6 +32,7 @@
  * ablations compute wrong results by construction and are never built into the product.
  */
 #include "cpecan_device.h"
+#include "cpecan_sweep.h"
 
 #ifndef SY_R
 #define SY_R 4 /* waves per workgroup: 4 (bands up to 248 k-mers) or 3 (up to 184; five workgroups fit a CU) */
@@ -307,17 +308,6 @@ __device__ __forceinline__ double shl1(double old, double src) {
 template <typename V> __device__ __forceinline__ V ld_agent(V *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-/* Per-alignment state handed between the forward-window and backward-window kernels. */
-struct SyState {
-    int d;            /* last forward diagonal completed */
-    int tracedBackTo; /* as in getPosteriorProbsWithBanding (:903) */
-    int finished;     /* forward reached the last diagonal */
-    int bandAi;       /* band cursor (anchor rectangle) at diagonal d */
-    int winValid, winTop, winFrom, winTo, winAtEnd; /* traceback window for the backward kernel */
-    int expectPending; /* Baum-Welch: the window's backward cells are in the B ring, not yet summed */
-    long long nPairs, nTot, cells;
-};
 
 struct Geometry {
     int lane, wave, waveBelow, waveAbove;
@@ -642,12 +632,6 @@ __device__ void forward_window(const DevItem &it, const DevParams &P, const int2
         }
     }
 }
-
-/* per-window bookkeeping kept in HBM scratch (private to the alignment's workgroup) */
-struct WinTotal {
-    int t, xmin, xmax, nxmin, nxmax, second;
-    double total;
-};
 
 /*
  * Backward sweep + posterior decode of one traceback window (:921-992), in three phases:

@@ -1,0 +1,1619 @@
+/*
+ * cpecan_kernel_wave.hip -- the throughput kernels: banded forward / backward / posterior DP of the
+ * 3-state strawMan signal machine, ONE WAVE PER ALIGNMENT, several cells per lane.
+ *
+ * Mapping (designed for CDNA4's 64-lane waves):
+ *   - an alignment is swept by a single wave; the band's k-mers live in P = 64 * L register slots,
+ *     slot s = x mod P held by lane s / L as its cell number s % L ("layer"): a lane owns L
+ *     consecutive k-mers, with their emission constants resident in VGPRs while they are in the band.
+ *   - one loop iteration = one anti-diagonal = L independent cell bodies per lane.  A cell's
+ *     neighbour (x-1, .) is the same lane's previous layer, a register, except for layer 0, which takes
+ *     layer L-1 of the lane below: ONE wave rotation (DPP wave_ror / wave_rol) of three values per
+ *     diagonal, whatever L is.  No LDS exchange, no barrier, no second wave to wait for.
+ *   - cells outside the band cost no select: a slot whose k-mer is not in the band holds the "not a
+ *     k-mer" constants (every emission -inf), so its cells come out -inf by themselves and nothing it
+ *     holds can reach a cell of the band (forward: parked rows; backward: parked gap-X sums and a dummy
+ *     ring row of -inf emissions for the lanes that have no cell on a diagonal).
+ *   - band edges move by at most one k-mer per diagonal; the launch's edge steps sit in LDS as two
+ *     bit strings, so entering / leaving k-mers are found on the scalar unit.
+ *   - forward cells go to HBM once into a per-alignment ring of diagonals
+ *     ([diagonal][layer][Fm,Fx,Fy,pm,py][lane]) and are read once by the sweep back, four diagonals
+ *     ahead of use; the forward sweep's inputs (events, k-mer rows) are staged in LDS per block of
+ *     diagonals, so neither loop waits for a load it has just issued.
+ *   - two kernels per traceback window, sequenced by the C-ABI layer (cpecan_hip.hip); SyState and the
+ *     ring carry over.  The posterior decode works from candidate lists the sweep back collects; a
+ *     window whose candidates cannot be trusted is swept again with the exact totals in hand.
+ * MFMA is not used: the recurrence is a scan with an approximate log-add, not a contraction.
+ *
+ * Numerics: identical to the general kernel and the CPU oracle, bit for bit (cpecan_device.h; the
+ * division (x - mu) / sigma is a Markstein-corrected multiply by the host-rounded reciprocal).
+ *
+ * Reference: getPosteriorProbsWithBanding impl/pairwiseAligner.c:870-1006, diagonalCalculation* :681-863,
+ * stateMachine3_cellCalculate impl/stateMachine.c:1305-1334, logAdd impl/pairwiseAligner.c:238-255.
+ */
+#include "cpecan_device.h"
+#include "cpecan_sweep.h"
+
+#ifndef WV_L
+#define WV_L 3 /* cells per lane: 1..4 (bands up to 56, 120, 184, 248 k-mers) */
+#endif
+#define WV_P (64 * WV_L)
+#if WV_L == 4
+#define WV_SYM(n) n##_l4
+#elif WV_L == 3
+#define WV_SYM(n) n##_l3
+#elif WV_L == 2
+#define WV_SYM(n) n##_l2
+#else
+#define WV_SYM(n) n##_l1
+#endif
+#define WV_ROW 20            /* doubles per column of the track: 16 emission constants, gap-X sums (open, extend, switch), gap-X */
+#define WV_ROWN 32           /* LDS ring of k-mer rows (>= the feed block)                              */
+#define WV_FEED_MAX 32       /* diagonals per feed block of the forward sweep                            */
+#define WV_BITWORDS 256      /* band edge steps kept in LDS: 32 diagonals per word, circular (ringD <= 8192) */
+#define WV_RING_VALUES 5     /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
+#define WV_LAYER_BYTES (WV_RING_VALUES * 64 * 8)
+#define WV_ROW_DOUBLES (WV_L * WV_RING_VALUES * 64)
+#define WV_PREFETCH 4        /* diagonals the backward sweep fetches ahead (== its unroll factor) */
+#define WV_CAND_SLACK 0.25   /* candidates: cells within this (log units) below the posterior threshold */
+#define WV_CAND_PER_DIAG 4   /* candidate capacity, in records per ring diagonal and layer */
+#define WV_EXPECT_CHUNKS 8   /* workgroups that share one window's diagonals in the expectation pass */
+
+#define WV_FOR_LAYER_1(jv, ...) { constexpr int J = 0; (void) (jv); __VA_ARGS__ }
+#define WV_FOR_LAYER_2(jv, ...) if ((jv) == 0) { constexpr int J = 0; __VA_ARGS__ } else { constexpr int J = 1; __VA_ARGS__ }
+#define WV_FOR_LAYER_3(jv, ...) if ((jv) == 0) { constexpr int J = 0; __VA_ARGS__ } else if ((jv) == 1) { constexpr int J = 1; __VA_ARGS__ } else { constexpr int J = 2; __VA_ARGS__ }
+#define WV_FOR_LAYER_4(jv, ...) if ((jv) == 0) { constexpr int J = 0; __VA_ARGS__ } else if ((jv) == 1) { constexpr int J = 1; __VA_ARGS__ } else if ((jv) == 2) { constexpr int J = 2; __VA_ARGS__ } else { constexpr int J = 3; __VA_ARGS__ }
+#if WV_L == 4
+#define WV_FOR_LAYER WV_FOR_LAYER_4
+#elif WV_L == 3
+#define WV_FOR_LAYER WV_FOR_LAYER_3
+#elif WV_L == 2
+#define WV_FOR_LAYER WV_FOR_LAYER_2
+#else
+#define WV_FOR_LAYER WV_FOR_LAYER_1
+#endif
+
+namespace {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const d2 lds_d2;
+typedef lds_d2 *lds_d2p;
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni64(long long v) {
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) v);
+    const int hi = __builtin_amdgcn_readfirstlane((int) (v >> 32));
+    return ((long long) hi << 32) | lo;
+}
+__device__ __forceinline__ double uni64_d(double v) {
+    return __longlong_as_double(uni64(__double_as_longlong(v)));
+}
+template <typename T> __device__ __forceinline__ unsigned lds_addr(const T *p) {
+    return (unsigned) (size_t) (const __attribute__((address_space(3))) T *) p;
+}
+/* the work item as wave-uniform (scalar) values */
+__device__ __forceinline__ DevItem uniform_item(const DevItem &s) {
+    DevItem d;
+    d.lX = uni64(s.lX); d.lY = uni64(s.lY); d.xOff = uni64(s.xOff); d.yOff = uni64(s.yOff);
+    d.anchorOff = 0; d.nAnchors = 0; d.diagBase = uni64(s.diagBase); d.cellBase = 0;
+    d.nCells = 0; d.pairBase = uni64(s.pairBase); d.pairCap = uni64(s.pairCap);
+    d.totBase = uni64(s.totBase); d.totCap = uni64(s.totCap); d.bwsBase = 0;
+    d.model = uni(s.model); d.raggedL = uni(s.raggedL); d.raggedR = uni(s.raggedR); d.maxWidth = uni(s.maxWidth);
+    return d;
+}
+template <typename V> __device__ __forceinline__ V ld_agent(V *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/* d < 7.5 ? r : hi as one compare and two lane selects the compiler cannot turn into a divergent branch
+ * around the cubic (it does, given the chance, and the sweep then pays a branch per logAdd) */
+__device__ __forceinline__ double sel_below(double d, double r, double hi) {
+    int lo_, hi_;
+    const double thr = 7.5;
+    asm("v_cmp_gt_f64 vcc, %2, %3\n\tv_cndmask_b32 %0, %4, %6, vcc\n\tv_cndmask_b32 %1, %5, %7, vcc"
+        : "=&v"(lo_), "=&v"(hi_)
+        : "s"(thr), "v"(d), "v"(__double2loint(hi)), "v"(__double2hiint(hi)), "v"(__double2loint(r)),
+          "v"(__double2hiint(r))
+        : "vcc");
+    return __hiloint2double(hi_, lo_);
+}
+
+/* logAdd (impl/pairwiseAligner.c:238-255), branch-free and bit-identical: hi/lo are the operands as the
+ * reference's two branches order them; its "smaller operand is -inf" and ">= 7.5" exits both yield hi, and
+ * (-inf) - (-inf) = NaN fails d < 7.5 exactly like those exits.  The cubic's four float-literal
+ * coefficients come from a 512-byte LDS table indexed by n = ceil(2d) (the pieces' limits 1, 2.5, 4.5 are
+ * multiples of 1/2 and 2d is exact, so n decides the piece without a comparison); NaN converts to 0 and
+ * d >= 7.5 is clamped: either way the cubic is discarded. */
+__device__ __forceinline__ double ladd(double x, double y, unsigned coefAddr) {
+    double hi, lo;
+    asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(x), "v"(y));
+    asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(y));
+    const double d = hi - lo;
+    int n;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(d + d)));
+    n = n < 15 ? n : 15;
+    const lds_d2p c = (lds_d2p) (coefAddr + (unsigned) n * 32u);
+    const d2 c32 = c[0], c10 = c[1];
+    const double r = ((c32.x * d + c32.y) * d + c10.x) * d + c10.y + lo;
+    return sel_below(d, r, hi);
+}
+/* N independent logAdds, stage by stage, so that their table reads are in flight together */
+template <int N> __device__ __forceinline__ void laddN(double (&acc)[N], const double (&y)[N], unsigned coefAddr) {
+    double hi[N], lo[N], d[N];
+    d2 c32[N], c10[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        asm("v_max_f64 %0, %1, %2" : "=v"(hi[k]) : "v"(acc[k]), "v"(y[k]));
+        asm("v_min_f64 %0, %1, %2" : "=v"(lo[k]) : "v"(acc[k]), "v"(y[k]));
+        d[k] = hi[k] - lo[k];
+        int n;
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(d[k] + d[k])));
+        n = n < 15 ? n : 15;
+        const lds_d2p c = (lds_d2p) (coefAddr + (unsigned) n * 32u);
+        c32[k] = c[0];
+        c10[k] = c[1];
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double r = ((c32[k].x * d[k] + c32[k].y) * d[k] + c10[k].x) * d[k] + c10[k].y + lo[k];
+        acc[k] = sel_below(d[k], r, hi[k]);
+    }
+}
+__device__ __forceinline__ void init_coef(double *coef) {
+    const float t[16] = { -0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
+                          -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
+                          -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
+                          -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f };
+    const int n = threadIdx.x >> 2, piece = n <= 2 ? 0 : n <= 5 ? 1 : n <= 9 ? 2 : 3;
+    coef[threadIdx.x] = (double) t[piece * 4 + (threadIdx.x & 3)];
+}
+
+/* log N(x; mu, sd) = K + (-0.5*a*a), a = (x-mu)/sd (impl/stateMachine.c:333-343); the quotient is
+ * q + fma(-q, sd, t) * rsd with q = t*rsd, rsd = RN(1/sd): Markstein's correction step, which rounds to
+ * the same double as the division.  sd == 0 rows carry rsd = 0, K = -inf => -inf. */
+__device__ __forceinline__ double lgauss(double x, double mu, double sd, double rsd, double K) {
+    const double t = x - mu;
+    const double q = t * rsd;
+    const double rem = __fma_rn(-q, sd, t);
+    const double a = __fma_rn(rem, rsd, q);
+    return K + (-0.5 * a * a);
+}
+
+/* lane i <- lane i-1, lane 0 <- lane 63 (DPP wave_ror:1) */
+__device__ __forceinline__ double ror1(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x13C, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x13C, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+/* lane i <- lane i+1, lane 63 <- lane 0 (DPP wave_rol:1) */
+__device__ __forceinline__ double rol1(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x134, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x134, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast(double v, int srcLane) { /* srcLane wave-uniform */
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
+    return __hiloint2double(hi, lo);
+}
+
+/* a slot's k-mer constants, as a track row lays them out */
+struct Prm {
+    d2 a[WV_ROW / 2]; /* (mu,sd) (rsd,K1) (nmu,nsd) (rnsd,K2) | the same for the gap-Y table | (pxo,pxe) (pxs,px) */
+};
+/* load of a whole row from LDS into one layer's registers in every lane (start-up) */
+__device__ __forceinline__ void load_row_all(Prm &p, unsigned rowAddr) {
+    const lds_d2p r = (lds_d2p) rowAddr;
+#pragma unroll
+    for (int k = 0; k < WV_ROW / 2; k++) p.a[k] = r[k];
+}
+/* A k-mer enters (or leaves) the band: its row (or the "not a k-mer" row) is loaded from LDS into the registers
+ * of ONE slot -- lane laneMask, layer sel -- and the lane masks of the band are updated.  The layer is a run-time
+ * (wave-uniform) value and registers cannot be indexed, so the select sits inside one asm statement: seen from
+ * the compiler there is no control flow and no copy of the L x 20 constants around it. */
+#define WV_SLOT_ASM(MASKOP)                                                                                     \
+    unsigned long long sv;                                                                                       \
+    asm volatile("s_mov_b64 %[sv], exec\n\t"                                                                      \
+                 "s_mov_b64 exec, %[m]\n\t" WV_SLOT_BODY(MASKOP)                                                   \
+                 "s_mov_b64 exec, %[sv]\n\t"                                                                      \
+                 "s_waitcnt lgkmcnt(0)"                                                                            \
+                 : [sv] "=&s"(sv) WV_SLOT_OUTS                                                                     \
+                 : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel)                                             \
+                 : "memory", "scc");
+#if WV_L == 1
+#define WV_SLOT_BODY(MASKOP) "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" 
+#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0])
+#elif WV_L == 2
+#define WV_SLOT_BODY(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1])
+#elif WV_L == 3
+#define WV_SLOT_BODY(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" "ds_read_b128 %[c9], %[a] offset:144\n\t" MASKOP " %[k2], %[k2], %[m]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [c9] "+v"(p[2].a[9]), [k2] "+s"(mask[2])
+#elif WV_L == 4
+#define WV_SLOT_BODY(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" "ds_read_b128 %[c9], %[a] offset:144\n\t" MASKOP " %[k2], %[k2], %[m]\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\t" "ds_read_b128 %[d1], %[a] offset:16\n\t" "ds_read_b128 %[d2], %[a] offset:32\n\t" "ds_read_b128 %[d3], %[a] offset:48\n\t" "ds_read_b128 %[d4], %[a] offset:64\n\t" "ds_read_b128 %[d5], %[a] offset:80\n\t" "ds_read_b128 %[d6], %[a] offset:96\n\t" "ds_read_b128 %[d7], %[a] offset:112\n\t" "ds_read_b128 %[d8], %[a] offset:128\n\t" "ds_read_b128 %[d9], %[a] offset:144\n\t" MASKOP " %[k3], %[k3], %[m]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [c9] "+v"(p[2].a[9]), [k2] "+s"(mask[2]), [d0] "+v"(p[3].a[0]), [d1] "+v"(p[3].a[1]), [d2] "+v"(p[3].a[2]), [d3] "+v"(p[3].a[3]), [d4] "+v"(p[3].a[4]), [d5] "+v"(p[3].a[5]), [d6] "+v"(p[3].a[6]), [d7] "+v"(p[3].a[7]), [d8] "+v"(p[3].a[8]), [d9] "+v"(p[3].a[9]), [k3] "+s"(mask[3])
+#endif
+__device__ __forceinline__ void slot_enter(Prm (&p)[WV_L], unsigned long long (&mask)[WV_L], unsigned rowAddr,
+                                           unsigned long long laneMask, int sel) {
+    WV_SLOT_ASM("s_or_b64")
+}
+__device__ __forceinline__ void slot_leave(Prm (&p)[WV_L], unsigned long long (&mask)[WV_L], unsigned rowAddr,
+                                           unsigned long long laneMask, int sel) {
+    WV_SLOT_ASM("s_andn2_b64")
+}
+
+/* lane-masked stores of one layer's cells of a diagonal: Fm, pm, py (and Fx, Fy where they are read again) */
+__device__ __forceinline__ void store_cells3(unsigned long long laneMask, const double *rowBase, unsigned voff,
+                                             double fm, double pm, double py) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "global_store_dwordx2 %2, %3, %6\n\t"
+                 "global_store_dwordx2 %2, %4, %6 offset:1536\n\t"
+                 "global_store_dwordx2 %2, %5, %6 offset:2048\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(laneMask), "v"(voff), "v"(fm), "v"(pm), "v"(py), "s"(rowBase)
+                 : "memory");
+}
+__device__ __forceinline__ void store_cells2(unsigned long long laneMask, const double *rowBase, unsigned voff,
+                                             double fx, double fy) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "global_store_dwordx2 %2, %3, %5 offset:512\n\t"
+                 "global_store_dwordx2 %2, %4, %5 offset:1024\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(laneMask), "v"(voff), "v"(fx), "v"(fy), "s"(rowBase)
+                 : "memory");
+}
+
+/* the band: first and last matrix column (k-mer index) of every anti-diagonal, one int2 per diagonal in HBM
+ * (built by the host from band_construct's output) */
+__device__ __forceinline__ void band_load(const int2 *__restrict__ tab, int d, int &xmin, int &xmax) {
+    const int2 v = tab[d > 0 ? d : 0];
+    xmin = uni(v.x);
+    xmax = uni(v.y);
+}
+
+/* The edge steps of diagonals lo..hi into the LDS bit strings: bit d of stepMin is xmin(d) - xmin(d-1),
+ * bit d of stepMax is xmax(d) - xmax(d-1) (both 0 or 1: the host checked).  Each lane takes 16
+ * consecutive diagonals per round (17 table entries, all loads in flight together). */
+__device__ void stage_band_steps(unsigned (&bits)[2][WV_BITWORDS], const int2 *__restrict__ tab, int D, int lo, int hi) {
+    const int lane = threadIdx.x & 63;
+    for (int w = (lo >> 5) + lane; w <= (hi >> 5); w += 64) {
+        bits[0][w & (WV_BITWORDS - 1)] = 0u;
+        bits[1][w & (WV_BITWORDS - 1)] = 0u;
+    }
+    for (int base = lo & ~31; base <= hi; base += 1024) {
+        const int d0 = base + lane * 16;
+        int2 e[17];
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            int d = d0 - 1 + k;
+            d = d < 0 ? 0 : d > D ? D : d;
+            e[k] = tab[d];
+        }
+        unsigned mn = 0u, mx = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const bool in = d0 + k >= lo && d0 + k <= hi && d0 + k >= 1;
+            mn |= (in && e[k + 1].x != e[k].x ? 1u : 0u) << k;
+            mx |= (in && e[k + 1].y != e[k].y ? 1u : 0u) << k;
+        }
+        if (d0 <= hi) {
+            const int w = (d0 >> 5) & (WV_BITWORDS - 1), sh = (lane & 1) * 16;
+            if (mn) atomicOr(&bits[0][w], mn << sh);
+            if (mx) atomicOr(&bits[1][w], mx << sh);
+        }
+    }
+}
+
+/* The next traceback point (:917-921) from the band alone: the first diagonal above dAfter that is at
+ * least dMin and narrow enough, or the last diagonal D.  512 diagonals per round. */
+__device__ int next_traceback_point(const int2 *__restrict__ tab, int D, int dAfter, long long dMin, long long widthLimit) {
+    const long long b0 = dAfter + 1 > dMin ? dAfter + 1 : dMin;
+    if (b0 >= D) return D;
+    const int lane = threadIdx.x & 63;
+    for (int base = (int) b0;; base += 512) {
+        int first = 8;
+#pragma unroll
+        for (int k = 7; k >= 0; k--) {
+            const int d = base + lane * 8 + k;
+            if (d >= D) first = k; /* the last diagonal is a traceback point whatever its width */
+            else {
+                const int2 v = tab[d];
+                if ((long long) (v.y - v.x + 1) <= widthLimit) first = k;
+            }
+        }
+        const unsigned long long m = __ballot(first < 8);
+        if (m != 0ull) {
+            const int l0 = __ffsll((long long) m) - 1;
+            const int d = base + l0 * 8 + __builtin_amdgcn_readlane(first, l0);
+            return d < D ? d : D;
+        }
+    }
+}
+
+struct FwdShared {
+    double coef[64];
+    double ev[(2 * WV_P + WV_L) * 2];       /* events (mean, noise) by index mod P, mirrored */
+    double rows[(WV_ROWN + 1) * WV_ROW];    /* k-mer rows by column mod WV_ROWN; row WV_ROWN = "not a k-mer" */
+    unsigned bits[2][WV_BITWORDS];
+};
+
+/*
+ * Forward sweep of one alignment from its saved diagonal up to (and including) the next traceback
+ * point; describes the window for the backward kernel.
+ */
+template <bool SW> __device__ void forward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
+                               const double *__restrict__ track, const double *__restrict__ events,
+                               const double *__restrict__ model, double *ring, int ringD, SyState *state,
+                               FwdShared &sh) {
+    constexpr int L = WV_L;
+    const int lane = threadIdx.x & 63;
+    const int lX = (int) it.lX, lY = (int) it.lY, D = lX + lY;
+    const double *__restrict__ ev = events + 3 * it.yOff;
+    const unsigned cf = lds_addr(sh.coef);
+    const unsigned rowsAddr = lds_addr(sh.rows), parkAddr = rowsAddr + WV_ROWN * WV_ROW * 8;
+    const int ringMask = ringD - 1;
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) T[i] = model[i];
+    /* the feed block: events of a block are staged one block ahead of their first use, so the ring of P
+     * events must hold the band's events and a block's worth more */
+    int feed = WV_P - it.maxWidth;
+    feed = feed > WV_FEED_MAX ? WV_FEED_MAX : feed & ~1;
+
+    const int d0 = uni(ld_agent(&state->d));
+    const int tracedBackTo = uni(ld_agent(&state->tracedBackTo));
+    long long cells = uni64(ld_agent(&state->cells));
+
+    /* the "not a k-mer" row: every emission -inf */
+    if (lane < WV_ROW) {
+        const bool inf = lane == CP_K1 || lane == CP_K2 || lane == CP_YK1 || lane == CP_YK2 || lane >= 16;
+        sh.rows[WV_ROWN * WV_ROW + lane] = inf ? CP_NEG_INF : 0.0;
+    }
+    for (int i = lane; i < (2 * WV_P + WV_L) * 2; i += 64) sh.ev[i] = 0.0;
+
+    /* ---- per-slot state: layer j of this lane is slot lane * L + j ---- */
+    Prm prm[L];
+    double Am[L], Ax[L], Ay[L]; /* forward cells of the last diagonal done      */
+    double Bm[L], Bx[L], By[L]; /* ... and of the one before                    */
+    double RAm, RAx, RAy, RBm, RBx, RBy; /* layer L-1 of the lane below, same two diagonals */
+    unsigned long long mask[L];  /* lanes whose slot holds a k-mer of the band   */
+    unsigned voff[L];
+    int xmin, xmax;              /* band of the last diagonal done               */
+    int inL, inJ, outL, outJ;    /* slots of k-mers xmax + 1 (next to enter) and xmin (next to leave) */
+#pragma unroll
+    for (int j = 0; j < L; j++) voff[j] = (unsigned) (j * WV_LAYER_BYTES + lane * 8);
+
+    if (d0 == 0) {
+        /* diagonal 0: the single cell (0,0) holds the start vector (:897-898, stateMachine.c:1168-1177) */
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            load_row_all(prm[j], parkAddr);
+            Am[j] = Ax[j] = Ay[j] = Bm[j] = Bx[j] = By[j] = CP_NEG_INF;
+            mask[j] = 0ull;
+        }
+        if (lane == 0) {
+            Am[0] = it.raggedL ? CP_NEG_INF : 0.0;
+            Ax[0] = it.raggedL ? 0.0 : CP_NEG_INF;
+            Ay[0] = Ax[0];
+        }
+        mask[0] = 1ull;
+        store_cells3(1ull, ring, voff[0], Am[0], 0.0, 0.0);
+        store_cells2(1ull, ring, voff[0], Ax[0], Ay[0]);
+        /* the dummy row the sweep back reads for lanes without a cell: -inf everywhere */
+        for (int i = lane; i < WV_ROW_DOUBLES; i += 64) ring[(long long) ringD * WV_ROW_DOUBLES + i] = CP_NEG_INF;
+        RBm = RBx = RBy = CP_NEG_INF;
+        cells += 1;
+        xmin = xmax = 0;
+        inL = 1 / L; inJ = 1 % L;
+        outL = 0; outJ = 0;
+        /* column 0 scores the "not a k-mer" sentinel (sequence_getKmer index -1, :314-318): its row is the parked one */
+    } else {
+        /* resume at d0: constants of the k-mers in the band, forward cells of d0 and d0-1 */
+        int qmin, qmax;
+        band_load(bandTab, d0 - 1, qmin, qmax);
+        band_load(bandTab, d0, xmin, xmax);
+        const double *r1 = ring + (long long) (d0 & ringMask) * WV_ROW_DOUBLES;
+        const double *r2 = ring + (long long) ((d0 - 1) & ringMask) * WV_ROW_DOUBLES;
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const int s = lane * L + j;
+            int xs = s + ((xmin - s + WV_P - 1) / WV_P) * WV_P; /* the k-mer >= xmin that lives in this slot */
+            const bool v1 = xs <= xmax;
+            int xq = s + ((qmin - s + WV_P - 1) / WV_P) * WV_P;
+            const bool v2 = xq <= qmax;
+            load_row_all(prm[j], parkAddr);
+            if (v1) {
+                const d2 *src = (const d2 *) (track + (long long) xs * WV_ROW);
+#pragma unroll
+                for (int k = 0; k < WV_ROW / 2; k++) prm[j].a[k] = src[k];
+            }
+            /* ring slots of cells outside the band hold stale data: mask per lane */
+            Am[j] = v1 ? r1[j * (WV_RING_VALUES * 64) + lane] : CP_NEG_INF;
+            Ax[j] = v1 ? r1[j * (WV_RING_VALUES * 64) + 64 + lane] : CP_NEG_INF;
+            Ay[j] = v1 ? r1[j * (WV_RING_VALUES * 64) + 128 + lane] : CP_NEG_INF;
+            Bm[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + lane] : CP_NEG_INF;
+            Bx[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + 64 + lane] : CP_NEG_INF;
+            By[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + 128 + lane] : CP_NEG_INF;
+            mask[j] = __ballot(v1);
+        }
+        RBm = ror1(Bm[L - 1]); RBx = ror1(Bx[L - 1]); RBy = ror1(By[L - 1]);
+        const int si = (xmax + 1) % WV_P, so = xmin % WV_P;
+        inL = si / L; inJ = si % L;
+        outL = so / L; outJ = so % L;
+    }
+    RAm = RAx = RAy = CP_NEG_INF;
+
+    /*
+     * Which diagonals need all three states in the ring.  The sweep back reads only the match cell of
+     * a diagonal, except where it refreshes totalProbability (every 10th decoded diagonal, counted
+     * down from the first one of ITS window: it then reads every state of that diagonal and of the
+     * one below), and this sweep resumes from the last two diagonals of a launch.  Where the windows
+     * will start is a function of the band alone, so it is known here: this launch ends at topW; its
+     * diagonals up to fromW are decoded by window W (first decoded diagonal tpA), the ones above by
+     * the next window (tpB).  Everywhere else the two gap states are not stored.
+     */
+    const long long widthLimit = P.expansion * 2 + 1;
+    const int topW = next_traceback_point(bandTab, D, d0, tracedBackTo + P.minDiags, widthLimit);
+    const bool endW = topW == D;
+    const int fromW = topW - (endW ? 0 : (int) P.tbDiags + 1);
+    const int tpA = topW < fromW ? topW : fromW;
+    int tpB = tpA;
+    bool allFull = false;
+    if (!endW) {
+        const int topN = next_traceback_point(bandTab, D, topW, fromW + P.minDiags, widthLimit);
+        const int fromN = topN - (topN == D ? 0 : (int) P.tbDiags + 1);
+        tpB = topN < fromN ? topN : fromN;
+        allFull = tpB < topW; /* windows shorter than the traceback margin: keep everything */
+    }
+    if (P.mode != 0) allFull = true; /* the expectation pass reads every state of every diagonal */
+    int rA = ((tpA - (d0 + 1)) % 10 + 10) % 10, rB = endW ? 0x40000000 : ((tpB - (d0 + 1)) % 10 + 10) % 10;
+    const int fullFrom = allFull ? -0x40000000 : topW - 1;
+
+    stage_band_steps(sh.bits, bandTab, D, d0 + 1, topW);
+
+    int evHi = d0 - xmax - 1;  /* first event not yet staged: the lowest index diagonal d0 + 1 can ask for */
+    int evHiMod = ((evHi % WV_P) + WV_P) % WV_P;
+    int rowHi = xmax + 1;      /* first k-mer row not yet staged */
+    unsigned dmod16 = (unsigned) ((d0 + 1) % WV_P) * 16u; /* 16 * (d mod P) of the diagonal being computed */
+    /* byte address of this lane's layer-(L-1) event on a diagonal d: 16 * ((d - L * (lane + 1)) mod P), split
+     * into the wave-uniform 16 * (d mod P) and a lane constant; the ring is mirrored, so the sum needs no wrap */
+    const unsigned evLane = lds_addr(sh.ev) + 16u * (unsigned) ((WV_P - L * (lane + 1) % WV_P) % WV_P);
+    unsigned wMin = 0u, wMax = 0u;
+
+    auto step = [&](const int d, const bool full, double (&cm)[L], double (&cx)[L], double (&cy)[L],
+                    double (&qm)[L], double (&qx)[L], double (&qy)[L], double &rlm, double &rlx, double &rly,
+                    const double rmm, const double rmx, const double rmy) __attribute__((always_inline)) {
+        /* the band of diagonal d: leaving k-mer first (its slot is parked), then the entering one */
+        const unsigned bi = (unsigned) d & 31u;
+        if (bi == 0u || d == d0 + 1) {
+            wMin = (unsigned) uni((int) sh.bits[0][(d >> 5) & (WV_BITWORDS - 1)]);
+            wMax = (unsigned) uni((int) sh.bits[1][(d >> 5) & (WV_BITWORDS - 1)]);
+        }
+        if ((wMin >> bi) & 1u) {
+            slot_leave(prm, mask, parkAddr, 1ull << outL, outJ);
+            xmin++;
+            if (++outJ == L) { outJ = 0; outL = (outL + 1) & 63; }
+        }
+        if ((wMax >> bi) & 1u) {
+            xmax++;
+            const unsigned ra = rowsAddr + (unsigned) (xmax & (WV_ROWN - 1)) * (WV_ROW * 8);
+            slot_enter(prm, mask, ra, 1ull << inL, inJ);
+            if (++inJ == L) { inJ = 0; inL = (inL + 1) & 63; }
+        }
+        cells += xmax - xmin + 1;
+        /* layer L-1 of the lane below, last diagonal (its value of the diagonal before is rm*) */
+        rlm = ror1(cm[L - 1]); rlx = ror1(cx[L - 1]); rly = ror1(cy[L - 1]);
+        const unsigned ea = evLane + dmod16;
+        dmod16 = dmod16 + 16u == WV_P * 16u ? 0u : dmod16 + 16u;
+        double *rowBase = ring + (long long) (d & ringMask) * WV_ROW_DOUBLES;
+        d2 e[L];
+#pragma unroll
+        for (int j = 0; j < L; j++) e[j] = *(lds_d2p) (ea + 16u * (unsigned) (L - 1 - j));
+        /* cell_calculateForward: to[t] = logAdd(to[t], from[f] + (eP + tP)) (:365-376) in the order of
+         * stateMachine3_cellCalculate (stateMachine.c:1314-1333); the gap-X sums eP + tP are the row's (built with
+         * the same additions by the track kernel).  The L cells of a lane are independent: their logAdds are
+         * taken stage by stage, so that the L table reads of a stage are in flight together. */
+        double pm[L], py[L], nm[L], nx[L], ny[L], t1[L];
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const Prm &p = prm[j];
+            pm[j] = lgauss(e[j].x, p.a[0].x, p.a[0].y, p.a[1].x, p.a[1].y)
+                    + lgauss(e[j].y, p.a[2].x, p.a[2].y, p.a[3].x, p.a[3].y);
+            py[j] = lgauss(e[j].x, p.a[4].x, p.a[4].y, p.a[5].x, p.a[5].y)
+                    + lgauss(e[j].y, p.a[6].x, p.a[6].y, p.a[7].x, p.a[7].y);
+        }
+#pragma unroll
+        for (int j = 0; j < L; j++) { /* gap X from the lower cell: (x-1, y) on the last diagonal */
+            nx[j] = (j ? cm[j ? j - 1 : 0] : rlm) + prm[j].a[8].x;
+            t1[j] = (j ? cx[j ? j - 1 : 0] : rlx) + prm[j].a[8].y;
+        }
+        laddN<L>(nx, t1, cf);
+        if (SW) {
+#pragma unroll
+            for (int j = 0; j < L; j++) t1[j] = (j ? cy[j ? j - 1 : 0] : rly) + prm[j].a[9].x;
+            laddN<L>(nx, t1, cf);
+        }
+#pragma unroll
+        for (int j = 0; j < L; j++) { /* match from the middle cell: (x-1, y-1) on the diagonal before */
+            nm[j] = (j ? qm[j ? j - 1 : 0] : rmm) + (pm[j] + T[T_MATCH_CONTINUE]);
+            t1[j] = (j ? qx[j ? j - 1 : 0] : rmx) + (pm[j] + T[T_MATCH_FROM_GAP_X]);
+        }
+        laddN<L>(nm, t1, cf);
+#pragma unroll
+        for (int j = 0; j < L; j++) { /* gap Y from the upper cell: (x, y-1) on the last diagonal */
+            ny[j] = cm[j] + (py[j] + T[T_GAP_OPEN_Y]);
+            t1[j] = cy[j] + (py[j] + T[T_GAP_EXTEND_Y]);
+        }
+        laddN<L>(ny, t1, cf);
+#pragma unroll
+        for (int j = 0; j < L; j++) t1[j] = (j ? qy[j ? j - 1 : 0] : rmy) + (pm[j] + T[T_MATCH_FROM_GAP_Y]);
+        laddN<L>(nm, t1, cf);
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            store_cells3(mask[j], rowBase, voff[j], nm[j], pm[j], py[j]);
+            store_cells2(full ? mask[j] : 0ull, rowBase, voff[j], nx[j], ny[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < L; j++) { qm[j] = nm[j]; qx[j] = nx[j]; qy[j] = ny[j]; }
+    };
+
+    const long long tbFromL = tracedBackTo + P.minDiags;
+    const int tbFrom = (int) (tbFromL < 0x7fffffff ? tbFromL : 0x7fffffff);
+    const int tbWidth = (int) (widthLimit < 0x7fffffff ? widthLimit : 0x7fffffff);
+    auto finish = [&](const int d) __attribute__((always_inline)) {
+        /* traceback point (:917-921) reached: hand the window to the backward kernel */
+        const bool atEnd = d == D;
+        if (!(atEnd || (d >= tbFrom && xmax - xmin < tbWidth))) return false;
+        if (lane == 0) {
+            const int from = d - (atEnd ? 0 : (int) P.tbDiags + 1);
+            state->d = d;
+            state->finished = atEnd ? 1 : 0;
+            state->winValid = 1;
+            state->winTop = d;
+            state->winFrom = from;
+            state->winTo = tracedBackTo;
+            state->winAtEnd = atEnd ? 1 : 0;
+            state->tracedBackTo = from;
+            state->cells = cells;
+        }
+        return true;
+    };
+
+#pragma unroll 1
+    for (int db = d0 + 1; db <= D; db += feed) {
+        {
+            /* stage what this block of diagonals can ask for: the top cell's event index d - xmin - 1 and the
+             * entering k-mer xmax + 1 each advance by at most one per diagonal */
+            const int evTo = db + feed - 1 - xmin, rowTo = (xmax + feed + 1 <= lX + 1) ? xmax + feed + 1 : lX + 1;
+#pragma unroll 1
+            for (int e0 = evHi; e0 < evTo; e0 += 64) {
+                const int e = e0 + lane;
+                int pos = evHiMod + lane;
+                pos = pos >= WV_P ? pos - WV_P : pos;
+                if (e < evTo) {
+                    const bool ok = e >= 0 && e < lY; /* index -1 is NULLEVENT (:261): it only ever meets -inf cells */
+                    d2 v;
+                    v.x = ok ? ev[3 * (long long) e] : 0.0;
+                    v.y = ok ? ev[3 * (long long) e + 1] : 0.0;
+                    d2 *dst = (d2 *) sh.ev;
+                    dst[pos] = v;
+                    dst[pos + WV_P] = v;
+                    if (pos < L) dst[pos + 2 * WV_P] = v;
+                }
+                evHiMod = (evHiMod + 64) % WV_P;
+            }
+            if (evTo > evHi) {
+                evHiMod = ((evTo % WV_P) + WV_P) % WV_P;
+                evHi = evTo;
+            }
+#pragma unroll 1
+            for (int i = rowHi * WV_ROW + lane; i < rowTo * WV_ROW; i += 64) {
+                const int x = i / WV_ROW, jj = i - x * WV_ROW;
+                sh.rows[(x & (WV_ROWN - 1)) * WV_ROW + jj] = track[i];
+            }
+            if (rowTo > rowHi) rowHi = rowTo;
+        }
+        const int dbEnd = db + feed - 1 < D ? db + feed - 1 : D;
+        unsigned fullMask = 0u; /* bit k: diagonal db + k keeps all three states */
+#pragma unroll 1
+        for (int k = 0; k < feed; k++) {
+            const int dj = db + k;
+            const int rHere = dj <= fromW ? rA : rB, rAbove = dj + 1 <= fromW ? rA : rB;
+            fullMask |= (dj >= fullFrom || rHere == 0 || rAbove == 1 ? 1u : 0u) << k;
+            rA = rA == 0 ? 9 : rA - 1;
+            rB = rB == 0 ? 9 : rB - 1;
+        }
+#pragma unroll 1
+        for (int d = db; d <= dbEnd; d += 2) {
+            step(d, ((fullMask >> (d - db)) & 1u) != 0u, Am, Ax, Ay, Bm, Bx, By, RAm, RAx, RAy, RBm, RBx, RBy);
+            if (finish(d)) return;
+            step(d + 1, ((fullMask >> (d + 1 - db)) & 1u) != 0u, Bm, Bx, By, Am, Ax, Ay, RBm, RBx, RBy, RAm, RAx, RAy);
+            if (finish(d + 1)) return;
+        }
+    }
+}
+
+
+/* ------------------------------------------------------------------------------------------------------
+ * The sweep back.
+ * ------------------------------------------------------------------------------------------------------ */
+
+/* a slot's gap-X sums (eP + tP for the three transitions into gap X) and its gap-X emission */
+struct Px {
+    d2 a, b; /* (open, extend) (switch, emission) */
+};
+#if WV_L == 1
+#define WV_PX_BODY "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" 
+#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b)
+#define WV_MASK_OR "s_or_b64 %[k0], %[k0], %[m]\n\t" 
+#define WV_MASK_ANDN2 "s_andn2_b64 %[k0], %[k0], %[m]\n\t" 
+#define WV_MASK_OUTS [k0] "+s"(mask[0])
+#elif WV_L == 2
+#define WV_PX_BODY "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\tds_read_b128 %[b1], %[a] offset:16\n\t" "9:\n\t" 
+#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b)
+#define WV_MASK_OR "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_or_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_or_b64 %[k1], %[k1], %[m]\n9:\n\t" 
+#define WV_MASK_ANDN2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_andn2_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_andn2_b64 %[k1], %[k1], %[m]\n9:\n\t" 
+#define WV_MASK_OUTS [k0] "+s"(mask[0]), [k1] "+s"(mask[1])
+#elif WV_L == 3
+#define WV_PX_BODY "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\tds_read_b128 %[b1], %[a] offset:16\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\tds_read_b128 %[c1], %[a] offset:16\n\t" "9:\n\t" 
+#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b), [c0] "+v"(p[2].a), [c1] "+v"(p[2].b)
+#define WV_MASK_OR "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_or_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_or_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_or_b64 %[k2], %[k2], %[m]\n9:\n\t" 
+#define WV_MASK_ANDN2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_andn2_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_andn2_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_andn2_b64 %[k2], %[k2], %[m]\n9:\n\t" 
+#define WV_MASK_OUTS [k0] "+s"(mask[0]), [k1] "+s"(mask[1]), [k2] "+s"(mask[2])
+#elif WV_L == 4
+#define WV_PX_BODY "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\tds_read_b128 %[b1], %[a] offset:16\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\tds_read_b128 %[c1], %[a] offset:16\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\tds_read_b128 %[d1], %[a] offset:16\n\t" "9:\n\t" 
+#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b), [c0] "+v"(p[2].a), [c1] "+v"(p[2].b), [d0] "+v"(p[3].a), [d1] "+v"(p[3].b)
+#define WV_MASK_OR "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_or_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_or_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\ts_or_b64 %[k2], %[k2], %[m]\n\ts_branch 9f\n3:\n\ts_or_b64 %[k3], %[k3], %[m]\n9:\n\t" 
+#define WV_MASK_ANDN2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_andn2_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_andn2_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\ts_andn2_b64 %[k2], %[k2], %[m]\n\ts_branch 9f\n3:\n\ts_andn2_b64 %[k3], %[k3], %[m]\n9:\n\t" 
+#define WV_MASK_OUTS [k0] "+s"(mask[0]), [k1] "+s"(mask[1]), [k2] "+s"(mask[2]), [k3] "+s"(mask[3])
+#endif
+/* lane-masked load of a gap-X row from LDS into ONE slot (lane laneMask, layer sel: run-time, wave-uniform) */
+__device__ __forceinline__ void px_install(Px (&p)[WV_L], unsigned rowAddr, unsigned long long laneMask, int sel) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_mov_b64 exec, %[m]\n\t" WV_PX_BODY
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [sv] "=&s"(sv) WV_PX_OUTS
+                 : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel)
+                 : "memory", "scc");
+}
+/* mask[sel] |= bit / &= ~bit on the scalar unit, sel a run-time value */
+__device__ __forceinline__ void mask_set(unsigned long long (&mask)[WV_L], unsigned long long bit, int sel) {
+    asm volatile(WV_MASK_OR : WV_MASK_OUTS : [m] "s"(bit), [sel] "s"(sel) : "scc");
+}
+__device__ __forceinline__ void mask_clear(unsigned long long (&mask)[WV_L], unsigned long long bit, int sel) {
+    asm volatile(WV_MASK_ANDN2 : WV_MASK_OUTS : [m] "s"(bit), [sel] "s"(sel) : "scc");
+}
+/* lane-masked stores of one layer's backward cells (Baum-Welch: the B ring) */
+__device__ __forceinline__ void store_b3(unsigned long long laneMask, const double *rowBase, unsigned voff,
+                                         double bm, double bx, double by) {
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "global_store_dwordx2 %2, %3, %6\n\t"
+                 "global_store_dwordx2 %2, %4, %6 offset:512\n\t"
+                 "global_store_dwordx2 %2, %5, %6 offset:1024\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(sv)
+                 : "s"(laneMask), "v"(voff), "v"(bm), "v"(bx), "v"(by), "s"(rowBase)
+                 : "memory");
+}
+
+/* logAdd-fold of one value per lane into acc (wave-uniform in and out), lanes in ascending order; visits only
+ * the lanes that can change the running value */
+__device__ __forceinline__ double wave_fold(double acc, double v, unsigned cf) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long after = ~0ull;
+#pragma unroll 1
+    for (;;) {
+        const bool eff = ((after >> lane) & 1ull) && (v > CP_NEG_INF) && !(acc - v >= 7.5);
+        const unsigned long long m = __ballot(eff);
+        if (m == 0ull) break;
+        const int first = __ffsll((long long) m) - 1;
+        acc = ladd(acc, bcast(v, first), cf);
+        after = first >= 63 ? 0ull : (~0ull << (first + 1));
+    }
+    return acc;
+}
+
+struct ItemOut {
+    long long *pairs;
+    double *logp;
+    long long pairCap;
+    long long *totXay;
+    double *totVal;
+    long long totCap;
+    long long nPairs, nTot;
+};
+
+#define WV_PXN 64 /* LDS ring of gap-X rows, by column */
+struct BwdShared {
+    double coef[64];
+    double pxr[(WV_PXN + 1) * 4]; /* gap-X rows by column mod WV_PXN; row WV_PXN = -inf */
+    unsigned bits[2][WV_BITWORDS];
+    double vbuf[64];
+    int part[64];
+    int scan, carry;
+};
+
+/* hits of a diagonal in slots before slot s (s = 0..P), from its per-layer lane masks */
+__device__ __forceinline__ int hits_before(const unsigned long long (&m)[WV_L], int s) {
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < WV_L; j++) {
+        const int q = s - j <= 0 ? 0 : (s - j + WV_L - 1) / WV_L; /* lanes l with l * L + j < s */
+        n += __popcll(q >= 64 ? m[j] : m[j] & ((1ull << q) - 1ull));
+    }
+    return n;
+}
+/* rank of slot s among the hits of its diagonal in k-mer order: the band starts at slot s0 and wraps */
+__device__ __forceinline__ int rank_in_diagonal(const unsigned long long (&m)[WV_L], int s0, int s) {
+    const int b0 = hits_before(m, s0), b = hits_before(m, s);
+    if (s >= s0) return b - b0;
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < WV_L; j++) total += __popcll(m[j]);
+    return total - b0 + b;
+}
+
+/*
+ * Backward sweep + posterior decode of one traceback window (:921-992), in three phases:
+ *  S  the sweep back: one anti-diagonal per iteration, cells and messages in registers; it collects the
+ *     decode candidates and, on the diagonals where the reference refreshes totalProbability, the per-cell
+ *     terms of that sum (HBM scratch);
+ *  T  totalProbability (:736-754) for every refresh of the window at once: the reference's order-dependent
+ *     logAdd fold is inherently serial, so each THREAD folds one diagonal's terms privately, in the
+ *     reference's order;
+ *  D  diagonalCalculationPosteriorMatchProbs (:756-795) from the candidate lists: hits are marked per
+ *     diagonal, prefix-summed in emission order (diagonals descending, x-y ascending) and written.
+ * A window whose candidates cannot be trusted (the totals stray from the sweep's estimate, a list overflows,
+ * threshold 0) is swept once more with the exact totals in hand and decoded in the loop.
+ * The device selects pairs by the exponent (F+B)-total >= log(threshold) - margin; exp(), the exact
+ * threshold test and floor(p * 1e7) (:776-786) are finished on the host with the reference's libm
+ * (cpecan_hip.hip), so the integer posteriors are the reference's to the bit.
+ */
+template <bool SW>
+__device__ void backward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
+                                const double *__restrict__ track, const double *__restrict__ model,
+                                double *ring, int ringD, SyState *state, ItemOut &out, BwdShared &sh,
+                                int *offBuf, WinTotal *wtot, double *vw, unsigned long long *msk, int2 *candKx,
+                                double *candFb, double *bring) {
+    constexpr int L = WV_L;
+    const int lane = threadIdx.x & 63;
+    const int D = (int) (it.lX + it.lY);
+    const unsigned cf = lds_addr(sh.coef);
+    const unsigned pxAddr = lds_addr(sh.pxr), pxPark = pxAddr + WV_PXN * 32;
+    const int ringMask = ringD - 1;
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) T[i] = model[i];
+
+    const int dTop = uni(ld_agent(&state->winTop)), tracedBackFrom = uni(ld_agent(&state->winFrom)),
+              tracedBackTo = uni(ld_agent(&state->winTo));
+    const bool atEnd = uni(ld_agent(&state->winAtEnd)) != 0;
+    const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
+    const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
+    const int candCap = WV_CAND_PER_DIAG * WV_L * ringD;
+    if (lane < 4) sh.pxr[WV_PXN * 4 + lane] = CP_NEG_INF;
+    if (lane == 0) sh.scan = (P.scanDecode != 0 || !(P.logThrSlack > CP_NEG_INF)) ? 1 : 0;
+    stage_band_steps(sh.bits, bandTab, D, tracedBackTo + 1, dTop);
+
+    unsigned voff[L];
+#pragma unroll
+    for (int j = 0; j < L; j++) voff[j] = (unsigned) (j * WV_LAYER_BYTES + lane * 8);
+    const unsigned dummyOff = (unsigned) ((long long) ringD * WV_ROW_DOUBLES * 8);
+    int nTotWin = 0, nCand = 0;
+    double totEst = CP_NEG_INF;
+
+    /* ------------------------------ phase S: the sweep back ------------------------------ */
+    auto sweep = [&](const bool direct) __attribute__((always_inline)) {
+        int bxmin, bxmax; /* band of the diagonal being computed */
+        band_load(bandTab, dTop, bxmin, bxmax);
+        /* this slot's k-mer on a diagonal: the one in (xmax - P, xmax] */
+        unsigned long long m0[L];
+        Px px[L];
+        double Bm[L], Bx[L], By[L]; /* backward cells of the diagonal above (t+1) */
+        double Um[L], Uy[L];        /* upper-block sums of t+1: By + (gap-Y emission + tP)          */
+        double hB[L], hP[L];        /* B.match and match emission of t+2 (the middle block's source) */
+        double pm1[L];              /* match emission of t+1 */
+        {
+            double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
+            if (atEnd && it.raggedR) {
+                e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
+                e1 = T[T_GAP_EXTEND_X];
+                e2 = T[T_GAP_EXTEND_Y];
+            } else {
+                e0 = T[T_MATCH_CONTINUE];
+                e1 = T[T_MATCH_FROM_GAP_X];
+                e2 = T[T_MATCH_FROM_GAP_Y];
+            }
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                const int sl = lane * L + j;
+                int xs = sl + ((bxmin - sl + WV_P - 1) / WV_P) * WV_P;
+                if (xs > bxmax) xs -= WV_P;
+                const bool v = xs >= bxmin;
+                m0[j] = __ballot(v);
+                Bm[j] = v ? e0 : CP_NEG_INF;
+                Bx[j] = v ? e1 : CP_NEG_INF;
+                By[j] = v ? e2 : CP_NEG_INF;
+                const d2 *src = (const d2 *) (track + (long long) (v ? xs : 0) * WV_ROW + 16);
+                const d2 ninf = { CP_NEG_INF, CP_NEG_INF };
+                px[j].a = v ? src[0] : ninf;
+                px[j].b = v ? src[1] : ninf;
+                Um[j] = Uy[j] = hB[j] = CP_NEG_INF;
+                hP[j] = pm1[j] = CP_NEG_INF;
+            }
+        }
+        double rpo = rol1(px[0].a.x), rpe = rol1(px[0].a.y), rps = SW ? rol1(px[0].b.x) : 0.0;
+
+        /* the fetch cursor: band, lane masks and slot counters of the diagonal whose ring row is fetched next.
+         * A diagonal's forward match cell and two emissions are fetched WV_PREFETCH diagonals before the sweep
+         * reaches it (vmcnt is one in-order queue: a fetch consumed at once would cost an HBM round trip per
+         * diagonal); the loop is unrolled by the depth, so every in-flight diagonal has registers of its own.
+         * A lane with no cell on that diagonal reads the dummy row (-inf): its emissions are then -inf and
+         * whatever its slot holds cannot reach a cell of the band. */
+        unsigned long long fm[L];
+#pragma unroll
+        for (int j = 0; j < L; j++) fm[j] = m0[j];
+        int fxmin = bxmin, fxmax = bxmax;
+        int topL, topJ, botL, botJ; /* slots of k-mers fxmax (next to leave) and fxmin - 1 (next to enter) */
+        {
+            const int st = fxmax % WV_P, sb = (fxmin - 1 + WV_P) % WV_P;
+            topL = st / L; topJ = st % L;
+            botL = sb / L; botJ = sb % L;
+        }
+        unsigned fwMin = 0u, fwMax = 0u;
+        bool fFirst = true;
+        struct Rec {
+            unsigned long long m[L]; /* lanes with a cell on the diagonal */
+            int leave, lL, lJ;       /* the k-mer that left the band at the top, coming down to this diagonal */
+            int enter, eL, eJ, eX;   /* the k-mer that entered at the bottom */
+        };
+        struct Q {
+            double f[L], pm[L], py[L];
+        };
+        auto fetch = [&](const int tau, Rec &r, Q &q) __attribute__((always_inline)) {
+            r.leave = r.enter = 0;
+            r.lL = r.lJ = r.eL = r.eJ = r.eX = 0;
+            if (tau > tracedBackTo && tau < dTop) {
+                /* band(tau) from band(tau + 1): the steps of diagonal tau + 1 */
+                const unsigned bi = (unsigned) (tau + 1) & 31u;
+                if (bi == 31u || fFirst) {
+                    fwMin = (unsigned) uni((int) sh.bits[0][((tau + 1) >> 5) & (WV_BITWORDS - 1)]);
+                    fwMax = (unsigned) uni((int) sh.bits[1][((tau + 1) >> 5) & (WV_BITWORDS - 1)]);
+                    fFirst = false;
+                }
+                if ((fwMax >> bi) & 1u) {
+                    r.leave = 1; r.lL = topL; r.lJ = topJ;
+                    mask_clear(fm, 1ull << topL, topJ);
+                    fxmax--;
+                    if (--topJ < 0) { topJ = L - 1; topL = (topL + 63) & 63; }
+                }
+                if ((fwMin >> bi) & 1u) {
+                    r.enter = 1; r.eL = botL; r.eJ = botJ; r.eX = fxmin - 1;
+                    mask_set(fm, 1ull << botL, botJ);
+                    fxmin--;
+                    if (--botJ < 0) { botJ = L - 1; botL = (botL + 63) & 63; }
+                }
+            }
+            const bool live = tau > tracedBackTo;
+            const unsigned rowOff = (unsigned) ((long long) (tau & ringMask) * (WV_ROW_DOUBLES * 8));
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                r.m[j] = live ? fm[j] : 0ull;
+                unsigned off;
+                const unsigned real = rowOff + voff[j], dummy = dummyOff + voff[j];
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(off) : "v"(dummy), "v"(real), "s"(r.m[j]));
+                const double *p = (const double *) ((const char *) ring + off);
+                q.f[j] = p[0];
+                q.pm[j] = p[3 * 64];
+                q.py[j] = p[4 * 64];
+            }
+        };
+
+        Rec r0, r1, r2, r3;
+        Q q0, q1, q2, q3;
+        fetch(dTop, r0, q0);
+        fetch(dTop - 1, r1, q1);
+        fetch(dTop - 2, r2, q2);
+        fetch(dTop - 3, r3, q3);
+
+        unsigned long long mAbove[L]; /* lanes with a cell on t+1 */
+#pragma unroll
+        for (int j = 0; j < L; j++) mAbove[j] = 0ull;
+        int nxmin = bxmin, nxmax = bxmax; /* band of t+1 */
+        int calcs = 0;
+        long long emitted = 0; /* direct decode: pairs written by this window so far */
+        double candThr = CP_NEG_INF, totCur = CP_NEG_INF;
+        nTotWin = 0;
+        nCand = 0;
+        int pxLo = bxmin; /* gap-X rows of columns >= pxLo - WV_PXN/2 ... are staged */
+
+        auto step = [&](const int t, Rec &r, Q &q) __attribute__((always_inline)) {
+            /* this diagonal's forward values (their loads were issued four diagonals ago), then the fetch that
+             * re-uses their registers */
+            double qF[L], qPm[L], qPy[L];
+            unsigned long long mt[L];
+#pragma unroll
+            for (int j = 0; j < L; j++) { qF[j] = q.f[j]; qPm[j] = q.pm[j]; qPy[j] = q.py[j]; mt[j] = r.m[j]; }
+            const int leave = r.leave, lL = r.lL, lJ = r.lJ, enter = r.enter, eL = r.eL, eJ = r.eJ, eX = r.eX;
+            fetch(t - WV_PREFETCH, r, q);
+            if (t < dTop) {
+                nxmin = bxmin; nxmax = bxmax;
+                bxmax -= leave;
+                bxmin -= enter;
+                /* of slot+1: B.match and match emission of t+2 (middle block), B.gapX of t+1 with its k-mer's
+                 * gap-X sums (lower block of t+1); layer L-1 takes them from layer 0 of the lane above */
+                const double rhB = rol1(hB[0]), rhP = rol1(hP[0]), rBx = rol1(Bx[0]);
+                /* gather form of cell_calculateBackward (:378-389): (t+2) middle block, then (t+1, smaller x-y)
+                 * upper block, then (t+1, larger x-y) lower block -- the reference's scatter order per state */
+                double bm[L], bx[L], by[L], y1[L], sBx[L];
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    const double sB = j < L - 1 ? hB[j < L - 1 ? j + 1 : 0] : rhB, sP = j < L - 1 ? hP[j < L - 1 ? j + 1 : 0] : rhP;
+                    sBx[j] = j < L - 1 ? Bx[j < L - 1 ? j + 1 : 0] : rBx;
+                    bm[j] = sB + (sP + T[T_MATCH_CONTINUE]);
+                    bx[j] = sB + (sP + T[T_MATCH_FROM_GAP_X]);
+                    by[j] = sB + (sP + T[T_MATCH_FROM_GAP_Y]);
+                }
+                laddN<L>(bm, Um, cf);
+                laddN<L>(by, Uy, cf);
+#pragma unroll
+                for (int j = 0; j < L; j++) y1[j] = sBx[j] + (j < L - 1 ? px[j < L - 1 ? j + 1 : 0].a.x : rpo);
+                laddN<L>(bm, y1, cf);
+#pragma unroll
+                for (int j = 0; j < L; j++) y1[j] = sBx[j] + (j < L - 1 ? px[j < L - 1 ? j + 1 : 0].a.y : rpe);
+                laddN<L>(bx, y1, cf);
+                if (SW) {
+#pragma unroll
+                    for (int j = 0; j < L; j++) y1[j] = sBx[j] + (j < L - 1 ? px[j < L - 1 ? j + 1 : 0].b.x : rps);
+                    laddN<L>(by, y1, cf);
+                }
+#pragma unroll
+                for (int j = 0; j < L; j++) {
+                    hB[j] = Bm[j]; hP[j] = pm1[j];
+                    Bm[j] = bm[j]; Bx[j] = bx[j]; By[j] = by[j];
+                }
+                /* the gap-X sums above belong to the cells of t+1, the senders of the lower block: the slots of the
+                 * k-mer that left the band at the top (parked) and of the one that entered at the bottom change
+                 * hands only now, for the diagonals below */
+                bool touch0 = false;
+                if (leave) {
+                    px_install(px, pxPark, 1ull << lL, lJ);
+                    touch0 = lJ == 0;
+                }
+                if (enter) {
+                    px_install(px, pxAddr + (unsigned) (eX & (WV_PXN - 1)) * 32u, 1ull << eL, eJ);
+                    touch0 = touch0 || eJ == 0;
+                }
+                if (touch0) {
+                    rpo = rol1(px[0].a.x);
+                    rpe = rol1(px[0].a.y);
+                    if (SW) rps = rol1(px[0].b.x);
+                }
+            }
+            /* what this diagonal hands down: the upper-block sums stay in the slot */
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                Um[j] = By[j] + (qPy[j] + T[T_GAP_OPEN_Y]);
+                Uy[j] = By[j] + (qPy[j] + T[T_GAP_EXTEND_Y]);
+            }
+            if (t <= tracedBackFrom) {
+                double fb[L];
+#pragma unroll
+                for (int j = 0; j < L; j++) fb[j] = qF[j] + Bm[j];
+                const int kPost = tPost0 - t;
+                if (calcs++ % 10 == 0) {
+                    if (direct) totCur = uni64_d(ld_agent(&wtot[kPost / 10].total));
+                    else {
+                        /* per-cell terms of diagonalCalculationTotalProbability (:736-754), folded in phase T:
+                         * v = cell_dotProduct(forward[t], backward[t]) (:391-397) and w = matches stepping over
+                         * t: forward[t-1] --match--> the cells of t+1, dotted with backward[t+1] */
+                        const bool second = t + 1 <= dTop;
+                        int pxmin, pxmax;
+                        band_load(bandTab, t - 1, pxmin, pxmax);
+                        const int sMin = bxmin % WV_P, sMinN = nxmin % WV_P;
+                        const double *rowT = ring + (long long) (t & ringMask) * WV_ROW_DOUBLES;
+                        const double *rowB = ring + (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
+                        double vv[L], ww[L];
+                        double fx[L], fy[L], s0[L], s1[L], s2[L];
+                        bool tv[L], nv[L];
+#pragma unroll
+                        for (int j = 0; j < L; j++) {
+                            const int sl = lane * L + j;
+                            tv[j] = ((mt[j] >> lane) & 1ull) != 0ull;
+                            nv[j] = second && ((mAbove[j] >> lane) & 1ull) != 0ull;
+                            const int xN = nxmin + (sl - sMinN + (sl < sMinN ? WV_P : 0)); /* this slot's k-mer on t+1 */
+                            const bool below = nv[j] && xN - 1 >= pxmin && xN - 1 <= pxmax;
+                            const int sb = sl == 0 ? WV_P - 1 : sl - 1; /* the slot of k-mer xN - 1 */
+                            const double *pa = rowT + (tv[j] ? j * (WV_RING_VALUES * 64) + lane : 0);
+                            const double *pb = rowB + (below ? (sb % L) * (WV_RING_VALUES * 64) + sb / L : 0);
+                            fx[j] = pa[64]; fy[j] = pa[128];
+                            s0[j] = pb[0]; s1[j] = pb[64]; s2[j] = pb[128];
+                            if (!below) s0[j] = s1[j] = s2[j] = CP_NEG_INF;
+                            (void) sMin;
+                        }
+#pragma unroll
+                        for (int j = 0; j < L; j++) {
+                            double v = CP_NEG_INF, w = CP_NEG_INF;
+                            if (tv[j]) {
+                                v = fb[j];
+                                v = ladd(v, fx[j] + Bx[j], cf);
+                                v = ladd(v, fy[j] + By[j], cf);
+                                vw[((long long) nTotWin * 2 + 0) * WV_P + lane * L + j] = v;
+                            }
+                            if (nv[j]) {
+                                double mm = s0[j] + (hP[j] + T[T_MATCH_CONTINUE]);
+                                mm = ladd(mm, s1[j] + (hP[j] + T[T_MATCH_FROM_GAP_X]), cf);
+                                mm = ladd(mm, s2[j] + (hP[j] + T[T_MATCH_FROM_GAP_Y]), cf);
+                                w = mm + hB[j];
+                                vw[((long long) nTotWin * 2 + 1) * WV_P + lane * L + j] = w;
+                            }
+                            vv[j] = v; ww[j] = w;
+                        }
+                        if (nTotWin == 0) {
+                            /* the estimate: the same terms folded in any order (it only steers the candidate
+                             * test; the exact, ordered folds are phase T's) */
+                            double acc = CP_NEG_INF;
+#pragma unroll
+                            for (int j = 0; j < L; j++) acc = wave_fold(acc, vv[j], cf);
+#pragma unroll
+                            for (int j = 0; j < L; j++) acc = wave_fold(acc, ww[j], cf);
+                            totEst = acc;
+                            candThr = P.logThrSlack > CP_NEG_INF ? acc + (P.logThrSlack - WV_CAND_SLACK) : __builtin_huge_val();
+                        }
+                        if (lane == 0) {
+                            WinTotal w;
+                            w.t = t; w.xmin = bxmin; w.xmax = bxmax; w.nxmin = nxmin; w.nxmax = nxmax;
+                            w.second = second ? 1 : 0;
+                            w.total = CP_NEG_INF;
+                            wtot[nTotWin] = w;
+                        }
+                        nTotWin++;
+                    }
+                }
+                if (P.mode != 0) {
+                    /* Baum-Welch: the backward cells go to their own ring for the expectation kernel */
+                    const double *rowB = bring + (long long) (t & ringMask) * (WV_L * 3 * 64);
+#pragma unroll
+                    for (int j = 0; j < L; j++)
+                        store_b3(mt[j], rowB, (unsigned) (j * (3 * 64 * 8) + lane * 8), Bm[j], Bx[j], By[j]);
+                } else if (direct) {
+                    /* the window's second sweep: exact totals are known, pairs leave in emission order */
+                    unsigned long long hm[L];
+                    bool hit[L];
+                    const int sMin = bxmin % WV_P;
+                    const int xlo = bxmin > 1 ? bxmin : 1, xhi = bxmax < t - 1 ? bxmax : t - 1;
+                    unsigned long long any = 0ull;
+#pragma unroll
+                    for (int j = 0; j < L; j++) {
+                        const int sl = lane * L + j;
+                        const int x = bxmin + (sl - sMin + (sl < sMin ? WV_P : 0));
+                        const double ee = fb[j] - totCur;
+                        hit[j] = ((mt[j] >> lane) & 1ull) != 0ull && x >= xlo && x <= xhi && ee >= P.logThrSlack;
+                        hm[j] = __ballot(hit[j]);
+                        any |= hm[j];
+                    }
+                    if (any != 0ull) {
+                        int total = 0;
+#pragma unroll
+                        for (int j = 0; j < L; j++) {
+                            const int sl = lane * L + j;
+                            if (hit[j]) {
+                                const int x = bxmin + (sl - sMin + (sl < sMin ? WV_P : 0));
+                                const long long idx = out.nPairs + emitted + rank_in_diagonal(hm, sMin, sl);
+                                if (idx < out.pairCap) {
+                                    long long *o = out.pairs + idx * 3;
+                                    o[0] = 0;
+                                    o[1] = x - 1;
+                                    o[2] = t - x - 1;
+                                    out.logp[idx] = fb[j] - totCur;
+                                }
+                            }
+                            total += __popcll(hm[j]);
+                        }
+                        emitted += total;
+                    }
+                } else {
+                    /* decode candidates: cells within WV_CAND_SLACK of the threshold against the estimate */
+#pragma unroll
+                    for (int j = 0; j < L; j++) {
+                        const bool cand = fb[j] >= candThr;
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm != 0ull) {
+                            const int ci = nCand + __popcll(cm & ((1ull << lane) - 1ull));
+                            if (cand && ci < candCap) {
+                                const int sl = lane * L + j, sMin = bxmin % WV_P;
+                                candKx[ci] = make_int2(kPost, bxmin + (sl - sMin + (sl < sMin ? WV_P : 0)));
+                                candFb[ci] = fb[j];
+                            }
+                            nCand += __popcll(cm);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < L; j++) { pm1[j] = qPm[j]; mAbove[j] = mt[j]; }
+        };
+
+        int t = dTop;
+#pragma unroll 1
+        for (;;) {
+            if (((dTop - t) & 31) == 0) {
+                /* gap-X rows of the k-mers that can enter during the next 32 diagonals */
+                for (int i = lane; i < 32 * 4; i += 64) {
+                    const int x = bxmin - 1 - (i >> 2);
+                    if (x >= 0) sh.pxr[(x & (WV_PXN - 1)) * 4 + (i & 3)] = track[(long long) x * WV_ROW + 16 + (i & 3)];
+                }
+                (void) pxLo;
+            }
+            if (t <= tracedBackTo) break;
+            step(t, r0, q0); t--;
+            if (t <= tracedBackTo) break;
+            step(t, r1, q1); t--;
+            if (t <= tracedBackTo) break;
+            step(t, r2, q2); t--;
+            if (t <= tracedBackTo) break;
+            step(t, r3, q3); t--;
+        }
+        if (direct) out.nPairs += emitted;
+    };
+
+    bool direct = false;
+#pragma unroll 1
+    for (;;) {
+        sweep(direct);
+        if (direct) return;
+        if (nCand > candCap && lane == 0) sh.scan = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the refresh terms in scratch are read back below */
+
+        /* ------------------------------ phase T: the totals ------------------------------ */
+#pragma unroll 1
+        for (int k0 = 0; k0 < 2 * nTotWin; k0 += 64) {
+            const int k = k0 + lane;
+            double acc = CP_NEG_INF;
+            WinTotal w;
+            w.second = 0; w.t = 0; w.xmin = w.xmax = w.nxmin = w.nxmax = 0;
+            const int f = k & 1;
+            if (k < 2 * nTotWin) {
+                w = wtot[k >> 1];
+                if (f == 0 || w.second) {
+                    const int lo = f ? w.nxmin : w.xmin, hi = f ? w.nxmax : w.xmax;
+                    const double *src = vw + ((long long) (k >> 1) * 2 + f) * WV_P;
+                    double v[8], nv[8]; /* the next eight terms are in flight while these eight are folded */
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = lo + j <= hi ? ld_agent(src + (lo + j) % WV_P) : CP_NEG_INF;
+#pragma unroll 1
+                    for (int x0 = lo; x0 <= hi; x0 += 8) {
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            nv[j] = x0 + 8 + j <= hi ? ld_agent(src + (x0 + 8 + j) % WV_P) : CP_NEG_INF;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) acc = ladd(acc, v[j], cf); /* dpDiagonal_dotProduct :587-597 */
+#pragma unroll
+                        for (int j = 0; j < 8; j++) v[j] = nv[j];
+                    }
+                }
+            }
+            sh.vbuf[lane] = acc;
+            __builtin_amdgcn_wave_barrier();
+            const double partner = sh.vbuf[(lane + 1) & 63];
+            if (k < 2 * nTotWin && f == 0) {
+                double tot = acc;
+                if (w.second) tot = ladd(acc, partner, cf);
+                wtot[k >> 1].total = tot;
+                if (!(fabs(tot - totEst) <= WV_CAND_SLACK)) sh.scan = 1; /* also catches NaN and infinities */
+                const long long o = out.nTot + (k >> 1);
+                if (o < out.totCap) {
+                    out.totXay[o] = w.t;
+                    out.totVal[o] = tot;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        out.nTot += nTotWin;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the totals are read back by the decode / the second sweep */
+        if (P.mode != 0 || nPost <= 0) return;
+        if (uni(sh.scan) == 0) break;
+        direct = true;
+    }
+
+    /* ------------------------------ phase D: the aligned pairs ------------------------------ */
+    for (int i = lane; i < nPost * 4; i += 64) msk[i] = 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+        for (int i = lane; i < nCand; i += 64) {
+            const int2 kx = ld_agent(candKx + i);
+            const int k = kx.x, x = kx.y, t = tPost0 - k;
+            const double ee = ld_agent(candFb + i) - ld_agent(&wtot[k / 10].total);
+            if (!(x >= 1 && x <= t - 1 && ee >= P.logThrSlack)) continue;
+            const int sl = x % WV_P;
+            if (!pass) {
+                atomicOr(msk + k * 4ll + sl % L, 1ull << (sl / L));
+                continue;
+            }
+            unsigned long long mm[L];
+#pragma unroll
+            for (int j = 0; j < L; j++) mm[j] = ld_agent(msk + k * 4ll + j);
+            const int rank = rank_in_diagonal(mm, bandTab[t].x % WV_P, sl);
+            const long long idx = out.nPairs + ld_agent(offBuf + k) + rank;
+            if (idx < out.pairCap) {
+                long long *o = out.pairs + idx * 3;
+                o[0] = 0;
+                o[1] = x - 1;
+                o[2] = t - x - 1;
+                out.logp[idx] = ee;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        if (!pass) {
+            /* hits per diagonal from the masks; exclusive prefix in emission order */
+            int carry = 0;
+#pragma unroll 1
+            for (int base = 0; base < nPost; base += 8 * 64) {
+                const int b0 = base + lane * 8;
+                int h[8], sum = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    h[j] = 0;
+                    if (b0 + j < nPost) {
+#pragma unroll
+                        for (int q = 0; q < L; q++) h[j] += __popcll(ld_agent(msk + (b0 + j) * 4ll + q));
+                    }
+                    sum += h[j];
+                }
+                int inc = sum;
+#pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                    const int up = __shfl_up(inc, o2);
+                    if (lane >= o2) inc += up;
+                }
+                int o = carry + inc - sum;
+                carry += __builtin_amdgcn_readlane(inc, 63);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    if (b0 + j < nPost) {
+                        offBuf[b0 + j] = o;
+                        o += h[j];
+                    }
+            }
+            if (lane == 0) sh.carry = carry;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        }
+    }
+    out.nPairs += uni(sh.carry);
+}
+
+} // namespace
+
+/* One wave per alignment: forward sweep up to its next traceback point.  Two instantiations: a -inf
+ * gapY->gapX transition (the nanopore default, stateMachine.c:1287) contributes logAdd(acc, -inf) == acc, and the
+ * build without that term is the one a batch runs on when none of its models has the transition. */
+template <bool SW> __device__ __forceinline__ void wv_forward_kernel(
+    const DevItem *__restrict__ items, long long nItems, const DevParams &P,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ events,
+    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD,
+    SyState *states, FwdShared &sh) {
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    SyState *state = states + idx;
+    const DevItem it = uniform_item(items[idx]);
+    if (state->finished || it.lX + it.lY == 0) return;
+    init_coef(sh.coef);
+    forward_window<SW>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW, events,
+                       models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, state, sh);
+}
+extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_forward)(
+    const DevItem *__restrict__ items, long long nItems, DevParams P,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ events,
+    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, SyState *states) {
+    __shared__ FwdShared sh;
+    wv_forward_kernel<false>(items, nItems, P, bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
+                             states, sh);
+}
+extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_forward_sw)(
+    const DevItem *__restrict__ items, long long nItems, DevParams P,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ events,
+    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, SyState *states) {
+    __shared__ FwdShared sh;
+    wv_forward_kernel<true>(items, nItems, P, bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
+                            states, sh);
+}
+
+/* One wave per alignment: backward sweep + posterior decode of the window just described. */
+template <bool SW> __device__ __forceinline__ void wv_backward_kernel(
+    const DevItem *__restrict__ items, long long nItems, const DevParams &P,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
+    long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
+    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window,
+    BwdShared &sh) {
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    SyState *state = states + idx;
+    if (!state->winValid) return;
+    const DevItem it = uniform_item(items[idx]);
+    init_coef(sh.coef);
+    ItemOut out;
+    out.pairs = pairs + it.pairBase * 3;
+    out.logp = pairLogp + it.pairBase;
+    out.pairCap = it.pairCap;
+    out.totXay = totXay + it.totBase;
+    out.totVal = totVal + it.totBase;
+    out.totCap = it.totCap;
+    out.nPairs = uni64(state->nPairs);
+    out.nTot = uni64(state->nTot);
+    char *sc = scratch + idx * scratchBytes;
+    const long long nW = (long long) ringD / 10 + 8;
+    int *offBuf = (int *) sc;
+    WinTotal *wtot = (WinTotal *) (sc + 2ll * ringD * sizeof(int));
+    double *vw = (double *) (sc + 2ll * ringD * sizeof(int) + nW * sizeof(WinTotal));
+    unsigned long long *msk = (unsigned long long *) (sc + 2ll * ringD * sizeof(int)
+                                                      + nW * (sizeof(WinTotal) + 2 * WV_P * sizeof(double)));
+    int2 *candKx = (int2 *) ((char *) msk + 4ll * ringD * sizeof(unsigned long long));
+    double *candFb = (double *) ((char *) candKx + (long long) WV_L * WV_CAND_PER_DIAG * ringD * sizeof(int2));
+    backward_window<SW>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW,
+                        models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, state, out,
+                        sh, offBuf, wtot, vw, msk, candKx, candFb,
+                        Bring ? Bring + idx * ((long long) ringD * WV_L * 3 * 64) : nullptr);
+    if (threadIdx.x == 0) {
+        state->nPairs = out.nPairs;
+        state->nTot = out.nTot;
+        state->winValid = 0;
+        state->expectPending = P.mode != 0 ? window + 1 : 0; /* which launch's window the B ring holds */
+    }
+}
+extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_backward)(
+    const DevItem *__restrict__ items, long long nItems, DevParams P,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
+    long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
+    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window) {
+    __shared__ BwdShared sh;
+    wv_backward_kernel<false>(items, nItems, P, bandTab, track, trackBase, models, Fring, ringDoubles, ringD, states,
+                              pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window, sh);
+}
+extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_backward_sw)(
+    const DevItem *__restrict__ items, long long nItems, DevParams P,
+    const int2 *__restrict__ bandTab, const double *__restrict__ track,
+    const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
+    long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
+    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window) {
+    __shared__ BwdShared sh;
+    wv_backward_kernel<true>(items, nItems, P, bandTab, track, trackBase, models, Fring, ringDoubles, ringD, states,
+                             pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window, sh);
+}
+
+/*
+ * Baum-Welch expectations of the traceback window the backward kernel just swept
+ * (diagonalCalculation_Expectations :841-863 with cell_signal_updateTransAndKmerSkipExpectations :426-443).
+ * By now every operand is in HBM -- forward cells and the two event-dependent emissions in the forward ring,
+ * backward cells in the B ring, the window's exact totals in scratch -- so this is an element-wise pass
+ * with no recurrence: per cell eight exp(F.from + B.to + (eP + tP) - total), summed per thread and reduced
+ * once per window.  64 * L threads: wave j takes layer j of the ring rows, lane by lane.  A thread keeps the
+ * sum of its k-mer's gap-X expectations in a register and adds it to the k-mer's bin when its slot moves to
+ * another k-mer.  The match block is skipped where forward[t-2] has been freed by then, as in the reference.
+ */
+extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
+    const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,
+    const double *__restrict__ track, const long long *__restrict__ trackBase,
+    const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
+    long long ringDoubles, const double *Bring, int ringD, SyState *states, const char *scratch,
+    long long scratchBytes, double *expect, int window) {
+    constexpr int L = WV_L;
+    __shared__ double sExp[16];
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    const SyState *state = states + idx;
+    if (state->expectPending != window + 1) return;
+    const DevItem it = uniform_item(items[idx]);
+    const int lane = threadIdx.x & 63, j = uni(threadIdx.x >> 6);
+    const int sl = lane * L + j, sb = sl == 0 ? WV_P - 1 : sl - 1; /* this thread's slot and the one below it */
+    const int ringMask = ringD - 1;
+    const double *ring = Fring + idx * ringDoubles;
+    const double *own = ring + j * (WV_RING_VALUES * 64) + lane;
+    const double *blw = ring + (sb % L) * (WV_RING_VALUES * 64) + sb / L;
+    const double *bown = Bring + idx * ((long long) ringD * L * 3 * 64) + j * (3 * 64) + lane;
+    const double *tr = track + trackBase[idx] * WV_ROW;
+    const unsigned short *kx = kidx + it.xOff;
+    const int2 *tab = bandTab + it.diagBase;
+    const WinTotal *wtot = (const WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int));
+    const int dTop = uni(state->winTop), from = uni(state->winFrom), to = uni(state->winTo);
+    const int tPost0 = dTop < from ? dTop : from;
+    double *dst = expect + (long long) it.model * (9 + 4096 + 1);
+
+    double acc[8]; /* M>X X>X Y>X | M>M X>M Y>M | M>Y Y>Y */
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = 0.0;
+    double lik = 0.0, gapSum = 0.0;
+    int gapX = -1; /* matrix column whose gap-X expectations gapSum holds */
+
+    const int perChunk = (tPost0 - to + (int) gridDim.y - 1) / (int) gridDim.y;
+    const int tHi = tPost0 - (int) blockIdx.y * perChunk;             /* this workgroup: diagonals tHi .. tLo+1 */
+    const int tLo = tHi - perChunk > to ? tHi - perChunk : to;
+    if (tHi <= to) return;
+    int b0min, b0max, b1min, b1max, b2min, b2max;
+    band_load(tab, tHi, b0min, b0max);
+    band_load(tab, tHi - 1, b1min, b1max);
+    int xs = sl + ((b0min - sl + WV_P - 1) / WV_P) * WV_P; /* this slot's k-mer: the one in (xmax-P, xmax] */
+    if (xs > b0max) xs -= WV_P;
+#pragma unroll 1
+    for (int t = tHi; t > tLo; t--) {
+        band_load(tab, t - 2, b2min, b2max);
+        if (xs > b0max) xs -= WV_P;
+        const int x = xs;
+        const double total = wtot[(tPost0 - t) / 10].total;
+        if (threadIdx.x == 0) lik += total;
+        if (x >= b0min) { /* the cell (t, x) exists */
+            const long long rt = (long long) (t & ringMask) * WV_ROW_DOUBLES, r1 = (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES,
+                            r2 = (long long) ((t - 2) & ringMask) * WV_ROW_DOUBLES;
+            const double *bc = bown + (long long) (t & ringMask) * (L * 3 * 64);
+            const double Bm = bc[0], Bx = bc[64], By = bc[128];
+            const bool vLower = x - 1 >= b1min && x - 1 <= b1max;
+            const bool vMiddle = t - 2 >= to && x - 1 >= b2min && x - 1 <= b2max;
+            const bool vUpper = x >= b1min && x <= b1max;
+            if (vLower) {
+                const double l0 = blw[r1], l1 = blw[r1 + 64], l2 = blw[r1 + 128];
+                const double *row = tr + (long long) x * WV_ROW;
+                const double p0 = exp(l0 + Bx + row[16] - total);
+                const double p1 = exp(l1 + Bx + row[17] - total);
+                const double p2 = exp(l2 + Bx + row[18] - total);
+                acc[0] += p0;
+                acc[1] += p1;
+                acc[2] += p2;
+                if (x != gapX) {
+                    if (gapX > 0) {
+                        const int k = kx[gapX - 1];
+                        if (k < 4096) atomicAdd(dst + 9 + k, gapSum);
+                    }
+                    gapX = x;
+                    gapSum = 0.0;
+                }
+                gapSum += p0;
+                gapSum += p1;
+                gapSum += p2;
+            }
+            if (vMiddle) {
+                const double m0 = blw[r2], m1 = blw[r2 + 64], m2 = blw[r2 + 128];
+                const double eP = own[rt + 3 * 64];
+                acc[3] += exp(m0 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_CONTINUE]) - total);
+                acc[4] += exp(m1 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_FROM_GAP_X]) - total);
+                acc[5] += exp(m2 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_FROM_GAP_Y]) - total);
+            }
+            if (vUpper) {
+                const double u0 = own[r1], u2 = own[r1 + 128];
+                const double eP = own[rt + 4 * 64];
+                acc[6] += exp(u0 + By + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_GAP_OPEN_Y]) - total);
+                acc[7] += exp(u2 + By + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_GAP_EXTEND_Y]) - total);
+            }
+        }
+        b0min = b1min; b0max = b1max;
+        b1min = b2min; b1max = b2max;
+    }
+    if (gapX > 0) {
+        const int k = kx[gapX - 1];
+        if (k < 4096) atomicAdd(dst + 9 + k, gapSum);
+    }
+    /* block reduction of the per-thread sums, then one atomic per value */
+    if (threadIdx.x < 16) sExp[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int slot[8] = { 0 * 3 + 1, 1 * 3 + 1, 2 * 3 + 1, 0 * 3 + 0, 1 * 3 + 0, 2 * 3 + 0, 0 * 3 + 2, 2 * 3 + 2 };
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        double v = acc[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+        if (lane == 0) atomicAdd(&sExp[slot[i]], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) atomicAdd(dst + threadIdx.x, sExp[threadIdx.x]);
+    if (threadIdx.x == 0) atomicAdd(dst + 9 + 4096, lik);
+}
+
+#if WV_L == 4
+/* per-item track of emission constants, wave layout: column x (0..lX) = the 16 emission constants of the k-mer
+ * that matrix column x scores (column 0 = the "not a k-mer" sentinel, sequence_getKmer index -1, :314-318),
+ * its gap-X emission plus each of the three transitions into gap X (the eP + tP of cell_calculate*), and the
+ * emission itself */
+extern "C" __global__ void cpecan_k_wv_track(const DevItem *__restrict__ items, long long nItems,
+                                             const long long *__restrict__ trackBase,
+                                             const unsigned short *__restrict__ kidx,
+                                             const double *__restrict__ models, double *track) {
+    const long long item = blockIdx.y;
+    if (item >= nItems) return;
+    const DevItem it = items[item];
+    const double *model = models + (long long) it.model * CP_MODEL_STRIDE;
+    const double *rows = model + CP_MODEL_HEADER;
+    const long long n = (it.lX + 1) * WV_ROW;
+    double *dst = track + trackBase[item] * WV_ROW;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long) gridDim.x * blockDim.x) {
+        const long long x = i / WV_ROW;
+        const int jj = (int) (i - x * WV_ROW);
+        const int k = x == 0 ? 4096 : (int) kidx[it.xOff + x - 1];
+        const double *r = rows + (long long) k * CP_ROW;
+        double v;
+        if (jj < 16) v = r[jj];
+        else if (jj == 16) v = r[CP_GAPX] + model[T_GAP_OPEN_X];
+        else if (jj == 17) v = r[CP_GAPX] + model[T_GAP_EXTEND_X];
+        else if (jj == 18) v = r[CP_GAPX] + model[T_GAP_SWITCH_TO_X];
+        else v = r[CP_GAPX];
+        dst[i] = v;
+    }
+}
+extern "C" int cpecan_wave_launch_track(hipStream_t stream, const DevItem *items, long long nItems,
+                                        const double *track, const long long *trackBase,
+                                        const unsigned short *kidx, const double *models, void *states, int maxLX) {
+    int bx = (int) ((((long long) maxLX + 1) * WV_ROW + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(cpecan_k_wv_track, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items, nItems,
+                       trackBase, kidx, models, (double *) track);
+    if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(SyState), stream) != hipSuccess) return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int cpecan_wave_track_row_doubles(void) { return WV_ROW; }
+#endif
+
+extern "C" int WV_SYM(cpecan_wave_max_width)(void) { return WV_P - 8; }
+extern "C" int WV_SYM(cpecan_wave_rows)(void) { return WV_L; }
+extern "C" int WV_SYM(cpecan_wave_ring_row_doubles)(void) { return WV_ROW_DOUBLES; }
+extern "C" int WV_SYM(cpecan_wave_bring_row_doubles)(void) { return WV_L * 3 * 64; }
+/* HBM scratch per alignment: [hit offsets | window totals | their terms | hit masks | candidate list] */
+extern "C" long long WV_SYM(cpecan_wave_scratch_bytes)(int ringD) {
+    return 2ll * ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * WV_P * sizeof(double))
+           + 4ll * ringD * sizeof(unsigned long long)
+           + (long long) WV_L * WV_CAND_PER_DIAG * ringD * (sizeof(int2) + sizeof(double));
+}
+extern "C" int WV_SYM(cpecan_wave_launch_forward)(hipStream_t stream, const DevItem *items, long long nItems,
+                                                  DevParams P, const void *bandTab, const double *track,
+                                                  const long long *trackBase, const double *events,
+                                                  const double *models, double *Fring, long long ringDoubles,
+                                                  int ringD, void *states, int withSwitch) {
+    if (withSwitch)
+        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward_sw), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems,
+                           P, (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
+                           (SyState *) states);
+    else
+        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems, P,
+                           (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
+                           (SyState *) states);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const DevItem *items, long long nItems,
+                                                   DevParams P, const void *bandTab, const double *track,
+                                                   const long long *trackBase, const double *models, double *Fring,
+                                                   long long ringDoubles, int ringD, void *states, long long *pairs,
+                                                   double *pairLogp, long long *totXay, double *totVal, char *scratch,
+                                                   long long scratchBytes, double *Bring, int window, int withSwitch) {
+    if (withSwitch)
+        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_backward_sw), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems,
+                           P, (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
+                           (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window);
+    else
+        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_backward), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems, P,
+                           (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
+                           (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevItem *items, long long nItems,
+                                                 DevParams P, const void *bandTab, const double *track,
+                                                 const long long *trackBase, const unsigned short *kidx,
+                                                 const double *models, const double *Fring, long long ringDoubles,
+                                                 const double *Bring, int ringD, void *states, const char *scratch,
+                                                 long long scratchBytes, double *expect, int window) {
+    hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_expect), dim3((unsigned) nItems, WV_EXPECT_CHUNKS), dim3(WV_P), 0, stream,
+                       items, nItems, P, (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles,
+                       Bring, ringD, (SyState *) states, scratch, scratchBytes, expect, window);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

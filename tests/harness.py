@@ -63,14 +63,14 @@ def run_oracle_item(batch, i, bp, ragged=(0, 0), transitions=None, dump=False, e
 
 def assert_same_pairs(g, r, exact_logp=True):
     """GPU result g vs oracle result r for one item: same cells, same order; the exponent
-    (F+B)-total is bit-identical; the integer posterior may differ by 1 where the device exp()
-    and the host libm exp() round differently (tolerance written here: |dp| <= 1 of 1e7)."""
+    (F+B)-total is bit-identical, and so is the integer posterior floor(p * 1e7): the device selects pairs by the
+    exponent, exp() and the threshold test are finished by the C-ABI layer with the host libm, the one the
+    reference (and the oracle) calls (impl/pairwiseAligner.c:776-786)."""
     gt, rt = g["triples"], r["triples"]
     if exact_logp:
         assert len(gt) == len(rt), (len(gt), len(rt))
-        assert np.array_equal(gt[:, 1:], rt[:, 1:])
         assert np.array_equal(g["logp"], r["logp"])
-        assert np.abs(gt[:, 0] - rt[:, 0]).max(initial=0) <= 1
+        assert np.array_equal(gt, rt)
     else:
         gd = {(int(x), int(y)): int(p) for p, x, y in gt}
         rd = {(int(x), int(y)): int(p) for p, x, y in rt}

@@ -42,7 +42,7 @@ def test_random_case(ctx, case):
     info = b.info()
     if info["kernel"] == "systolic":
         w = info["max_band_width"]
-        assert info["waves_per_workgroup"] == 1 + (w > 56) + (w > 120) + (w > 184)
+        assert info["waves_per_workgroup"] == 2 + (w > 120) + (w > 184)
     b.close()
     for i in range(2):
         ref = run_oracle_item(batch, i, bp, case["ragged"])
