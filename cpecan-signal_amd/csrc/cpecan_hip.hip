@@ -116,7 +116,7 @@ SY_DECLARE(_r3)
     extern "C" int cpecan_wave_launch_forward##sfx(hipStream_t, const DevItem *, long long, DevParams,            \
                                                    const void *, const double *, const long long *,               \
                                                    const double *, const double *, double *, long long, int,     \
-                                                   void *, int);                                                  \
+                                                   void *, int, int);                                             \
     extern "C" int cpecan_wave_launch_backward##sfx(hipStream_t, const DevItem *, long long, DevParams,           \
                                                     const void *, const double *, const long long *,              \
                                                     const double *, double *, long long, int, void *,             \
@@ -134,6 +134,9 @@ extern "C" int cpecan_wave_launch_track(hipStream_t stream, const DevItem *items
                                         const double *track, const long long *trackBase,
                                         const unsigned short *kidx, const double *models, void *states, int maxLX);
 extern "C" int cpecan_wave_track_row_doubles(void);
+extern "C" int cpecan_wave_state_bytes(void);
+extern "C" int cpecan_wave_launch_counts(hipStream_t stream, const void *states, long long nItems, long long *nPairs,
+                                         long long *nTot, long long *nCells);
 
 struct SyBuild { /* one build of the throughput kernels */
     int rows;  /* waves per workgroup (systolic) or cells per lane (wave) */
@@ -143,7 +146,7 @@ struct SyBuild { /* one build of the throughput kernels */
     int (*bring_row_doubles)(void);
     long long (*scratch_bytes)(int);
     int (*launch_forward)(hipStream_t, const DevItem *, long long, DevParams, const void *, const double *,
-                          const long long *, const double *, const double *, double *, long long, int, void *, int);
+                          const long long *, const double *, const double *, double *, long long, int, void *, int, int);
     int (*launch_backward)(hipStream_t, const DevItem *, long long, DevParams, const void *, const double *,
                            const long long *, const double *, double *, long long, int, void *, long long *, double *,
                            long long *, double *, char *, long long, double *, int, int);
@@ -153,7 +156,8 @@ struct SyBuild { /* one build of the throughput kernels */
     { r, false, cpecan_systolic_max_width##sfx, cpecan_systolic_ring_row_doubles##sfx,                            \
       cpecan_systolic_bring_row_doubles##sfx, cpecan_systolic_scratch_bytes##sfx,                                 \
       [](hipStream_t st, const DevItem *it, long long n, DevParams P, const void *bt, const double *tr,           \
-         const long long *tb, const double *ev, const double *mo, double *F, long long rd, int D, void *S, int) { \
+         const long long *tb, const double *ev, const double *mo, double *F, long long rd, int D, void *S, int,   \
+         int) {                                                                                                   \
           return cpecan_systolic_launch_forward##sfx(st, it, n, P, bt, tr, tb, ev, mo, F, rd, D, S);              \
       },                                                                                                          \
       [](hipStream_t st, const DevItem *it, long long n, DevParams P, const void *bt, const double *tr,           \
@@ -297,7 +301,8 @@ struct cpecan_batch {
      * its own, so that the tail of one group's kernel overlaps the other groups' kernels (a launch
      * lasts as long as its slowest workgroup).  evStage: per group, one event after every kernel. */
     int nGroups = 1;
-    std::vector<hipStream_t> gStream;
+    std::vector<hipStream_t> gStream, gStreamB; /* gStreamB: the wave kernels' backward sweeps (see batch_run) */
+    int stateBytes = 0;
     std::vector<hipEvent_t> evStage, evJoin;
     hipEvent_t evFork = nullptr;
     std::vector<long long> hNPairs, hNTot, hNCells;
@@ -647,6 +652,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     for (hipEvent_t e : b->evJoin) (void) hipEventDestroy(e);
     if (b->evFork) (void) hipEventDestroy(b->evFork);
     for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
+    for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
     delete b;
     (void) hipGetLastError(); /* a failed clean-up call must not surface as the "last error" of a later launch */
     return CPECAN_OK;
@@ -889,13 +895,11 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         b->nWorkers = (int) nItems;
         b->nWindows = maxWindows;
         b->ringD = 64;
-        while (b->ringD < maxSpan + 4) b->ringD *= 2; /* the kernels mask with ringD-1 */
+        /* the kernels mask with ringD-1.  The wave kernels sweep window w back while the forward sweep of window w+1
+         * is writing: the ring holds two windows */
+        while (b->ringD < (b->sy->wave && maxWindows > 1 ? 2 * maxSpan + 8 : maxSpan + 4)) b->ringD *= 2;
         /* the wave kernels keep one more row behind the ring: the -inf row lanes without a cell read */
         b->ringDoubles = (long long) (b->ringD + (b->sy->wave ? 1 : 0)) * b->sy->ring_row_doubles();
-        if (b->sy->wave && b->ringD > 8192) {
-            delete b;
-            return fail(CPECAN_EINVAL, "traceback windows of %d diagonals: the throughput kernels hold at most 8192", maxSpan);
-        }
         if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
@@ -914,7 +918,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         }
         {
             const char *g = getenv("CPECAN_SYSTOLIC_GROUPS");
-            int G = g ? atoi(g) : 2;
+            int G = g ? atoi(g) : b->sy->wave ? 1 : 2;
             if (G < 1) G = 1;
             if (G > 8) G = 8;
             if ((int64_t) G > nItems) G = (int) nItems;
@@ -922,12 +926,17 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             b->gStream.assign((size_t) G, nullptr);
             b->evJoin.assign((size_t) G, nullptr);
             for (auto &st : b->gStream) B_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            if (b->sy->wave) {
+                b->gStreamB.assign((size_t) G, nullptr);
+                for (auto &st : b->gStreamB) B_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            }
             for (auto &e : b->evJoin) B_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             B_TRY(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         }
         if (mode == CPECAN_MODE_EXPECTATIONS)
             B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) b->sy->bring_row_doubles()));
-        B_TRY(b->syStates.alloc((size_t) nItems * (size_t) cpecan_systolic_state_bytes()));
+        b->stateBytes = b->sy->wave ? cpecan_wave_state_bytes() : cpecan_systolic_state_bytes();
+        B_TRY(b->syStates.alloc((size_t) nItems * (size_t) b->stateBytes));
         b->scratchBytes = (b->sy->scratch_bytes(b->ringD) + 63) / 64 * 64;
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
         B_TRY(b->track.alloc((size_t) trackTotal * (size_t) b->trackRow));
@@ -1056,10 +1065,13 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            b->dbgB.p, b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
     } else {
-        /* one pass: the per-item track of emission constants (a function of the inputs, rebuilt
-         * every run inside the timed region), then for every traceback window the forward kernel
-         * followed by the backward kernel; an event after each kernel gives per-kernel times */
-        const int G = b->nGroups, perGroup = 2 * b->nWindows + 1;
+        /* one pass: the per-item track of emission constants (a function of the inputs, rebuilt every run inside the
+         * timed region), then for every traceback window the forward kernel and the backward kernel.  The wave
+         * kernels run the two on streams of their own: the sweep back of window w overlaps the forward sweep of
+         * window w+1 of the same alignments (each SIMD then holds a forward and a backward wave), and forward w+2,
+         * which re-uses window w's ring rows, waits for the sweep back of w.  Events around every kernel give
+         * per-kernel times and carry the dependencies. */
+        const int G = b->nGroups, perGroup = 4 * b->nWindows + 1;
         if (b->evStage.size() != (size_t) (G * perGroup)) {
             for (hipEvent_t e : b->evStage) (void) hipEventDestroy(e);
             b->evStage.assign((size_t) (G * perGroup), nullptr);
@@ -1077,47 +1089,50 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
         const long long per = (b->nItems + G - 1) / G;
         for (int gi = 0; gi < G && rc == 0; gi++) {
             const long long i0 = gi * per, n = std::min<long long>(per, b->nItems - i0);
-            hipStream_t st = b->gStream[(size_t) gi];
+            hipStream_t sF = b->gStream[(size_t) gi], sB = b->sy->wave ? b->gStreamB[(size_t) gi] : sF;
             hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup;
-            HIP_TRY(hipStreamWaitEvent(st, b->evFork, 0));
-            HIP_TRY(hipEventRecord(ev[0], st));
+            HIP_TRY(hipStreamWaitEvent(sF, b->evFork, 0));
+            if (sB != sF) HIP_TRY(hipStreamWaitEvent(sB, b->evFork, 0));
+            HIP_TRY(hipEventRecord(ev[0], sF));
             const long long bringRow = b->sy->bring_row_doubles();
             for (int w = 0; w < b->nWindows && rc == 0; w++) {
+                hipEvent_t *e4 = ev + 1 + 4 * w;
+                if (sB != sF && w >= 2) HIP_TRY(hipStreamWaitEvent(sF, ev[1 + 4 * (w - 2) + 3], 0));
+                HIP_TRY(hipEventRecord(e4[0], sF));
                 /* the kernels index everything per alignment by blockIdx: shift the bases */
                 if (n > 0)
-                    rc = b->sy->launch_forward(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
-                                                        b->trackBase.p + i0, b->events.p, c->models.p,
-                                                        b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
-                                                        b->ringD,
-                                                        b->syStates.p + i0 * cpecan_systolic_state_bytes(), withSwitch);
-                HIP_TRY(hipEventRecord(ev[2 * w + 1], st));
+                    rc = b->sy->launch_forward(sF, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                                               b->trackBase.p + i0, b->events.p, c->models.p,
+                                               b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles, b->ringD,
+                                               b->syStates.p + i0 * b->stateBytes, w, withSwitch);
+                HIP_TRY(hipEventRecord(e4[1], sF));
+                if (sB != sF) HIP_TRY(hipStreamWaitEvent(sB, e4[1], 0));
+                HIP_TRY(hipEventRecord(e4[2], sB));
                 if (rc == 0 && n > 0)
-                    rc = b->sy->launch_backward(st, b->items.p + i0, n, b->P, b->bandTab.p,
-                                                         b->track.p, b->trackBase.p + i0, c->models.p,
-                                                         b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
-                                                         b->ringD,
-                                                         b->syStates.p + i0 * cpecan_systolic_state_bytes(),
-                                                         b->pairs.p, b->pairLogp.p, b->totXay.p, b->totVal.p,
-                                                         b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
-                                                         b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD * bringRow
-                                                                    : nullptr, w, withSwitch);
+                    rc = b->sy->launch_backward(sB, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                                                b->trackBase.p + i0, c->models.p,
+                                                b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles, b->ringD,
+                                                b->syStates.p + i0 * b->stateBytes, b->pairs.p, b->pairLogp.p,
+                                                b->totXay.p, b->totVal.p, b->syScratch.p + i0 * b->scratchBytes,
+                                                b->scratchBytes,
+                                                b->Bring.p ? b->Bring.p + i0 * (long long) b->ringD * bringRow : nullptr,
+                                                w, withSwitch);
                 if (rc == 0 && n > 0 && b->mode == CPECAN_MODE_EXPECTATIONS)
-                    rc = b->sy->launch_expect(st, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
-                                                       b->trackBase.p + i0, b->kidx.p, c->models.p,
-                                                       b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
-                                                       b->Bring.p + i0 * (long long) b->ringD * bringRow,
-                                                       b->ringD, b->syStates.p + i0 * cpecan_systolic_state_bytes(),
-                                                       b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes,
-                                                       b->expect.p, w);
-                HIP_TRY(hipEventRecord(ev[2 * w + 2], st));
+                    rc = b->sy->launch_expect(sB, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
+                                              b->trackBase.p + i0, b->kidx.p, c->models.p,
+                                              b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
+                                              b->Bring.p + i0 * (long long) b->ringD * bringRow, b->ringD,
+                                              b->syStates.p + i0 * b->stateBytes,
+                                              b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes, b->expect.p, w);
+                HIP_TRY(hipEventRecord(e4[3], sB));
             }
-            HIP_TRY(hipEventRecord(b->evJoin[(size_t) gi], st));
+            HIP_TRY(hipEventRecord(b->evJoin[(size_t) gi], sB)); /* the last sweep back follows every forward sweep */
             HIP_TRY(hipStreamWaitEvent(c->stream, b->evJoin[(size_t) gi], 0));
         }
         if (rc == 0)
-            rc = cpecan_systolic_launch_counts(c->stream, b->syStates.p, b->nItems, b->nPairs.p,
-                                               b->nTot.p, b->nCells.p);
-        if (rc != 0) return fail(CPECAN_EHIP, "systolic kernel launch failed: %s",
+            rc = (b->sy->wave ? cpecan_wave_launch_counts : cpecan_systolic_launch_counts)(
+                c->stream, b->syStates.p, b->nItems, b->nPairs.p, b->nTot.p, b->nCells.p);
+        if (rc != 0) return fail(CPECAN_EHIP, "throughput kernel launch failed: %s",
                                  hipGetErrorString(hipGetLastError()));
     }
     HIP_TRY(hipEventRecord(b->ev2, c->stream));
@@ -1138,13 +1153,13 @@ int cpecan_hip_batch_stage_ms(cpecan_batch *b, float *msForward, float *msBackwa
     HIP_TRY(hipSetDevice(b->ctx->device));
     HIP_TRY(hipEventSynchronize(b->ev2));
     float f = 0, k = 0;
-    const int perGroup = 2 * b->nWindows + 1;
+    const int perGroup = 4 * b->nWindows + 1;
     for (int gi = 0; gi < b->nGroups; gi++)
         for (int w = 0; w < b->nWindows; w++) {
-            const hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup;
+            const hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup + 1 + 4 * w;
             float a = 0, c2 = 0;
-            HIP_TRY(hipEventElapsedTime(&a, ev[2 * w], ev[2 * w + 1]));
-            HIP_TRY(hipEventElapsedTime(&c2, ev[2 * w + 1], ev[2 * w + 2]));
+            HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+            HIP_TRY(hipEventElapsedTime(&c2, ev[2], ev[3]));
             f += a;
             k += c2;
         }
@@ -1232,7 +1247,8 @@ static int ensure_counts(cpecan_batch *b) {
     }
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     const double threshold = b->P.threshold;
-    for (int64_t i = 0; i < b->nItems; i++) {
+    /* (in expectation mode the HDP machine's pair buffer carries event-to-k-mer assignments, not posteriors) */
+    for (int64_t i = 0; i < b->nItems && b->mode == CPECAN_MODE_POSTERIOR; i++) {
         const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
         long long *t = b->hPairs.data() + o * 3;
         double *lp = b->hLogp.data() + o;

@@ -20,7 +20,7 @@
  *     ([diagonal][layer][Fm,Fx,Fy,pm,py][lane]) and are read once by the sweep back, four diagonals
  *     ahead of use; the forward sweep's inputs (events, k-mer rows) are staged in LDS per block of
  *     diagonals, so neither loop waits for a load it has just issued.
- *   - two kernels per traceback window, sequenced by the C-ABI layer (cpecan_hip.hip); SyState and the
+ *   - two kernels per traceback window, sequenced by the C-ABI layer (cpecan_hip.hip); WvState and the
  *     ring carry over.  The posterior decode works from candidate lists the sweep back collects; a
  *     window whose candidates cannot be trusted is swept again with the exact totals in hand.
  * MFMA is not used: the recurrence is a scan with an approximate log-add, not a contraction.
@@ -50,11 +50,11 @@
 #define WV_ROW 20            /* doubles per column of the track: 16 emission constants, gap-X sums (open, extend, switch), gap-X */
 #define WV_ROWN 32           /* LDS ring of k-mer rows (>= the feed block)                              */
 #define WV_FEED_MAX 32       /* diagonals per feed block of the forward sweep                            */
-#define WV_BITWORDS 256      /* band edge steps kept in LDS: 32 diagonals per word, circular (ringD <= 8192) */
+#define WV_BITWORDS 256      /* band edge steps kept in LDS: 32 diagonals per word, circular, re-staged in halves */
 #define WV_RING_VALUES 5     /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
 #define WV_LAYER_BYTES (WV_RING_VALUES * 64 * 8)
 #define WV_ROW_DOUBLES (WV_L * WV_RING_VALUES * 64)
-#define WV_PREFETCH 4        /* diagonals the backward sweep fetches ahead (== its unroll factor) */
+#define WV_PREFETCH 3        /* diagonals the backward sweep fetches ahead (== its unroll factor) */
 #define WV_CAND_SLACK 0.25   /* candidates: cells within this (log units) below the posterior threshold */
 #define WV_CAND_PER_DIAG 4   /* candidate capacity, in records per ring diagonal and layer */
 #define WV_EXPECT_CHUNKS 8   /* workgroups that share one window's diagonals in the expectation pass */
@@ -195,6 +195,23 @@ __device__ __forceinline__ double bcast(double v, int srcLane) { /* srcLane wave
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), srcLane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srcLane);
     return __hiloint2double(hi, lo);
+}
+
+/* logAdd-fold of one value per lane into acc (wave-uniform in and out), lanes in ascending order; visits only
+ * the lanes that can change the running value */
+__device__ __forceinline__ double wave_fold(double acc, double v, unsigned cf) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long after = ~0ull;
+#pragma unroll 1
+    for (;;) {
+        const bool eff = ((after >> lane) & 1ull) && (v > CP_NEG_INF) && !(acc - v >= 7.5);
+        const unsigned long long m = __ballot(eff);
+        if (m == 0ull) break;
+        const int first = __ffsll((long long) m) - 1;
+        acc = ladd(acc, bcast(v, first), cf);
+        after = first >= 63 ? 0ull : (~0ull << (first + 1));
+    }
+    return acc;
 }
 
 /* a slot's k-mer constants, as a track row lays them out */
@@ -349,8 +366,8 @@ struct FwdShared {
  */
 template <bool SW> __device__ void forward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
                                const double *__restrict__ track, const double *__restrict__ events,
-                               const double *__restrict__ model, double *ring, int ringD, SyState *state,
-                               FwdShared &sh) {
+                               const double *__restrict__ model, double *ring, int ringD, WvState *state,
+                               int window, FwdShared &sh) {
     constexpr int L = WV_L;
     const int lane = threadIdx.x & 63;
     const int lX = (int) it.lX, lY = (int) it.lY, D = lX + lY;
@@ -440,12 +457,12 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             Bm[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + lane] : CP_NEG_INF;
             Bx[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + 64 + lane] : CP_NEG_INF;
             By[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + 128 + lane] : CP_NEG_INF;
-            mask[j] = __ballot(v1);
+            mask[j] = (unsigned long long) uni64((long long) __ballot(v1));
         }
         RBm = ror1(Bm[L - 1]); RBx = ror1(Bx[L - 1]); RBy = ror1(By[L - 1]);
         const int si = (xmax + 1) % WV_P, so = xmin % WV_P;
-        inL = si / L; inJ = si % L;
-        outL = so / L; outJ = so % L;
+        inL = uni(si / L); inJ = uni(si % L);
+        outL = uni(so / L); outJ = uni(so % L);
     }
     RAm = RAx = RAy = CP_NEG_INF;
 
@@ -475,7 +492,9 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
     int rA = ((tpA - (d0 + 1)) % 10 + 10) % 10, rB = endW ? 0x40000000 : ((tpB - (d0 + 1)) % 10 + 10) % 10;
     const int fullFrom = allFull ? -0x40000000 : topW - 1;
 
-    stage_band_steps(sh.bits, bandTab, D, d0 + 1, topW);
+    /* the circular bit strings hold 8192 diagonals: longer launches are staged 4096 diagonals (whole words) at a time */
+    int bitsHi = topW - d0 > 4096 ? ((d0 + 1 + 4096) & ~31) - 1 : topW;
+    stage_band_steps(sh.bits, bandTab, D, d0 + 1, bitsHi);
 
     int evHi = d0 - xmax - 1;  /* first event not yet staged: the lowest index diagonal d0 + 1 can ask for */
     int evHiMod = ((evHi % WV_P) + WV_P) % WV_P;
@@ -566,19 +585,34 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
     const long long tbFromL = tracedBackTo + P.minDiags;
     const int tbFrom = (int) (tbFromL < 0x7fffffff ? tbFromL : 0x7fffffff);
     const int tbWidth = (int) (widthLimit < 0x7fffffff ? widthLimit : 0x7fffffff);
-    auto finish = [&](const int d) __attribute__((always_inline)) {
+    auto finish = [&](const int d, const double (&fm)[L], const double (&fx)[L], const double (&fy)[L])
+                      __attribute__((always_inline)) {
         /* traceback point (:917-921) reached: hand the window to the backward kernel */
         const bool atEnd = d == D;
         if (!(atEnd || (d >= tbFrom && xmax - xmin < tbWidth))) return false;
+        /* what the sweep back will find as totalProbability, near enough: the cells of this diagonal dotted with
+         * the end vector it starts from (stateMachine.c:1179-1207); cells outside the band are -inf by themselves */
+        double e0, e1, e2;
+        if (atEnd && it.raggedR) {
+            e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
+            e1 = T[T_GAP_EXTEND_X];
+            e2 = T[T_GAP_EXTEND_Y];
+        } else {
+            e0 = T[T_MATCH_CONTINUE];
+            e1 = T[T_MATCH_FROM_GAP_X];
+            e2 = T[T_MATCH_FROM_GAP_Y];
+        }
+        double est = CP_NEG_INF;
+#pragma unroll
+        for (int j = 0; j < L; j++) est = wave_fold(est, ladd(ladd(fm[j] + e0, fx[j] + e1, cf), fy[j] + e2, cf), cf);
         if (lane == 0) {
             const int from = d - (atEnd ? 0 : (int) P.tbDiags + 1);
+            WvWindow w;
+            w.valid = 1; w.top = d; w.from = from; w.to = tracedBackTo; w.atEnd = atEnd ? 1 : 0; w.pad = 0;
+            w.est = est;
+            state->win[window & 1] = w;
             state->d = d;
             state->finished = atEnd ? 1 : 0;
-            state->winValid = 1;
-            state->winTop = d;
-            state->winFrom = from;
-            state->winTo = tracedBackTo;
-            state->winAtEnd = atEnd ? 1 : 0;
             state->tracedBackTo = from;
             state->cells = cells;
         }
@@ -587,6 +621,11 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
 
 #pragma unroll 1
     for (int db = d0 + 1; db <= D; db += feed) {
+        if (db + feed > bitsHi && bitsHi < topW) {
+            const int hi = topW - bitsHi > 4096 ? bitsHi + 4096 : topW;
+            stage_band_steps(sh.bits, bandTab, D, bitsHi + 1, hi);
+            bitsHi = hi;
+        }
         {
             /* stage what this block of diagonals can ask for: the top cell's event index d - xmin - 1 and the
              * entering k-mer xmax + 1 each advance by at most one per diagonal */
@@ -632,9 +671,9 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
 #pragma unroll 1
         for (int d = db; d <= dbEnd; d += 2) {
             step(d, ((fullMask >> (d - db)) & 1u) != 0u, Am, Ax, Ay, Bm, Bx, By, RAm, RAx, RAy, RBm, RBx, RBy);
-            if (finish(d)) return;
+            if (finish(d, Bm, Bx, By)) return;
             step(d + 1, ((fullMask >> (d + 1 - db)) & 1u) != 0u, Bm, Bx, By, Am, Ax, Ay, RBm, RBx, RBy, RAm, RAx, RAy);
-            if (finish(d + 1)) return;
+            if (finish(d + 1, Am, Ax, Ay)) return;
         }
     }
 }
@@ -686,10 +725,12 @@ __device__ __forceinline__ void px_install(Px (&p)[WV_L], unsigned rowAddr, unsi
 }
 /* mask[sel] |= bit / &= ~bit on the scalar unit, sel a run-time value */
 __device__ __forceinline__ void mask_set(unsigned long long (&mask)[WV_L], unsigned long long bit, int sel) {
-    asm volatile(WV_MASK_OR : WV_MASK_OUTS : [m] "s"(bit), [sel] "s"(sel) : "scc");
+#pragma unroll
+    for (int j = 0; j < WV_L; j++) mask[j] |= sel == j ? bit : 0ull;
 }
 __device__ __forceinline__ void mask_clear(unsigned long long (&mask)[WV_L], unsigned long long bit, int sel) {
-    asm volatile(WV_MASK_ANDN2 : WV_MASK_OUTS : [m] "s"(bit), [sel] "s"(sel) : "scc");
+#pragma unroll
+    for (int j = 0; j < WV_L; j++) mask[j] &= ~(sel == j ? bit : 0ull);
 }
 /* lane-masked stores of one layer's backward cells (Baum-Welch: the B ring) */
 __device__ __forceinline__ void store_b3(unsigned long long laneMask, const double *rowBase, unsigned voff,
@@ -704,23 +745,6 @@ __device__ __forceinline__ void store_b3(unsigned long long laneMask, const doub
                  : "=&s"(sv)
                  : "s"(laneMask), "v"(voff), "v"(bm), "v"(bx), "v"(by), "s"(rowBase)
                  : "memory");
-}
-
-/* logAdd-fold of one value per lane into acc (wave-uniform in and out), lanes in ascending order; visits only
- * the lanes that can change the running value */
-__device__ __forceinline__ double wave_fold(double acc, double v, unsigned cf) {
-    const int lane = threadIdx.x & 63;
-    unsigned long long after = ~0ull;
-#pragma unroll 1
-    for (;;) {
-        const bool eff = ((after >> lane) & 1ull) && (v > CP_NEG_INF) && !(acc - v >= 7.5);
-        const unsigned long long m = __ballot(eff);
-        if (m == 0ull) break;
-        const int first = __ffsll((long long) m) - 1;
-        acc = ladd(acc, bcast(v, first), cf);
-        after = first >= 63 ? 0ull : (~0ull << (first + 1));
-    }
-    return acc;
 }
 
 struct ItemOut {
@@ -779,12 +803,15 @@ __device__ __forceinline__ int rank_in_diagonal(const unsigned long long (&m)[WV
  * threshold test and floor(p * 1e7) (:776-786) are finished on the host with the reference's libm
  * (cpecan_hip.hip), so the integer posteriors are the reference's to the bit.
  */
-template <bool SW>
+#define WV_KIND_POSTERIOR 0 /* sweep, collect decode candidates, totals, decode */
+#define WV_KIND_REDO 1      /* sweep once more with the exact totals in hand, pairs leave in the loop */
+#define WV_KIND_EXPECT 2    /* sweep, park the backward cells for the expectation kernel, totals */
+template <bool SW, int KIND>
 __device__ void backward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
                                 const double *__restrict__ track, const double *__restrict__ model,
-                                double *ring, int ringD, SyState *state, ItemOut &out, BwdShared &sh,
-                                int *offBuf, WinTotal *wtot, double *vw, unsigned long long *msk, int2 *candKx,
-                                double *candFb, double *bring) {
+                                double *ring, int ringD, const WvWindow &win, ItemOut &out, BwdShared &sh,
+                                int *offBuf, WinTotal *wtot, double *vw, double *rf, unsigned long long *msk,
+                                int2 *candKx, double *candFb, double *bring, bool &redo) {
     constexpr int L = WV_L;
     const int lane = threadIdx.x & 63;
     const int D = (int) (it.lX + it.lY);
@@ -795,29 +822,33 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
 
-    const int dTop = uni(ld_agent(&state->winTop)), tracedBackFrom = uni(ld_agent(&state->winFrom)),
-              tracedBackTo = uni(ld_agent(&state->winTo));
-    const bool atEnd = uni(ld_agent(&state->winAtEnd)) != 0;
+    const int dTop = uni(win.top), tracedBackFrom = uni(win.from), tracedBackTo = uni(win.to);
+    const bool atEnd = uni(win.atEnd) != 0;
     const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
     const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
     const int candCap = WV_CAND_PER_DIAG * WV_L * ringD;
     if (lane < 4) sh.pxr[WV_PXN * 4 + lane] = CP_NEG_INF;
     if (lane == 0) sh.scan = (P.scanDecode != 0 || !(P.logThrSlack > CP_NEG_INF)) ? 1 : 0;
-    stage_band_steps(sh.bits, bandTab, D, tracedBackTo + 1, dTop);
 
     unsigned voff[L];
 #pragma unroll
     for (int j = 0; j < L; j++) voff[j] = (unsigned) (j * WV_LAYER_BYTES + lane * 8);
     const unsigned dummyOff = (unsigned) ((long long) ringD * WV_ROW_DOUBLES * 8);
     int nTotWin = 0, nCand = 0;
-    double totEst = CP_NEG_INF;
+    /* the forward kernel's estimate of this window's totalProbability steers the candidate test; phase T checks
+     * every exact total of the window against it */
+    const double totEst = uni64_d(win.est);
+    const double candThr = P.logThrSlack > CP_NEG_INF ? totEst + (P.logThrSlack - WV_CAND_SLACK) : __builtin_huge_val();
 
     /* ------------------------------ phase S: the sweep back ------------------------------ */
-    auto sweep = [&](const bool direct) __attribute__((always_inline)) {
+    {
         int bxmin, bxmax; /* band of the diagonal being computed */
         band_load(bandTab, dTop, bxmin, bxmax);
+        /* the circular bit strings hold 8192 diagonals: longer windows are staged 4096 diagonals (whole words) at a time */
+        int bitsLo = dTop - tracedBackTo > 4096 ? (dTop - 4096) & ~31 : tracedBackTo + 1;
+        stage_band_steps(sh.bits, bandTab, D, bitsLo, dTop);
         /* this slot's k-mer on a diagonal: the one in (xmax - P, xmax] */
-        unsigned long long m0[L];
+        unsigned long long fm[L]; /* the fetch cursor's lane masks */
         Px px[L];
         double Bm[L], Bx[L], By[L]; /* backward cells of the diagonal above (t+1) */
         double Um[L], Uy[L];        /* upper-block sums of t+1: By + (gap-Y emission + tP)          */
@@ -840,7 +871,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 int xs = sl + ((bxmin - sl + WV_P - 1) / WV_P) * WV_P;
                 if (xs > bxmax) xs -= WV_P;
                 const bool v = xs >= bxmin;
-                m0[j] = __ballot(v);
+                fm[j] = (unsigned long long) uni64((long long) __ballot(v));
                 Bm[j] = v ? e0 : CP_NEG_INF;
                 Bx[j] = v ? e1 : CP_NEG_INF;
                 By[j] = v ? e2 : CP_NEG_INF;
@@ -860,29 +891,28 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
          * diagonal); the loop is unrolled by the depth, so every in-flight diagonal has registers of its own.
          * A lane with no cell on that diagonal reads the dummy row (-inf): its emissions are then -inf and
          * whatever its slot holds cannot reach a cell of the band. */
-        unsigned long long fm[L];
-#pragma unroll
-        for (int j = 0; j < L; j++) fm[j] = m0[j];
-        int fxmin = bxmin, fxmax = bxmax;
-        int topL, topJ, botL, botJ; /* slots of k-mers fxmax (next to leave) and fxmin - 1 (next to enter) */
+        int fxmin = bxmin;
+        int topL, topJ, botL, botJ; /* slots of the fetch cursor's top k-mer (next to leave) and of the k-mer below its
+                                       band (next to enter) */
         {
-            const int st = fxmax % WV_P, sb = (fxmin - 1 + WV_P) % WV_P;
-            topL = st / L; topJ = st % L;
-            botL = sb / L; botJ = sb % L;
+            const int st = bxmax % WV_P, sb = (bxmin - 1 + WV_P) % WV_P;
+            topL = uni(st / L); topJ = uni(st % L); /* (readfirstlane: the compiler would otherwise divide on the vector unit
+                                                       and then fail to bring the masks these steer back to scalars) */
+            botL = uni(sb / L); botJ = uni(sb % L);
         }
         unsigned fwMin = 0u, fwMax = 0u;
         bool fFirst = true;
         struct Rec {
             unsigned long long m[L]; /* lanes with a cell on the diagonal */
-            int leave, lL, lJ;       /* the k-mer that left the band at the top, coming down to this diagonal */
-            int enter, eL, eJ, eX;   /* the k-mer that entered at the bottom */
+            unsigned ev;             /* what changed coming down to this diagonal: bit 0 the top k-mer left the band (its
+                                        slot: lane bits 2-7, layer bits 8-9), bit 1 a k-mer entered at the bottom (lane
+                                        bits 10-15, layer bits 16-17, its column mod WV_PXN bits 18-23) */
         };
         struct Q {
             double f[L], pm[L], py[L];
         };
         auto fetch = [&](const int tau, Rec &r, Q &q) __attribute__((always_inline)) {
-            r.leave = r.enter = 0;
-            r.lL = r.lJ = r.eL = r.eJ = r.eX = 0;
+            unsigned ev = 0u;
             if (tau > tracedBackTo && tau < dTop) {
                 /* band(tau) from band(tau + 1): the steps of diagonal tau + 1 */
                 const unsigned bi = (unsigned) (tau + 1) & 31u;
@@ -892,18 +922,20 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                     fFirst = false;
                 }
                 if ((fwMax >> bi) & 1u) {
-                    r.leave = 1; r.lL = topL; r.lJ = topJ;
+                    ev |= 1u | (unsigned) topL << 2 | (unsigned) topJ << 8;
                     mask_clear(fm, 1ull << topL, topJ);
-                    fxmax--;
-                    if (--topJ < 0) { topJ = L - 1; topL = (topL + 63) & 63; }
+                    topJ = uni(topJ - 1); /* (readfirstlane: see above) */
+                    if (topJ < 0) { topJ = L - 1; topL = uni((topL + 63) & 63); }
                 }
                 if ((fwMin >> bi) & 1u) {
-                    r.enter = 1; r.eL = botL; r.eJ = botJ; r.eX = fxmin - 1;
+                    ev |= 2u | (unsigned) botL << 10 | (unsigned) botJ << 16 | (unsigned) ((fxmin - 1) & (WV_PXN - 1)) << 18;
                     mask_set(fm, 1ull << botL, botJ);
                     fxmin--;
-                    if (--botJ < 0) { botJ = L - 1; botL = (botL + 63) & 63; }
+                    botJ = uni(botJ - 1);
+                    if (botJ < 0) { botJ = L - 1; botL = uni((botL + 63) & 63); }
                 }
             }
+            r.ev = ev;
             const bool live = tau > tracedBackTo;
             const unsigned rowOff = (unsigned) ((long long) (tau & ringMask) * (WV_ROW_DOUBLES * 8));
 #pragma unroll
@@ -919,37 +951,30 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             }
         };
 
-        Rec r0, r1, r2, r3;
-        Q q0, q1, q2, q3;
+        Rec r0, r1, r2;
+        Q q0, q1, q2;
         fetch(dTop, r0, q0);
         fetch(dTop - 1, r1, q1);
         fetch(dTop - 2, r2, q2);
-        fetch(dTop - 3, r3, q3);
 
-        unsigned long long mAbove[L]; /* lanes with a cell on t+1 */
-#pragma unroll
-        for (int j = 0; j < L; j++) mAbove[j] = 0ull;
         int nxmin = bxmin, nxmax = bxmax; /* band of t+1 */
         int calcs = 0;
-        long long emitted = 0; /* direct decode: pairs written by this window so far */
-        double candThr = CP_NEG_INF, totCur = CP_NEG_INF;
-        nTotWin = 0;
-        nCand = 0;
-        int pxLo = bxmin; /* gap-X rows of columns >= pxLo - WV_PXN/2 ... are staged */
+        long long emitted = 0; /* KIND_REDO: pairs written by this window so far */
+        double totCur = CP_NEG_INF;
 
         auto step = [&](const int t, Rec &r, Q &q) __attribute__((always_inline)) {
-            /* this diagonal's forward values (their loads were issued four diagonals ago), then the fetch that
-             * re-uses their registers */
+            /* this diagonal's forward values (their loads were issued WV_PREFETCH diagonals ago), then the fetch
+             * that re-uses their registers */
             double qF[L], qPm[L], qPy[L];
             unsigned long long mt[L];
 #pragma unroll
             for (int j = 0; j < L; j++) { qF[j] = q.f[j]; qPm[j] = q.pm[j]; qPy[j] = q.py[j]; mt[j] = r.m[j]; }
-            const int leave = r.leave, lL = r.lL, lJ = r.lJ, enter = r.enter, eL = r.eL, eJ = r.eJ, eX = r.eX;
+            const unsigned ev = r.ev;
             fetch(t - WV_PREFETCH, r, q);
             if (t < dTop) {
                 nxmin = bxmin; nxmax = bxmax;
-                bxmax -= leave;
-                bxmin -= enter;
+                bxmax -= (int) (ev & 1u);
+                bxmin -= (int) ((ev >> 1) & 1u);
                 /* of slot+1: B.match and match emission of t+2 (middle block), B.gapX of t+1 with its k-mer's
                  * gap-X sums (lower block of t+1); layer L-1 takes them from layer 0 of the lane above */
                 const double rhB = rol1(hB[0]), rhP = rol1(hP[0]), rBx = rol1(Bx[0]);
@@ -985,19 +1010,21 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 /* the gap-X sums above belong to the cells of t+1, the senders of the lower block: the slots of the
                  * k-mer that left the band at the top (parked) and of the one that entered at the bottom change
                  * hands only now, for the diagonals below */
-                bool touch0 = false;
-                if (leave) {
-                    px_install(px, pxPark, 1ull << lL, lJ);
-                    touch0 = lJ == 0;
-                }
-                if (enter) {
-                    px_install(px, pxAddr + (unsigned) (eX & (WV_PXN - 1)) * 32u, 1ull << eL, eJ);
-                    touch0 = touch0 || eJ == 0;
-                }
-                if (touch0) {
-                    rpo = rol1(px[0].a.x);
-                    rpe = rol1(px[0].a.y);
-                    if (SW) rps = rol1(px[0].b.x);
+                if (ev != 0u) {
+                    bool touch0 = false;
+                    if (ev & 1u) {
+                        px_install(px, pxPark, 1ull << ((ev >> 2) & 63u), (int) ((ev >> 8) & 3u));
+                        touch0 = ((ev >> 8) & 3u) == 0u;
+                    }
+                    if (ev & 2u) {
+                        px_install(px, pxAddr + ((ev >> 18) & 63u) * 32u, 1ull << ((ev >> 10) & 63u), (int) ((ev >> 16) & 3u));
+                        touch0 = touch0 || ((ev >> 16) & 3u) == 0u;
+                    }
+                    if (touch0) {
+                        rpo = rol1(px[0].a.x);
+                        rpe = rol1(px[0].a.y);
+                        if (SW) rps = rol1(px[0].b.x);
+                    }
                 }
             }
             /* what this diagonal hands down: the upper-block sums stay in the slot */
@@ -1012,81 +1039,38 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 for (int j = 0; j < L; j++) fb[j] = qF[j] + Bm[j];
                 const int kPost = tPost0 - t;
                 if (calcs++ % 10 == 0) {
-                    if (direct) totCur = uni64_d(ld_agent(&wtot[kPost / 10].total));
+                    if (KIND == WV_KIND_REDO) totCur = uni64_d(ld_agent(&wtot[kPost / 10].total));
                     else {
-                        /* per-cell terms of diagonalCalculationTotalProbability (:736-754), folded in phase T:
-                         * v = cell_dotProduct(forward[t], backward[t]) (:391-397) and w = matches stepping over
-                         * t: forward[t-1] --match--> the cells of t+1, dotted with backward[t+1] */
-                        const bool second = t + 1 <= dTop;
-                        int pxmin, pxmax;
-                        band_load(bandTab, t - 1, pxmin, pxmax);
-                        const int sMin = bxmin % WV_P, sMinN = nxmin % WV_P;
-                        const double *rowT = ring + (long long) (t & ringMask) * WV_ROW_DOUBLES;
-                        const double *rowB = ring + (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
-                        double vv[L], ww[L];
-                        double fx[L], fy[L], s0[L], s1[L], s2[L];
-                        bool tv[L], nv[L];
+                        /* a refresh of totalProbability (:956-966): its per-cell terms need forward cells of two more
+                         * diagonals, an HBM round trip the sweep does not wait for: the backward operands are parked
+                         * in scratch -- B of this diagonal, B.match and the match emission of the one above -- and
+                         * phase T0 forms the terms after the sweep */
+                        double *dst = rf + (long long) nTotWin * (5 * WV_P) + lane;
 #pragma unroll
                         for (int j = 0; j < L; j++) {
-                            const int sl = lane * L + j;
-                            tv[j] = ((mt[j] >> lane) & 1ull) != 0ull;
-                            nv[j] = second && ((mAbove[j] >> lane) & 1ull) != 0ull;
-                            const int xN = nxmin + (sl - sMinN + (sl < sMinN ? WV_P : 0)); /* this slot's k-mer on t+1 */
-                            const bool below = nv[j] && xN - 1 >= pxmin && xN - 1 <= pxmax;
-                            const int sb = sl == 0 ? WV_P - 1 : sl - 1; /* the slot of k-mer xN - 1 */
-                            const double *pa = rowT + (tv[j] ? j * (WV_RING_VALUES * 64) + lane : 0);
-                            const double *pb = rowB + (below ? (sb % L) * (WV_RING_VALUES * 64) + sb / L : 0);
-                            fx[j] = pa[64]; fy[j] = pa[128];
-                            s0[j] = pb[0]; s1[j] = pb[64]; s2[j] = pb[128];
-                            if (!below) s0[j] = s1[j] = s2[j] = CP_NEG_INF;
-                            (void) sMin;
-                        }
-#pragma unroll
-                        for (int j = 0; j < L; j++) {
-                            double v = CP_NEG_INF, w = CP_NEG_INF;
-                            if (tv[j]) {
-                                v = fb[j];
-                                v = ladd(v, fx[j] + Bx[j], cf);
-                                v = ladd(v, fy[j] + By[j], cf);
-                                vw[((long long) nTotWin * 2 + 0) * WV_P + lane * L + j] = v;
-                            }
-                            if (nv[j]) {
-                                double mm = s0[j] + (hP[j] + T[T_MATCH_CONTINUE]);
-                                mm = ladd(mm, s1[j] + (hP[j] + T[T_MATCH_FROM_GAP_X]), cf);
-                                mm = ladd(mm, s2[j] + (hP[j] + T[T_MATCH_FROM_GAP_Y]), cf);
-                                w = mm + hB[j];
-                                vw[((long long) nTotWin * 2 + 1) * WV_P + lane * L + j] = w;
-                            }
-                            vv[j] = v; ww[j] = w;
-                        }
-                        if (nTotWin == 0) {
-                            /* the estimate: the same terms folded in any order (it only steers the candidate
-                             * test; the exact, ordered folds are phase T's) */
-                            double acc = CP_NEG_INF;
-#pragma unroll
-                            for (int j = 0; j < L; j++) acc = wave_fold(acc, vv[j], cf);
-#pragma unroll
-                            for (int j = 0; j < L; j++) acc = wave_fold(acc, ww[j], cf);
-                            totEst = acc;
-                            candThr = P.logThrSlack > CP_NEG_INF ? acc + (P.logThrSlack - WV_CAND_SLACK) : __builtin_huge_val();
+                            dst[(0 * L + j) * 64] = Bm[j];
+                            dst[(1 * L + j) * 64] = Bx[j];
+                            dst[(2 * L + j) * 64] = By[j];
+                            dst[(3 * L + j) * 64] = hB[j];
+                            dst[(4 * L + j) * 64] = hP[j];
                         }
                         if (lane == 0) {
                             WinTotal w;
                             w.t = t; w.xmin = bxmin; w.xmax = bxmax; w.nxmin = nxmin; w.nxmax = nxmax;
-                            w.second = second ? 1 : 0;
+                            w.second = t + 1 <= dTop ? 1 : 0;
                             w.total = CP_NEG_INF;
                             wtot[nTotWin] = w;
                         }
                         nTotWin++;
                     }
                 }
-                if (P.mode != 0) {
+                if (KIND == WV_KIND_EXPECT) {
                     /* Baum-Welch: the backward cells go to their own ring for the expectation kernel */
                     const double *rowB = bring + (long long) (t & ringMask) * (WV_L * 3 * 64);
 #pragma unroll
                     for (int j = 0; j < L; j++)
                         store_b3(mt[j], rowB, (unsigned) (j * (3 * 64 * 8) + lane * 8), Bm[j], Bx[j], By[j]);
-                } else if (direct) {
+                } else if (KIND == WV_KIND_REDO) {
                     /* the window's second sweep: exact totals are known, pairs leave in emission order */
                     unsigned long long hm[L];
                     bool hit[L];
@@ -1141,19 +1125,23 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 }
             }
 #pragma unroll
-            for (int j = 0; j < L; j++) { pm1[j] = qPm[j]; mAbove[j] = mt[j]; }
+            for (int j = 0; j < L; j++) pm1[j] = qPm[j];
         };
 
         int t = dTop;
 #pragma unroll 1
         for (;;) {
-            if (((dTop - t) & 31) == 0) {
-                /* gap-X rows of the k-mers that can enter during the next 32 diagonals */
+            if ((dTop - t) % 30 == 0) {
+                /* gap-X rows of the k-mers that can enter during the next 30 diagonals */
                 for (int i = lane; i < 32 * 4; i += 64) {
                     const int x = bxmin - 1 - (i >> 2);
                     if (x >= 0) sh.pxr[(x & (WV_PXN - 1)) * 4 + (i & 3)] = track[(long long) x * WV_ROW + 16 + (i & 3)];
                 }
-                (void) pxLo;
+            }
+            if (t - 64 < bitsLo && bitsLo > tracedBackTo + 1) {
+                const int lo = bitsLo - tracedBackTo - 1 > 4096 ? bitsLo - 4096 : tracedBackTo + 1;
+                stage_band_steps(sh.bits, bandTab, D, lo, bitsLo - 1);
+                bitsLo = lo;
             }
             if (t <= tracedBackTo) break;
             step(t, r0, q0); t--;
@@ -1161,69 +1149,119 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             step(t, r1, q1); t--;
             if (t <= tracedBackTo) break;
             step(t, r2, q2); t--;
-            if (t <= tracedBackTo) break;
-            step(t, r3, q3); t--;
         }
-        if (direct) out.nPairs += emitted;
-    };
+        if (KIND == WV_KIND_REDO) out.nPairs += emitted;
+    }
+    if (KIND == WV_KIND_REDO) return;
+    if (nCand > candCap && lane == 0) sh.scan = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the parked operands in scratch are read back below */
 
-    bool direct = false;
+    /* -------------------- phase T0: the per-cell terms of every refresh -------------------- */
+    /* diagonalCalculationTotalProbability (:736-754): v = cell_dotProduct(forward[t], backward[t]) (:391-397) and
+     * w = matches stepping over t: forward[t-1] --match--> the cells of t+1, dotted with backward[t+1] (only the
+     * match state of that clone is ever above -inf).  Lanes keep the sweep's slots; a refresh's loads are all
+     * issued before its arithmetic. */
 #pragma unroll 1
-    for (;;) {
-        sweep(direct);
-        if (direct) return;
-        if (nCand > candCap && lane == 0) sh.scan = 1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the refresh terms in scratch are read back below */
+    for (int n = 0; n < nTotWin; n++) {
+        const WinTotal w = wtot[n];
+        const int t = uni(w.t), xmn = uni(w.xmin), xmx = uni(w.xmax), nmn = uni(w.nxmin), nmx = uni(w.nxmax);
+        const bool second = uni(w.second) != 0;
+        int pxmin, pxmax;
+        band_load(bandTab, t - 1, pxmin, pxmax);
+        const int sMin = xmn % WV_P, sMinN = nmn % WV_P;
+        const double *rowT = ring + (long long) (t & ringMask) * WV_ROW_DOUBLES;
+        const double *rowB = ring + (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
+        const double *src = rf + (long long) n * (5 * WV_P) + lane;
+        double fmv[L], fx[L], fy[L], s0[L], s1[L], s2[L], bm[L], bx[L], by[L], hb[L], hp[L];
+        bool tv[L], nv[L];
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const int sl = lane * L + j;
+            const int xT = xmn + (sl - sMin + (sl < sMin ? WV_P : 0));   /* this slot's k-mer on t ... */
+            const int xN = nmn + (sl - sMinN + (sl < sMinN ? WV_P : 0)); /* ... and on t+1 */
+            tv[j] = xT <= xmx;
+            nv[j] = second && xN <= nmx;
+            const bool below = nv[j] && xN - 1 >= pxmin && xN - 1 <= pxmax;
+            const int sb = sl == 0 ? WV_P - 1 : sl - 1; /* the slot of k-mer xN - 1 */
+            const double *pa = rowT + (tv[j] ? j * (WV_RING_VALUES * 64) + lane : 0);
+            const double *pb = rowB + (below ? (sb % L) * (WV_RING_VALUES * 64) + sb / L : 0);
+            fmv[j] = pa[0]; fx[j] = pa[64]; fy[j] = pa[128];
+            s0[j] = pb[0]; s1[j] = pb[64]; s2[j] = pb[128];
+            bm[j] = ld_agent(src + (0 * L + j) * 64);
+            bx[j] = ld_agent(src + (1 * L + j) * 64);
+            by[j] = ld_agent(src + (2 * L + j) * 64);
+            hb[j] = ld_agent(src + (3 * L + j) * 64);
+            hp[j] = ld_agent(src + (4 * L + j) * 64);
+            if (!below) s0[j] = s1[j] = s2[j] = CP_NEG_INF;
+        }
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            if (tv[j]) {
+                double v = fmv[j] + bm[j];
+                v = ladd(v, fx[j] + bx[j], cf);
+                v = ladd(v, fy[j] + by[j], cf);
+                vw[((long long) n * 2 + 0) * WV_P + lane * L + j] = v;
+            }
+            if (nv[j]) {
+                double mm = s0[j] + (hp[j] + T[T_MATCH_CONTINUE]);
+                mm = ladd(mm, s1[j] + (hp[j] + T[T_MATCH_FROM_GAP_X]), cf);
+                mm = ladd(mm, s2[j] + (hp[j] + T[T_MATCH_FROM_GAP_Y]), cf);
+                vw[((long long) n * 2 + 1) * WV_P + lane * L + j] = mm + hb[j];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 
-        /* ------------------------------ phase T: the totals ------------------------------ */
+    /* ------------------------------ phase T: the totals ------------------------------ */
 #pragma unroll 1
-        for (int k0 = 0; k0 < 2 * nTotWin; k0 += 64) {
-            const int k = k0 + lane;
-            double acc = CP_NEG_INF;
-            WinTotal w;
-            w.second = 0; w.t = 0; w.xmin = w.xmax = w.nxmin = w.nxmax = 0;
-            const int f = k & 1;
-            if (k < 2 * nTotWin) {
-                w = wtot[k >> 1];
-                if (f == 0 || w.second) {
-                    const int lo = f ? w.nxmin : w.xmin, hi = f ? w.nxmax : w.xmax;
-                    const double *src = vw + ((long long) (k >> 1) * 2 + f) * WV_P;
-                    double v[8], nv[8]; /* the next eight terms are in flight while these eight are folded */
+    for (int k0 = 0; k0 < 2 * nTotWin; k0 += 64) {
+        const int k = k0 + lane;
+        double acc = CP_NEG_INF;
+        WinTotal w;
+        w.second = 0; w.t = 0; w.xmin = w.xmax = w.nxmin = w.nxmax = 0;
+        const int f = k & 1;
+        if (k < 2 * nTotWin) {
+            w = wtot[k >> 1];
+            if (f == 0 || w.second) {
+                const int lo = f ? w.nxmin : w.xmin, hi = f ? w.nxmax : w.xmax;
+                const double *src = vw + ((long long) (k >> 1) * 2 + f) * WV_P;
+                double v[8], nv[8]; /* the next eight terms are in flight while these eight are folded */
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = lo + j <= hi ? ld_agent(src + (lo + j) % WV_P) : CP_NEG_INF;
+                for (int j = 0; j < 8; j++) v[j] = lo + j <= hi ? ld_agent(src + (lo + j) % WV_P) : CP_NEG_INF;
 #pragma unroll 1
-                    for (int x0 = lo; x0 <= hi; x0 += 8) {
+                for (int x0 = lo; x0 <= hi; x0 += 8) {
 #pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            nv[j] = x0 + 8 + j <= hi ? ld_agent(src + (x0 + 8 + j) % WV_P) : CP_NEG_INF;
+                    for (int j = 0; j < 8; j++)
+                        nv[j] = x0 + 8 + j <= hi ? ld_agent(src + (x0 + 8 + j) % WV_P) : CP_NEG_INF;
 #pragma unroll
-                        for (int j = 0; j < 8; j++) acc = ladd(acc, v[j], cf); /* dpDiagonal_dotProduct :587-597 */
+                    for (int j = 0; j < 8; j++) acc = ladd(acc, v[j], cf); /* dpDiagonal_dotProduct :587-597 */
 #pragma unroll
-                        for (int j = 0; j < 8; j++) v[j] = nv[j];
-                    }
+                    for (int j = 0; j < 8; j++) v[j] = nv[j];
                 }
             }
-            sh.vbuf[lane] = acc;
-            __builtin_amdgcn_wave_barrier();
-            const double partner = sh.vbuf[(lane + 1) & 63];
-            if (k < 2 * nTotWin && f == 0) {
-                double tot = acc;
-                if (w.second) tot = ladd(acc, partner, cf);
-                wtot[k >> 1].total = tot;
-                if (!(fabs(tot - totEst) <= WV_CAND_SLACK)) sh.scan = 1; /* also catches NaN and infinities */
-                const long long o = out.nTot + (k >> 1);
-                if (o < out.totCap) {
-                    out.totXay[o] = w.t;
-                    out.totVal[o] = tot;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
         }
-        out.nTot += nTotWin;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the totals are read back by the decode / the second sweep */
-        if (P.mode != 0 || nPost <= 0) return;
-        if (uni(sh.scan) == 0) break;
-        direct = true;
+        sh.vbuf[lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+        const double partner = sh.vbuf[(lane + 1) & 63];
+        if (k < 2 * nTotWin && f == 0) {
+            double tot = acc;
+            if (w.second) tot = ladd(acc, partner, cf);
+            wtot[k >> 1].total = tot;
+            if (!(fabs(tot - totEst) <= WV_CAND_SLACK)) sh.scan = 1; /* also catches NaN and infinities */
+            const long long o = out.nTot + (k >> 1);
+            if (o < out.totCap) {
+                out.totXay[o] = w.t;
+                out.totVal[o] = tot;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    out.nTot += nTotWin;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the totals are read back by the decode / the second sweep */
+    if (KIND == WV_KIND_EXPECT || nPost <= 0) return;
+    if (uni(sh.scan) != 0) {
+        redo = true; /* the candidates cannot be trusted: the re-sweep kernel decodes this window */
+        return;
     }
 
     /* ------------------------------ phase D: the aligned pairs ------------------------------ */
@@ -1303,47 +1341,57 @@ template <bool SW> __device__ __forceinline__ void wv_forward_kernel(
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
     const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD,
-    SyState *states, FwdShared &sh) {
+    WvState *states, int window, FwdShared &sh) {
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
-    SyState *state = states + idx;
+    WvState *state = states + idx;
     const DevItem it = uniform_item(items[idx]);
     if (state->finished || it.lX + it.lY == 0) return;
     init_coef(sh.coef);
     forward_window<SW>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW, events,
-                       models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, state, sh);
+                       models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, state, window,
+                       sh);
 }
 extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_forward)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
-    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, SyState *states) {
+    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, WvState *states, int window) {
     __shared__ FwdShared sh;
     wv_forward_kernel<false>(items, nItems, P, bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
-                             states, sh);
+                             states, window, sh);
 }
 extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_forward_sw)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
-    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, SyState *states) {
+    const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, WvState *states, int window) {
     __shared__ FwdShared sh;
     wv_forward_kernel<true>(items, nItems, P, bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
-                            states, sh);
+                            states, window, sh);
 }
 
-/* One wave per alignment: backward sweep + posterior decode of the window just described. */
-template <bool SW> __device__ __forceinline__ void wv_backward_kernel(
+/* One wave per alignment: backward sweep + posterior decode of the window just described.  win[].valid: 1 = the
+ * forward kernel has described the window, 2 = swept, but its candidates could not be trusted: the re-sweep kernel
+ * (launched after every backward kernel; it returns at once otherwise) decodes it, 0 = done. */
+template <bool SW, int KIND> __device__ __forceinline__ void wv_backward_kernel(
     const DevItem *__restrict__ items, long long nItems, const DevParams &P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
-    long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
+    long long ringDoubles, int ringD, WvState *states, long long *pairs, double *pairLogp,
     long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window,
     BwdShared &sh) {
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
-    SyState *state = states + idx;
-    if (!state->winValid) return;
+    WvState *state = states + idx;
+    WvWindow win;
+    {
+        const WvWindow *w = &state->win[window & 1];
+        win.valid = ld_agent(&w->valid); win.top = ld_agent(&w->top); win.from = ld_agent(&w->from);
+        win.to = ld_agent(&w->to); win.atEnd = ld_agent(&w->atEnd); win.pad = 0;
+        win.est = ld_agent(&w->est);
+    }
+    if (uni(win.valid) != (KIND == WV_KIND_REDO ? 2 : 1)) return;
     const DevItem it = uniform_item(items[idx]);
     init_coef(sh.coef);
     ItemOut out;
@@ -1353,48 +1401,47 @@ template <bool SW> __device__ __forceinline__ void wv_backward_kernel(
     out.totXay = totXay + it.totBase;
     out.totVal = totVal + it.totBase;
     out.totCap = it.totCap;
-    out.nPairs = uni64(state->nPairs);
-    out.nTot = uni64(state->nTot);
+    out.nPairs = uni64(ld_agent(&state->nPairs));
+    out.nTot = uni64(ld_agent(&state->nTot));
     char *sc = scratch + idx * scratchBytes;
     const long long nW = (long long) ringD / 10 + 8;
     int *offBuf = (int *) sc;
     WinTotal *wtot = (WinTotal *) (sc + 2ll * ringD * sizeof(int));
     double *vw = (double *) (sc + 2ll * ringD * sizeof(int) + nW * sizeof(WinTotal));
-    unsigned long long *msk = (unsigned long long *) (sc + 2ll * ringD * sizeof(int)
-                                                      + nW * (sizeof(WinTotal) + 2 * WV_P * sizeof(double)));
+    double *rf = vw + nW * 2 * WV_P;
+    unsigned long long *msk = (unsigned long long *) (rf + nW * 5 * WV_P);
     int2 *candKx = (int2 *) ((char *) msk + 4ll * ringD * sizeof(unsigned long long));
     double *candFb = (double *) ((char *) candKx + (long long) WV_L * WV_CAND_PER_DIAG * ringD * sizeof(int2));
-    backward_window<SW>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW,
-                        models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, state, out,
-                        sh, offBuf, wtot, vw, msk, candKx, candFb,
-                        Bring ? Bring + idx * ((long long) ringD * WV_L * 3 * 64) : nullptr);
+    bool redo = false;
+    backward_window<SW, KIND>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW,
+                              models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, win,
+                              out, sh, offBuf, wtot, vw, rf, msk, candKx, candFb,
+                              Bring ? Bring + idx * ((long long) ringD * WV_L * 3 * 64) : nullptr, redo);
     if (threadIdx.x == 0) {
         state->nPairs = out.nPairs;
         state->nTot = out.nTot;
-        state->winValid = 0;
-        state->expectPending = P.mode != 0 ? window + 1 : 0; /* which launch's window the B ring holds */
+        state->win[window & 1].valid = redo ? 2 : 0;
+        if (KIND == WV_KIND_EXPECT) state->expectPending = window + 1; /* which launch's window the B ring holds */
     }
 }
-extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_backward)(
-    const DevItem *__restrict__ items, long long nItems, DevParams P,
-    const int2 *__restrict__ bandTab, const double *__restrict__ track,
-    const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
-    long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
-    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window) {
-    __shared__ BwdShared sh;
-    wv_backward_kernel<false>(items, nItems, P, bandTab, track, trackBase, models, Fring, ringDoubles, ringD, states,
-                              pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window, sh);
-}
-extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_backward_sw)(
-    const DevItem *__restrict__ items, long long nItems, DevParams P,
-    const int2 *__restrict__ bandTab, const double *__restrict__ track,
-    const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
-    long long ringDoubles, int ringD, SyState *states, long long *pairs, double *pairLogp,
-    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window) {
-    __shared__ BwdShared sh;
-    wv_backward_kernel<true>(items, nItems, P, bandTab, track, trackBase, models, Fring, ringDoubles, ringD, states,
-                             pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window, sh);
-}
+#define WV_BACKWARD_KERNEL(name, SW, KIND)                                                                        \
+    extern "C" __global__ __launch_bounds__(64) void WV_SYM(name)(                                                \
+        const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,       \
+        const double *__restrict__ track, const long long *__restrict__ trackBase,                                \
+        const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, WvState *states,      \
+        long long *pairs, double *pairLogp, long long *totXay, double *totVal, char *scratch,                     \
+        long long scratchBytes, double *Bring, int window) {                                                      \
+        __shared__ BwdShared sh;                                                                                  \
+        wv_backward_kernel<SW, KIND>(items, nItems, P, bandTab, track, trackBase, models, Fring, ringDoubles,     \
+                                     ringD, states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes,       \
+                                     Bring, window, sh);                                                          \
+    }
+WV_BACKWARD_KERNEL(cpecan_k_wv_backward, false, WV_KIND_POSTERIOR)
+WV_BACKWARD_KERNEL(cpecan_k_wv_backward_sw, true, WV_KIND_POSTERIOR)
+WV_BACKWARD_KERNEL(cpecan_k_wv_resweep, false, WV_KIND_REDO)
+WV_BACKWARD_KERNEL(cpecan_k_wv_resweep_sw, true, WV_KIND_REDO)
+WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em, false, WV_KIND_EXPECT)
+WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em_sw, true, WV_KIND_EXPECT)
 
 /*
  * Baum-Welch expectations of the traceback window the backward kernel just swept
@@ -1410,13 +1457,13 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,
     const double *__restrict__ track, const long long *__restrict__ trackBase,
     const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
-    long long ringDoubles, const double *Bring, int ringD, SyState *states, const char *scratch,
+    long long ringDoubles, const double *Bring, int ringD, WvState *states, const char *scratch,
     long long scratchBytes, double *expect, int window) {
     constexpr int L = WV_L;
     __shared__ double sExp[16];
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
-    const SyState *state = states + idx;
+    const WvState *state = states + idx;
     if (state->expectPending != window + 1) return;
     const DevItem it = uniform_item(items[idx]);
     const int lane = threadIdx.x & 63, j = uni(threadIdx.x >> 6);
@@ -1430,7 +1477,8 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const unsigned short *kx = kidx + it.xOff;
     const int2 *tab = bandTab + it.diagBase;
     const WinTotal *wtot = (const WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int));
-    const int dTop = uni(state->winTop), from = uni(state->winFrom), to = uni(state->winTo);
+    const int dTop = uni(state->win[window & 1].top), from = uni(state->win[window & 1].from),
+              to = uni(state->win[window & 1].to);
     const int tPost0 = dTop < from ? dTop : from;
     double *dst = expect + (long long) it.model * (9 + 4096 + 1);
 
@@ -1559,19 +1607,35 @@ extern "C" int cpecan_wave_launch_track(hipStream_t stream, const DevItem *items
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(cpecan_k_wv_track, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items, nItems,
                        trackBase, kidx, models, (double *) track);
-    if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(SyState), stream) != hipSuccess) return -1;
+    if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(WvState), stream) != hipSuccess) return -1;
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int cpecan_wave_track_row_doubles(void) { return WV_ROW; }
+extern "C" int cpecan_wave_state_bytes(void) { return (int) sizeof(WvState); }
+/* results of the per-alignment states into the batch's count arrays */
+extern "C" __global__ void cpecan_k_wv_counts(const WvState *states, long long nItems, long long *nPairs,
+                                              long long *nTot, long long *nCells) {
+    const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nItems) return;
+    nPairs[i] = states[i].nPairs;
+    nTot[i] = states[i].nTot;
+    nCells[i] = states[i].cells;
+}
+extern "C" int cpecan_wave_launch_counts(hipStream_t stream, const void *states, long long nItems, long long *nPairs,
+                                         long long *nTot, long long *nCells) {
+    hipLaunchKernelGGL(cpecan_k_wv_counts, dim3((unsigned) ((nItems + 255) / 256)), dim3(256), 0, stream,
+                       (const WvState *) states, nItems, nPairs, nTot, nCells);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 #endif
 
 extern "C" int WV_SYM(cpecan_wave_max_width)(void) { return WV_P - 8; }
 extern "C" int WV_SYM(cpecan_wave_rows)(void) { return WV_L; }
 extern "C" int WV_SYM(cpecan_wave_ring_row_doubles)(void) { return WV_ROW_DOUBLES; }
 extern "C" int WV_SYM(cpecan_wave_bring_row_doubles)(void) { return WV_L * 3 * 64; }
-/* HBM scratch per alignment: [hit offsets | window totals | their terms | hit masks | candidate list] */
+/* HBM scratch per alignment: [hit offsets | window totals | their terms | the parked operands | hit masks | candidate list] */
 extern "C" long long WV_SYM(cpecan_wave_scratch_bytes)(int ringD) {
-    return 2ll * ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 2 * WV_P * sizeof(double))
+    return 2ll * ringD * sizeof(int) + ((long long) ringD / 10 + 8) * (sizeof(WinTotal) + 7 * WV_P * sizeof(double))
            + 4ll * ringD * sizeof(unsigned long long)
            + (long long) WV_L * WV_CAND_PER_DIAG * ringD * (sizeof(int2) + sizeof(double));
 }
@@ -1579,15 +1643,15 @@ extern "C" int WV_SYM(cpecan_wave_launch_forward)(hipStream_t stream, const DevI
                                                   DevParams P, const void *bandTab, const double *track,
                                                   const long long *trackBase, const double *events,
                                                   const double *models, double *Fring, long long ringDoubles,
-                                                  int ringD, void *states, int withSwitch) {
+                                                  int ringD, void *states, int window, int withSwitch) {
     if (withSwitch)
         hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward_sw), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems,
                            P, (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
-                           (SyState *) states);
+                           (WvState *) states, window);
     else
         hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems, P,
                            (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
-                           (SyState *) states);
+                           (WvState *) states, window);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const DevItem *items, long long nItems,
@@ -1596,14 +1660,20 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
                                                    long long ringDoubles, int ringD, void *states, long long *pairs,
                                                    double *pairLogp, long long *totXay, double *totVal, char *scratch,
                                                    long long scratchBytes, double *Bring, int window, int withSwitch) {
-    if (withSwitch)
-        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_backward_sw), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems,
-                           P, (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
-                           (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window);
-    else
-        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_backward), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems, P,
-                           (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
-                           (SyState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window);
+#define WV_LAUNCH_B(k)                                                                                            \
+    hipLaunchKernelGGL(WV_SYM(k), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems, P,                 \
+                       (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,               \
+                       (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window)
+    if (P.mode != 0) {
+        if (withSwitch) WV_LAUNCH_B(cpecan_k_wv_backward_em_sw);
+        else WV_LAUNCH_B(cpecan_k_wv_backward_em);
+    } else {
+        /* the sweep with decode candidates, then the kernel that sweeps once more the windows whose candidates
+         * could not be trusted (it returns at once for the others) */
+        if (withSwitch) { WV_LAUNCH_B(cpecan_k_wv_backward_sw); WV_LAUNCH_B(cpecan_k_wv_resweep_sw); }
+        else { WV_LAUNCH_B(cpecan_k_wv_backward); WV_LAUNCH_B(cpecan_k_wv_resweep); }
+    }
+#undef WV_LAUNCH_B
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevItem *items, long long nItems,
@@ -1614,6 +1684,6 @@ extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevIt
                                                  long long scratchBytes, double *expect, int window) {
     hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_expect), dim3((unsigned) nItems, WV_EXPECT_CHUNKS), dim3(WV_P), 0, stream,
                        items, nItems, P, (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles,
-                       Bring, ringD, (SyState *) states, scratch, scratchBytes, expect, window);
+                       Bring, ringD, (WvState *) states, scratch, scratchBytes, expect, window);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

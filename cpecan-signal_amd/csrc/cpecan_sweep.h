@@ -16,6 +16,22 @@ struct SyState {
     long long nPairs, nTot, cells;
 };
 
+/* The wave kernels' record: the forward kernel of launch w describes its window in win[w & 1] while the backward
+ * kernel of launch w - 1 may still be working from the other entry (the two run concurrently). */
+struct WvWindow {
+    int valid, top, from, to, atEnd, pad;
+    double est; /* estimate of the window's totalProbability: the forward cells of its top diagonal dotted with the
+                   end vector the sweep back starts from (any fold order; it only steers the candidate test) */
+};
+struct WvState {
+    int d;            /* last forward diagonal completed */
+    int tracedBackTo; /* as in getPosteriorProbsWithBanding (impl/pairwiseAligner.c:903) */
+    int finished;     /* forward reached the last diagonal */
+    int expectPending; /* Baum-Welch: the window's backward cells are in the B ring, not yet summed */
+    WvWindow win[2];
+    long long nPairs, nTot, cells;
+};
+
 /* per-window bookkeeping of one totalProbability refresh, kept in HBM scratch (private to the alignment) */
 struct WinTotal {
     int t, xmin, xmax, nxmin, nxmax, second;
