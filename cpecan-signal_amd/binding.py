@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpecan_hip.so")
+LIB_PATH = os.environ.get("CPECAN_HIP_LIB") or os.path.join(_HERE, "libcpecan_hip.so")  # (the override serves tools/ablate_wave.sh)
 
 OK, ENODEVICE, EINVAL, EHIP, EOVERFLOW, EBAND = 0, -1, -2, -3, -4, -5
 MODE_POSTERIOR, MODE_EXPECTATIONS = 0, 1

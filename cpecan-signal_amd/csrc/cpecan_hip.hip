@@ -1108,7 +1108,8 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                 HIP_TRY(hipEventRecord(e4[1], sF));
                 if (sB != sF) HIP_TRY(hipStreamWaitEvent(sB, e4[1], 0));
                 HIP_TRY(hipEventRecord(e4[2], sB));
-                if (rc == 0 && n > 0)
+                static const bool fwdOnly = getenv("CPECAN_TIMING_FORWARD_ONLY") != nullptr; /* timing study: wrong results */
+                if (rc == 0 && n > 0 && !fwdOnly)
                     rc = b->sy->launch_backward(sB, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                 b->trackBase.p + i0, c->models.p,
                                                 b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles, b->ringD,

@@ -17,7 +17,7 @@
  *   - band edges move by at most one k-mer per diagonal; the launch's edge steps sit in LDS as two
  *     bit strings, so entering / leaving k-mers are found on the scalar unit.
  *   - forward cells go to HBM once into a per-alignment ring of diagonals
- *     ([diagonal][layer][Fm,Fx,Fy,pm,py][lane]) and are read once by the sweep back, four diagonals
+ *     ([diagonal][layer][(Fm,pm) x 64 | py x 64 | (Fx,Fy) x 64]) and are read once by the sweep back, three diagonals
  *     ahead of use; the forward sweep's inputs (events, k-mer rows) are staged in LDS per block of
  *     diagonals, so neither loop waits for a load it has just issued.
  *   - two kernels per traceback window, sequenced by the C-ABI layer (cpecan_hip.hip); WvState and the
@@ -53,12 +53,24 @@
 #define WV_BITWORDS 256      /* band edge steps kept in LDS: 32 diagonals per word, circular, re-staged in halves */
 #define WV_RING_VALUES 5     /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
 #define WV_LAYER_BYTES (WV_RING_VALUES * 64 * 8)
+/* a layer of a ring row, in doubles: 64 (Fm, pm) pairs | 64 py | 64 (Fx, Fy) pairs -- what the sweep back reads on
+ * every diagonal is one 16-byte and one 8-byte access per lane */
+#define WV_LAYER_DOUBLES (WV_RING_VALUES * 64)
+#define WV_OFF_FM(lane) ((lane) * 2)
+#define WV_OFF_PM(lane) ((lane) * 2 + 1)
+#define WV_OFF_PY(lane) (128 + (lane))
+#define WV_OFF_FX(lane) (192 + (lane) * 2)
+#define WV_OFF_FY(lane) (192 + (lane) * 2 + 1)
 #define WV_ROW_DOUBLES (WV_L * WV_RING_VALUES * 64)
-#define WV_PREFETCH 3        /* diagonals the backward sweep fetches ahead (== its unroll factor) */
+#define WV_PREFETCH 2        /* diagonals the backward sweep fetches ahead (== its unroll factor) */
 #define WV_CAND_SLACK 0.25   /* candidates: cells within this (log units) below the posterior threshold */
 #define WV_CAND_PER_DIAG 4   /* candidate capacity, in records per ring diagonal and layer */
 #define WV_EXPECT_CHUNKS 8   /* workgroups that share one window's diagonals in the expectation pass */
+#define WV_WPB 1             /* alignments (waves) per workgroup of the sweeps: a workgroup's four waves are placed on the
+                                four SIMDs of a CU, which single-wave workgroups are not promised */
 
+/* -DWV_ABL_* are timing-study switches (tools/ablate_wave.sh): they compute wrong results by construction and are
+ * never built into the product */
 #define WV_FOR_LAYER_1(jv, ...) { constexpr int J = 0; (void) (jv); __VA_ARGS__ }
 #define WV_FOR_LAYER_2(jv, ...) if ((jv) == 0) { constexpr int J = 0; __VA_ARGS__ } else { constexpr int J = 1; __VA_ARGS__ }
 #define WV_FOR_LAYER_3(jv, ...) if ((jv) == 0) { constexpr int J = 0; __VA_ARGS__ } else if ((jv) == 1) { constexpr int J = 1; __VA_ARGS__ } else { constexpr int J = 2; __VA_ARGS__ }
@@ -76,8 +88,16 @@
 namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) const d2 lds_d2;
 typedef lds_d2 *lds_d2p;
+#else
+typedef const d2 *lds_d2p; /* (the host pass only parses the kernels) */
+#define lds_d2p_cast(a) ((lds_d2p) (size_t) (a))
+#endif
+#ifndef lds_d2p_cast
+#define lds_d2p_cast(a) ((lds_d2p) (a))
+#endif
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ long long uni64(long long v) {
@@ -132,40 +152,56 @@ __device__ __forceinline__ double ladd(double x, double y, unsigned coefAddr) {
     int n;
     asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(d + d)));
     n = n < 15 ? n : 15;
-    const lds_d2p c = (lds_d2p) (coefAddr + (unsigned) n * 32u);
+    const lds_d2p c = lds_d2p_cast(coefAddr + (unsigned) n * 32u);
     const d2 c32 = c[0], c10 = c[1];
     const double r = ((c32.x * d + c32.y) * d + c10.x) * d + c10.y + lo;
     return sel_below(d, r, hi);
 }
-/* N independent logAdds, stage by stage, so that their table reads are in flight together */
-template <int N> __device__ __forceinline__ void laddN(double (&acc)[N], const double (&y)[N], unsigned coefAddr) {
+/* N independent logAdds, stage by stage, so that their table reads are in flight together; the two halves can be
+ * called apart, with the first half of the next batch in between: the sweeps keep two batches in flight */
+template <int N> struct LaddPending {
     double hi[N], lo[N], d[N];
     d2 c32[N], c10[N];
+};
+template <int N> __device__ __forceinline__ void ladd_issue(LaddPending<N> &p, const double (&acc)[N], const double (&y)[N],
+                                                            unsigned coefAddr) {
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        asm("v_max_f64 %0, %1, %2" : "=v"(hi[k]) : "v"(acc[k]), "v"(y[k]));
-        asm("v_min_f64 %0, %1, %2" : "=v"(lo[k]) : "v"(acc[k]), "v"(y[k]));
-        d[k] = hi[k] - lo[k];
+        asm("v_max_f64 %0, %1, %2" : "=v"(p.hi[k]) : "v"(acc[k]), "v"(y[k]));
+        asm("v_min_f64 %0, %1, %2" : "=v"(p.lo[k]) : "v"(acc[k]), "v"(y[k]));
+        p.d[k] = p.hi[k] - p.lo[k];
         int n;
-        asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(d[k] + d[k])));
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(p.d[k] + p.d[k])));
         n = n < 15 ? n : 15;
-        const lds_d2p c = (lds_d2p) (coefAddr + (unsigned) n * 32u);
-        c32[k] = c[0];
-        c10[k] = c[1];
+        const lds_d2p c = lds_d2p_cast(coefAddr + (unsigned) n * 32u);
+        p.c32[k] = c[0];
+        p.c10[k] = c[1];
     }
+}
+template <int N> __device__ __forceinline__ void ladd_finish(const LaddPending<N> &p, double (&acc)[N]) {
 #pragma unroll
     for (int k = 0; k < N; k++) {
-        const double r = ((c32[k].x * d[k] + c32[k].y) * d[k] + c10[k].x) * d[k] + c10[k].y + lo[k];
-        acc[k] = sel_below(d[k], r, hi[k]);
+        const double r = ((p.c32[k].x * p.d[k] + p.c32[k].y) * p.d[k] + p.c10[k].x) * p.d[k] + p.c10[k].y + p.lo[k];
+        acc[k] = sel_below(p.d[k], r, p.hi[k]);
     }
+}
+template <int N> __device__ __forceinline__ void laddN(double (&acc)[N], const double (&y)[N], unsigned coefAddr) {
+#ifdef WV_ABL_LADD
+#pragma unroll
+    for (int k = 0; k < N; k++) acc[k] = acc[k] > y[k] ? acc[k] : y[k];
+    return;
+#endif
+    LaddPending<N> p;
+    ladd_issue<N>(p, acc, y, coefAddr);
+    ladd_finish<N>(p, acc);
 }
 __device__ __forceinline__ void init_coef(double *coef) {
     const float t[16] = { -0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
                           -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
                           -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
                           -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f };
-    const int n = threadIdx.x >> 2, piece = n <= 2 ? 0 : n <= 5 ? 1 : n <= 9 ? 2 : 3;
-    coef[threadIdx.x] = (double) t[piece * 4 + (threadIdx.x & 3)];
+    const int l = threadIdx.x & 63, n = l >> 2, piece = n <= 2 ? 0 : n <= 5 ? 1 : n <= 9 ? 2 : 3;
+    coef[l] = (double) t[piece * 4 + (l & 3)];
 }
 
 /* log N(x; mu, sd) = K + (-0.5*a*a), a = (x-mu)/sd (impl/stateMachine.c:333-343); the quotient is
@@ -220,71 +256,59 @@ struct Prm {
 };
 /* load of a whole row from LDS into one layer's registers in every lane (start-up) */
 __device__ __forceinline__ void load_row_all(Prm &p, unsigned rowAddr) {
-    const lds_d2p r = (lds_d2p) rowAddr;
+    const lds_d2p r = lds_d2p_cast(rowAddr);
 #pragma unroll
-    for (int k = 0; k < WV_ROW / 2; k++) p.a[k] = r[k];
+    for (int k = 0; k < WV_ROW / 2; k++) p.a[k] = r[k]; /* (pairs a build never reads are dropped by the compiler) */
 }
 /* A k-mer enters (or leaves) the band: its row (or the "not a k-mer" row) is loaded from LDS into the registers
  * of ONE slot -- lane laneMask, layer sel -- and the lane masks of the band are updated.  The layer is a run-time
  * (wave-uniform) value and registers cannot be indexed, so the select sits inside one asm statement: seen from
- * the compiler there is no control flow and no copy of the L x 20 constants around it. */
-#define WV_SLOT_ASM(MASKOP)                                                                                     \
+ * the compiler there is no control flow and no copy of the L x 20 constants around it.  fl[layer] is the lane's own
+ * "my slot holds a k-mer of the band" flag: it predicates the ring stores. */
+#define WV_SLOT_ASM(MASKOP, FLAGV, BODY, OUTS)                                                                  \
     unsigned long long sv;                                                                                       \
     asm volatile("s_mov_b64 %[sv], exec\n\t"                                                                      \
-                 "s_mov_b64 exec, %[m]\n\t" WV_SLOT_BODY(MASKOP)                                                   \
+                 "s_mov_b64 exec, %[m]\n\t" BODY(MASKOP)                                                           \
                  "s_mov_b64 exec, %[sv]\n\t"                                                                      \
                  "s_waitcnt lgkmcnt(0)"                                                                            \
-                 : [sv] "=&s"(sv) WV_SLOT_OUTS                                                                     \
-                 : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel)                                             \
+                 : [sv] "=&s"(sv) OUTS                                                                             \
+                 : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel), [fv] "s"(FLAGV)                            \
                  : "memory", "scc");
 #if WV_L == 1
-#define WV_SLOT_BODY(MASKOP) "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" 
-#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0])
+#define WV_SLOT_BODY9(MASKOP) "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" 
+#define WV_SLOT_OUTS9 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0])
+#define WV_SLOT_BODY10(MASKOP) "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" 
+#define WV_SLOT_OUTS10 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0])
 #elif WV_L == 2
-#define WV_SLOT_BODY(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\t" "9:\n\t" 
-#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1])
+#define WV_SLOT_BODY9(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" MASKOP " %[k1], %[k1], %[m]\n\tv_mov_b32 %[f1], %[fv]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS9 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [k1] "+s"(mask[1]), [f1] "+v"(fl[1])
+#define WV_SLOT_BODY10(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\tv_mov_b32 %[f1], %[fv]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS10 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [f1] "+v"(fl[1])
 #elif WV_L == 3
-#define WV_SLOT_BODY(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" "ds_read_b128 %[c9], %[a] offset:144\n\t" MASKOP " %[k2], %[k2], %[m]\n\t" "9:\n\t" 
-#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [c9] "+v"(p[2].a[9]), [k2] "+s"(mask[2])
+#define WV_SLOT_BODY9(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" MASKOP " %[k1], %[k1], %[m]\n\tv_mov_b32 %[f1], %[fv]\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" MASKOP " %[k2], %[k2], %[m]\n\tv_mov_b32 %[f2], %[fv]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS9 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [k1] "+s"(mask[1]), [f1] "+v"(fl[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [k2] "+s"(mask[2]), [f2] "+v"(fl[2])
+#define WV_SLOT_BODY10(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\tv_mov_b32 %[f1], %[fv]\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" "ds_read_b128 %[c9], %[a] offset:144\n\t" MASKOP " %[k2], %[k2], %[m]\n\tv_mov_b32 %[f2], %[fv]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS10 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [f1] "+v"(fl[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [c9] "+v"(p[2].a[9]), [k2] "+s"(mask[2]), [f2] "+v"(fl[2])
 #elif WV_L == 4
-#define WV_SLOT_BODY(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" "ds_read_b128 %[c9], %[a] offset:144\n\t" MASKOP " %[k2], %[k2], %[m]\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\t" "ds_read_b128 %[d1], %[a] offset:16\n\t" "ds_read_b128 %[d2], %[a] offset:32\n\t" "ds_read_b128 %[d3], %[a] offset:48\n\t" "ds_read_b128 %[d4], %[a] offset:64\n\t" "ds_read_b128 %[d5], %[a] offset:80\n\t" "ds_read_b128 %[d6], %[a] offset:96\n\t" "ds_read_b128 %[d7], %[a] offset:112\n\t" "ds_read_b128 %[d8], %[a] offset:128\n\t" "ds_read_b128 %[d9], %[a] offset:144\n\t" MASKOP " %[k3], %[k3], %[m]\n\t" "9:\n\t" 
-#define WV_SLOT_OUTS , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [c9] "+v"(p[2].a[9]), [k2] "+s"(mask[2]), [d0] "+v"(p[3].a[0]), [d1] "+v"(p[3].a[1]), [d2] "+v"(p[3].a[2]), [d3] "+v"(p[3].a[3]), [d4] "+v"(p[3].a[4]), [d5] "+v"(p[3].a[5]), [d6] "+v"(p[3].a[6]), [d7] "+v"(p[3].a[7]), [d8] "+v"(p[3].a[8]), [d9] "+v"(p[3].a[9]), [k3] "+s"(mask[3])
+#define WV_SLOT_BODY9(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" MASKOP " %[k1], %[k1], %[m]\n\tv_mov_b32 %[f1], %[fv]\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" MASKOP " %[k2], %[k2], %[m]\n\tv_mov_b32 %[f2], %[fv]\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\t" "ds_read_b128 %[d1], %[a] offset:16\n\t" "ds_read_b128 %[d2], %[a] offset:32\n\t" "ds_read_b128 %[d3], %[a] offset:48\n\t" "ds_read_b128 %[d4], %[a] offset:64\n\t" "ds_read_b128 %[d5], %[a] offset:80\n\t" "ds_read_b128 %[d6], %[a] offset:96\n\t" "ds_read_b128 %[d7], %[a] offset:112\n\t" "ds_read_b128 %[d8], %[a] offset:128\n\t" MASKOP " %[k3], %[k3], %[m]\n\tv_mov_b32 %[f3], %[fv]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS9 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [k1] "+s"(mask[1]), [f1] "+v"(fl[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [k2] "+s"(mask[2]), [f2] "+v"(fl[2]), [d0] "+v"(p[3].a[0]), [d1] "+v"(p[3].a[1]), [d2] "+v"(p[3].a[2]), [d3] "+v"(p[3].a[3]), [d4] "+v"(p[3].a[4]), [d5] "+v"(p[3].a[5]), [d6] "+v"(p[3].a[6]), [d7] "+v"(p[3].a[7]), [d8] "+v"(p[3].a[8]), [k3] "+s"(mask[3]), [f3] "+v"(fl[3])
+#define WV_SLOT_BODY10(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\tv_mov_b32 %[f1], %[fv]\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" "ds_read_b128 %[c9], %[a] offset:144\n\t" MASKOP " %[k2], %[k2], %[m]\n\tv_mov_b32 %[f2], %[fv]\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\t" "ds_read_b128 %[d1], %[a] offset:16\n\t" "ds_read_b128 %[d2], %[a] offset:32\n\t" "ds_read_b128 %[d3], %[a] offset:48\n\t" "ds_read_b128 %[d4], %[a] offset:64\n\t" "ds_read_b128 %[d5], %[a] offset:80\n\t" "ds_read_b128 %[d6], %[a] offset:96\n\t" "ds_read_b128 %[d7], %[a] offset:112\n\t" "ds_read_b128 %[d8], %[a] offset:128\n\t" "ds_read_b128 %[d9], %[a] offset:144\n\t" MASKOP " %[k3], %[k3], %[m]\n\tv_mov_b32 %[f3], %[fv]\n\t" "9:\n\t" 
+#define WV_SLOT_OUTS10 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [f1] "+v"(fl[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [c9] "+v"(p[2].a[9]), [k2] "+s"(mask[2]), [f2] "+v"(fl[2]), [d0] "+v"(p[3].a[0]), [d1] "+v"(p[3].a[1]), [d2] "+v"(p[3].a[2]), [d3] "+v"(p[3].a[3]), [d4] "+v"(p[3].a[4]), [d5] "+v"(p[3].a[5]), [d6] "+v"(p[3].a[6]), [d7] "+v"(p[3].a[7]), [d8] "+v"(p[3].a[8]), [d9] "+v"(p[3].a[9]), [k3] "+s"(mask[3]), [f3] "+v"(fl[3])
 #endif
-__device__ __forceinline__ void slot_enter(Prm (&p)[WV_L], unsigned long long (&mask)[WV_L], unsigned rowAddr,
-                                           unsigned long long laneMask, int sel) {
-    WV_SLOT_ASM("s_or_b64")
+/* (the row's tenth pair -- the switch sum and the raw gap-X emission -- is only loaded by the builds that use it) */
+template <bool SW> __device__ __forceinline__ void slot_enter(Prm (&p)[WV_L], unsigned long long (&mask)[WV_L],
+                                                             unsigned (&fl)[WV_L], unsigned rowAddr,
+                                                             unsigned long long laneMask, int sel) {
+    if (SW) { WV_SLOT_ASM("s_or_b64", 1, WV_SLOT_BODY10, WV_SLOT_OUTS10) }
+    else { WV_SLOT_ASM("s_or_b64", 1, WV_SLOT_BODY9, WV_SLOT_OUTS9) }
 }
-__device__ __forceinline__ void slot_leave(Prm (&p)[WV_L], unsigned long long (&mask)[WV_L], unsigned rowAddr,
-                                           unsigned long long laneMask, int sel) {
-    WV_SLOT_ASM("s_andn2_b64")
+template <bool SW> __device__ __forceinline__ void slot_leave(Prm (&p)[WV_L], unsigned long long (&mask)[WV_L],
+                                                             unsigned (&fl)[WV_L], unsigned rowAddr,
+                                                             unsigned long long laneMask, int sel) {
+    if (SW) { WV_SLOT_ASM("s_andn2_b64", 0, WV_SLOT_BODY10, WV_SLOT_OUTS10) }
+    else { WV_SLOT_ASM("s_andn2_b64", 0, WV_SLOT_BODY9, WV_SLOT_OUTS9) }
 }
 
-/* lane-masked stores of one layer's cells of a diagonal: Fm, pm, py (and Fx, Fy where they are read again) */
-__device__ __forceinline__ void store_cells3(unsigned long long laneMask, const double *rowBase, unsigned voff,
-                                             double fm, double pm, double py) {
-    unsigned long long sv;
-    asm volatile("s_mov_b64 %0, exec\n\t"
-                 "s_mov_b64 exec, %1\n\t"
-                 "global_store_dwordx2 %2, %3, %6\n\t"
-                 "global_store_dwordx2 %2, %4, %6 offset:1536\n\t"
-                 "global_store_dwordx2 %2, %5, %6 offset:2048\n\t"
-                 "s_mov_b64 exec, %0"
-                 : "=&s"(sv)
-                 : "s"(laneMask), "v"(voff), "v"(fm), "v"(pm), "v"(py), "s"(rowBase)
-                 : "memory");
-}
-__device__ __forceinline__ void store_cells2(unsigned long long laneMask, const double *rowBase, unsigned voff,
-                                             double fx, double fy) {
-    unsigned long long sv;
-    asm volatile("s_mov_b64 %0, exec\n\t"
-                 "s_mov_b64 exec, %1\n\t"
-                 "global_store_dwordx2 %2, %3, %5 offset:512\n\t"
-                 "global_store_dwordx2 %2, %4, %5 offset:1024\n\t"
-                 "s_mov_b64 exec, %0"
-                 : "=&s"(sv)
-                 : "s"(laneMask), "v"(voff), "v"(fx), "v"(fy), "s"(rowBase)
-                 : "memory");
-}
 
 /* the band: first and last matrix column (k-mer index) of every anti-diagonal, one int2 per diagonal in HBM
  * (built by the host from band_construct's output) */
@@ -400,11 +424,9 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
     double Bm[L], Bx[L], By[L]; /* ... and of the one before                    */
     double RAm, RAx, RAy, RBm, RBx, RBy; /* layer L-1 of the lane below, same two diagonals */
     unsigned long long mask[L];  /* lanes whose slot holds a k-mer of the band   */
-    unsigned voff[L];
+    unsigned fl[L];              /* the same, per lane: 1 or 0                    */
     int xmin, xmax;              /* band of the last diagonal done               */
     int inL, inJ, outL, outJ;    /* slots of k-mers xmax + 1 (next to enter) and xmin (next to leave) */
-#pragma unroll
-    for (int j = 0; j < L; j++) voff[j] = (unsigned) (j * WV_LAYER_BYTES + lane * 8);
 
     if (d0 == 0) {
         /* diagonal 0: the single cell (0,0) holds the start vector (:897-898, stateMachine.c:1168-1177) */
@@ -413,6 +435,7 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             load_row_all(prm[j], parkAddr);
             Am[j] = Ax[j] = Ay[j] = Bm[j] = Bx[j] = By[j] = CP_NEG_INF;
             mask[j] = 0ull;
+            fl[j] = 0u;
         }
         if (lane == 0) {
             Am[0] = it.raggedL ? CP_NEG_INF : 0.0;
@@ -420,8 +443,11 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             Ay[0] = Ax[0];
         }
         mask[0] = 1ull;
-        store_cells3(1ull, ring, voff[0], Am[0], 0.0, 0.0);
-        store_cells2(1ull, ring, voff[0], Ax[0], Ay[0]);
+        if (lane == 0) {
+            fl[0] = 1u;
+            ring[WV_OFF_FM(0)] = Am[0]; ring[WV_OFF_PM(0)] = 0.0; ring[WV_OFF_PY(0)] = 0.0;
+            ring[WV_OFF_FX(0)] = Ax[0]; ring[WV_OFF_FY(0)] = Ay[0];
+        }
         /* the dummy row the sweep back reads for lanes without a cell: -inf everywhere */
         for (int i = lane; i < WV_ROW_DOUBLES; i += 64) ring[(long long) ringD * WV_ROW_DOUBLES + i] = CP_NEG_INF;
         RBm = RBx = RBy = CP_NEG_INF;
@@ -451,13 +477,14 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
                 for (int k = 0; k < WV_ROW / 2; k++) prm[j].a[k] = src[k];
             }
             /* ring slots of cells outside the band hold stale data: mask per lane */
-            Am[j] = v1 ? r1[j * (WV_RING_VALUES * 64) + lane] : CP_NEG_INF;
-            Ax[j] = v1 ? r1[j * (WV_RING_VALUES * 64) + 64 + lane] : CP_NEG_INF;
-            Ay[j] = v1 ? r1[j * (WV_RING_VALUES * 64) + 128 + lane] : CP_NEG_INF;
-            Bm[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + lane] : CP_NEG_INF;
-            Bx[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + 64 + lane] : CP_NEG_INF;
-            By[j] = v2 ? r2[j * (WV_RING_VALUES * 64) + 128 + lane] : CP_NEG_INF;
+            Am[j] = v1 ? r1[j * WV_LAYER_DOUBLES + WV_OFF_FM(lane)] : CP_NEG_INF;
+            Ax[j] = v1 ? r1[j * WV_LAYER_DOUBLES + WV_OFF_FX(lane)] : CP_NEG_INF;
+            Ay[j] = v1 ? r1[j * WV_LAYER_DOUBLES + WV_OFF_FY(lane)] : CP_NEG_INF;
+            Bm[j] = v2 ? r2[j * WV_LAYER_DOUBLES + WV_OFF_FM(lane)] : CP_NEG_INF;
+            Bx[j] = v2 ? r2[j * WV_LAYER_DOUBLES + WV_OFF_FX(lane)] : CP_NEG_INF;
+            By[j] = v2 ? r2[j * WV_LAYER_DOUBLES + WV_OFF_FY(lane)] : CP_NEG_INF;
             mask[j] = (unsigned long long) uni64((long long) __ballot(v1));
+            fl[j] = v1 ? 1u : 0u;
         }
         RBm = ror1(Bm[L - 1]); RBx = ror1(Bx[L - 1]); RBy = ror1(By[L - 1]);
         const int si = (xmax + 1) % WV_P, so = xmin % WV_P;
@@ -495,6 +522,9 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
     /* the circular bit strings hold 8192 diagonals: longer launches are staged 4096 diagonals (whole words) at a time */
     int bitsHi = topW - d0 > 4096 ? ((d0 + 1 + 4096) & ~31) - 1 : topW;
     stage_band_steps(sh.bits, bandTab, D, d0 + 1, bitsHi);
+#ifdef WV_ABL_PRIOF
+    __builtin_amdgcn_s_setprio(2);
+#endif
 
     int evHi = d0 - xmax - 1;  /* first event not yet staged: the lowest index diagonal d0 + 1 can ask for */
     int evHiMod = ((evHi % WV_P) + WV_P) % WV_P;
@@ -515,14 +545,14 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             wMax = (unsigned) uni((int) sh.bits[1][(d >> 5) & (WV_BITWORDS - 1)]);
         }
         if ((wMin >> bi) & 1u) {
-            slot_leave(prm, mask, parkAddr, 1ull << outL, outJ);
+            slot_leave<SW>(prm, mask, fl, parkAddr, 1ull << outL, outJ);
             xmin++;
             if (++outJ == L) { outJ = 0; outL = (outL + 1) & 63; }
         }
         if ((wMax >> bi) & 1u) {
             xmax++;
             const unsigned ra = rowsAddr + (unsigned) (xmax & (WV_ROWN - 1)) * (WV_ROW * 8);
-            slot_enter(prm, mask, ra, 1ull << inL, inJ);
+            slot_enter<SW>(prm, mask, fl, ra, 1ull << inL, inJ);
             if (++inJ == L) { inJ = 0; inL = (inL + 1) & 63; }
         }
         cells += xmax - xmin + 1;
@@ -533,7 +563,7 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
         double *rowBase = ring + (long long) (d & ringMask) * WV_ROW_DOUBLES;
         d2 e[L];
 #pragma unroll
-        for (int j = 0; j < L; j++) e[j] = *(lds_d2p) (ea + 16u * (unsigned) (L - 1 - j));
+        for (int j = 0; j < L; j++) e[j] = *lds_d2p_cast(ea + 16u * (unsigned) (L - 1 - j));
         /* cell_calculateForward: to[t] = logAdd(to[t], from[f] + (eP + tP)) (:365-376) in the order of
          * stateMachine3_cellCalculate (stateMachine.c:1314-1333); the gap-X sums eP + tP are the row's (built with
          * the same additions by the track kernel).  The L cells of a lane are independent: their logAdds are
@@ -542,41 +572,67 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const Prm &p = prm[j];
+#ifdef WV_ABL_EMIT
+            pm[j] = e[j].x + p.a[1].y;
+            py[j] = e[j].y + p.a[5].y;
+#else
             pm[j] = lgauss(e[j].x, p.a[0].x, p.a[0].y, p.a[1].x, p.a[1].y)
                     + lgauss(e[j].y, p.a[2].x, p.a[2].y, p.a[3].x, p.a[3].y);
             py[j] = lgauss(e[j].x, p.a[4].x, p.a[4].y, p.a[5].x, p.a[5].y)
                     + lgauss(e[j].y, p.a[6].x, p.a[6].y, p.a[7].x, p.a[7].y);
+#endif
         }
+        double t2[L], t3[L], t4[L];
+        LaddPending<L> pa, pb;
 #pragma unroll
         for (int j = 0; j < L; j++) { /* gap X from the lower cell: (x-1, y) on the last diagonal */
             nx[j] = (j ? cm[j ? j - 1 : 0] : rlm) + prm[j].a[8].x;
             t1[j] = (j ? cx[j ? j - 1 : 0] : rlx) + prm[j].a[8].y;
         }
-        laddN<L>(nx, t1, cf);
-        if (SW) {
-#pragma unroll
-            for (int j = 0; j < L; j++) t1[j] = (j ? cy[j ? j - 1 : 0] : rly) + prm[j].a[9].x;
-            laddN<L>(nx, t1, cf);
-        }
+        ladd_issue<L>(pa, nx, t1, cf);
 #pragma unroll
         for (int j = 0; j < L; j++) { /* match from the middle cell: (x-1, y-1) on the diagonal before */
             nm[j] = (j ? qm[j ? j - 1 : 0] : rmm) + (pm[j] + T[T_MATCH_CONTINUE]);
-            t1[j] = (j ? qx[j ? j - 1 : 0] : rmx) + (pm[j] + T[T_MATCH_FROM_GAP_X]);
+            t2[j] = (j ? qx[j ? j - 1 : 0] : rmx) + (pm[j] + T[T_MATCH_FROM_GAP_X]);
         }
-        laddN<L>(nm, t1, cf);
+        ladd_issue<L>(pb, nm, t2, cf);
+        ladd_finish<L>(pa, nx);
 #pragma unroll
         for (int j = 0; j < L; j++) { /* gap Y from the upper cell: (x, y-1) on the last diagonal */
             ny[j] = cm[j] + (py[j] + T[T_GAP_OPEN_Y]);
-            t1[j] = cy[j] + (py[j] + T[T_GAP_EXTEND_Y]);
+            t3[j] = cy[j] + (py[j] + T[T_GAP_EXTEND_Y]);
         }
-        laddN<L>(ny, t1, cf);
+        ladd_issue<L>(pa, ny, t3, cf);
+        ladd_finish<L>(pb, nm);
 #pragma unroll
-        for (int j = 0; j < L; j++) t1[j] = (j ? qy[j ? j - 1 : 0] : rmy) + (pm[j] + T[T_MATCH_FROM_GAP_Y]);
-        laddN<L>(nm, t1, cf);
+        for (int j = 0; j < L; j++) t4[j] = (j ? qy[j ? j - 1 : 0] : rmy) + (pm[j] + T[T_MATCH_FROM_GAP_Y]);
+        ladd_issue<L>(pb, nm, t4, cf);
+        ladd_finish<L>(pa, ny);
+        if (SW) {
+#pragma unroll
+            for (int j = 0; j < L; j++) t1[j] = (j ? cy[j ? j - 1 : 0] : rly) + prm[j].a[9].x;
+            ladd_issue<L>(pa, nx, t1, cf);
+        }
+        ladd_finish<L>(pb, nm);
+        if (SW) ladd_finish<L>(pa, nx);
 #pragma unroll
         for (int j = 0; j < L; j++) {
-            store_cells3(mask[j], rowBase, voff[j], nm[j], pm[j], py[j]);
-            store_cells2(full ? mask[j] : 0ull, rowBase, voff[j], nx[j], ny[j]);
+            /* only cells of the band go to the ring (plain predicated stores: the compiler spreads them over the
+             * arithmetic; exec-masking them by hand in asm blocks at the end of the step cost a third of the sweep) */
+#ifndef WV_ABL_FSTORE
+            if (fl[j] != 0u) {
+                double *q = rowBase + j * WV_LAYER_DOUBLES;
+                d2 pr;
+                pr.x = nm[j]; pr.y = pm[j];
+                *(d2 *) (q + WV_OFF_FM(lane)) = pr;
+                q[WV_OFF_PY(lane)] = py[j];
+                if (full) {
+                    d2 gxy;
+                    gxy.x = nx[j]; gxy.y = ny[j];
+                    *(d2 *) (q + WV_OFF_FX(lane)) = gxy;
+                }
+            }
+#endif
         }
 #pragma unroll
         for (int j = 0; j < L; j++) { qm[j] = nm[j]; qx[j] = nx[j]; qy[j] = ny[j]; }
@@ -626,6 +682,9 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             stage_band_steps(sh.bits, bandTab, D, bitsHi + 1, hi);
             bitsHi = hi;
         }
+#ifdef WV_ABL_FFEED
+        if (db == d0 + 1)
+#endif
         {
             /* stage what this block of diagonals can ask for: the top cell's event index d - xmin - 1 and the
              * entering k-mer xmax + 1 each advance by at most one per diagonal */
@@ -688,40 +747,41 @@ struct Px {
     d2 a, b; /* (open, extend) (switch, emission) */
 };
 #if WV_L == 1
-#define WV_PX_BODY "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" 
-#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b)
-#define WV_MASK_OR "s_or_b64 %[k0], %[k0], %[m]\n\t" 
-#define WV_MASK_ANDN2 "s_andn2_b64 %[k0], %[k0], %[m]\n\t" 
-#define WV_MASK_OUTS [k0] "+s"(mask[0])
+#define WV_PX_BODY1 "ds_read_b128 %[a0], %[a]\n\t" 
+#define WV_PX_OUTS1 , [a0] "+v"(p[0].a)
+#define WV_PX_BODY2 "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" 
+#define WV_PX_OUTS2 , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b)
 #elif WV_L == 2
-#define WV_PX_BODY "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\tds_read_b128 %[b1], %[a] offset:16\n\t" "9:\n\t" 
-#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b)
-#define WV_MASK_OR "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_or_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_or_b64 %[k1], %[k1], %[m]\n9:\n\t" 
-#define WV_MASK_ANDN2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_andn2_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_andn2_b64 %[k1], %[k1], %[m]\n9:\n\t" 
-#define WV_MASK_OUTS [k0] "+s"(mask[0]), [k1] "+s"(mask[1])
+#define WV_PX_BODY1 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\t" "9:\n\t" 
+#define WV_PX_OUTS1 , [a0] "+v"(p[0].a), [b0] "+v"(p[1].a)
+#define WV_PX_BODY2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "9:\n\t" 
+#define WV_PX_OUTS2 , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b)
 #elif WV_L == 3
-#define WV_PX_BODY "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\tds_read_b128 %[b1], %[a] offset:16\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\tds_read_b128 %[c1], %[a] offset:16\n\t" "9:\n\t" 
-#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b), [c0] "+v"(p[2].a), [c1] "+v"(p[2].b)
-#define WV_MASK_OR "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_or_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_or_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_or_b64 %[k2], %[k2], %[m]\n9:\n\t" 
-#define WV_MASK_ANDN2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_andn2_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_andn2_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_andn2_b64 %[k2], %[k2], %[m]\n9:\n\t" 
-#define WV_MASK_OUTS [k0] "+s"(mask[0]), [k1] "+s"(mask[1]), [k2] "+s"(mask[2])
+#define WV_PX_BODY1 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\t" "9:\n\t" 
+#define WV_PX_OUTS1 , [a0] "+v"(p[0].a), [b0] "+v"(p[1].a), [c0] "+v"(p[2].a)
+#define WV_PX_BODY2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "s_branch 9f\n2:\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "9:\n\t" 
+#define WV_PX_OUTS2 , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b), [c0] "+v"(p[2].a), [c1] "+v"(p[2].b)
 #elif WV_L == 4
-#define WV_PX_BODY "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\tds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\tds_read_b128 %[b1], %[a] offset:16\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\tds_read_b128 %[c1], %[a] offset:16\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\tds_read_b128 %[d1], %[a] offset:16\n\t" "9:\n\t" 
-#define WV_PX_OUTS , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b), [c0] "+v"(p[2].a), [c1] "+v"(p[2].b), [d0] "+v"(p[3].a), [d1] "+v"(p[3].b)
-#define WV_MASK_OR "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_or_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_or_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\ts_or_b64 %[k2], %[k2], %[m]\n\ts_branch 9f\n3:\n\ts_or_b64 %[k3], %[k3], %[m]\n9:\n\t" 
-#define WV_MASK_ANDN2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\ts_andn2_b64 %[k0], %[k0], %[m]\n\ts_branch 9f\n1:\n\ts_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\ts_andn2_b64 %[k1], %[k1], %[m]\n\ts_branch 9f\n2:\n\ts_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\ts_andn2_b64 %[k2], %[k2], %[m]\n\ts_branch 9f\n3:\n\ts_andn2_b64 %[k3], %[k3], %[m]\n9:\n\t" 
-#define WV_MASK_OUTS [k0] "+s"(mask[0]), [k1] "+s"(mask[1]), [k2] "+s"(mask[2]), [k3] "+s"(mask[3])
+#define WV_PX_BODY1 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\t" "9:\n\t" 
+#define WV_PX_OUTS1 , [a0] "+v"(p[0].a), [b0] "+v"(p[1].a), [c0] "+v"(p[2].a), [d0] "+v"(p[3].a)
+#define WV_PX_BODY2 "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\t" "ds_read_b128 %[d1], %[a] offset:16\n\t" "9:\n\t" 
+#define WV_PX_OUTS2 , [a0] "+v"(p[0].a), [a1] "+v"(p[0].b), [b0] "+v"(p[1].a), [b1] "+v"(p[1].b), [c0] "+v"(p[2].a), [c1] "+v"(p[2].b), [d0] "+v"(p[3].a), [d1] "+v"(p[3].b)
 #endif
-/* lane-masked load of a gap-X row from LDS into ONE slot (lane laneMask, layer sel: run-time, wave-uniform) */
-__device__ __forceinline__ void px_install(Px (&p)[WV_L], unsigned rowAddr, unsigned long long laneMask, int sel) {
-    unsigned long long sv;
-    asm volatile("s_mov_b64 %[sv], exec\n\t"
-                 "s_mov_b64 exec, %[m]\n\t" WV_PX_BODY
-                 "s_mov_b64 exec, %[sv]\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : [sv] "=&s"(sv) WV_PX_OUTS
-                 : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel)
+/* lane-masked load of a gap-X row from LDS into ONE slot (lane laneMask, layer sel: run-time, wave-uniform); the
+ * row's second pair (switch sum, raw emission) only in the builds that use it */
+#define WV_PX_ASM(BODY, OUTS)                                                                                     \
+    unsigned long long sv;                                                                                       \
+    asm volatile("s_mov_b64 %[sv], exec\n\t"                                                                      \
+                 "s_mov_b64 exec, %[m]\n\t" BODY                                                                   \
+                 "s_mov_b64 exec, %[sv]\n\t"                                                                      \
+                 "s_waitcnt lgkmcnt(0)"                                                                            \
+                 : [sv] "=&s"(sv) OUTS                                                                             \
+                 : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel)                                             \
                  : "memory", "scc");
+template <bool SW> __device__ __forceinline__ void px_install(Px (&p)[WV_L], unsigned rowAddr, unsigned long long laneMask,
+                                                             int sel) {
+    if (SW) { WV_PX_ASM(WV_PX_BODY2, WV_PX_OUTS2) }
+    else { WV_PX_ASM(WV_PX_BODY1, WV_PX_OUTS1) }
 }
 /* mask[sel] |= bit / &= ~bit on the scalar unit, sel a run-time value */
 __device__ __forceinline__ void mask_set(unsigned long long (&mask)[WV_L], unsigned long long bit, int sel) {
@@ -762,9 +822,7 @@ struct BwdShared {
     double coef[64];
     double pxr[(WV_PXN + 1) * 4]; /* gap-X rows by column mod WV_PXN; row WV_PXN = -inf */
     unsigned bits[2][WV_BITWORDS];
-    double vbuf[64];
-    int part[64];
-    int scan, carry;
+    int rec[128][8]; /* phase T0: a refresh's diagonal, its band and the bands of its neighbours */
 };
 
 /* hits of a diagonal in slots before slot s (s = 0..P), from its per-layer lane masks */
@@ -788,30 +846,25 @@ __device__ __forceinline__ int rank_in_diagonal(const unsigned long long (&m)[WV
 }
 
 /*
- * Backward sweep + posterior decode of one traceback window (:921-992), in three phases:
- *  S  the sweep back: one anti-diagonal per iteration, cells and messages in registers; it collects the
- *     decode candidates and, on the diagonals where the reference refreshes totalProbability, the per-cell
- *     terms of that sum (HBM scratch);
- *  T  totalProbability (:736-754) for every refresh of the window at once: the reference's order-dependent
- *     logAdd fold is inherently serial, so each THREAD folds one diagonal's terms privately, in the
- *     reference's order;
- *  D  diagonalCalculationPosteriorMatchProbs (:756-795) from the candidate lists: hits are marked per
- *     diagonal, prefix-summed in emission order (diagonals descending, x-y ascending) and written.
- * A window whose candidates cannot be trusted (the totals stray from the sweep's estimate, a list overflows,
- * threshold 0) is swept once more with the exact totals in hand and decoded in the loop.
+ * The sweep back of one traceback window (:921-992): one anti-diagonal per iteration, cells and messages in
+ * registers.  It collects the decode candidates -- cells whose F.match + B.match lies within WV_CAND_SLACK of the
+ * posterior threshold measured against the forward kernel's estimate of the window's totalProbability -- and, on
+ * the diagonals where the reference refreshes totalProbability, parks the backward operands of that sum in HBM
+ * scratch.  The totals and the decode are the post kernel's (cpecan_k_wv_post); a window whose candidates cannot
+ * be trusted is swept once more (WV_KIND_REDO) with the exact totals in hand and decoded in the loop.
  * The device selects pairs by the exponent (F+B)-total >= log(threshold) - margin; exp(), the exact
  * threshold test and floor(p * 1e7) (:776-786) are finished on the host with the reference's libm
  * (cpecan_hip.hip), so the integer posteriors are the reference's to the bit.
  */
-#define WV_KIND_POSTERIOR 0 /* sweep, collect decode candidates, totals, decode */
+#define WV_KIND_POSTERIOR 0 /* sweep, collect decode candidates */
 #define WV_KIND_REDO 1      /* sweep once more with the exact totals in hand, pairs leave in the loop */
-#define WV_KIND_EXPECT 2    /* sweep, park the backward cells for the expectation kernel, totals */
+#define WV_KIND_EXPECT 2    /* sweep, park the backward cells for the expectation kernel */
 template <bool SW, int KIND>
 __device__ void backward_window(const DevItem &it, const DevParams &P, const int2 *__restrict__ bandTab,
                                 const double *__restrict__ track, const double *__restrict__ model,
                                 double *ring, int ringD, const WvWindow &win, ItemOut &out, BwdShared &sh,
-                                int *offBuf, WinTotal *wtot, double *vw, double *rf, unsigned long long *msk,
-                                int2 *candKx, double *candFb, double *bring, bool &redo) {
+                                WinTotal *wtot, double *vw, double *rf, int2 *candKx, double *candFb, double *bring,
+                                int &nTotOut, int &nCandOut) {
     constexpr int L = WV_L;
     const int lane = threadIdx.x & 63;
     const int D = (int) (it.lX + it.lY);
@@ -825,14 +878,15 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
     const int dTop = uni(win.top), tracedBackFrom = uni(win.from), tracedBackTo = uni(win.to);
     const bool atEnd = uni(win.atEnd) != 0;
     const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
-    const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
     const int candCap = WV_CAND_PER_DIAG * WV_L * ringD;
     if (lane < 4) sh.pxr[WV_PXN * 4 + lane] = CP_NEG_INF;
-    if (lane == 0) sh.scan = (P.scanDecode != 0 || !(P.logThrSlack > CP_NEG_INF)) ? 1 : 0;
 
-    unsigned voff[L];
+    unsigned voffA[L], voffB[L]; /* byte offsets of this lane's (Fm, pm) pair and of its py inside a ring row */
 #pragma unroll
-    for (int j = 0; j < L; j++) voff[j] = (unsigned) (j * WV_LAYER_BYTES + lane * 8);
+    for (int j = 0; j < L; j++) {
+        voffA[j] = (unsigned) ((j * WV_LAYER_DOUBLES + WV_OFF_FM(lane)) * 8);
+        voffB[j] = (unsigned) ((j * WV_LAYER_DOUBLES + WV_OFF_PY(lane)) * 8);
+    }
     const unsigned dummyOff = (unsigned) ((long long) ringD * WV_ROW_DOUBLES * 8);
     int nTotWin = 0, nCand = 0;
     /* the forward kernel's estimate of this window's totalProbability steers the candidate test; phase T checks
@@ -842,6 +896,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
 
     /* ------------------------------ phase S: the sweep back ------------------------------ */
     {
+#ifdef WV_ABL_PRIOB
+        __builtin_amdgcn_s_setprio(2);
+#endif
         int bxmin, bxmax; /* band of the diagonal being computed */
         band_load(bandTab, dTop, bxmin, bxmax);
         /* the circular bit strings hold 8192 diagonals: longer windows are staged 4096 diagonals (whole words) at a time */
@@ -940,22 +997,27 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             const unsigned rowOff = (unsigned) ((long long) (tau & ringMask) * (WV_ROW_DOUBLES * 8));
 #pragma unroll
             for (int j = 0; j < L; j++) {
+#ifdef WV_ABL_BLOAD
+                r.m[j] = live && tau == -5 ? fm[j] : 0ull;
+#else
                 r.m[j] = live ? fm[j] : 0ull;
-                unsigned off;
-                const unsigned real = rowOff + voff[j], dummy = dummyOff + voff[j];
-                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(off) : "v"(dummy), "v"(real), "s"(r.m[j]));
-                const double *p = (const double *) ((const char *) ring + off);
-                q.f[j] = p[0];
-                q.pm[j] = p[3 * 64];
-                q.py[j] = p[4 * 64];
+#endif
+                unsigned offA, offB;
+                const unsigned realA = rowOff + voffA[j], dummyA = dummyOff + voffA[j];
+                const unsigned realB = rowOff + voffB[j], dummyB = dummyOff + voffB[j];
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(offA) : "v"(dummyA), "v"(realA), "s"(r.m[j]));
+                asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(offB) : "v"(dummyB), "v"(realB), "s"(r.m[j]));
+                const d2 fp = *(const d2 *) ((const char *) ring + offA);
+                q.f[j] = fp.x;
+                q.pm[j] = fp.y;
+                q.py[j] = *(const double *) ((const char *) ring + offB);
             }
         };
 
-        Rec r0, r1, r2;
-        Q q0, q1, q2;
+        Rec r0, r1;
+        Q q0, q1;
         fetch(dTop, r0, q0);
         fetch(dTop - 1, r1, q1);
-        fetch(dTop - 2, r2, q2);
 
         int nxmin = bxmin, nxmax = bxmax; /* band of t+1 */
         int calcs = 0;
@@ -989,19 +1051,26 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                     bx[j] = sB + (sP + T[T_MATCH_FROM_GAP_X]);
                     by[j] = sB + (sP + T[T_MATCH_FROM_GAP_Y]);
                 }
-                laddN<L>(bm, Um, cf);
-                laddN<L>(by, Uy, cf);
-#pragma unroll
-                for (int j = 0; j < L; j++) y1[j] = sBx[j] + (j < L - 1 ? px[j < L - 1 ? j + 1 : 0].a.x : rpo);
-                laddN<L>(bm, y1, cf);
+                double y2[L];
+                LaddPending<L> pa, pb;
+                ladd_issue<L>(pa, bm, Um, cf);
+                ladd_issue<L>(pb, by, Uy, cf);
 #pragma unroll
                 for (int j = 0; j < L; j++) y1[j] = sBx[j] + (j < L - 1 ? px[j < L - 1 ? j + 1 : 0].a.y : rpe);
-                laddN<L>(bx, y1, cf);
+                ladd_finish<L>(pa, bm);
+                ladd_issue<L>(pa, bx, y1, cf);
+#pragma unroll
+                for (int j = 0; j < L; j++) y2[j] = sBx[j] + (j < L - 1 ? px[j < L - 1 ? j + 1 : 0].a.x : rpo);
+                ladd_finish<L>(pb, by);
+                ladd_issue<L>(pb, bm, y2, cf);
+                ladd_finish<L>(pa, bx);
                 if (SW) {
 #pragma unroll
                     for (int j = 0; j < L; j++) y1[j] = sBx[j] + (j < L - 1 ? px[j < L - 1 ? j + 1 : 0].b.x : rps);
-                    laddN<L>(by, y1, cf);
+                    ladd_issue<L>(pa, by, y1, cf);
                 }
+                ladd_finish<L>(pb, bm);
+                if (SW) ladd_finish<L>(pa, by);
 #pragma unroll
                 for (int j = 0; j < L; j++) {
                     hB[j] = Bm[j]; hP[j] = pm1[j];
@@ -1013,11 +1082,11 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 if (ev != 0u) {
                     bool touch0 = false;
                     if (ev & 1u) {
-                        px_install(px, pxPark, 1ull << ((ev >> 2) & 63u), (int) ((ev >> 8) & 3u));
+                        px_install<SW>(px, pxPark, 1ull << ((ev >> 2) & 63u), (int) ((ev >> 8) & 3u));
                         touch0 = ((ev >> 8) & 3u) == 0u;
                     }
                     if (ev & 2u) {
-                        px_install(px, pxAddr + ((ev >> 18) & 63u) * 32u, 1ull << ((ev >> 10) & 63u), (int) ((ev >> 16) & 3u));
+                        px_install<SW>(px, pxAddr + ((ev >> 18) & 63u) * 32u, 1ull << ((ev >> 10) & 63u), (int) ((ev >> 16) & 3u));
                         touch0 = touch0 || ((ev >> 16) & 3u) == 0u;
                     }
                     if (touch0) {
@@ -1131,7 +1200,11 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
         int t = dTop;
 #pragma unroll 1
         for (;;) {
+#ifdef WV_ABL_BFEED
+            if (t == dTop) {
+#else
             if ((dTop - t) % 30 == 0) {
+#endif
                 /* gap-X rows of the k-mers that can enter during the next 30 diagonals */
                 for (int i = lane; i < 32 * 4; i += 64) {
                     const int x = bxmin - 1 - (i >> 2);
@@ -1147,188 +1220,101 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             step(t, r0, q0); t--;
             if (t <= tracedBackTo) break;
             step(t, r1, q1); t--;
-            if (t <= tracedBackTo) break;
-            step(t, r2, q2); t--;
         }
         if (KIND == WV_KIND_REDO) out.nPairs += emitted;
     }
+    nTotOut = nTotWin;
+    nCandOut = nCand;
     if (KIND == WV_KIND_REDO) return;
-    if (nCand > candCap && lane == 0) sh.scan = 1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the parked operands in scratch are read back below */
 
     /* -------------------- phase T0: the per-cell terms of every refresh -------------------- */
     /* diagonalCalculationTotalProbability (:736-754): v = cell_dotProduct(forward[t], backward[t]) (:391-397) and
      * w = matches stepping over t: forward[t-1] --match--> the cells of t+1, dotted with backward[t+1] (only the
-     * match state of that clone is ever above -inf).  Lanes keep the sweep's slots; a refresh's loads are all
-     * issued before its arithmetic. */
+     * match state of that clone is ever above -inf).  Lanes keep the sweep's slots.  Nothing here depends on the
+     * refresh before: the records of all refreshes go to LDS first, and a refresh's operands are fetched while the
+     * one before is being worked on. */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the parked operands are read back below (same wave: the
+                                                                   stores only have to have left; an agent-scope fence would
+                                                                   write back the whole L2, the forward kernel's ring included) */
+    struct Ops {
+        double fm, fx, fy, s0, s1, s2, bm, bx, by, hb, hp;
+    };
 #pragma unroll 1
-    for (int n = 0; n < nTotWin; n++) {
-        const WinTotal w = wtot[n];
-        const int t = uni(w.t), xmn = uni(w.xmin), xmx = uni(w.xmax), nmn = uni(w.nxmin), nmx = uni(w.nxmax);
-        const bool second = uni(w.second) != 0;
-        int pxmin, pxmax;
-        band_load(bandTab, t - 1, pxmin, pxmax);
-        const int sMin = xmn % WV_P, sMinN = nmn % WV_P;
-        const double *rowT = ring + (long long) (t & ringMask) * WV_ROW_DOUBLES;
-        const double *rowB = ring + (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
-        const double *src = rf + (long long) n * (5 * WV_P) + lane;
-        double fmv[L], fx[L], fy[L], s0[L], s1[L], s2[L], bm[L], bx[L], by[L], hb[L], hp[L];
-        bool tv[L], nv[L];
-#pragma unroll
-        for (int j = 0; j < L; j++) {
-            const int sl = lane * L + j;
+    for (int base = 0; base < nTotWin; base += 128) {
+        const int cnt = nTotWin - base < 128 ? nTotWin - base : 128;
+        for (int i = lane; i < cnt; i += 64) {
+            const WinTotal *w = wtot + base + i;
+            const int t = ld_agent(&w->t);
+            const int2 b = bandTab[t - 1 > 0 ? t - 1 : 0];
+            sh.rec[i][0] = t; sh.rec[i][1] = ld_agent(&w->xmin); sh.rec[i][2] = ld_agent(&w->xmax);
+            sh.rec[i][3] = ld_agent(&w->nxmin); sh.rec[i][4] = ld_agent(&w->nxmax); sh.rec[i][5] = ld_agent(&w->second);
+            sh.rec[i][6] = b.x; sh.rec[i][7] = b.y;
+        }
+        auto flags = [&](const int i, const int j, bool &tv, bool &nv, bool &below) __attribute__((always_inline)) {
+            const int xmn = uni(sh.rec[i][1]), xmx = uni(sh.rec[i][2]), nmn = uni(sh.rec[i][3]), nmx = uni(sh.rec[i][4]);
+            const bool second = uni(sh.rec[i][5]) != 0;
+            const int pxmin = uni(sh.rec[i][6]), pxmax = uni(sh.rec[i][7]);
+            const int sl = lane * L + j, sMin = xmn % WV_P, sMinN = nmn % WV_P;
             const int xT = xmn + (sl - sMin + (sl < sMin ? WV_P : 0));   /* this slot's k-mer on t ... */
             const int xN = nmn + (sl - sMinN + (sl < sMinN ? WV_P : 0)); /* ... and on t+1 */
-            tv[j] = xT <= xmx;
-            nv[j] = second && xN <= nmx;
-            const bool below = nv[j] && xN - 1 >= pxmin && xN - 1 <= pxmax;
-            const int sb = sl == 0 ? WV_P - 1 : sl - 1; /* the slot of k-mer xN - 1 */
-            const double *pa = rowT + (tv[j] ? j * (WV_RING_VALUES * 64) + lane : 0);
-            const double *pb = rowB + (below ? (sb % L) * (WV_RING_VALUES * 64) + sb / L : 0);
-            fmv[j] = pa[0]; fx[j] = pa[64]; fy[j] = pa[128];
-            s0[j] = pb[0]; s1[j] = pb[64]; s2[j] = pb[128];
-            bm[j] = ld_agent(src + (0 * L + j) * 64);
-            bx[j] = ld_agent(src + (1 * L + j) * 64);
-            by[j] = ld_agent(src + (2 * L + j) * 64);
-            hb[j] = ld_agent(src + (3 * L + j) * 64);
-            hp[j] = ld_agent(src + (4 * L + j) * 64);
-            if (!below) s0[j] = s1[j] = s2[j] = CP_NEG_INF;
-        }
+            tv = xT <= xmx;
+            nv = second && xN <= nmx;
+            below = nv && xN - 1 >= pxmin && xN - 1 <= pxmax;
+        };
+        auto issue = [&](const int i, Ops (&o)[L]) __attribute__((always_inline)) {
+            const int t = uni(sh.rec[i][0]);
+            const double *rowT = ring + (long long) (t & ringMask) * WV_ROW_DOUBLES;
+            const double *rowB = ring + (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
+            const double *src = rf + (long long) (base + i) * (5 * WV_P) + lane;
 #pragma unroll
-        for (int j = 0; j < L; j++) {
-            if (tv[j]) {
-                double v = fmv[j] + bm[j];
-                v = ladd(v, fx[j] + bx[j], cf);
-                v = ladd(v, fy[j] + by[j], cf);
-                vw[((long long) n * 2 + 0) * WV_P + lane * L + j] = v;
+            for (int j = 0; j < L; j++) {
+                bool tv, nv, below;
+                flags(i, j, tv, nv, below);
+                const int sl = lane * L + j, sb = sl == 0 ? WV_P - 1 : sl - 1; /* the slot of the k-mer below */
+                const double *pa = rowT + (tv ? j : 0) * WV_LAYER_DOUBLES;
+                const double *pb = rowB + (below ? sb % L : 0) * WV_LAYER_DOUBLES;
+                const int la = tv ? lane : 0, lb = below ? sb / L : 0;
+                o[j].fm = pa[WV_OFF_FM(la)]; o[j].fx = pa[WV_OFF_FX(la)]; o[j].fy = pa[WV_OFF_FY(la)];
+                o[j].s0 = pb[WV_OFF_FM(lb)]; o[j].s1 = pb[WV_OFF_FX(lb)]; o[j].s2 = pb[WV_OFF_FY(lb)];
+                /* (plain loads: these lines were written by this wave, behind a release fence, and never read before) */
+                o[j].bm = src[(0 * L + j) * 64];
+                o[j].bx = src[(1 * L + j) * 64];
+                o[j].by = src[(2 * L + j) * 64];
+                o[j].hb = src[(3 * L + j) * 64];
+                o[j].hp = src[(4 * L + j) * 64];
             }
-            if (nv[j]) {
-                double mm = s0[j] + (hp[j] + T[T_MATCH_CONTINUE]);
-                mm = ladd(mm, s1[j] + (hp[j] + T[T_MATCH_FROM_GAP_X]), cf);
-                mm = ladd(mm, s2[j] + (hp[j] + T[T_MATCH_FROM_GAP_Y]), cf);
-                vw[((long long) n * 2 + 1) * WV_P + lane * L + j] = mm + hb[j];
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-
-    /* ------------------------------ phase T: the totals ------------------------------ */
-#pragma unroll 1
-    for (int k0 = 0; k0 < 2 * nTotWin; k0 += 64) {
-        const int k = k0 + lane;
-        double acc = CP_NEG_INF;
-        WinTotal w;
-        w.second = 0; w.t = 0; w.xmin = w.xmax = w.nxmin = w.nxmax = 0;
-        const int f = k & 1;
-        if (k < 2 * nTotWin) {
-            w = wtot[k >> 1];
-            if (f == 0 || w.second) {
-                const int lo = f ? w.nxmin : w.xmin, hi = f ? w.nxmax : w.xmax;
-                const double *src = vw + ((long long) (k >> 1) * 2 + f) * WV_P;
-                double v[8], nv[8]; /* the next eight terms are in flight while these eight are folded */
+        };
+        auto work = [&](const int i, const Ops (&o)[L]) __attribute__((always_inline)) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = lo + j <= hi ? ld_agent(src + (lo + j) % WV_P) : CP_NEG_INF;
-#pragma unroll 1
-                for (int x0 = lo; x0 <= hi; x0 += 8) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++)
-                        nv[j] = x0 + 8 + j <= hi ? ld_agent(src + (x0 + 8 + j) % WV_P) : CP_NEG_INF;
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc = ladd(acc, v[j], cf); /* dpDiagonal_dotProduct :587-597 */
-#pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = nv[j];
+            for (int j = 0; j < L; j++) {
+                bool tv, nv, below;
+                flags(i, j, tv, nv, below);
+                if (tv) {
+                    double v = o[j].fm + o[j].bm;
+                    v = ladd(v, o[j].fx + o[j].bx, cf);
+                    v = ladd(v, o[j].fy + o[j].by, cf);
+                    vw[((long long) (base + i) * 2 + 0) * WV_P + lane * L + j] = v;
+                }
+                if (nv) {
+                    const double s0 = below ? o[j].s0 : CP_NEG_INF, s1 = below ? o[j].s1 : CP_NEG_INF,
+                                 s2 = below ? o[j].s2 : CP_NEG_INF;
+                    double mm = s0 + (o[j].hp + T[T_MATCH_CONTINUE]);
+                    mm = ladd(mm, s1 + (o[j].hp + T[T_MATCH_FROM_GAP_X]), cf);
+                    mm = ladd(mm, s2 + (o[j].hp + T[T_MATCH_FROM_GAP_Y]), cf);
+                    vw[((long long) (base + i) * 2 + 1) * WV_P + lane * L + j] = mm + o[j].hb;
                 }
             }
-        }
-        sh.vbuf[lane] = acc;
-        __builtin_amdgcn_wave_barrier();
-        const double partner = sh.vbuf[(lane + 1) & 63];
-        if (k < 2 * nTotWin && f == 0) {
-            double tot = acc;
-            if (w.second) tot = ladd(acc, partner, cf);
-            wtot[k >> 1].total = tot;
-            if (!(fabs(tot - totEst) <= WV_CAND_SLACK)) sh.scan = 1; /* also catches NaN and infinities */
-            const long long o = out.nTot + (k >> 1);
-            if (o < out.totCap) {
-                out.totXay[o] = w.t;
-                out.totVal[o] = tot;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    out.nTot += nTotWin;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* the totals are read back by the decode / the second sweep */
-    if (KIND == WV_KIND_EXPECT || nPost <= 0) return;
-    if (uni(sh.scan) != 0) {
-        redo = true; /* the candidates cannot be trusted: the re-sweep kernel decodes this window */
-        return;
-    }
-
-    /* ------------------------------ phase D: the aligned pairs ------------------------------ */
-    for (int i = lane; i < nPost * 4; i += 64) msk[i] = 0ull;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    for (int pass = 0; pass < 2; pass++) {
+        };
+        Ops oa[L], ob[L];
+        issue(0, oa);
 #pragma unroll 1
-        for (int i = lane; i < nCand; i += 64) {
-            const int2 kx = ld_agent(candKx + i);
-            const int k = kx.x, x = kx.y, t = tPost0 - k;
-            const double ee = ld_agent(candFb + i) - ld_agent(&wtot[k / 10].total);
-            if (!(x >= 1 && x <= t - 1 && ee >= P.logThrSlack)) continue;
-            const int sl = x % WV_P;
-            if (!pass) {
-                atomicOr(msk + k * 4ll + sl % L, 1ull << (sl / L));
-                continue;
-            }
-            unsigned long long mm[L];
-#pragma unroll
-            for (int j = 0; j < L; j++) mm[j] = ld_agent(msk + k * 4ll + j);
-            const int rank = rank_in_diagonal(mm, bandTab[t].x % WV_P, sl);
-            const long long idx = out.nPairs + ld_agent(offBuf + k) + rank;
-            if (idx < out.pairCap) {
-                long long *o = out.pairs + idx * 3;
-                o[0] = 0;
-                o[1] = x - 1;
-                o[2] = t - x - 1;
-                out.logp[idx] = ee;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
-        if (!pass) {
-            /* hits per diagonal from the masks; exclusive prefix in emission order */
-            int carry = 0;
-#pragma unroll 1
-            for (int base = 0; base < nPost; base += 8 * 64) {
-                const int b0 = base + lane * 8;
-                int h[8], sum = 0;
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    h[j] = 0;
-                    if (b0 + j < nPost) {
-#pragma unroll
-                        for (int q = 0; q < L; q++) h[j] += __popcll(ld_agent(msk + (b0 + j) * 4ll + q));
-                    }
-                    sum += h[j];
-                }
-                int inc = sum;
-#pragma unroll
-                for (int o2 = 1; o2 < 64; o2 <<= 1) {
-                    const int up = __shfl_up(inc, o2);
-                    if (lane >= o2) inc += up;
-                }
-                int o = carry + inc - sum;
-                carry += __builtin_amdgcn_readlane(inc, 63);
-#pragma unroll
-                for (int j = 0; j < 8; j++)
-                    if (b0 + j < nPost) {
-                        offBuf[b0 + j] = o;
-                        o += h[j];
-                    }
-            }
-            if (lane == 0) sh.carry = carry;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        for (int i = 0; i < cnt; i += 2) {
+            if (i + 1 < cnt) issue(i + 1, ob);
+            work(i, oa);
+            if (i + 2 < cnt) issue(i + 2, oa);
+            if (i + 1 < cnt) work(i + 1, ob);
         }
     }
-    out.nPairs += uni(sh.carry);
 }
 
 } // namespace
@@ -1341,8 +1327,9 @@ template <bool SW> __device__ __forceinline__ void wv_forward_kernel(
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
     const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD,
-    WvState *states, int window, FwdShared &sh) {
-    const long long idx = blockIdx.x;
+    WvState *states, int window, FwdShared (&shs)[WV_WPB]) {
+    const long long idx = (long long) blockIdx.x * WV_WPB + uni(threadIdx.x >> 6);
+    FwdShared &sh = shs[uni(threadIdx.x >> 6)];
     if (idx >= nItems) return;
     WvState *state = states + idx;
     const DevItem it = uniform_item(items[idx]);
@@ -1352,43 +1339,42 @@ template <bool SW> __device__ __forceinline__ void wv_forward_kernel(
                        models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, state, window,
                        sh);
 }
-extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_forward)(
+extern "C" __global__ __launch_bounds__(64 * WV_WPB) void WV_SYM(cpecan_k_wv_forward)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
     const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, WvState *states, int window) {
-    __shared__ FwdShared sh;
+    __shared__ FwdShared sh[WV_WPB];
     wv_forward_kernel<false>(items, nItems, P, bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
                              states, window, sh);
 }
-extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_forward_sw)(
+extern "C" __global__ __launch_bounds__(64 * WV_WPB) void WV_SYM(cpecan_k_wv_forward_sw)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ events,
     const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, WvState *states, int window) {
-    __shared__ FwdShared sh;
+    __shared__ FwdShared sh[WV_WPB];
     wv_forward_kernel<true>(items, nItems, P, bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
                             states, window, sh);
 }
 
-/* One wave per alignment: backward sweep + posterior decode of the window just described.  win[].valid: 1 = the
- * forward kernel has described the window, 2 = swept, but its candidates could not be trusted: the re-sweep kernel
- * (launched after every backward kernel; it returns at once otherwise) decodes it, 0 = done. */
+/* One wave per alignment: the sweep back of the window the forward kernel just described (win[].valid: see
+ * cpecan_sweep.h).  What follows the sweep -- the refresh terms, the totals, the decode -- is the post kernel's. */
 template <bool SW, int KIND> __device__ __forceinline__ void wv_backward_kernel(
     const DevItem *__restrict__ items, long long nItems, const DevParams &P,
     const int2 *__restrict__ bandTab, const double *__restrict__ track,
     const long long *__restrict__ trackBase, const double *__restrict__ models, double *Fring,
     long long ringDoubles, int ringD, WvState *states, long long *pairs, double *pairLogp,
-    long long *totXay, double *totVal, char *scratch, long long scratchBytes, double *Bring, int window,
-    BwdShared &sh) {
-    const long long idx = blockIdx.x;
+    char *scratch, long long scratchBytes, double *Bring, int window, BwdShared (&shs)[WV_WPB]) {
+    const long long idx = (long long) blockIdx.x * WV_WPB + uni(threadIdx.x >> 6);
+    BwdShared &sh = shs[uni(threadIdx.x >> 6)];
     if (idx >= nItems) return;
     WvState *state = states + idx;
     WvWindow win;
     {
         const WvWindow *w = &state->win[window & 1];
         win.valid = ld_agent(&w->valid); win.top = ld_agent(&w->top); win.from = ld_agent(&w->from);
-        win.to = ld_agent(&w->to); win.atEnd = ld_agent(&w->atEnd); win.pad = 0;
+        win.to = ld_agent(&w->to); win.atEnd = ld_agent(&w->atEnd); win.nCand = win.nRefresh = win.pad = 0;
         win.est = ld_agent(&w->est);
     }
     if (uni(win.valid) != (KIND == WV_KIND_REDO ? 2 : 1)) return;
@@ -1398,43 +1384,45 @@ template <bool SW, int KIND> __device__ __forceinline__ void wv_backward_kernel(
     out.pairs = pairs + it.pairBase * 3;
     out.logp = pairLogp + it.pairBase;
     out.pairCap = it.pairCap;
-    out.totXay = totXay + it.totBase;
-    out.totVal = totVal + it.totBase;
-    out.totCap = it.totCap;
+    out.totXay = nullptr;
+    out.totVal = nullptr;
+    out.totCap = 0;
     out.nPairs = uni64(ld_agent(&state->nPairs));
-    out.nTot = uni64(ld_agent(&state->nTot));
+    out.nTot = 0;
     char *sc = scratch + idx * scratchBytes;
     const long long nW = (long long) ringD / 10 + 8;
-    int *offBuf = (int *) sc;
     WinTotal *wtot = (WinTotal *) (sc + 2ll * ringD * sizeof(int));
     double *vw = (double *) (sc + 2ll * ringD * sizeof(int) + nW * sizeof(WinTotal));
     double *rf = vw + nW * 2 * WV_P;
     unsigned long long *msk = (unsigned long long *) (rf + nW * 5 * WV_P);
     int2 *candKx = (int2 *) ((char *) msk + 4ll * ringD * sizeof(unsigned long long));
     double *candFb = (double *) ((char *) candKx + (long long) WV_L * WV_CAND_PER_DIAG * ringD * sizeof(int2));
-    bool redo = false;
+    int nTot = 0, nCand = 0;
     backward_window<SW, KIND>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW,
                               models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, win,
-                              out, sh, offBuf, wtot, vw, rf, msk, candKx, candFb,
-                              Bring ? Bring + idx * ((long long) ringD * WV_L * 3 * 64) : nullptr, redo);
-    if (threadIdx.x == 0) {
-        state->nPairs = out.nPairs;
-        state->nTot = out.nTot;
-        state->win[window & 1].valid = redo ? 2 : 0;
-        if (KIND == WV_KIND_EXPECT) state->expectPending = window + 1; /* which launch's window the B ring holds */
+                              out, sh, wtot, vw, rf, candKx, candFb,
+                              Bring ? Bring + idx * ((long long) ringD * WV_L * 3 * 64) : nullptr, nTot, nCand);
+    if ((threadIdx.x & 63) == 0) {
+        WvWindow *w = &state->win[window & 1];
+        if (KIND == WV_KIND_REDO) {
+            state->nPairs = out.nPairs;
+            w->valid = 0;
+        } else {
+            w->nCand = nCand;
+            w->nRefresh = nTot;
+            w->valid = 3;
+        }
     }
 }
 #define WV_BACKWARD_KERNEL(name, SW, KIND)                                                                        \
-    extern "C" __global__ __launch_bounds__(64) void WV_SYM(name)(                                                \
+    extern "C" __global__ __launch_bounds__(64 * WV_WPB) void WV_SYM(name)(                                       \
         const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,       \
         const double *__restrict__ track, const long long *__restrict__ trackBase,                                \
         const double *__restrict__ models, double *Fring, long long ringDoubles, int ringD, WvState *states,      \
-        long long *pairs, double *pairLogp, long long *totXay, double *totVal, char *scratch,                     \
-        long long scratchBytes, double *Bring, int window) {                                                      \
-        __shared__ BwdShared sh;                                                                                  \
+        long long *pairs, double *pairLogp, char *scratch, long long scratchBytes, double *Bring, int window) {   \
+        __shared__ BwdShared sh[WV_WPB];                                                                          \
         wv_backward_kernel<SW, KIND>(items, nItems, P, bandTab, track, trackBase, models, Fring, ringDoubles,     \
-                                     ringD, states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes,       \
-                                     Bring, window, sh);                                                          \
+                                     ringD, states, pairs, pairLogp, scratch, scratchBytes, Bring, window, sh);   \
     }
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward, false, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_sw, true, WV_KIND_POSTERIOR)
@@ -1442,6 +1430,200 @@ WV_BACKWARD_KERNEL(cpecan_k_wv_resweep, false, WV_KIND_REDO)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep_sw, true, WV_KIND_REDO)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em, false, WV_KIND_EXPECT)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em_sw, true, WV_KIND_EXPECT)
+
+/*
+ * What follows a sweep back, one 256-thread workgroup per alignment (none of it is a recurrence along the
+ * diagonals, so it is spread over four waves and over many resident workgroups instead of waiting inside the
+ * sweep's single wave):
+ *  T  the totals of the window's totalProbability refreshes (their per-cell terms were formed by the sweep's wave,
+ *     phase T0): the reference's order-dependent logAdd fold is inherently serial, so each THREAD folds one
+ *     diagonal's terms privately, in the reference's order (dpDiagonal_dotProduct :587-597);
+ *  D  diagonalCalculationPosteriorMatchProbs (:756-795) from the sweep's candidate list: hits are marked per
+ *     diagonal, prefix-summed in emission order (diagonals descending, x-y ascending) and written.  A window
+ *     whose candidates cannot be trusted (a total strays from the forward kernel's estimate, the list overflowed,
+ *     threshold 0) is left to the re-sweep kernel.
+ */
+struct PostShared {
+    double coef[64];
+    double vbuf[256];
+    int part[4];
+    int scan, carry;
+};
+extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
+    const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTabAll,
+    const double *__restrict__ models, const double *Fring, long long ringDoubles, int ringD, WvState *states,
+    long long *pairs, double *pairLogp, long long *totXay, double *totVal, char *scratch, long long scratchBytes,
+    int window) {
+    constexpr int L = WV_L;
+    __shared__ PostShared sh;
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    WvState *state = states + idx;
+    WvWindow *wp = &state->win[window & 1];
+    if (uni(ld_agent(&wp->valid)) != 3) return;
+    const DevItem it = uniform_item(items[idx]);
+    const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
+    if (tid < 64) init_coef(sh.coef);
+    const int dTop = uni(ld_agent(&wp->top)), tracedBackFrom = uni(ld_agent(&wp->from)), tracedBackTo = uni(ld_agent(&wp->to));
+    const int nTotWin = uni(ld_agent(&wp->nRefresh)), nCand = uni(ld_agent(&wp->nCand));
+    const double totEst = uni64_d(ld_agent(&wp->est));
+    const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
+    const int nPost = tPost0 - tracedBackTo;                         /* diagonals decoded      */
+    const int candCap = WV_CAND_PER_DIAG * WV_L * ringD;
+    if (tid == 0) sh.scan = (P.scanDecode != 0 || !(P.logThrSlack > CP_NEG_INF) || nCand > candCap) ? 1 : 0;
+    __syncthreads();
+    const unsigned cf = lds_addr(sh.coef);
+    const int2 *bandTab = bandTabAll + it.diagBase;
+    (void) models; (void) Fring; (void) ringDoubles;
+    char *sc = scratch + idx * scratchBytes;
+    const long long nW = (long long) ringD / 10 + 8;
+    int *offBuf = (int *) sc;
+    WinTotal *wtot = (WinTotal *) (sc + 2ll * ringD * sizeof(int));
+    double *vw = (double *) (sc + 2ll * ringD * sizeof(int) + nW * sizeof(WinTotal));
+    const double *rf = vw + nW * 2 * WV_P;
+    unsigned long long *msk = (unsigned long long *) (rf + nW * 5 * WV_P);
+    const int2 *candKx = (const int2 *) ((char *) msk + 4ll * ringD * sizeof(unsigned long long));
+    const double *candFb = (const double *) ((const char *) candKx + (long long) WV_L * WV_CAND_PER_DIAG * ringD * sizeof(int2));
+    long long nPairs0 = uni64(ld_agent(&state->nPairs)), nTot0 = uni64(ld_agent(&state->nTot));
+
+    /* ------------------------------ phase T: the totals ------------------------------ */
+    /* (plain loads throughout: what this kernel reads was written by an earlier kernel, or by this workgroup
+     * before a __syncthreads(); atomic loads would each be waited for on their own) */
+#pragma unroll 1
+    for (int k0 = 0; k0 < 2 * nTotWin; k0 += 256) {
+        const int k = k0 + tid;
+        double acc = CP_NEG_INF;
+        WinTotal w;
+        w.second = 0; w.t = 0; w.xmin = w.xmax = w.nxmin = w.nxmax = 0;
+        const int f = k & 1;
+        if (k < 2 * nTotWin) {
+            w = wtot[k >> 1];
+            if (f == 0 || w.second) {
+                const int lo = f ? w.nxmin : w.xmin, hi = f ? w.nxmax : w.xmax;
+                const double *src = vw + ((long long) (k >> 1) * 2 + f) * WV_P;
+                double v[8], nv[8]; /* the next eight terms are in flight while these eight are folded */
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = lo + q <= hi ? src[(lo + q) % WV_P] : CP_NEG_INF;
+#pragma unroll 1
+                for (int x0 = lo; x0 <= hi; x0 += 8) {
+#pragma unroll
+                    for (int q = 0; q < 8; q++)
+                        nv[q] = x0 + 8 + q <= hi ? src[(x0 + 8 + q) % WV_P] : CP_NEG_INF;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) acc = ladd(acc, v[q], cf);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) v[q] = nv[q];
+                }
+            }
+        }
+        sh.vbuf[tid] = acc;
+        __syncthreads();
+        const double partner = sh.vbuf[(tid + 1) & 255];
+        if (k < 2 * nTotWin && f == 0) {
+            double tot = acc;
+            if (w.second) tot = ladd(acc, partner, cf);
+            wtot[k >> 1].total = tot;
+            if (!(fabs(tot - totEst) <= WV_CAND_SLACK)) sh.scan = 1; /* also catches NaN and infinities */
+            const long long o = nTot0 + (k >> 1);
+            if (o < it.totCap) {
+                totXay[it.totBase + o] = w.t;
+                totVal[it.totBase + o] = tot;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (P.mode != 0 || nPost <= 0 || sh.scan != 0) {
+        if (tid == 0) {
+            state->nTot = nTot0 + nTotWin;
+            /* Baum-Welch: nothing to decode; otherwise a window whose candidates cannot be trusted goes to the
+             * re-sweep kernel (the exact totals are in scratch by now) */
+            wp->valid = (P.mode == 0 && nPost > 0) ? 2 : 0;
+            if (P.mode != 0) state->expectPending = window + 1; /* which launch's window the B ring holds */
+        }
+        return;
+    }
+
+    /* ------------------------------ phase D: the aligned pairs ------------------------------ */
+    long long *outPairs = pairs + it.pairBase * 3;
+    double *outLogp = pairLogp + it.pairBase;
+    for (int i = tid; i < nPost * 4; i += 256) msk[i] = 0ull;
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+#pragma unroll 1
+        for (int i = tid; i < nCand; i += 256) {
+            const int2 kx = candKx[i];
+            const int k = kx.x, x = kx.y, t = tPost0 - k;
+            const double ee = candFb[i] - wtot[k / 10].total;
+            if (!(x >= 1 && x <= t - 1 && ee >= P.logThrSlack)) continue;
+            const int sl = x % WV_P;
+            if (!pass) {
+                atomicOr(msk + k * 4ll + sl % L, 1ull << (sl / L));
+                continue;
+            }
+            unsigned long long mm[L];
+#pragma unroll
+            for (int j = 0; j < L; j++) mm[j] = msk[k * 4ll + j];
+            const int rank = rank_in_diagonal(mm, bandTab[t].x % WV_P, sl);
+            const long long o = nPairs0 + offBuf[k] + rank;
+            if (o < it.pairCap) {
+                long long *dst = outPairs + o * 3;
+                dst[0] = 0;
+                dst[1] = x - 1;
+                dst[2] = t - x - 1;
+                outLogp[o] = ee;
+            }
+        }
+            __syncthreads();
+        if (!pass) {
+            /* hits per diagonal from the masks; exclusive prefix in emission order */
+            int carry = 0;
+#pragma unroll 1
+            for (int base = 0; base < nPost; base += 8 * 256) {
+                const int b0 = base + tid * 8;
+                int h[8], sum = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    h[q] = 0;
+                    if (b0 + q < nPost) {
+#pragma unroll
+                        for (int j = 0; j < L; j++) h[q] += __popcll(msk[(b0 + q) * 4ll + j]);
+                    }
+                    sum += h[q];
+                }
+                int inc = sum;
+#pragma unroll
+                for (int o2 = 1; o2 < 64; o2 <<= 1) {
+                    const int up = __shfl_up(inc, o2);
+                    if (lane >= o2) inc += up;
+                }
+                __syncthreads(); /* part[] of the previous round has been read */
+                if (lane == 63) sh.part[wv] = inc;
+                __syncthreads();
+                int o = carry + inc - sum;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; w2++) {
+                    const int c = sh.part[w2];
+                    if (w2 < wv) o += c;
+                    carry += c;
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++)
+                    if (b0 + q < nPost) {
+                        offBuf[b0 + q] = o;
+                        o += h[q];
+                    }
+            }
+            if (tid == 0) sh.carry = carry;
+                    __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        state->nPairs = nPairs0 + sh.carry;
+        state->nTot = nTot0 + nTotWin;
+        wp->valid = 0;
+    }
+}
 
 /*
  * Baum-Welch expectations of the traceback window the backward kernel just swept
@@ -1470,8 +1652,9 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const int sl = lane * L + j, sb = sl == 0 ? WV_P - 1 : sl - 1; /* this thread's slot and the one below it */
     const int ringMask = ringD - 1;
     const double *ring = Fring + idx * ringDoubles;
-    const double *own = ring + j * (WV_RING_VALUES * 64) + lane;
-    const double *blw = ring + (sb % L) * (WV_RING_VALUES * 64) + sb / L;
+    const double *own = ring + j * WV_LAYER_DOUBLES;            /* this thread's layer of a ring row, its lane `lane` */
+    const double *blw = ring + (sb % L) * WV_LAYER_DOUBLES;     /* the slot below: layer sb % L, lane sb / L */
+    const int lb = sb / L;
     const double *bown = Bring + idx * ((long long) ringD * L * 3 * 64) + j * (3 * 64) + lane;
     const double *tr = track + trackBase[idx] * WV_ROW;
     const unsigned short *kx = kidx + it.xOff;
@@ -1513,7 +1696,7 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
             const bool vMiddle = t - 2 >= to && x - 1 >= b2min && x - 1 <= b2max;
             const bool vUpper = x >= b1min && x <= b1max;
             if (vLower) {
-                const double l0 = blw[r1], l1 = blw[r1 + 64], l2 = blw[r1 + 128];
+                const double l0 = blw[r1 + WV_OFF_FM(lb)], l1 = blw[r1 + WV_OFF_FX(lb)], l2 = blw[r1 + WV_OFF_FY(lb)];
                 const double *row = tr + (long long) x * WV_ROW;
                 const double p0 = exp(l0 + Bx + row[16] - total);
                 const double p1 = exp(l1 + Bx + row[17] - total);
@@ -1534,15 +1717,15 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
                 gapSum += p2;
             }
             if (vMiddle) {
-                const double m0 = blw[r2], m1 = blw[r2 + 64], m2 = blw[r2 + 128];
-                const double eP = own[rt + 3 * 64];
+                const double m0 = blw[r2 + WV_OFF_FM(lb)], m1 = blw[r2 + WV_OFF_FX(lb)], m2 = blw[r2 + WV_OFF_FY(lb)];
+                const double eP = own[rt + WV_OFF_PM(lane)];
                 acc[3] += exp(m0 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_CONTINUE]) - total);
                 acc[4] += exp(m1 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_FROM_GAP_X]) - total);
                 acc[5] += exp(m2 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_FROM_GAP_Y]) - total);
             }
             if (vUpper) {
-                const double u0 = own[r1], u2 = own[r1 + 128];
-                const double eP = own[rt + 4 * 64];
+                const double u0 = own[r1 + WV_OFF_FM(lane)], u2 = own[r1 + WV_OFF_FY(lane)];
+                const double eP = own[rt + WV_OFF_PY(lane)];
                 acc[6] += exp(u0 + By + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_GAP_OPEN_Y]) - total);
                 acc[7] += exp(u2 + By + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_GAP_EXTEND_Y]) - total);
             }
@@ -1645,11 +1828,11 @@ extern "C" int WV_SYM(cpecan_wave_launch_forward)(hipStream_t stream, const DevI
                                                   const double *models, double *Fring, long long ringDoubles,
                                                   int ringD, void *states, int window, int withSwitch) {
     if (withSwitch)
-        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward_sw), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems,
+        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward_sw), dim3((unsigned) ((nItems + WV_WPB - 1) / WV_WPB)), dim3(64 * WV_WPB), 0, stream, items, nItems,
                            P, (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
                            (WvState *) states, window);
     else
-        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems, P,
+        hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_forward), dim3((unsigned) ((nItems + WV_WPB - 1) / WV_WPB)), dim3(64 * WV_WPB), 0, stream, items, nItems, P,
                            (const int2 *) bandTab, track, trackBase, events, models, Fring, ringDoubles, ringD,
                            (WvState *) states, window);
     return hipGetLastError() == hipSuccess ? 0 : -1;
@@ -1661,19 +1844,28 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
                                                    double *pairLogp, long long *totXay, double *totVal, char *scratch,
                                                    long long scratchBytes, double *Bring, int window, int withSwitch) {
 #define WV_LAUNCH_B(k)                                                                                            \
-    hipLaunchKernelGGL(WV_SYM(k), dim3((unsigned) nItems), dim3(64), 0, stream, items, nItems, P,                 \
+    hipLaunchKernelGGL(WV_SYM(k), dim3((unsigned) ((nItems + WV_WPB - 1) / WV_WPB)), dim3(64 * WV_WPB), 0, stream, items, nItems, P, \
                        (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,               \
-                       (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, Bring, window)
+                       (WvState *) states, pairs, pairLogp, scratch, scratchBytes, Bring, window)
+#define WV_LAUNCH_POST                                                                                            \
+    hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_post), dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems, P, \
+                       (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD,                \
+                       (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, window)
     if (P.mode != 0) {
         if (withSwitch) WV_LAUNCH_B(cpecan_k_wv_backward_em_sw);
         else WV_LAUNCH_B(cpecan_k_wv_backward_em);
+        WV_LAUNCH_POST;
     } else {
-        /* the sweep with decode candidates, then the kernel that sweeps once more the windows whose candidates
-         * could not be trusted (it returns at once for the others) */
-        if (withSwitch) { WV_LAUNCH_B(cpecan_k_wv_backward_sw); WV_LAUNCH_B(cpecan_k_wv_resweep_sw); }
-        else { WV_LAUNCH_B(cpecan_k_wv_backward); WV_LAUNCH_B(cpecan_k_wv_resweep); }
+        /* the sweep with decode candidates, the window's totals and decode, then the kernel that sweeps once more
+         * the windows whose candidates could not be trusted (it returns at once for the others) */
+        if (withSwitch) WV_LAUNCH_B(cpecan_k_wv_backward_sw);
+        else WV_LAUNCH_B(cpecan_k_wv_backward);
+        WV_LAUNCH_POST;
+        if (withSwitch) WV_LAUNCH_B(cpecan_k_wv_resweep_sw);
+        else WV_LAUNCH_B(cpecan_k_wv_resweep);
     }
 #undef WV_LAUNCH_B
+#undef WV_LAUNCH_POST
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevItem *items, long long nItems,

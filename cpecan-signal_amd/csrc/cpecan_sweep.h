@@ -19,7 +19,10 @@ struct SyState {
 /* The wave kernels' record: the forward kernel of launch w describes its window in win[w & 1] while the backward
  * kernel of launch w - 1 may still be working from the other entry (the two run concurrently). */
 struct WvWindow {
-    int valid, top, from, to, atEnd, pad;
+    int valid; /* 1: described by the forward kernel; 3: swept back, its totals and pairs are the post kernel's to do;
+                  2: its candidates could not be trusted, the re-sweep kernel decodes it; 0: done */
+    int top, from, to, atEnd;
+    int nCand, nRefresh, pad; /* what the sweep back left in scratch for the post kernel */
     double est; /* estimate of the window's totalProbability: the forward cells of its top diagonal dotted with the
                    end vector the sweep back starts from (any fold order; it only steers the candidate test) */
 };

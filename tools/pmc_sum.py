@@ -7,5 +7,5 @@ for d in sys.argv[1:]:
             k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
             tot[k] += float(r["Counter_Value"]); n[k] += 1
 for (k, c) in sorted(tot):
-    if k.startswith("cpecan_k_sy_f") or k.startswith("cpecan_k_sy_b"):
+    if k.startswith("cpecan_k_sy_f") or k.startswith("cpecan_k_sy_b") or k.startswith("cpecan_k_wv_"):
         print("%-24s %-34s %18.0f  launches %d" % (k, c, tot[(k, c)], n[(k, c)]))
