@@ -9,7 +9,7 @@
  * cell is computed on the host; a missing GPU or a C-ABI error aborts with a message, which is the
  * reference's own error convention (st_errAbort).
  */
-#include "cpecan_api.h"
+#include "cpecan_host_private.h"
 
 #include "cpecan_hip.h"
 
@@ -20,7 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-static void die(const char *fmt, ...) {
+void cpecan_die(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vfprintf(stderr, fmt, ap);
@@ -28,6 +28,7 @@ static void die(const char *fmt, ...) {
     fputc('\n', stderr);
     exit(1);
 }
+#define die cpecan_die
 #define CHECK(call)                                                                              \
     do {                                                                                         \
         int rc_ = (call);                                                                        \
@@ -190,11 +191,6 @@ double emissions_symbol_getMatchProb(const double *emissionMatchProbs, void *x, 
     const int iX = base_index(x), iY = base_index(y);
     return iX < 4 && iY < 4 ? emissionMatchProbs[iX * 4 + iY] : -INFINITY;
 }
-void cell_updateExpectations(double *fromCells, double *toCells, int64_t from, int64_t to, double eP,
-                             double tP, void *extraArgs) {
-    (void) fromCells; (void) toCells; (void) from; (void) to; (void) eP; (void) tP; (void) extraArgs;
-    die("cpecan: cell_updateExpectations is a marker; discrete-HMM expectations are not on the GPU path");
-}
 void emissions_symbol_setEmissionsToDefaults(StateMachine *sM) {
     const double EMISSION_MATCH = -2.1149196655034745, EMISSION_TRANSVERSION = -4.5691014376830479,
                  EMISSION_TRANSITION = -3.9833860032220842;
@@ -212,14 +208,15 @@ StateMachine *stateMachine5_construct(StateMachineType type, int64_t parameterSe
                                       double (*matchProbFcn)(const double *, void *, void *),
                                       void (*cellCalcUpdateExpFcn)(double *, double *, int64_t, int64_t, double,
                                                                    double, void *)) {
-    (void) cellCalcUpdateExpFcn;
     if (type != fiveState && type != fiveStateAsymmetric) die("Wrong type for five state %i", (int) type);
     if (parameterSetSize != SYMBOL_NUMBER_NO_N)
-        die("cpecan: the 5-state machine on the GPU path works on single bases (parameterSetSize 4)");
-    if (gapXProbFcn != emissions_symbol_getGapProb || gapYProbFcn != emissions_symbol_getGapProb ||
-        matchProbFcn != emissions_symbol_getMatchProb)
-        die("cpecan: the 5-state machine on the GPU path needs the emissions_symbol_* getters");
+        die("cpecan: the 5-state machine works on single bases (parameterSetSize 4)");
     StateMachine5 *s = calloc(1, sizeof *s);
+    s->getXGapProbFcn = gapXProbFcn;
+    s->getYGapProbFcn = gapYProbFcn;
+    s->getMatchProbFcn = matchProbFcn;
+    cpecan_sm5_set_functions(s);
+    s->model.cellCalculateUpdateExpectations = cellCalcUpdateExpFcn;
     s->TRANSITION_MATCH_CONTINUE = -0.030064059121770816;
     s->TRANSITION_MATCH_FROM_SHORT_GAP_X = -1.272871422049609;
     s->TRANSITION_MATCH_FROM_LONG_GAP_X = -5.673280173170473;
@@ -265,6 +262,11 @@ StateMachine *getStrawManStateMachine3(const char *modelFile) {
     s->model.EMISSION_GAP_Y_PROBS = calloc((size_t) tableLen, sizeof(double));
     s->model.EMISSION_GAP_X_PROBS = calloc(NUM_OF_KMERS, sizeof(double));
     stateMachine3_setTransitionsToNanoporeDefaults((StateMachine *) s);
+    s->getXGapProbFcn = emissions_kmer_getGapProb;
+    s->getYGapProbFcn = emissions_signal_strawManGetKmerEventMatchProb;
+    s->getMatchProbFcn = emissions_signal_strawManGetKmerEventMatchProb;
+    cpecan_sm3_set_functions(s);
+    s->model.cellCalculateUpdateExpectations = cell_signal_updateTransAndKmerSkipExpectations;
     for (int64_t i = 0; i < NUM_OF_KMERS; i++) s->model.EMISSION_GAP_X_PROBS[i] = -2.3025850929940455;
     if (modelFile) {
         /* 3 lines: match table, 30 skip bins (used by the vanilla/echelon models only), Y-gap table */
@@ -280,12 +282,6 @@ StateMachine *getStrawManStateMachine3(const char *modelFile) {
 }
 
 /* ---- NanoporeHDP: the reader of serialized HDPs (impl/nanopore_hdp.c:845-870, impl/hdp.c:3009-3273) ---- */
-struct _nanopore_hdp {
-    char alphabet[32];
-    int64_t alphabetSize, kmerLength, numDps, gridLength, nRows;
-    double *grid, *y, *slope; /* y, slope: nRows x gridLength */
-    int32_t *kmerRow;         /* per k-mer id: row of the nearest observed ancestor (impl/hdp.c:2588-2590) */
-};
 static char *read_line(FILE *f) { /* one line of any length, without the newline; NULL at EOF */
     size_t cap = 1 << 16, n = 0;
     char *buf = malloc(cap);
@@ -402,11 +398,6 @@ char *get_nanopore_hdp_alphabet(NanoporeHDP *h) {
     memcpy(c, h->alphabet, (size_t) h->alphabetSize);
     return c;
 }
-double get_nanopore_kmer_density(NanoporeHDP *nhdp, void *kmer, void *x) {
-    (void) nhdp; (void) kmer; (void) x;
-    die("cpecan: get_nanopore_kmer_density is a marker; densities are evaluated on the device");
-    return 0.0;
-}
 /* ---- NanoporeRead (impl/nanopore.c) ------------------------------------------------------------------ */
 static void line_int64s(FILE *f, int64_t *dst, int64_t n, const char *what) {
     char *l = read_line(f), *p = l, *e;
@@ -488,6 +479,11 @@ StateMachine *getHdpStateMachine3(NanoporeHDP *hdp) {
     s->hdpModel = hdp;
     /* StateMachine3_HDP starts with the same nine transitions as StateMachine3 */
     stateMachine3_setTransitionsToNanoporeDefaults((StateMachine *) s);
+    s->getXGapProbFcn = emissions_kmer_getGapProb;
+    s->getYGapProbFcn = get_nanopore_kmer_density;
+    s->getMatchProbFcn = get_nanopore_kmer_density;
+    cpecan_sm3hdp_set_functions(s);
+    s->model.cellCalculateUpdateExpectations = cell_signal_updateTransAndKmerSkipExpectations2;
     return (StateMachine *) s;
 }
 
@@ -502,6 +498,11 @@ StateMachine *getSignalStateMachine3Vanilla(const char *modelFile) {
     s->DEFAULT_END_MATCH_PROB = -0.23552123624314988;
     s->DEFAULT_END_FROM_X_PROB = -1.6269694202638481;
     s->DEFAULT_END_FROM_Y_PROB = -4.3187242127300092;
+    s->getKmerSkipProb = emissions_signal_getBetaOrAlphaSkipProb;
+    s->getScaledMatchProbFcn = emissions_signal_getEventMatchProbWithTwoDists;
+    s->getMatchProbFcn = emissions_signal_getEventMatchProbWithTwoDists;
+    cpecan_sm3vanilla_set_functions(s);
+    s->model.cellCalculateUpdateExpectations = cell_signal_updateBetaAndAlphaProb;
     const int64_t tableLen = 1 + NUM_OF_KMERS * MODEL_PARAMS;
     s->model.EMISSION_MATCH_PROBS = calloc((size_t) tableLen, sizeof(double));
     s->model.EMISSION_GAP_Y_PROBS = calloc((size_t) tableLen, sizeof(double));
@@ -547,19 +548,14 @@ int64_t emissions_discrete_getKmerIndex(void *kmer) {
     return x;
 }
 
+int64_t emissions_discrete_getKmerIndexFromKmer(void *kmer) { return emissions_discrete_getKmerIndex(kmer); }
+
 void stateMachine_destruct(StateMachine *sM) {
     if (!sM) return;
     free(sM->EMISSION_MATCH_PROBS);
     free(sM->EMISSION_GAP_X_PROBS);
     free(sM->EMISSION_GAP_Y_PROBS);
     free(sM);
-}
-
-void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *f, DpMatrix *b,
-                                            Sequence *sX, Sequence *sY, double total,
-                                            PairwiseAlignmentParameters *p, void *extraArgs) {
-    (void) sM; (void) xay; (void) f; (void) b; (void) sX; (void) sY; (void) total; (void) p; (void) extraArgs;
-    die("cpecan: diagonalCalculationPosteriorMatchProbs is a marker for the GPU path, not a host function");
 }
 
 /* ---- Diagonal / Band / BandIterator / logAdd / filterToRemoveOverlap (host integer utilities) ---------- */
@@ -712,6 +708,10 @@ static cpecan_ctx *context(void) {
  * (sequence_getKmer3), 0 under the 3-state strawMan machine (sequence_getKmer); anything else is not on
  * the GPU path */
 static int check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY) {
+    if (!cpecan_sm_functions_known(sM))
+        die("cpecan: this StateMachine carries a cellCalculate or emission function of the caller's own; the GPU path "
+            "implements the reference's models only (symbol, strawMan, vanilla two-distribution and HDP emissions) "
+            "and there is no CPU path to fall back to");
     if ((sM->type == fiveState || sM->type == fiveStateAsymmetric) && sM->stateNumber == 5) {
         if (sX->get != sequence_getBase || sY->get != sequence_getBase)
             die("cpecan: the 5-state machine needs sequence_getBase element getters on both sequences");
@@ -1006,11 +1006,14 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                     CHECK(cpecan_hip_batch_fetch_pairs(batch, k, tri, NULL, np[k] + 1));
                     for (int64_t q = 0; q < np[k]; q++) {
                         const int64_t x = tri[3 * q + 1] + origin[k].x1, y = tri[3 * q + 2] + origin[k].y1;
-                        if (hmm->numberOfAssignments == hmm->capacity) {
+                        if (hmm->numberOfAssignments == hmm->capacity || !hmm->assignmentXY) {
                             hmm->capacity = hmm->capacity ? 2 * hmm->capacity : 1024;
                             hmm->eventAssignments = realloc(hmm->eventAssignments, sizeof(double) * (size_t) hmm->capacity);
                             hmm->kmerAssignments = realloc(hmm->kmerAssignments, (size_t) hmm->capacity * (KMER_LENGTH + 1));
+                            hmm->assignmentXY = realloc(hmm->assignmentXY, sizeof(int64_t) * 2 * (size_t) hmm->capacity);
                         }
+                        hmm->assignmentXY[2 * hmm->numberOfAssignments] = x >= 0 ? x : 0;
+                        hmm->assignmentXY[2 * hmm->numberOfAssignments + 1] = y;
                         char *dst = hmm->kmerAssignments + hmm->numberOfAssignments * (KMER_LENGTH + 1);
                         memcpy(dst, (const char *) sXs[i]->elements + (x >= 0 ? x : 0), KMER_LENGTH);
                         dst[KMER_LENGTH] = 0;
@@ -1100,13 +1103,13 @@ stList *getAlignedPairsWithoutBanding(StateMachine *sM, void *cX, void *cY, int6
     return out;
 }
 
-void getSignalExpectationsUsingAnchors(StateMachine *sM, ContinuousPairHmmExpectations *hmm, Sequence *SsX,
+void cpecan_getSignalExpectationsUsingAnchors(StateMachine *sM, ContinuousPairHmmExpectations *hmm, Sequence *SsX,
                                        Sequence *SsY, stList *anchorPairs, PairwiseAlignmentParameters *p,
                                        bool raggedL, bool raggedR) {
     run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmm);
 }
 
-void continuousPairHmm_normalize(ContinuousPairHmmExpectations *hmm) {
+void cpecan_pairHmmExpectations_normalize(ContinuousPairHmmExpectations *hmm) {
     for (int from = 0; from < 3; from++) { /* hmmDiscrete_normalize2, impl/discreteHmm.c:125-136 */
         double total = 0.0;
         for (int to = 0; to < 3; to++) total += hmm->transitions[from * 3 + to];
@@ -1117,7 +1120,7 @@ void continuousPairHmm_normalize(ContinuousPairHmmExpectations *hmm) {
     for (int i = 0; i < NUM_OF_KMERS; i++) hmm->individualKmerGapProbs[i] = hmm->individualKmerGapProbs[i] / total;
 }
 
-void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM, ContinuousPairHmmExpectations *hmm) {
+void cpecan_pairHmmExpectations_load(StateMachine *sM, ContinuousPairHmmExpectations *hmm) {
     StateMachine3 *s = (StateMachine3 *) sM;
     const double *t = hmm->transitions;
     s->TRANSITION_MATCH_CONTINUE = log(t[match * 3 + match]);
@@ -1133,7 +1136,7 @@ void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM, Continuo
 }
 
 /* ---- .hmm files of the strawMan expectations (impl/continuousHmm.c:234-370) --------------------------- */
-void continuousPairHmm_writeToFile(ContinuousPairHmmExpectations *hmm, FILE *fh) {
+void cpecan_pairHmmExpectations_write(ContinuousPairHmmExpectations *hmm, FILE *fh) {
     fprintf(fh, "%i\t%lld\t%lld\t\n", (int) threeState, 3ll, (long long) NUM_OF_KMERS);
     for (int i = 0; i < 9; i++)
         if (isnan(hmm->transitions[i])) { /* hmmContinuous_checkTransitions :48-58: nothing more is written */
@@ -1145,7 +1148,7 @@ void continuousPairHmm_writeToFile(ContinuousPairHmmExpectations *hmm, FILE *fh)
     for (int i = 0; i < NUM_OF_KMERS; i++) fprintf(fh, "%f\t", hmm->individualKmerGapProbs[i]);
     fprintf(fh, "\n");
 }
-ContinuousPairHmmExpectations *continuousPairHmm_loadFromFile(const char *fileName) {
+ContinuousPairHmmExpectations *cpecan_pairHmmExpectations_read(const char *fileName) {
     FILE *f = fopen(fileName, "r");
     if (!f) die("cpecan: cannot open %s", fileName);
     double hdr[3], line[10];
@@ -1412,21 +1415,63 @@ StateMachine *getStateMachine5(Hmm *hmmD, StateMachineFunctions *sMfs) {
     return (StateMachine *) s;
 }
 
-void diagonalCalculation_Expectations(StateMachine *sM, int64_t xay, DpMatrix *f, DpMatrix *b, Sequence *sX,
-                                      Sequence *sY, double total, PairwiseAlignmentParameters *p, void *extra) {
-    (void) sM; (void) xay; (void) f; (void) b; (void) sX; (void) sY; (void) total; (void) p; (void) extra;
-    die("cpecan: diagonalCalculation_Expectations is a marker for the GPU path, not a host function");
-}
 void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, Sequence *SsX, Sequence *SsY,
                                  stList *anchorPairs, PairwiseAlignmentParameters *p,
                                  DiagonalPosteriorProbFn fn, bool raggedL, bool raggedR) {
     if (fn != diagonalCalculation_Expectations)
         die("cpecan: the GPU path implements diagonalCalculation_Expectations only");
-    if ((sM->type != fiveState && sM->type != fiveStateAsymmetric) || hmmExpectations->stateNumber != 5 ||
-        hmmExpectations->symbolSetSize != SYMBOL_NUMBER_NO_N)
-        die("cpecan: getExpectationsUsingAnchors takes a 5-state machine and a 5-state, 4-symbol Hmm "
-            "(signal machines: getSignalExpectationsUsingAnchors)");
-    run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmmExpectations);
+    if (hmmExpectations->type != sM->type && !(sM->type == fiveState && hmmExpectations->type == fiveStateAsymmetric))
+        die("cpecan: getExpectationsUsingAnchors: the Hmm (type %d) does not belong to the state machine (type %d)",
+            (int) hmmExpectations->type, (int) sM->type);
+    switch (sM->type) {
+    case fiveState:
+    case fiveStateAsymmetric:
+        if (hmmExpectations->stateNumber != 5 || hmmExpectations->symbolSetSize != SYMBOL_NUMBER_NO_N)
+            die("cpecan: the 5-state E-step takes a 5-state, 4-symbol Hmm");
+        run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmmExpectations);
+        return;
+    case threeState: {
+        /* the sums the reference's cell_signal_updateTransAndKmerSkipExpectations (:426-443) makes one exp() at a
+         * time, taken on the GPU and handed to the Hmm through its own add functions */
+        ContinuousPairHmmExpectations *e = calloc(1, sizeof *e);
+        cpecan_getSignalExpectationsUsingAnchors(sM, e, SsX, SsY, anchorPairs, p, raggedL, raggedR);
+        hmmExpectations->likelihood += e->likelihood;
+        for (int64_t from = 0; from < 3; from++)
+            for (int64_t to = 0; to < 3; to++)
+                hmmExpectations->addToTransitionExpectationFcn(hmmExpectations, from, to, e->transitions[from * 3 + to]);
+        for (int64_t k = 0; k < NUM_OF_KMERS; k++)
+            if (e->individualKmerGapProbs[k] != 0.0)
+                hmmExpectations->addToEmissionExpectationFcn(hmmExpectations, 0, k, 0, e->individualKmerGapProbs[k]);
+        free(e);
+        return;
+    }
+    case vanilla: {
+        VanillaHmmExpectations e;
+        memset(&e, 0, sizeof e);
+        cpecan_getVanillaExpectationsUsingAnchors(sM, &e, SsX, SsY, anchorPairs, p, raggedL, raggedR);
+        hmmExpectations->likelihood += e.likelihood;
+        for (int64_t bin = 0; bin < 60; bin++)
+            hmmExpectations->addToTransitionExpectationFcn(hmmExpectations, bin, 0, e.kmerSkipBins[bin]);
+        return;
+    }
+    case threeStateHdp: {
+        HdpHmm *h = (HdpHmm *) hmmExpectations;
+        HdpHmmExpectations *e = cpecan_hdpExpectations_construct(0.0, h->threshold);
+        cpecan_getHdpExpectationsUsingAnchors(sM, e, SsX, SsY, anchorPairs, p, raggedL, raggedR);
+        hmmExpectations->likelihood += e->likelihood;
+        for (int64_t from = 0; from < 3; from++)
+            for (int64_t to = 0; to < 3; to++)
+                hmmExpectations->addToTransitionExpectationFcn(hmmExpectations, from, to, e->transitions[from * 3 + to]);
+        /* as the reference's cell_signal_updateTransAndKmerSkipExpectations2 does: pointers into SsX and SsY */
+        for (int64_t i = 0; i < e->numberOfAssignments; i++)
+            h->addToAssignments(hmmExpectations, (char *) SsX->elements + e->assignmentXY[2 * i],
+                                (double *) SsY->elements + NB_EVENT_PARAMS * e->assignmentXY[2 * i + 1]);
+        cpecan_hdpExpectations_destruct(e);
+        return;
+    }
+    default:
+        die("cpecan: getExpectationsUsingAnchors: no E-step for state machine type %d", (int) sM->type);
+    }
 }
 void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY, int64_t lX, int64_t lY,
                      PairwiseAlignmentParameters *p, void *(*getFcn)(void *, int64_t),
@@ -1485,40 +1530,41 @@ void sequence_padSequence(Sequence *sequence) {
 }
 
 /* ---- vanilla machine: E-step entry and the M-step of its skip bins (impl/continuousHmm.c:420-462) ------- */
-void getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations *hmm, Sequence *SsX,
+void cpecan_getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations *hmm, Sequence *SsX,
                                         Sequence *SsY, stList *anchorPairs, PairwiseAlignmentParameters *p,
                                         bool raggedL, bool raggedR) {
     if (sM->type != vanilla) die("cpecan: getVanillaExpectationsUsingAnchors takes a StateMachine3Vanilla");
     run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmm);
 }
-void vanillaHmm_normalizeKmerSkipBins(VanillaHmmExpectations *hmm) {
+void cpecan_vanillaExpectations_normalize(VanillaHmmExpectations *hmm) {
     double total = 0.0; /* alpha and beta bins together, as the reference does */
     for (int i = 0; i < 60; i++) total += hmm->kmerSkipBins[i];
     for (int i = 0; i < 60; i++) hmm->kmerSkipBins[i] = hmm->kmerSkipBins[i] / total;
 }
-void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, VanillaHmmExpectations *hmm) {
+void cpecan_vanillaExpectations_load(StateMachine *sM, VanillaHmmExpectations *hmm) {
     if (sM->type != vanilla) die("you gave me the wrong type of HMM");
     for (int i = 0; i < 60; i++) sM->EMISSION_GAP_X_PROBS[i] = hmm->kmerSkipBins[i];
 }
 
 /* ---- HDP machine: E-step entry, transition M-step and the .expectations file (impl/continuousHmm.c:631-753) -- */
-HdpHmmExpectations *hdpHmm_constructEmpty(double pseudocount, double threshold) {
+HdpHmmExpectations *cpecan_hdpExpectations_construct(double pseudocount, double threshold) {
     HdpHmmExpectations *h = calloc(1, sizeof *h);
     for (int i = 0; i < 9; i++) h->transitions[i] = pseudocount;
     h->threshold = threshold;
     return h;
 }
-void hdpHmm_destruct(HdpHmmExpectations *hmm) {
+void cpecan_hdpExpectations_destruct(HdpHmmExpectations *hmm) {
     free(hmm->eventAssignments);
     free(hmm->kmerAssignments);
+    free(hmm->assignmentXY);
     free(hmm);
 }
-void getHdpExpectationsUsingAnchors(StateMachine *sM, HdpHmmExpectations *hmm, Sequence *SsX, Sequence *SsY,
+void cpecan_getHdpExpectationsUsingAnchors(StateMachine *sM, HdpHmmExpectations *hmm, Sequence *SsX, Sequence *SsY,
                                     stList *anchorPairs, PairwiseAlignmentParameters *p, bool raggedL, bool raggedR) {
     if (sM->type != threeStateHdp) die("cpecan: getHdpExpectationsUsingAnchors takes a StateMachine3_HDP");
     run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmm);
 }
-void hdpHmm_loadTransitions(StateMachine *sM, HdpHmmExpectations *hmm) {
+void cpecan_hdpExpectations_load(StateMachine *sM, HdpHmmExpectations *hmm) {
     StateMachine3_HDP *s = (StateMachine3_HDP *) sM;
     const double *t = hmm->transitions;
     s->TRANSITION_MATCH_CONTINUE = log(t[match * 3 + match]);
@@ -1531,7 +1577,7 @@ void hdpHmm_loadTransitions(StateMachine *sM, HdpHmmExpectations *hmm) {
     s->TRANSITION_GAP_EXTEND_Y = log(t[shortGapY * 3 + shortGapY]);
     s->TRANSITION_GAP_SWITCH_TO_X = log(t[shortGapY * 3 + shortGapX]);
 }
-void hdpHmm_writeToFile(HdpHmmExpectations *hmm, FILE *fh) {
+void cpecan_hdpExpectations_write(HdpHmmExpectations *hmm, FILE *fh) {
     fprintf(fh, "%i\t%lld\t%lf\t%lld\t\n", (int) threeStateHdp, 3ll, hmm->threshold,
             (long long) hmm->numberOfAssignments);
     for (int i = 0; i < 9; i++)
@@ -1635,7 +1681,7 @@ stList *getAlignedPairs(StateMachine *sM, void *cX, void *cY, int64_t lX, int64_
 }
 
 /* ---- .hmm of the vanilla machine, .expectations reader of the HDP machine (impl/continuousHmm.c:477-900) ----- */
-void vanillaHmm_writeToFile(VanillaHmmExpectations *hmm, StateMachine *sM, FILE *fh) {
+void cpecan_vanillaExpectations_write(VanillaHmmExpectations *hmm, StateMachine *sM, FILE *fh) {
     if (sM->type != vanilla) die("you gave me the wrong type of HMM");
     fprintf(fh, "%i\t%lld\t%lld\t\n", (int) vanilla, 3ll, (long long) NUM_OF_KMERS);
     for (int i = 0; i < 60; i++)
@@ -1651,7 +1697,7 @@ void vanillaHmm_writeToFile(VanillaHmmExpectations *hmm, StateMachine *sM, FILE 
     for (int64_t i = 0; i < n; i++) fprintf(fh, "%f\t", sM->EMISSION_GAP_Y_PROBS[i]);
     fprintf(fh, "\n");
 }
-VanillaHmmExpectations *vanillaHmm_loadFromFile(const char *fileName, StateMachine *sM) {
+VanillaHmmExpectations *cpecan_vanillaExpectations_read(const char *fileName, StateMachine *sM) {
     FILE *f = fopen(fileName, "r");
     if (!f) die("cpecan: cannot open %s", fileName);
     double hdr[3], line[61];
@@ -1676,14 +1722,14 @@ VanillaHmmExpectations *vanillaHmm_loadFromFile(const char *fileName, StateMachi
     fclose(f);
     return hmm;
 }
-HdpHmmExpectations *hdpHmm_loadFromFile(const char *fileName) {
+HdpHmmExpectations *cpecan_hdpExpectations_read(const char *fileName) {
     FILE *f = fopen(fileName, "r");
     if (!f) die("cpecan: cannot open %s", fileName);
     double hdr[4], line[10];
     const int64_t nh = line_doubles(f, hdr, 4);
     if (nh != 4) die("ERROR loading hdpHmm, got %lld tokens should get 4", (long long) nh);
     if ((int64_t) hdr[1] != 3) die("cpecan: %s: %lld states", fileName, (long long) hdr[1]);
-    HdpHmmExpectations *hmm = hdpHmm_constructEmpty(0.0, hdr[2]);
+    HdpHmmExpectations *hmm = cpecan_hdpExpectations_construct(0.0, hdr[2]);
     const int64_t n = (int64_t) hdr[3];
     const int64_t nt = line_doubles(f, line, 10);
     if (nt != 10)

@@ -94,8 +94,14 @@ typedef enum {
 typedef enum { match = 0, shortGapX = 1, shortGapY = 2, longGapX = 3, longGapY = 4 } State;
 
 typedef struct _stateMachine StateMachine;
-struct _stateMachine { /* data members in the reference's order; the reference's function-pointer
-                          members follow them there and are not mirrored (they cannot run on the GPU) */
+/* The reference's "class" layout (inc/stateMachine.h:76-100): callers read the data members directly and may call
+ * through the pointers, so both sit where the reference's headers put them (checked by the _Static_asserts at the
+ * end of this header).  The pointers hold plain host C (cpecan_internals.c): they serve the reference's tested
+ * internals (cell_calculateForward, diagonalCalculation* ...) and callers of their own; the aligner entry points
+ * never go through them -- they recognise the known machines and run the GPU kernels. */
+typedef void (*DoTransitionFn)(double *fromCells, double *toCells, int64_t from, int64_t to, double eP, double tP,
+                               void *extraArgs);
+struct _stateMachine {
     StateMachineType type;
     int64_t stateNumber;
     int64_t matchState;
@@ -103,6 +109,14 @@ struct _stateMachine { /* data members in the reference's order; the reference's
     double *EMISSION_MATCH_PROBS;
     double *EMISSION_GAP_X_PROBS;
     double *EMISSION_GAP_Y_PROBS;
+    double (*startStateProb)(StateMachine *sM, int64_t state);
+    double (*endStateProb)(StateMachine *sM, int64_t state);
+    double (*raggedEndStateProb)(StateMachine *sM, int64_t state);
+    double (*raggedStartStateProb)(StateMachine *sM, int64_t state);
+    void (*cellCalculate)(StateMachine *sM, double *current, double *lower, double *middle, double *upper, void *cX,
+                          void *cY, DoTransitionFn doTransition, void *extraArgs);
+    void (*cellCalculateUpdateExpectations)(double *fromCells, double *toCells, int64_t from, int64_t to, double eP,
+                                            double tP, void *extraArgs);
 };
 typedef struct _StateMachine3 {
     StateMachine model;
@@ -115,6 +129,9 @@ typedef struct _StateMachine3 {
     double TRANSITION_GAP_EXTEND_Y;
     double TRANSITION_GAP_SWITCH_TO_X;
     double TRANSITION_GAP_SWITCH_TO_Y;
+    double (*getXGapProbFcn)(const double *emissionXGapProbs, void *i);
+    double (*getYGapProbFcn)(const double *emissionYGapProbs, void *x, void *y);
+    double (*getMatchProbFcn)(const double *emissionMatchProbs, void *x, void *y);
 } StateMachine3;
 
 /* 5-state symbol machine of DNA-against-DNA alignment (inc/stateMachine.h:104-124; data members) */
@@ -137,12 +154,14 @@ typedef struct _StateMachine5 {
     double TRANSITION_GAP_LONG_OPEN_Y;
     double TRANSITION_GAP_LONG_EXTEND_Y;
     double TRANSITION_GAP_LONG_SWITCH_TO_Y;
+    double (*getXGapProbFcn)(const double *emissionXGapProbs, void *i);
+    double (*getYGapProbFcn)(const double *emissionYGapProbs, void *i);
+    double (*getMatchProbFcn)(const double *emissionMatchProbs, void *x, void *y);
 } StateMachine5;
 #define SYMBOL_NUMBER_NO_N 4 /* inc/emissionMatrix.h */
 /* stateMachine5_construct (impl/stateMachine.c:896-965), the reference's own signature.  The emission
- * initialiser is called on the host; the three probability getters must be the symbol getters below
- * (they name the emission model the device code implements); the expectation updater is ignored
- * (posterior decode only). */
+ * initialiser is called on the host; the aligner's GPU path needs the three probability getters to be the symbol
+ * getters below (they name the emission model the device code implements). */
 StateMachine *stateMachine5_construct(StateMachineType type, int64_t parameterSetSize,
                                       void (*setEmissionsDefaults)(StateMachine *sM),
                                       double (*gapXProbFcn)(const double *, void *),
@@ -155,7 +174,7 @@ void emissions_symbol_setEmissionsToDefaults(StateMachine *sM);                 
 double emissions_symbol_getGapProb(const double *emissionGapProbs, void *base);            /* :155-163 */
 double emissions_symbol_getMatchProb(const double *emissionMatchProbs, void *x, void *y);  /* :165-173 */
 void cell_updateExpectations(double *fromCells, double *toCells, int64_t from, int64_t to, double eP,
-                             double tP, void *extraArgs); /* marker only (impl/pairwiseAligner.c:407) */
+                             double tP, void *extraArgs); /* impl/pairwiseAligner.c:407-424 (host) */
 
 /* 3-state vanilla signal machine (inc/stateMachine.h:219-231; data members) */
 typedef enum _strand { template = 0, complement = 1 } Strand;
@@ -166,6 +185,9 @@ typedef struct _StateMachine3vanilla {
     double DEFAULT_END_MATCH_PROB;
     double DEFAULT_END_FROM_X_PROB;
     double DEFAULT_END_FROM_Y_PROB;
+    double (*getKmerSkipProb)(StateMachine *sM, void *kmerList, bool getAlpha);
+    double (*getScaledMatchProbFcn)(const double *scaledEventModel, void *kmer, void *event);
+    double (*getMatchProbFcn)(const double *eventModel, void *kmer, void *event);
 } StateMachine3Vanilla;
 /* getSignalStateMachine3Vanilla (impl/stateMachine.c:1761): tables from a 3-line .model file, the 30
  * skip bins of its second line stored as beta and alpha (:284-297) */
@@ -208,7 +230,7 @@ NanoporeHDP *deserialize_nhdp(const char *filepath);
 void destroy_nanopore_hdp(NanoporeHDP *nhdp);
 int64_t get_nanopore_hdp_alphabet_size(NanoporeHDP *nhdp);
 char *get_nanopore_hdp_alphabet(NanoporeHDP *nhdp); /* a copy, as in the reference; caller frees */
-double get_nanopore_kmer_density(NanoporeHDP *nhdp, void *kmer, void *x); /* marker: runs on the device */
+double get_nanopore_kmer_density(NanoporeHDP *nhdp, void *kmer, void *x); /* impl/nanopore_hdp.c:390 (host; the aligner evaluates densities on the device) */
 typedef struct _StateMachine3_HDP {
     StateMachine model;
     double TRANSITION_MATCH_CONTINUE;
@@ -220,8 +242,10 @@ typedef struct _StateMachine3_HDP {
     double TRANSITION_GAP_EXTEND_Y;
     double TRANSITION_GAP_SWITCH_TO_X;
     double TRANSITION_GAP_SWITCH_TO_Y;
-    double (*getXGapProbFcn)(const double *emissionXGapProbs, void *i); /* unused: kept for the layout */
+    double (*getXGapProbFcn)(const double *emissionXGapProbs, void *i);
     NanoporeHDP *hdpModel;
+    double (*getYGapProbFcn)(NanoporeHDP *hdp, void *x, void *y);
+    double (*getMatchProbFcn)(NanoporeHDP *hdp, void *x, void *y);
 } StateMachine3_HDP;
 StateMachine *getHdpStateMachine3(NanoporeHDP *hdp); /* impl/stateMachine.c:1738 */
 
@@ -232,13 +256,15 @@ void stateMachine3_setTransitionsToNanoporeDefaults(StateMachine *sM);
 void emissions_signal_scaleModel(StateMachine *sM, double scale, double shift, double var,
                                  double scale_sd, double var_sd); /* :631-651 */
 int64_t emissions_discrete_getKmerIndex(void *kmer);              /* :120-139 */
+int64_t emissions_discrete_getKmerIndexFromKmer(void *kmer);      /* :141-153: the same over a copy of the 6 characters */
 void stateMachine_destruct(StateMachine *stateMachine);
 
 /* ---- the path (inc/pairwiseAligner.h:249-311) ---------------------------------------------------- */
-typedef struct _dpMatrix DpMatrix; /* opaque, never instantiated: kept for the callback signature */
+typedef struct _dpMatrix DpMatrix; /* opaque, as in the reference (host internals below) */
 typedef void (*DiagonalPosteriorProbFn)(StateMachine *, int64_t, DpMatrix *, DpMatrix *, Sequence *,
                                         Sequence *, double, PairwiseAlignmentParameters *, void *);
-/* marker: pass this as diagonalPosteriorProbFn, exactly as the reference's callers do */
+/* pass this as diagonalPosteriorProbFn, exactly as the reference's callers do: the aligner entry points recognise
+ * it and decode posteriors on the GPU; called directly it is the reference's host function over DpMatrix objects */
 void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,
                                             DpMatrix *backwardDpMatrix, Sequence *sX, Sequence *sY,
                                             double totalProbability, PairwiseAlignmentParameters *p,
@@ -311,7 +337,8 @@ Diagonal bandIterator_getPrevious(BandIterator *bandIterator);
 #define LOG_ZERO (-INFINITY)
 double logAdd(double x, double y); /* :235-255, host double arithmetic */
 
-/* ---- expectations for Baum-Welch (inc/continuousHmm.h:17-23, impl/continuousHmm.c:90-232) ------- */
+/* ---- flat sufficient statistics of the signal machines (additive: what the GPU E-step produces and the batch /
+ * distributed drivers reduce; the reference-shaped Hmm subclasses further down are filled from these) ------- */
 typedef struct _continuousPairHmmExpectations {
     double likelihood;
     double transitions[9];              /* [from * 3 + to] */
@@ -319,16 +346,15 @@ typedef struct _continuousPairHmmExpectations {
 } ContinuousPairHmmExpectations;
 /* getExpectationsUsingAnchors (:1571) with diagonalCalculation_Expectations for the strawMan model:
  * adds this alignment's expectations to *hmm */
-void getSignalExpectationsUsingAnchors(StateMachine *sM, ContinuousPairHmmExpectations *hmm,
+void cpecan_getSignalExpectationsUsingAnchors(StateMachine *sM, ContinuousPairHmmExpectations *hmm,
                                        Sequence *SsX, Sequence *SsY, stList *anchorPairs,
                                        PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,
                                        bool alignmentHasRaggedRightEnd);
-void continuousPairHmm_normalize(ContinuousPairHmmExpectations *hmm);                 /* :174-191 */
-void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM,
-                                                      ContinuousPairHmmExpectations *hmm); /* :206-232 */
+void cpecan_pairHmmExpectations_normalize(ContinuousPairHmmExpectations *hmm);                 /* :174-191 */
+void cpecan_pairHmmExpectations_load(StateMachine *sM, ContinuousPairHmmExpectations *hmm); /* :206-232 */
 
-void continuousPairHmm_writeToFile(ContinuousPairHmmExpectations *hmm, FILE *fileHandle);   /* :234-272 */
-ContinuousPairHmmExpectations *continuousPairHmm_loadFromFile(const char *fileName);         /* :274-370 */
+void cpecan_pairHmmExpectations_write(ContinuousPairHmmExpectations *hmm, FILE *fileHandle);   /* :234-272 */
+ContinuousPairHmmExpectations *cpecan_pairHmmExpectations_read(const char *fileName);         /* :274-370 */
 
 /* ---- expectations of the vanilla machine (VanillaHmm, impl/continuousHmm.c:373-466) ------------------- */
 typedef struct _vanillaHmmExpectations {
@@ -337,16 +363,16 @@ typedef struct _vanillaHmmExpectations {
 } VanillaHmmExpectations;
 /* getExpectationsUsingAnchors (:1571) with diagonalCalculation_Expectations for a StateMachine3Vanilla
  * (cell_signal_updateBetaAndAlphaProb :478-498): adds this alignment's expectations to *hmm */
-void getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations *hmm, Sequence *SsX,
+void cpecan_getVanillaExpectationsUsingAnchors(StateMachine *sM, VanillaHmmExpectations *hmm, Sequence *SsX,
                                         Sequence *SsY, stList *anchorPairs, PairwiseAlignmentParameters *p,
                                         bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
-void vanillaHmm_normalizeKmerSkipBins(VanillaHmmExpectations *hmm);                        /* :420-429 */
-void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, VanillaHmmExpectations *hmm); /* :452-462 */
+void cpecan_vanillaExpectations_normalize(VanillaHmmExpectations *hmm);                        /* :420-429 */
+void cpecan_vanillaExpectations_load(StateMachine *sM, VanillaHmmExpectations *hmm); /* :452-462 */
 /* the vanilla .hmm file (:477-626): header, 60 skip bins + likelihood, then the match table and the extra-event
  * table of the state machine the expectations were taken with (vanillaHmm_implantMatchModelsintoHmm :431-443).
  * The loader fills *hmm and, if sM is given, copies the two tables into it. */
-void vanillaHmm_writeToFile(VanillaHmmExpectations *hmm, StateMachine *sM, FILE *fileHandle);
-VanillaHmmExpectations *vanillaHmm_loadFromFile(const char *fileName, StateMachine *sM);
+void cpecan_vanillaExpectations_write(VanillaHmmExpectations *hmm, StateMachine *sM, FILE *fileHandle);
+VanillaHmmExpectations *cpecan_vanillaExpectations_read(const char *fileName, StateMachine *sM);
 
 /* ---- expectations of the HDP machine (HdpHmm, inc/continuousHmm.h:26-36, impl/continuousHmm.c:631-790) ----- */
 typedef struct _hdpHmmExpectations {
@@ -357,17 +383,19 @@ typedef struct _hdpHmmExpectations {
     int64_t capacity;
     double *eventAssignments;  /* [numberOfAssignments] event means */
     char *kmerAssignments;     /* [numberOfAssignments][KMER_LENGTH + 1], NUL-terminated copies */
+    int64_t *assignmentXY;     /* [numberOfAssignments][2]: where the k-mer and the event sit in the caller's SsX / SsY
+                                  (E-step only; NULL on an object read from a file) */
 } HdpHmmExpectations;
-HdpHmmExpectations *hdpHmm_constructEmpty(double pseudocount, double threshold);
-void hdpHmm_destruct(HdpHmmExpectations *hmm);
+HdpHmmExpectations *cpecan_hdpExpectations_construct(double pseudocount, double threshold);
+void cpecan_hdpExpectations_destruct(HdpHmmExpectations *hmm);
 /* getExpectationsUsingAnchors (:1571) with diagonalCalculation_Expectations for a StateMachine3_HDP
  * (cell_signal_updateTransAndKmerSkipExpectations2 :445-476): adds this alignment to *hmm */
-void getHdpExpectationsUsingAnchors(StateMachine *sM, HdpHmmExpectations *hmm, Sequence *SsX, Sequence *SsY,
+void cpecan_getHdpExpectationsUsingAnchors(StateMachine *sM, HdpHmmExpectations *hmm, Sequence *SsX, Sequence *SsY,
                                     stList *anchorPairs, PairwiseAlignmentParameters *p,
                                     bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
-void hdpHmm_loadTransitions(StateMachine *sM, HdpHmmExpectations *hmm);      /* :681-699 */
-void hdpHmm_writeToFile(HdpHmmExpectations *hmm, FILE *fileHandle);          /* :701-753, the .expectations file */
-HdpHmmExpectations *hdpHmm_loadFromFile(const char *fileName);               /* :755-900, without the HDP update */
+void cpecan_hdpExpectations_load(StateMachine *sM, HdpHmmExpectations *hmm);      /* :681-699 */
+void cpecan_hdpExpectations_write(HdpHmmExpectations *hmm, FILE *fileHandle);          /* :701-753, the .expectations file */
+HdpHmmExpectations *cpecan_hdpExpectations_read(const char *fileName);               /* :755-900, without the HDP update */
 
 /* ---- Hmm / HmmDiscrete: Baum-Welch for the 5-state symbol machine (inc/stateMachine.h:47-74,
  * inc/discreteHmm.h:9-52, impl/discreteHmm.c), the reference's own structs and signatures ---------- */
@@ -425,12 +453,15 @@ StateMachineFunctions *stateMachineFunctions_construct(double (*gapXProbFcn)(con
 /* the M-step: a 5-state machine from normalised expectations (impl/stateMachine.c:1698-1723 with
  * stateMachine5_loadSymmetric :1100-1154 for type fiveState, _loadAsymmetric :1051-1098 otherwise) */
 StateMachine *getStateMachine5(Hmm *hmmD, StateMachineFunctions *sMfs);
-/* marker, like diagonalCalculationPosteriorMatchProbs: names the per-diagonal function of the E-step */
+/* like diagonalCalculationPosteriorMatchProbs: names the per-diagonal function of the E-step for the aligner entry
+ * points (GPU); called directly it is the reference's host function (:841-863) */
 void diagonalCalculation_Expectations(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,
                                       DpMatrix *backwardDpMatrix, Sequence *sX, Sequence *sY,
                                       double totalProbability, PairwiseAlignmentParameters *p, void *extraArgs);
-/* the E-step of one alignment (impl/pairwiseAligner.c:1571-1591): adds to hmmExpectations through its
- * add functions.  GPU path: fiveState / fiveStateAsymmetric machines with an HmmDiscrete. */
+/* the E-step of one alignment (impl/pairwiseAligner.c:1571-1591): adds to hmmExpectations through its add
+ * functions.  Dispatch on sM->type as the reference's callers rely on (vanillaAlign.c:345-356): fiveState /
+ * fiveStateAsymmetric with an HmmDiscrete, threeState with a ContinuousPairHmm, vanilla with a VanillaHmm,
+ * threeStateHdp with an HdpHmm; every E-step runs on the GPU. */
 void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, Sequence *SsX, Sequence *SsY,
                                  stList *anchorPairs, PairwiseAlignmentParameters *p,
                                  DiagonalPosteriorProbFn diagonalCalcExpectationFcn,
@@ -465,6 +496,172 @@ stList **getAlignedPairsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Sequenc
                                           stList **anchors, PairwiseAlignmentParameters *p,
                                           bool alignmentHasRaggedLeftEnd,
                                           bool alignmentHasRaggedRightEnd);
+
+/* ---- the reference's own signal-EM interface (inc/continuousHmm.h:7-124): Hmm subclasses and their functions,
+ * same structs, names and signatures.  getExpectationsUsingAnchors (below, with the 5-state entry) dispatches on
+ * sM->type exactly as vanillaAlign.c:345-356 calls it; the E-step runs on the GPU and its sums go through the
+ * Hmm's own add functions. */
+typedef struct _hmmContinuous {
+    Hmm baseHmm;
+} HmmContinuous;
+typedef struct _strawManHmm {
+    HmmContinuous baseContinuousHmm;
+    double *transitions;
+    double *individualKmerGapProbs;
+} ContinuousPairHmm;
+typedef struct _vanillaHmm {
+    HmmContinuous baseContinuousHmm;
+    double *matchModel;
+    double *scaledMatchModel;
+    double *kmerSkipBins;
+    int64_t (*getKmerSkipBin)(double *matchModel, void *cX);
+} VanillaHmm;
+typedef struct _hdpHmm {
+    Hmm baseHmm;
+    double *transitions;
+    double threshold;
+    void (*addToAssignments)(Hmm *, void *, void *);
+    stList *eventAssignments; /* double * per assignment */
+    stList *kmerAssignments;  /* char * per assignment   */
+    int64_t numberOfAssignments;
+    NanoporeHDP *nhdp;
+} HdpHmm;
+Hmm *continuousPairHmm_constructEmpty(
+    double pseudocount, int64_t stateNumber, int64_t symbolSetSize, StateMachineType type,
+    void (*addToTransitionExpFcn)(Hmm *hmm, int64_t from, int64_t to, double p),
+    void (*setTransitionFcn)(Hmm *hmm, int64_t from, int64_t to, double p),
+    double (*getTransitionsExpFcn)(Hmm *hmm, int64_t from, int64_t to),
+    void (*addToKmerGapExpFcn)(Hmm *hmm, int64_t state, int64_t ki, int64_t ignore, double p),
+    void (*setKmerGapExpFcn)(Hmm *hmm, int64_t state, int64_t ki, int64_t ignore, double p),
+    double (*getKmerGapExpFcn)(Hmm *hmm, int64_t state, int64_t ki, int64_t ignore),
+    int64_t (*getElementIndexFcn)(void *));
+void continuousPairHmm_addToTransitionsExpectation(Hmm *hmm, int64_t from, int64_t to, double p);
+void continuousPairHmm_setTransitionExpectation(Hmm *hmm, int64_t from, int64_t to, double p);
+double continuousPairHmm_getTransitionExpectation(Hmm *hmm, int64_t from, int64_t to);
+void continuousPairHmm_addToKmerGapExpectation(Hmm *hmm, int64_t state, int64_t kmerIndex, int64_t ignore, double p);
+void continuousPairHmm_setKmerGapExpectation(Hmm *hmm, int64_t state, int64_t kmerIndex, int64_t ignore, double p);
+double continuousPairHmm_getKmerGapExpectation(Hmm *hmm, int64_t state, int64_t kmerIndex, int64_t ignore);
+void continuousPairHmm_loadTransitionsAndKmerGapProbs(StateMachine *sM, Hmm *hmm); /* :206-232 */
+void continuousPairHmm_normalize(Hmm *hmm);                                        /* :174-191 */
+void continuousPairHmm_randomize(Hmm *hmm);                                        /* :193-204 */
+void continuousPairHmm_destruct(Hmm *hmm);
+void continuousPairHmm_writeToFile(Hmm *hmm, FILE *fileHandle);                    /* :234-272 */
+Hmm *continuousPairHmm_loadFromFile(const char *fileName);                         /* :274-370 */
+Hmm *vanillaHmm_constructEmpty(double pseudocount, int64_t stateNumber, int64_t symbolSetSize, StateMachineType type,
+                               void (*addToKmerBinExpFcn)(Hmm *hmm, int64_t bin, int64_t ignore, double p),
+                               void (*setKmerBinFcn)(Hmm *hmm, int64_t bin, int64_t ignore, double p),
+                               double (*getKmerBinExpFcn)(Hmm *hmm, int64_t bin, int64_t ignore));
+void vanillaHmm_addToKmerSkipBinExpectation(Hmm *hmm, int64_t bin, int64_t ignore, double p);
+void vanillaHmm_setKmerSkipBinExpectation(Hmm *hmm, int64_t bin, int64_t ignore, double p);
+double vanillaHmm_getKmerSkipBinExpectation(Hmm *hmm, int64_t bin, int64_t ignore);
+void vanillaHmm_normalizeKmerSkipBins(Hmm *hmm);                                   /* :420-429 */
+void vanillaHmm_randomizeKmerSkipBins(Hmm *hmm);
+void vanillaHmm_loadKmerSkipBinExpectations(StateMachine *sM, Hmm *hmm);           /* :452-462 */
+void vanillaHmm_implantMatchModelsintoHmm(StateMachine *sM, Hmm *hmm);             /* :431-443 */
+void vanillaHmm_writeToFile(Hmm *hmm, FILE *fileHandle);                           /* :477-530 */
+Hmm *vanillaHmm_loadFromFile(const char *fileName);                                /* :532-626 */
+void vanillaHmm_destruct(Hmm *hmm);
+Hmm *hdpHmm_constructEmpty(double pseudocount, int64_t stateNumber, StateMachineType type, double threshold,
+                           void (*addToTransitionExpFcn)(Hmm *hmm, int64_t from, int64_t to, double p),
+                           void (*setTransitionFcn)(Hmm *hmm, int64_t from, int64_t to, double p),
+                           double (*getTransitionsExpFcn)(Hmm *hmm, int64_t from, int64_t to));
+void hdpHmm_loadTransitions(StateMachine *sM, Hmm *hmm);                           /* :681-699 */
+void hdpHmm_writeToFile(Hmm *hmm, FILE *fileHandle);                               /* :701-753 */
+Hmm *hdpHmm_loadFromFile(const char *fileName, NanoporeHDP *nHdp); /* :755-900: transitions and assignments; the
+                                                                       Gibbs update of nHdp is not part of this path */
+void hdpHmm_destruct(Hmm *hmm);
+void hmmContinuous_loadSignalHmm(const char *hmmFile, StateMachine *sM, StateMachineType type); /* :903-911 */
+void hmmContinuous_destruct(Hmm *hmm, StateMachineType type);
+Hmm *hmmContinuous_getEmptyHmm(StateMachineType type, double pseudocount, double threshold);    /* :913-945 */
+void hmmContinuous_normalize(Hmm *hmm, StateMachineType type);
+void hmmContinuous_writeToFile(const char *outFile, Hmm *hmm, StateMachineType type);
+int64_t hmmContinuous_howManyAssignments(Hmm *hmm);
+
+/* ---- the constructors that take plug-ins (inc/stateMachine.h:259-312) and the plug-ins themselves ------------ */
+StateMachine *stateMachine3_construct(StateMachineType type, int64_t parameterSetSize,
+                                      void (*setTransitionsToDefaults)(StateMachine *sM),
+                                      void (*setEmissionsDefaults)(StateMachine *sM, int64_t nbSkipParams),
+                                      double (*gapXProbFcn)(const double *, void *),
+                                      double (*gapYProbFcn)(const double *, void *, void *),
+                                      double (*matchProbFcn)(const double *, void *, void *),
+                                      void (*cellCalcUpdateExpFcn)(double *fromCells, double *toCells, int64_t from,
+                                                                   int64_t to, double eP, double tP, void *extraArgs));
+StateMachine *stateMachine3Hdp_construct(StateMachineType type, int64_t parameterSetSize,
+                                         void (*setTransitionsToDefaults)(StateMachine *sM),
+                                         void (*setEmissionsDefaults)(StateMachine *sM, int64_t nbSkipParams),
+                                         NanoporeHDP *hdpModel, double (*gapXProbFcn)(const double *, void *),
+                                         double (*gapYProbFcn)(NanoporeHDP *, void *, void *),
+                                         double (*matchProbFcn)(NanoporeHDP *, void *, void *),
+                                         void (*cellCalcUpdateExpFcn)(double *fromCells, double *toCells, int64_t from,
+                                                                      int64_t to, double eP, double tP,
+                                                                      void *extraArgs));
+StateMachine *stateMachine3Vanilla_construct(StateMachineType type, int64_t parameterSetSize,
+                                             void (*setEmissionsDefaults)(StateMachine *sM, int64_t nbSkipParams),
+                                             double (*xSkipProbFcn)(StateMachine *, void *, bool),
+                                             double (*scaledMatchProbFcn)(const double *, void *, void *),
+                                             double (*matchProbFcn)(const double *, void *, void *),
+                                             void (*cellCalcUpdateExpFcn)(double *fromCells, double *toCells,
+                                                                          int64_t from, int64_t to, double eP,
+                                                                          double tP, void *extraArgs));
+void emissions_signal_initEmissionsToZero(StateMachine *sM, int64_t nbSkipParams);                 /* :189-219 */
+double emissions_kmer_getGapProb(const double *emissionGapProbs, void *kmer);                      /* :175-187 */
+double emissions_signal_strawManGetKmerEventMatchProb(const double *eventModel, void *x_i, void *e_j); /* :595-629 */
+double emissions_signal_getEventMatchProbWithTwoDists(const double *eventModel, void *kmer, void *event); /* :499-528 */
+int64_t emissions_signal_getKmerSkipBin(double *matchModel, void *kmers);                          /* :388-419 */
+double emissions_signal_getBetaOrAlphaSkipProb(StateMachine *sM, void *kmers, bool getAlpha);      /* :421-428 */
+void cell_signal_updateTransAndKmerSkipExpectations(double *fromCells, double *toCells, int64_t from, int64_t to,
+                                                    double eP, double tP, void *extraArgs); /* pairwiseAligner.c:426 */
+void cell_signal_updateTransAndKmerSkipExpectations2(double *fromCells, double *toCells, int64_t from, int64_t to,
+                                                     double eP, double tP, void *extraArgs); /* :445 */
+void cell_signal_updateBetaAndAlphaProb(double *fromCells, double *toCells, int64_t from, int64_t to, double eP,
+                                        double tP, void *extraArgs); /* :478 */
+
+/* ---- internals the reference exports and tests (inc/pairwiseAligner.h:190-267): plain host C over DpMatrix
+ * objects, for callers and tests that drive the recurrence diagonal by diagonal themselves.  The aligner entry
+ * points above do not use them. */
+void cell_calculateForward(StateMachine *sM, double *current, double *lower, double *middle, double *upper, void *cX,
+                           void *cY, void *extraArgs);
+void cell_calculateBackward(StateMachine *sM, double *current, double *lower, double *middle, double *upper, void *cX,
+                            void *cY, void *extraArgs);
+double cell_dotProduct(double *cell1, double *cell2, int64_t stateNumber);
+double cell_dotProduct2(double *cell1, StateMachine *sM, double (*getStateValue)(StateMachine *, int64_t));
+typedef struct _dpDiagonal DpDiagonal;
+DpDiagonal *dpDiagonal_construct(Diagonal diagonal, int64_t stateNumber);
+DpDiagonal *dpDiagonal_clone(DpDiagonal *diagonal);
+bool dpDiagonal_equals(DpDiagonal *diagonal1, DpDiagonal *diagonal2);
+void dpDiagonal_destruct(DpDiagonal *dpDiagonal);
+double *dpDiagonal_getCell(DpDiagonal *dpDiagonal, int64_t xmy);
+double dpDiagonal_dotProduct(DpDiagonal *diagonal1, DpDiagonal *diagonal2);
+void dpDiagonal_zeroValues(DpDiagonal *diagonal);
+void dpDiagonal_initialiseValues(DpDiagonal *diagonal, StateMachine *sM, double (*getStateValue)(StateMachine *, int64_t));
+DpMatrix *dpMatrix_construct(int64_t diagonalNumber, int64_t stateNumber);
+void dpMatrix_destruct(DpMatrix *dpMatrix);
+DpDiagonal *dpMatrix_getDiagonal(DpMatrix *dpMatrix, int64_t xay);
+int64_t dpMatrix_getActiveDiagonalNumber(DpMatrix *dpMatrix);
+DpDiagonal *dpMatrix_createDiagonal(DpMatrix *dpMatrix, Diagonal diagonal);
+void dpMatrix_deleteDiagonal(DpMatrix *dpMatrix, int64_t xay);
+void diagonalCalculationForward(StateMachine *sM, int64_t xay, DpMatrix *dpMatrix, Sequence *sX, Sequence *sY);
+void diagonalCalculationBackward(StateMachine *sM, int64_t xay, DpMatrix *dpMatrix, Sequence *sX, Sequence *sY);
+double diagonalCalculationTotalProbability(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,
+                                           DpMatrix *backwardDpMatrix, Sequence *sX, Sequence *sY);
+
+/* ---- layout checks against the reference's headers (LP64): base struct 104 bytes, the subclasses' first transition
+ * at 104, their function pointers behind the transitions ---------------------------------------------------- */
+#include <stddef.h>
+_Static_assert(offsetof(struct _stateMachine, EMISSION_MATCH_PROBS) == 32, "StateMachine layout");
+_Static_assert(offsetof(struct _stateMachine, startStateProb) == 56, "StateMachine layout");
+_Static_assert(offsetof(struct _stateMachine, cellCalculate) == 88, "StateMachine layout");
+_Static_assert(sizeof(struct _stateMachine) == 104, "StateMachine layout");
+_Static_assert(offsetof(StateMachine3, TRANSITION_MATCH_CONTINUE) == 104, "StateMachine3 layout");
+_Static_assert(offsetof(StateMachine3, getXGapProbFcn) == 176 && sizeof(StateMachine3) == 200, "StateMachine3 layout");
+_Static_assert(offsetof(StateMachine5, getXGapProbFcn) == 240 && sizeof(StateMachine5) == 264, "StateMachine5 layout");
+_Static_assert(offsetof(StateMachine3_HDP, hdpModel) == 184 && sizeof(StateMachine3_HDP) == 208, "StateMachine3_HDP layout");
+_Static_assert(offsetof(StateMachine3Vanilla, getKmerSkipProb) == 144 && sizeof(StateMachine3Vanilla) == 168,
+               "StateMachine3Vanilla layout");
+_Static_assert(sizeof(struct _hmm) == 96 && offsetof(HmmDiscrete, transitions) == 96, "Hmm layout");
+_Static_assert(offsetof(ContinuousPairHmm, individualKmerGapProbs) == 104, "ContinuousPairHmm layout");
+_Static_assert(offsetof(VanillaHmm, getKmerSkipBin) == 120 && offsetof(HdpHmm, nhdp) == 144, "VanillaHmm / HdpHmm layout");
+_Static_assert(sizeof(PairwiseAlignmentParameters) == 72, "PairwiseAlignmentParameters layout");
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,10 @@ class StateMachine(C.Structure):
     _fields_ = [("type", C.c_int), ("stateNumber", C.c_int64), ("matchState", C.c_int64),
                 ("parameterSetSize", C.c_int64), ("EMISSION_MATCH_PROBS", C.POINTER(C.c_double)),
                 ("EMISSION_GAP_X_PROBS", C.POINTER(C.c_double)),
-                ("EMISSION_GAP_Y_PROBS", C.POINTER(C.c_double))]
+                ("EMISSION_GAP_Y_PROBS", C.POINTER(C.c_double))] + [
+                    (n, C.c_void_p) for n in ("startStateProb", "endStateProb", "raggedEndStateProb",
+                                              "raggedStartStateProb", "cellCalculate",
+                                              "cellCalculateUpdateExpectations")]
 
 
 class StateMachine3(C.Structure):
@@ -52,8 +55,8 @@ EXPORTS = [
     "getStrawManStateMachine3", "stateMachine3_setTransitionsToNanoporeDefaults",
     "emissions_signal_scaleModel", "emissions_discrete_getKmerIndex", "stateMachine_destruct",
     "diagonalCalculationPosteriorMatchProbs", "getAlignedPairsUsingAnchors",
-    "getAlignedPairsWithoutBanding", "getSplitPoints", "getSignalExpectationsUsingAnchors",
-    "continuousPairHmm_normalize", "continuousPairHmm_loadTransitionsAndKmerGapProbs",
+    "getAlignedPairsWithoutBanding", "getSplitPoints", "cpecan_getSignalExpectationsUsingAnchors",
+    "cpecan_pairHmmExpectations_normalize", "cpecan_pairHmmExpectations_load",
     "getAlignedPairsUsingAnchorsBatch", "sequence_getBase", "sequence_sliceNucleotideSequence",
     "stateMachine5_construct", "emissions_symbol_setEmissionsToDefaults", "emissions_symbol_getGapProb",
     "emissions_symbol_getMatchProb", "cell_updateExpectations", "sequence_getKmer2",
@@ -66,7 +69,7 @@ EXPORTS = [
     "bandIterator_construct", "bandIterator_destruct", "bandIterator_clone", "bandIterator_getNext",
     "bandIterator_getPrevious", "logAdd", "nanopore_loadNanoporeReadFromFile", "nanopore_remapAnchorPairs",
     "nanopore_remapAnchorPairsWithOffset", "nanopore_descaleNanoporeRead", "nanopore_nanoporeReadDestruct",
-    "continuousPairHmm_writeToFile", "continuousPairHmm_loadFromFile", "hmmDiscrete_constructEmpty",
+    "cpecan_pairHmmExpectations_write", "cpecan_pairHmmExpectations_read", "hmmDiscrete_constructEmpty",
     "hmmDiscrete_addToTransitionExpectation", "hmmDiscrete_setTransitionExpectation",
     "hmmDiscrete_getTransitionExpectation", "hmmDiscrete_addToEmissionExpectation",
     "hmmDiscrete_setEmissionExpectation", "hmmDiscrete_getEmissionExpectation",
@@ -75,18 +78,19 @@ EXPORTS = [
     "emissions_discrete_getBaseIndex", "stateMachineFunctions_construct", "getStateMachine5",
     "diagonalCalculation_Expectations", "getExpectationsUsingAnchors", "getExpectations",
     "getIndelProbabilities", "reweightAlignedPairs", "reweightAlignedPairs2", "sequence_padSequence",
-    "getVanillaExpectationsUsingAnchors", "vanillaHmm_normalizeKmerSkipBins",
-    "vanillaHmm_loadKmerSkipBinExpectations", "hdpHmm_constructEmpty", "hdpHmm_destruct",
-    "getHdpExpectationsUsingAnchors", "hdpHmm_loadTransitions", "hdpHmm_writeToFile", "writePosteriorProbs",
+    "cpecan_getVanillaExpectationsUsingAnchors", "cpecan_vanillaExpectations_normalize",
+    "cpecan_vanillaExpectations_load", "cpecan_hdpExpectations_construct", "cpecan_hdpExpectations_destruct",
+    "cpecan_getHdpExpectationsUsingAnchors", "cpecan_hdpExpectations_load", "cpecan_hdpExpectations_write", "writePosteriorProbs",
     "getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps", "getAlignedPairs",
-    "vanillaHmm_writeToFile", "vanillaHmm_loadFromFile", "hdpHmm_loadFromFile",
+    "cpecan_vanillaExpectations_write", "cpecan_vanillaExpectations_read", "cpecan_hdpExpectations_read",
 ]
 
 
 class HdpExpectations(C.Structure):
     _fields_ = [("likelihood", C.c_double), ("transitions", C.c_double * 9), ("threshold", C.c_double),
                 ("numberOfAssignments", C.c_int64), ("capacity", C.c_int64),
-                ("eventAssignments", C.POINTER(C.c_double)), ("kmerAssignments", C.POINTER(C.c_char))]
+                ("eventAssignments", C.POINTER(C.c_double)), ("kmerAssignments", C.POINTER(C.c_char)),
+                ("assignmentXY", C.POINTER(C.c_int64))]
 
 
 class VanillaExpectations(C.Structure):
@@ -220,8 +224,8 @@ def lib():
         L.hmmDiscrete_normalize2.argtypes = [HP, C.c_bool]
         L.hmmDiscrete_loadFromFile.restype = HP
         L.hmmDiscrete_loadFromFile.argtypes = [C.c_char_p]
-        L.continuousPairHmm_loadFromFile.restype = C.POINTER(Expectations)
-        L.continuousPairHmm_loadFromFile.argtypes = [C.c_char_p]
+        L.cpecan_pairHmmExpectations_read.restype = C.POINTER(Expectations)
+        L.cpecan_pairHmmExpectations_read.argtypes = [C.c_char_p]
         L.emissions_discrete_getBaseIndex.restype = C.c_int64
         L.emissions_discrete_getBaseIndex.argtypes = [C.c_char_p]
         L.stateMachineFunctions_construct.restype = vp
@@ -229,17 +233,17 @@ def lib():
         L.getStateMachine5.restype = C.POINTER(StateMachine5)
         L.getStateMachine5.argtypes = [HP, vp]
         L.getExpectationsUsingAnchors.argtypes = [vp, HP, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
-        L.getVanillaExpectationsUsingAnchors.argtypes = [vp, C.POINTER(VanillaExpectations), vp, vp, vp,
+        L.cpecan_getVanillaExpectationsUsingAnchors.argtypes = [vp, C.POINTER(VanillaExpectations), vp, vp, vp,
                                                          C.POINTER(Params), C.c_bool, C.c_bool]
-        L.vanillaHmm_normalizeKmerSkipBins.argtypes = [C.POINTER(VanillaExpectations)]
-        L.vanillaHmm_loadKmerSkipBinExpectations.argtypes = [vp, C.POINTER(VanillaExpectations)]
-        L.hdpHmm_constructEmpty.restype = C.POINTER(HdpExpectations)
-        L.hdpHmm_constructEmpty.argtypes = [C.c_double, C.c_double]
-        L.hdpHmm_destruct.argtypes = [C.POINTER(HdpExpectations)]
-        L.getHdpExpectationsUsingAnchors.argtypes = [vp, C.POINTER(HdpExpectations), vp, vp, vp, C.POINTER(Params),
+        L.cpecan_vanillaExpectations_normalize.argtypes = [C.POINTER(VanillaExpectations)]
+        L.cpecan_vanillaExpectations_load.argtypes = [vp, C.POINTER(VanillaExpectations)]
+        L.cpecan_hdpExpectations_construct.restype = C.POINTER(HdpExpectations)
+        L.cpecan_hdpExpectations_construct.argtypes = [C.c_double, C.c_double]
+        L.cpecan_hdpExpectations_destruct.argtypes = [C.POINTER(HdpExpectations)]
+        L.cpecan_getHdpExpectationsUsingAnchors.argtypes = [vp, C.POINTER(HdpExpectations), vp, vp, vp, C.POINTER(Params),
                                                      C.c_bool, C.c_bool]
-        L.hdpHmm_loadTransitions.argtypes = [vp, C.POINTER(HdpExpectations)]
-        L.hdpHmm_writeToFile.argtypes = [C.POINTER(HdpExpectations), vp]
+        L.cpecan_hdpExpectations_load.argtypes = [vp, C.POINTER(HdpExpectations)]
+        L.cpecan_hdpExpectations_write.argtypes = [C.POINTER(HdpExpectations), vp]
         L.writePosteriorProbs.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_double, C.c_double,
                                           C.POINTER(C.c_double), C.c_char_p, C.c_bool, C.c_char_p, C.c_int64,
                                           C.c_int64, vp, C.c_int]
@@ -248,11 +252,11 @@ def lib():
         L.getAlignedPairs.restype = vp
         L.getAlignedPairs.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, C.POINTER(Params), vp, vp, vp, C.c_bool,
                                       C.c_bool]
-        L.vanillaHmm_writeToFile.argtypes = [C.POINTER(VanillaExpectations), vp, vp]
-        L.vanillaHmm_loadFromFile.restype = C.POINTER(VanillaExpectations)
-        L.vanillaHmm_loadFromFile.argtypes = [C.c_char_p, vp]
-        L.hdpHmm_loadFromFile.restype = C.POINTER(HdpExpectations)
-        L.hdpHmm_loadFromFile.argtypes = [C.c_char_p]
+        L.cpecan_vanillaExpectations_write.argtypes = [C.POINTER(VanillaExpectations), vp, vp]
+        L.cpecan_vanillaExpectations_read.restype = C.POINTER(VanillaExpectations)
+        L.cpecan_vanillaExpectations_read.argtypes = [C.c_char_p, vp]
+        L.cpecan_hdpExpectations_read.restype = C.POINTER(HdpExpectations)
+        L.cpecan_hdpExpectations_read.argtypes = [C.c_char_p]
         L.getIndelProbabilities.restype = C.POINTER(C.c_int64)
         L.getIndelProbabilities.argtypes = [vp, C.c_int64, C.c_bool]
         L.reweightAlignedPairs2.restype = vp
@@ -276,10 +280,10 @@ def lib():
                                                     vp, vp, vp, C.c_bool, C.c_bool]
         L.getSplitPoints.restype = vp
         L.getSplitPoints.argtypes = [vp, C.c_int64, C.c_int64, C.c_int64, C.c_bool, C.c_bool]
-        L.getSignalExpectationsUsingAnchors.argtypes = [vp, C.POINTER(Expectations), vp, vp, vp,
+        L.cpecan_getSignalExpectationsUsingAnchors.argtypes = [vp, C.POINTER(Expectations), vp, vp, vp,
                                                         C.POINTER(Params), C.c_bool, C.c_bool]
-        L.continuousPairHmm_normalize.argtypes = [C.POINTER(Expectations)]
-        L.continuousPairHmm_loadTransitionsAndKmerGapProbs.argtypes = [vp, C.POINTER(Expectations)]
+        L.cpecan_pairHmmExpectations_normalize.argtypes = [C.POINTER(Expectations)]
+        L.cpecan_pairHmmExpectations_load.argtypes = [vp, C.POINTER(Expectations)]
         L.getAlignedPairsUsingAnchorsBatch.restype = C.POINTER(vp)
         L.getAlignedPairsUsingAnchorsBatch.argtypes = [C.c_int64, C.POINTER(vp), C.POINTER(vp),
                                                        C.POINTER(vp), C.POINTER(vp), C.POINTER(Params),
