@@ -110,6 +110,11 @@ class HmmDiscrete(C.Structure):
     _fields_ = [("baseHmm", Hmm), ("transitions", C.POINTER(C.c_double)), ("emissions", C.POINTER(C.c_double))]
 
 
+class ContinuousPairHmm(C.Structure):
+    _fields_ = [("baseHmm", Hmm), ("transitions", C.POINTER(C.c_double)),
+                ("individualKmerGapProbs", C.POINTER(C.c_double))]
+
+
 class StateMachine5(C.Structure):
     _fields_ = [("model", StateMachine)] + [(n, C.c_double) for n in (
         "MATCH_CONTINUE", "MATCH_FROM_SHORT_GAP_X", "MATCH_FROM_LONG_GAP_X", "GAP_SHORT_OPEN_X",
@@ -232,7 +237,10 @@ def lib():
         L.stateMachineFunctions_construct.argtypes = [vp, vp, vp]
         L.getStateMachine5.restype = C.POINTER(StateMachine5)
         L.getStateMachine5.argtypes = [HP, vp]
-        L.getExpectationsUsingAnchors.argtypes = [vp, HP, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
+        L.getExpectationsUsingAnchors.argtypes = [vp, vp, vp, vp, vp, C.POINTER(Params), vp, C.c_bool, C.c_bool]
+        L.hmmContinuous_getEmptyHmm.restype = vp
+        L.hmmContinuous_getEmptyHmm.argtypes = [C.c_int, C.c_double, C.c_double]
+        L.hmmContinuous_destruct.argtypes = [vp, C.c_int]
         L.cpecan_getVanillaExpectationsUsingAnchors.argtypes = [vp, C.POINTER(VanillaExpectations), vp, vp, vp,
                                                          C.POINTER(Params), C.c_bool, C.c_bool]
         L.cpecan_vanillaExpectations_normalize.argtypes = [C.POINTER(VanillaExpectations)]

@@ -146,6 +146,20 @@ def test_real_read_unbanded_986(template_model, zymo_read):
     assert tri[:, 0].min() > 0 and tri[:, 0].max() <= 10000000
 
 
+def test_real_read_unbanded_vanilla_953(template_model, zymo_read):
+    # tests/signalPairwiseTest.c:1295-1303 (test_vanilla_getAlignedPairsWithBanding): the vanilla machine as
+    # getSignalStateMachine3Vanilla leaves it (M->Y factor 0.17, E->E 0.55f; no strand call), scaled, the same read
+    # un-banded at the default threshold 0.01 -> exactly 953 aligned pairs.
+    match, skip, gapy = template_model
+    m = o.VanillaModel(match, skip, gapy, 0.17, float(np.float32(0.55))).scaled(*zymo_read["template_params"])
+    ref = zymo_read["reference"]
+    r = o.aligned_pairs_without_banding(m, ref, len(ref) - 5, zymo_read["template_events"], o.default_params())
+    tri = r["triples"]
+    assert len(tri) == 953
+    assert len({(int(x), int(y)) for _, x, y in tri}) == 953
+    assert tri[:, 0].min() > 0 and tri[:, 0].max() <= 10000000
+
+
 def test_banded_matches_unbanded_on_real_read(template_model, zymo_read):
     # The reference's banded count on this read (987, signalPairwiseTest.c:1163) needs lastz anchors,
     # which cannot be regenerated here.  What can be pinned: with a band that covers the whole

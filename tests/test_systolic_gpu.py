@@ -65,10 +65,11 @@ def test_systolic_matches_oracle(ctx, case, rows):
         assert_same_pairs(res[i], ref)
 
 
-@pytest.mark.parametrize("threshold", [0.01, 1e-4, 1e-7])
+@pytest.mark.parametrize("threshold", [0.0, 0.01, 1e-4, 1e-7])
 def test_systolic_decode_paths_agree(ctx, threshold, rows):
     # the candidate-list decode (default) and the full-scan decode (CPECAN_FLAG_SCAN_DECODE, also the
-    # path a window falls back to by itself; a tiny threshold makes long candidate lists)
+    # path a window falls back to by itself; a tiny threshold makes long candidate lists, threshold 0 emits every
+    # cell of the band with x, y > 0 and overflows the first pair allocation: the count-then-allocate re-run)
     batch = synth.make_batch(25, 3, 300, 620, anchor_every=50)
     bp = band_params(threshold, 100, 40, 60)
     a, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=(1, 1))
