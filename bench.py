@@ -1,29 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- banded pair-HMM forward/backward/posterior throughput on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--mode posterior|em]
 
-A step is one pass of the hot path (forward, checkpointed backward, posterior decode) over one
-synthetic batch per GPU: BASELINE.json configs[2], 1024 reads x (10k events x 5k k-mers), band
-(diagonalExpansion) 100, per-read scaled pore models.  Inputs are resident in HBM before the timed
-region.  Reads shard across ranks with no data-path collective (weak scaling: every GPU gets its
-own 1024 reads).  Consecutive steps are pipelined (--inflight 2): step s+1 works on another batch of 1024
-reads on a stream of its own and is issued before step s is waited for, so two passes overlap on the GPU the
-way queued batches do in service; the timed region still covers exactly K complete steps.  Rank 0 prints ONE
-JSON line.
+N > 1 without a rendezvous in the environment: this process starts its own N workers (one per GPU, through
+`python -m torch.distributed.run` on 127.0.0.1), before it touches a GPU itself, and passes their output on.  The
+driver's own `torch.distributed.run ... bench.py --gpus N` launch is recognised by WORLD_SIZE and runs as a worker.
+
+--mode posterior (default).  A step is one pass of the hot path (forward, checkpointed backward, posterior decode,
+the aligned pairs finished on the host) over one synthetic batch per GPU: BASELINE.json configs[2], 1024 reads x
+(10k events x 5k k-mers), band (diagonalExpansion) 100, per-read scaled pore models.  Inputs are resident in HBM
+before the timed region.  Reads shard across ranks with no data-path collective (weak scaling: every GPU gets its
+own 1024 reads).  Consecutive steps are pipelined (--inflight 2): step s+1 works on another batch of 1024 reads on
+streams of its own and is issued before step s is waited for, the way queued batches overlap in service; while the
+GPU works on one batch the host finishes the other's pairs (exp, threshold, floor with libm -- what makes the
+integer posteriors the reference's, bit for bit).  The timed region covers exactly K complete steps, pairs included.
+After it, rank 0 times ONE batch alone (--single-steps, each step waited for before the next is issued) on the
+wave-per-alignment kernels: roofline.frac_single_batch.
+
+--mode em.  BASELINE.json configs[3]: a step is one Baum-Welch iteration -- E-step of this rank's reads on the GPU
+(expectations summed on the device), ONE all-reduce of the [9 transitions | 4096 k-mer gaps | likelihood] vector
+over RCCL, M-step (normalise, reload the transitions and gap probabilities in place on the device).
 
 value      = in-band cells (each counted once) of all ranks / max-over-ranks wall time, Gcells/s
-roofline   = algorithmic bytes (48 B per cell: one fp64 write + one re-read of 3 states,
-             SURVEY.md section 8d) / average kernel duration measured with HIP events on the
-             library's own stream, against the 8 TB/s HBM peak
-cpu_baseline = the CPU oracle (a port of the reference's algorithm; the reference itself cannot be
-             built here) timed on rank 0 over the first reads of the same batch: on all host cores of
-             the job (a pool of forked workers, started before the process touches the GPU) and on
-             one thread.
+roofline   = algorithmic bytes (48 B per cell: one fp64 write + one re-read of 3 states) /
+             average duration of a pass, against the 8 TB/s HBM peak; dominant_kernel from HIP events on the
+             library's own streams
+cpu_baseline = the CPU oracle (a port of the reference's algorithm; the reference itself cannot be built here:
+             sonLib is absent) timed on rank 0 over the first reads of the same batch: on all host cores of the job
+             (a pool of forked workers, started before the process touches the GPU) and on one thread.
+
+--rehearse: the N-rank plumbing without a GPU (gloo; a step is the host band geometry of the rank's reads) -- what
+the CPU tests run with two ranks; its JSON line says so and carries no throughput claim.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -68,33 +81,122 @@ def cpu_all_cores(batch, band, per_core, cores):
             "sample": "first %d reads of the same batch, %d worker processes, oracle/cpecan_oracle.c" % (n, cores)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", choices=("posterior", "em"), default="posterior")
     ap.add_argument("--reads", type=int, default=1024)
     ap.add_argument("--events", type=int, default=10000)
     ap.add_argument("--kmers", type=int, default=5000)
     ap.add_argument("--band", type=int, default=100)
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 systolic")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 general, 2 register-resident")
+    ap.add_argument("--family", choices=("auto", "wave", "workgroup"), default="auto",
+                    help="register-resident kernels of the timed region: wave-per-alignment or workgroup-per-"
+                         "alignment; auto = workgroup when batches are pipelined (--inflight 2), wave otherwise")
     ap.add_argument("--cpu-reads", type=int, default=60,
                     help="reads timed on the CPU oracle, ~0.3 s each on one core (0: skip)")
     ap.add_argument("--cpu-cores", type=int, default=0,
                     help="worker processes of the all-core CPU baseline (0: the host cores this job may use, at most 16)")
     ap.add_argument("--check", type=int, default=2, help="reads compared with the oracle after the run")
     ap.add_argument("--inflight", type=int, default=2,
-                    help="batches in flight: step s+1 (another batch, its own stream) is issued before step s is "
+                    help="batches in flight: step s+1 (another batch, its own streams) is issued before step s is "
                          "waited for, as a server with queued batches would; every step is still one pass over "
                          "one batch and all K steps complete inside the timed region")
-    args = ap.parse_args()
+    ap.add_argument("--single-steps", type=int, default=12,
+                    help="steps of the single-batch measurement after the timed region (rank 0, N=1; 0: skip)")
+    ap.add_argument("--no-finalise", action="store_true",
+                    help="leave the pairs as (x, y, exponent) in HBM inside the timed region instead of finishing "
+                         "them on the host (GPU pass alone)")
+    ap.add_argument("--rehearse", action="store_true", help="no GPU: gloo ranks, host band geometry as the step")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started workers")
+    return ap.parse_args(argv)
 
+
+def launch_workers(args, argv):
+    """--gpus N from a plain command line: N worker processes, one per GPU, started before this process touches a
+    GPU; their stdout (rank 0's JSON line) is passed through, the exit code is theirs."""
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def make_items(cp, bt):
+    items = np.zeros(len(bt["items"]), cp.ITEM_DTYPE)
+    for i, it in enumerate(bt["items"]):
+        items[i] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"],
+                    it["n_anchors"], it["model"], 1, 1, 0)  # ragged ends, as vanillaAlign.c:203
+    return items
+
+
+def rehearse(args, rank, world):
+    """The ranks' plumbing on the CPU: rendezvous, shard by rank, barrier, max-over-ranks time, sum of cells, one JSON
+    line from rank 0.  The step is the host part of a pass that needs no GPU: the band table of every read."""
+    import torch
+    import torch.distributed as dist
+    import synth
+    from cpecan_load import binding
+    cp = binding()
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    bt = synth.make_batch(3 + 100 * rank, args.reads, args.kmers, args.events, anchor_every=50)
+
+    def step():
+        cells = 0
+        for it in bt["items"]:
+            an = bt["anchors"][it["anchor_offset"]: it["anchor_offset"] + it["n_anchors"]]
+            lo, hi = cp.band_construct(an, it["lX"], it["lY"], args.band)
+            cells += int(((hi - lo) // 2 + 1).sum())
+        return cells
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    cells = 0
+    for _ in range(args.steps):
+        cells = step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64)
+    ct = torch.tensor([cells], dtype=torch.int64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "banded fwd-bwd Gcells/s", "value": None, "unit": "Gcells/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * float(tt.item()) / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic; REHEARSAL on the CPU (gloo): host band geometry only, no GPU work, no throughput claim",
+            "config": {"workload": "%d reads/rank x (%d events x %d k-mers), diagonalExpansion %d"
+                                   % (args.reads, args.events, args.kmers, args.band),
+                       "cells_all_ranks": int(ct.item()), "cells_rank0": cells}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_workers(args, argv)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run" % args.gpus)
+    if args.rehearse:
+        return rehearse(args, rank, world)
 
     import torch
     import torch.distributed as dist
@@ -111,17 +213,30 @@ def main():
         # a one-GPU box of the pool gives a job 16 host cores, whatever os.cpu_count() says about the machine
         cores = args.cpu_cores or min(len(os.sched_getaffinity(0)), 16)
         cpu_all = cpu_all_cores(first_batch, args.band, max(1, args.cpu_reads * 2 // 3), cores)
-    from cpecan_load import binding
+    from cpecan_load import binding, em as load_em
     cp = binding()
+    bp = cp.BandParams(0.01, 1000, 40, args.band)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.mode == "em":
+        return bench_em(args, cp, load_em(), bp, rank, local_rank, world, dist, torch, synth, sync_all, first_batch,
+                        cpu_all)
 
     # ---- inputs: this rank's reads, uploaded before the timed region -------------------------
-    # `inflight` batches of distinct reads, each with a context (stream) of its own.  With two in flight every
-    # batch runs as ONE stream group (two kernels of 1024 workgroups overlap); alone, a batch is split into two
-    # groups so that its own forward and backward kernels overlap.
+    # `inflight` batches of distinct reads, each with a context (streams) of its own.  Pipelined batches run on the
+    # workgroup-per-alignment kernels, each as ONE stream group (two kernels of 1024 workgroups overlap); alone, a
+    # batch runs on the wave-per-alignment kernels, whose forward sweep of window w+1 overlaps the backward sweep of
+    # window w inside the batch.
     inflight = max(1, min(args.inflight, args.steps))
+    family = args.family if args.family != "auto" else ("workgroup" if inflight > 1 else "wave")
+    flags = cp.FLAG_WORKGROUP_KERNELS if family == "workgroup" else 0
     if inflight > 1 and "CPECAN_SYSTOLIC_GROUPS" not in os.environ:
         os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"
-    bp = cp.BandParams(0.01, 1000, 40, args.band)
     t_gen = t_models = t_upload = 0.0
     batches, ctxs, bs = [], [], []
     for j in range(inflight):
@@ -134,25 +249,28 @@ def main():
         t0 = time.time()
         cx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in bt["models"]])
         t_models += time.time() - t0
-        items = np.zeros(len(bt["items"]), cp.ITEM_DTYPE)
-        for i, it in enumerate(bt["items"]):
-            items[i] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"],
-                        it["n_anchors"], it["model"], 1, 1, 0)  # ragged ends, as vanillaAlign.c:203
         t0 = time.time()
-        bs.append(cp.Batch(cx, items, bt["x_chars"], bt["events"], bt["anchors"], bp,
-                           cp.MODE_POSTERIOR, args.kernel, 0))
+        bs.append(cp.Batch(cx, make_items(cp, bt), bt["x_chars"], bt["events"], bt["anchors"], bp,
+                           cp.MODE_POSTERIOR, args.kernel, flags))
         t_upload += time.time() - t0
         batches.append(bt)
         ctxs.append(cx)
     batch, b = batches[0], bs[0]
+    finalise = not args.no_finalise
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+    kernel_ms, stage, fin_s = [], [], []
 
-    kernel_ms, stage = [], []
+    def wait_for(j, record):
+        bs[j].sync()
+        if record:
+            kernel_ms.append(bs[j].elapsed_ms()[1])
+            if bs[j].info()["kernel"] == "systolic":
+                stage.append(bs[j].stage_ms())
+        if finalise:  # D2H of the candidates + exp/threshold/floor on the host threads; the GPU works on the other batch
+            t0 = time.perf_counter()
+            bs[j].counts()
+            if record:
+                fin_s.append(time.perf_counter() - t0)
 
     def run_steps(n, record):
         """n steps, step s on batch s % inflight; a batch is waited for only when it is needed again"""
@@ -160,20 +278,13 @@ def main():
         for s_ in range(n):
             j = s_ % inflight
             if pending[j]:
-                bs[j].sync()
-                if record:
-                    kernel_ms.append(bs[j].elapsed_ms()[1])
-                    if bs[j].info()["kernel"] == "systolic":
-                        stage.append(bs[j].stage_ms())
+                wait_for(j, record)
             bs[j].run()
             pending[j] = True
-        for j in range(inflight):
+        for k in range(inflight):  # the oldest first
+            j = (n + k) % inflight
             if pending[j]:
-                bs[j].sync()
-                if record:
-                    kernel_ms.append(bs[j].elapsed_ms()[1])
-                    if bs[j].info()["kernel"] == "systolic":
-                        stage.append(bs[j].stage_ms())
+                wait_for(j, record)
 
     run_steps(max(args.warmup, inflight if args.warmup > 0 else 0), False)
     sync_all()
@@ -186,7 +297,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    t0 = time.perf_counter()
     npairs, ntot, ncells = b.counts()
+    t_fetch = time.perf_counter() - t0  # nothing left to do when the timed region finished the pairs
     cells_of = [int(x.counts()[2].sum()) for x in bs]
     cells = int(round(sum(cells_of[s_ % inflight] for s_ in range(args.steps)) / args.steps))  # per step
     if world > 1:
@@ -200,78 +313,91 @@ def main():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
-        return
+        return 0
 
     ms_per_step = 1e3 * elapsed / args.steps
     gcells = total_cells * args.steps / elapsed / 1e9
     reads_per_s = args.reads * world * args.steps / elapsed
     # per-step time of this rank: with batches in flight the steps overlap, so it is the rank's wall time over
     # its steps (HIP-event times of single runs overlap one another)
-    avg_kernel_s = elapsed / args.steps if inflight > 1 else float(np.mean(kernel_ms)) / 1e3
+    avg_pass_s = elapsed / args.steps if inflight > 1 else max(float(np.mean(kernel_ms)) / 1e3, 1e-9)
     bytes_per_cell = 48.0
-    achieved = cells * bytes_per_cell / avg_kernel_s / 1e9
+    achieved = cells * bytes_per_cell / avg_pass_s / 1e9
+    info = b.info()
+
+    # ---- one batch alone (the figure the 40 % target is quoted on) ----------------------------
+    single = None
+    if args.single_steps > 0 and world == 1:
+        for x in bs[1:]:
+            x.close()
+        os.environ.pop("CPECAN_SYSTOLIC_GROUPS", None)
+        single = {}
+        for fam, fl in (("wave", 0), ("workgroup", cp.FLAG_WORKGROUP_KERNELS)):
+            sb = cp.Batch(ctxs[0], make_items(cp, batch), batch["x_chars"], batch["events"], batch["anchors"], bp,
+                          cp.MODE_POSTERIOR, args.kernel, fl)
+            for _ in range(3):
+                sb.run()
+                sb.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev_ms, st = [], []
+            for _ in range(args.single_steps):
+                sb.run()
+                sb.sync()
+                ev_ms.append(sb.elapsed_ms()[1])
+                if sb.info()["kernel"] == "systolic":
+                    st.append(sb.stage_ms())
+            torch.cuda.synchronize()
+            wall = (time.perf_counter() - t0) / args.single_steps
+            ms = float(np.mean(ev_ms))
+            t0 = time.perf_counter()
+            sb.counts()
+            t_fin = time.perf_counter() - t0
+            single[fam] = {"ms_per_pass": round(ms, 3), "wall_ms_per_pass": round(1e3 * wall, 3),
+                           "gcells_per_s": round(cells_of[0] / (ms / 1e3) / 1e9, 3),
+                           "frac": round(cells_of[0] * bytes_per_cell / (ms / 1e3) / 1e9 / 8000.0, 5),
+                           "host_finalise_ms": round(1e3 * t_fin, 2), "kernel": sb.info(),
+                           "stage": kernel_stage(sb.info(), st, cells_of[0])}
+            sb.close()
+
     # HBM traffic of one pass from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
     # rocprofv3 --pmc passes of this same command; summary committed under profiles/)
     traffic, traffic_note, valu = None, None, None
-    prof = os.path.join(ROOT, "profiles", "r01_rocprofv3_pmc_summary.json")
-    if os.path.exists(prof) and args.reads == 1024 and args.events == 10000 and args.kmers == 5000:
-        pm = json.load(open(prof))
-        # FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (the guide's rule; the
-        # calibration kernels in the same profile confirm it for this path's 8-byte-per-lane loads:
-        # reported/true = 0.5); WRITE_SIZE is exact
-        rd = 2.0 * pm["FETCH_SIZE_GB_per_pass"] * 1e9
-        wr = pm["WRITE_SIZE_GB_per_pass"] * 1e9
-        traffic = rd + wr
-        traffic_note = ("HBM bytes per pass over the batch from rocprofv3 --pmc (separate passes): "
-                        "2 x FETCH_SIZE = %.1f GB + WRITE_SIZE = %.1f GB; algorithmic %.1f GB"
-                        % (rd / 1e9, wr / 1e9, cells * 48.0 / 1e9))
-        valu = {k: round(v.get("valu_busy_fraction_of_simd_time", 0.0), 3) for k, v in pm.get("SQ", {}).items()}
+    for name in ("r02_rocprofv3_pmc_summary.json", "r01_rocprofv3_pmc_summary.json"):
+        prof = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(prof) and args.reads == 1024 and args.events == 10000 and args.kmers == 5000:
+            pm = json.load(open(prof))
+            # FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (the guide's rule; the
+            # calibration kernels in the same profile confirm it for this path's 8-byte-per-lane loads:
+            # reported/true = 0.5); WRITE_SIZE is exact
+            rd = 2.0 * pm["FETCH_SIZE_GB_per_pass"] * 1e9
+            wr = pm["WRITE_SIZE_GB_per_pass"] * 1e9
+            traffic = rd + wr
+            traffic_note = ("HBM bytes per pass over the batch from rocprofv3 --pmc (separate passes, profiles/%s): "
+                            "2 x FETCH_SIZE = %.1f GB + WRITE_SIZE = %.1f GB; algorithmic %.1f GB"
+                            % (name, rd / 1e9, wr / 1e9, cells * 48.0 / 1e9))
+            valu = {k: round(v.get("valu_busy_fraction_of_simd_time", 0.0), 3) for k, v in pm.get("SQ", {}).items()}
+            break
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_note": traffic_note,
-                "scope": "whole pass (all kernels of the path), 48 B per cell",
-                "kernel_ms": round(1e3 * avg_kernel_s, 3), "bytes_per_cell": bytes_per_cell,
+                "scope": "whole pass (all kernels of the path), 48 B per cell, %d batch(es) in flight, %s kernels"
+                         % (inflight, family),
+                "pass_ms": round(1e3 * avg_pass_s, 3), "bytes_per_cell": bytes_per_cell,
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
                 "fp64_valu_busy": valu,
-                "note": "fp64 log-space recurrence, not HBM-bound: fp64_valu_busy is the fraction of SIMD time "
-                        "with a VALU instruction executing (committed PMC profile); the rest is the dependency "
-                        "chain of an anti-diagonal (barrier, LDS exchange, serial log-adds) at 4 workgroups per "
-                        "CU -- DESIGN.md section 5"}
-    if stage:
-        f_ms = float(np.mean([x[0] for x in stage]))
-        k_ms = float(np.mean([x[1] for x in stage]))
-        n_l = stage[0][2]
-        sfx = "_r3" if b.info().get("waves_per_workgroup") == 3 else ""  # the three-wave build of the kernels
-        # dominant kernel: the backward-window kernel re-reads the 3 forward states of every cell
-        # once (24 B per cell); the forward-window kernel writes them once (24 B per cell)
-        roofline["dominant_kernel"] = {
-            "name": "cpecan_k_sy_backward" + sfx, "launches_per_pass": n_l,
-            "note": "launches of the batches in flight (and of a batch's stream groups) overlap, so the sum of "
-                    "launch durations exceeds the pass time",
-            "avg_launch_ms": round(k_ms / n_l, 4),
-            "algorithmic_bytes_per_launch": round(cells * 24.0 / n_l),
-            "achieved": round(cells * 24.0 / (k_ms / 1e3) / 1e9, 2),
-            "frac": round(cells * 24.0 / (k_ms / 1e3) / 1e9 / 8000.0, 5)}
-        roofline["forward_kernel"] = {
-            "name": "cpecan_k_sy_forward" + sfx, "launches_per_pass": n_l,
-            "avg_launch_ms": round(f_ms / n_l, 4),
-            "achieved": round(cells * 24.0 / (f_ms / 1e3) / 1e9, 2),
-            "frac": round(cells * 24.0 / (f_ms / 1e3) / 1e9 / 8000.0, 5)}
+                "note": "fp64 log-space recurrence with the reference's approximate logAdd reproduced bit for bit: "
+                        "bound by VALU issue (one fp64 instruction per SIMD per ~4 cycles), not by HBM -- "
+                        "DESIGN.md section 5 gives the instruction count per cell and the time it implies"}
+    if single:
+        best = max(single, key=lambda k: single[k]["frac"])
+        roofline["frac_single_batch"] = single[best]["frac"]
+        roofline["single_batch"] = dict(single, best=best,
+                                        note="ONE batch of %d reads, each pass waited for before the next is "
+                                             "issued; HIP-event time of the pass" % args.reads)
+    st = kernel_stage(info, stage, cells)
+    if st:
+        roofline.update(st)
 
-    if os.environ.get("CPECAN_PROF"):  # timing build (-DSY_PROFILE) only
-        import ctypes
-        buf = (ctypes.c_ulonglong * 80)()
-        if hasattr(cp.lib(), "cpecan_systolic_prof_fetch") and cp.lib().cpecan_systolic_prof_fetch(buf) == 0:
-            n = max(buf[72], 1)
-            sys.stderr.write("prof backward: %d windows, cycles per window: sweep %.0f totals %.0f | decode: pass0 %.0f sync %.0f prefix %.0f pass1 %.0f sync %.0f tail %.0f\n"
-                             % tuple([buf[72]] + [buf[64 + k] / n for k in range(8)]))
-            sys.stderr.write("prof backward: windows decoded by the scan %d, candidates per window %.0f\n" % (buf[73], buf[74] / n))
-            sys.stderr.write("prof backward: slowest window %d cycles (max over all windows; the device counter is cumulative over launches)\n" % buf[75])
-            sys.stderr.write("prof backward: window wall time (100 MHz ticks): mean %.0f max %d\n" % (buf[76] / n, buf[77]))
-            for w in range(4):
-                v = [buf[w * 16 + k] for k in range(12)]
-                na, ni = max(v[10], 1), max(v[11], 1)
-                sys.stderr.write("prof wave %d: active steps %d  cycles/step by section %s | inactive steps %d cycles/step %.0f\n"
-                                 % (w, v[10], " ".join("%.0f" % (x / na) for x in v[:9]), v[11], v[9] / ni))
     # ---- parity spot check + CPU baseline (oracle = checker / baseline only) -------------------
     check = {"reads": 0}
     cpu = None
@@ -298,31 +424,139 @@ def main():
                              % min(n_cpu, args.reads)}
             cpu = dict(cpu_all, single_core=one) if cpu_all else one
 
+    # from host buffers to host-visible pairs for one batch: table derivation + upload/band + pass + pairs
+    prep = (t_models + t_upload) / inflight
+    e2e = prep + ms_per_step / 1e3 + (0.0 if finalise else t_fetch)
     out = {
         "metric": "banded fwd-bwd Gcells/s", "value": round(gcells, 4), "unit": "Gcells/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "reads_per_s": round(reads_per_s, 1),
+        "end_to_end_reads_per_s": round(args.reads / e2e, 1),
         "config": {"workload": "BASELINE configs[2]: %d reads/GPU x (%d events x %d k-mers), "
                                "diagonalExpansion %d, 3-state strawMan signal HMM, per-read scaled "
                                "models, posterior decode" % (args.reads, args.events, args.kmers, args.band),
                    "cells_per_gpu": cells, "pairs_per_gpu": int(npairs.sum()),
-                   "kernel": b.info(),
+                   "kernel": info,
                    "batches_in_flight": inflight,
+                   "pairs_finished_on_host_inside_timed_region": finalise,
+                   "host_finalise_ms_per_step": round(1e3 * float(np.mean(fin_s)), 2) if fin_s else None,
                    "step_latency_ms": round(float(np.mean(kernel_ms)), 3),
                    "parallelism": "reads sharded over %d GPU(s), no collective" % world},
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity_check": check,
         "host_prep_s": {"generate": round(t_gen, 2), "derive_models": round(t_models, 2),
-                        "upload_and_band": round(t_upload, 2)},
+                        "upload_and_band": round(t_upload, 2),
+                        "end_to_end_note": "end_to_end_reads_per_s = reads / (derive_models + upload_and_band per "
+                                           "batch + one step incl. the pairs on the host); synthetic generation "
+                                           "is not part of it"},
     }
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
+
+
+def kernel_stage(info, stage, cells):
+    """forward-window / backward-window kernel figures from the per-window HIP events of the passes in `stage`"""
+    if not stage:
+        return None
+    f_ms = float(np.mean([x[0] for x in stage]))
+    k_ms = float(np.mean([x[1] for x in stage]))
+    n_l = stage[0][2]
+    if info.get("family") == "wave":
+        sfx = "_l%d" % info.get("cells_per_lane", 4)
+        fwd, bwd = "cpecan_k_wv_forward" + sfx, "cpecan_k_wv_backward" + sfx
+        extra = " (the backward figure includes the window's cpecan_k_wv_post launch: totals and decode)"
+    else:
+        sfx = {1: "_r1", 2: "_r2", 3: "_r3"}.get(info.get("waves_per_workgroup"), "")
+        fwd, bwd = "cpecan_k_sy_forward" + sfx, "cpecan_k_sy_backward" + sfx
+        extra = ""
+    # dominant kernel: the backward-window kernel re-reads the 3 forward states of every cell once (24 B per
+    # cell); the forward-window kernel writes them once (24 B per cell)
+    return {"dominant_kernel": {
+                "name": bwd, "launches_per_pass": n_l,
+                "note": "launches of the batches in flight (and a batch's own forward and backward sweeps) overlap, so "
+                        "the sum of launch durations exceeds the pass time" + extra,
+                "avg_launch_ms": round(k_ms / n_l, 4),
+                "algorithmic_bytes_per_launch": round(cells * 24.0 / n_l),
+                "achieved": round(cells * 24.0 / (k_ms / 1e3) / 1e9, 2),
+                "frac": round(cells * 24.0 / (k_ms / 1e3) / 1e9 / 8000.0, 5)},
+            "forward_kernel": {
+                "name": fwd, "launches_per_pass": n_l,
+                "avg_launch_ms": round(f_ms / n_l, 4),
+                "achieved": round(cells * 24.0 / (f_ms / 1e3) / 1e9, 2),
+                "frac": round(cells * 24.0 / (f_ms / 1e3) / 1e9 / 8000.0, 5)}}
+
+
+def bench_em(args, cp, em, bp, rank, local_rank, world, dist, torch, synth, sync_all, first_batch, cpu_all):
+    """BASELINE configs[3]: Baum-Welch iterations; per rank --reads reads (weak scaling), two concurrent batches"""
+    bt = first_batch if first_batch is not None else \
+        synth.make_batch(3 + 100 * rank, args.reads, args.kmers, args.events, anchor_every=50)
+    t0 = time.time()
+    ctxs = [cp.Context(local_rank), cp.Context(local_rank)]
+    gap_x = np.full(4096, -2.3025850929940455)
+    trans = np.array(cp.NANOPORE_TRANSITIONS, dtype=np.float64)
+    e_step = em.PersistentEStep(cp, ctxs, bt, bp, range(len(bt["items"])), trans, gap_x,
+                                dist if world > 1 else None, pseudocount=1e-4)
+    t_setup = time.time() - t0
+    state = {"t": trans, "g": gap_x, "lik": []}
+
+    def iteration():
+        e = e_step(state["t"], state["g"])      # E-step on the GPU + the all-reduce
+        state["lik"].append(float(e[-1]))
+        state["t"], state["g"] = em.m_step(e)   # normalise; the next E-step loads them in place on the device
+
+    for _ in range(max(args.warmup, 1)):
+        iteration()
+    sync_all()
+    state["lik"] = []
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        iteration()
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    cells = int(sum(int(b.counts()[2].sum()) for _, b in e_step.batches))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ct = torch.tensor([cells], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        total_cells = int(ct.item())
+    else:
+        total_cells = cells
+    info = e_step.batches[0][1].info()
+    e_step.close()
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        achieved = cells * 48.0 / (elapsed / args.steps) / 1e9
+        print(json.dumps({
+            "metric": "banded fwd-bwd Gcells/s", "value": round(total_cells * args.steps / elapsed / 1e9, 4),
+            "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "reads_per_s": round(args.reads * world * args.steps / elapsed, 1),
+            "config": {"workload": "BASELINE configs[3]: Baum-Welch iterations, %d reads/GPU x (%d events x %d "
+                                   "k-mers), diagonalExpansion %d; E-step on the GPU, one all-reduce of 4106 doubles "
+                                   "per iteration, M-step in place on the device"
+                                   % (args.reads, args.events, args.kmers, args.band),
+                       "cells_per_gpu": cells, "kernel": info, "setup_s": round(t_setup, 2),
+                       "running_likelihood": [round(v, 3) for v in state["lik"][:4]],
+                       "parallelism": "reads sharded over %d GPU(s); all-reduce(SUM) of the expectation vector "
+                                      "(RCCL)" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "scope": "whole iteration, 48 B per cell"},
+            "cpu_baseline": cpu_all}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

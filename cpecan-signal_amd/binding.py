@@ -25,6 +25,7 @@ FLAG_DEBUG_DUMP = 1
 FLAG_UNBANDED = 2
 FLAG_SCAN_DECODE = 4
 FLAG_EXPECTATIONS = 8
+FLAG_WORKGROUP_KERNELS = 16
 NUM_KMERS = 4096
 MODEL_TABLE_LEN = 1 + NUM_KMERS * 5
 EXPECTATION_LEN = 9 + NUM_KMERS + 1
@@ -42,7 +43,7 @@ EXPORTS = [
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
-    "cpecan_hip_batch_systolic_rows", "cpecan_hip_models_set_transitions",
+    "cpecan_hip_batch_systolic_rows", "cpecan_hip_batch_kernel_family", "cpecan_hip_models_set_transitions",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
     "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
     "cpecan_hip_modelsh_create", "cpecan_hip_batch_create_hdp",
@@ -391,6 +392,11 @@ class Batch:
             r = C.c_int32()
             _check(lib().cpecan_hip_batch_systolic_rows(self.h, C.byref(r)))
             out["waves_per_workgroup"] = r.value
+            f = C.c_int32()
+            _check(lib().cpecan_hip_batch_kernel_family(self.h, C.byref(f)))
+            out["family"] = "wave" if f.value else "workgroup"
+            if f.value:
+                out["cells_per_lane"] = r.value
         return out
 
     def counts(self):

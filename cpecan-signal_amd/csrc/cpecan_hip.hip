@@ -216,6 +216,12 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
+/* one candidate pair on its way to the host: coordinates and the exponent (F + B) - totalProbability */
+struct PackedPair {
+    int x, y;
+    double logp;
+};
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -311,6 +317,12 @@ struct cpecan_batch {
     std::vector<long long> hPairs; /* triples, packed per item at hPairBase */
     std::vector<double> hLogp;
     std::vector<long long> hPairBase;
+    /* the way back to the host: the candidates of all items packed into one device buffer of 16-byte records and
+     * copied in one piece into pinned memory */
+    DevBuf<long long> packBase;
+    DevBuf<PackedPair> packed;
+    PackedPair *hPacked = nullptr; /* hipHostMalloc */
+    size_t hPackedCap = 0;
     int trackRow = CP_ROW; /* doubles per column of the track */
     bool countsValid = false, ran = false;
 };
@@ -653,6 +665,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (b->evFork) (void) hipEventDestroy(b->evFork);
     for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
+    if (b->hPacked) (void) hipHostFree(b->hPacked);
     delete b;
     (void) hipGetLastError(); /* a failed clean-up call must not surface as the "last error" of a later launch */
     return CPECAN_OK;
@@ -833,7 +846,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         const char *rows = getenv("CPECAN_SYSTOLIC_ROWS");
         int r = rows ? atoi(rows) : 1;
         r = r < 1 ? 1 : r > 4 ? 4 : r;
-        const SyBuild *fam = use_wave_kernels() ? WV_BUILDS : SY_BUILDS;
+        const SyBuild *fam = (use_wave_kernels() && !(flags & CPECAN_FLAG_WORKGROUP_KERNELS)) ? WV_BUILDS : SY_BUILDS;
         while (r < 4 && globalMaxWidth > fam[r - 1].max_width()) r++;
         b->sy = &fam[r - 1];
         b->trackRow = b->sy->wave ? cpecan_wave_track_row_doubles() : CP_ROW;
@@ -1148,6 +1161,13 @@ int cpecan_hip_batch_systolic_rows(cpecan_batch *b, int32_t *rows) {
     return CPECAN_OK;
 }
 
+int cpecan_hip_batch_kernel_family(cpecan_batch *b, int32_t *wave) {
+    if (!b || !wave) return fail(CPECAN_EINVAL, "bad argument");
+    if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "not a register-resident batch");
+    *wave = b->sy->wave ? 1 : 0;
+    return CPECAN_OK;
+}
+
 int cpecan_hip_batch_stage_ms(cpecan_batch *b, float *msForward, float *msBackward, int32_t *launchesEach) {
     if (!b || !b->ran) return fail(CPECAN_EINVAL, "batch has not run");
     if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "only the systolic path has stages");
@@ -1203,6 +1223,20 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *b, float *msTotal, float *msKernel
  * selects pairs by the exponent (F+B)-total with a margin below log(threshold); exp(), the exact threshold test and
  * floor(p * 1e7) are finished here with the host libm, the one the reference calls
  * (diagonalCalculationPosteriorMatchProbs, impl/pairwiseAligner.c:776-786). */
+/* item i's first packBase[i + 1] - packBase[i] candidates, from its own region of the pair buffers to the packed one */
+extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
+                                               const double *logp, PackedPair *out) {
+    const DevItem &d = items[blockIdx.x];
+    const long long o = packBase[blockIdx.x], n = packBase[blockIdx.x + 1] - o;
+    for (long long k = threadIdx.x; k < n; k += blockDim.x) {
+        PackedPair r;
+        r.x = (int) pairs[(d.pairBase + k) * 3 + 1];
+        r.y = (int) pairs[(d.pairBase + k) * 3 + 2];
+        r.logp = logp[d.pairBase + k];
+        out[o + k] = r;
+    }
+}
+
 static int ensure_counts(cpecan_batch *b) {
     if (!b->ran) return fail(CPECAN_EINVAL, "batch has not run");
     if (b->countsValid) return CPECAN_OK;
@@ -1237,34 +1271,80 @@ static int ensure_counts(cpecan_batch *b) {
     const long long all = b->hPairBase[(size_t) b->nItems];
     b->hPairs.resize((size_t) all * 3);
     b->hLogp.resize((size_t) all);
-    for (int64_t i = 0; i < b->nItems; i++) {
-        const DevItem &d = b->hItems[(size_t) i];
-        const long long n = b->hPairBase[(size_t) i + 1] - b->hPairBase[(size_t) i], o = b->hPairBase[(size_t) i];
-        if (n == 0) continue;
-        HIP_TRY(hipMemcpyAsync(b->hPairs.data() + o * 3, b->pairs.p + d.pairBase * 3, (size_t) n * 3 * sizeof(long long),
-                               hipMemcpyDeviceToHost, b->ctx->stream));
-        HIP_TRY(hipMemcpyAsync(b->hLogp.data() + o, b->pairLogp.p + d.pairBase, (size_t) n * sizeof(double),
-                               hipMemcpyDeviceToHost, b->ctx->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-    const double threshold = b->P.threshold;
-    /* (in expectation mode the HDP machine's pair buffer carries event-to-k-mer assignments, not posteriors) */
-    for (int64_t i = 0; i < b->nItems && b->mode == CPECAN_MODE_POSTERIOR; i++) {
-        const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
-        long long *t = b->hPairs.data() + o * 3;
-        double *lp = b->hLogp.data() + o;
-        long long kept = 0;
-        for (long long k = 0; k < n; k++) {
-            double p = exp(lp[k]);
-            if (!(p >= threshold)) continue;
-            if (p > 1.0) p = 1.0;
-            t[kept * 3] = (long long) floor(p * 10000000.0);
-            t[kept * 3 + 1] = t[k * 3 + 1];
-            t[kept * 3 + 2] = t[k * 3 + 2];
-            lp[kept] = lp[k];
-            kept++;
+    if (b->mode != CPECAN_MODE_POSTERIOR) {
+        /* (in expectation mode the HDP machine's pair buffer carries event-to-k-mer assignments, not posteriors:
+         * short lists, copied as they are) */
+        for (int64_t i = 0; i < b->nItems; i++) {
+            const DevItem &d = b->hItems[(size_t) i];
+            const long long n = b->hPairBase[(size_t) i + 1] - b->hPairBase[(size_t) i], o = b->hPairBase[(size_t) i];
+            if (n == 0) continue;
+            HIP_TRY(hipMemcpyAsync(b->hPairs.data() + o * 3, b->pairs.p + d.pairBase * 3, (size_t) n * 3 * sizeof(long long),
+                                   hipMemcpyDeviceToHost, b->ctx->stream));
+            HIP_TRY(hipMemcpyAsync(b->hLogp.data() + o, b->pairLogp.p + d.pairBase, (size_t) n * sizeof(double),
+                                   hipMemcpyDeviceToHost, b->ctx->stream));
         }
-        b->hNPairs[(size_t) i] = kept;
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        b->countsValid = true;
+        return CPECAN_OK;
+    }
+    if (all > 0) {
+        if (b->packBase.n < (size_t) b->nItems + 1) HIP_TRY(b->packBase.alloc((size_t) b->nItems + 1));
+        if (b->packed.n < (size_t) all) HIP_TRY(b->packed.alloc((size_t) all + (size_t) all / 8));
+        if (b->hPackedCap < (size_t) all) {
+            if (b->hPacked) (void) hipHostFree(b->hPacked);
+            b->hPacked = nullptr;
+            b->hPackedCap = (size_t) all + (size_t) all / 8;
+            HIP_TRY(hipHostMalloc((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair), hipHostMallocDefault));
+        }
+        HIP_TRY(hipMemcpyAsync(b->packBase.p, b->hPairBase.data(), ((size_t) b->nItems + 1) * sizeof(long long),
+                               hipMemcpyHostToDevice, b->ctx->stream));
+        hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, b->ctx->stream,
+                           (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
+                           (const double *) b->pairLogp.p, b->packed.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->hPacked, b->packed.p, (size_t) all * sizeof(PackedPair), hipMemcpyDeviceToHost,
+                               b->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    }
+    /* exp(), the threshold test and floor(p * 1e7) with the host's libm, the one the reference calls
+     * (impl/pairwiseAligner.c:776-786); items are independent, so they are dealt to the host threads */
+    const double threshold = b->P.threshold;
+    const PackedPair *src = b->hPacked;
+    auto finish = [b, src, threshold](int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; i++) {
+            const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
+            long long *t = b->hPairs.data() + o * 3;
+            double *lp = b->hLogp.data() + o;
+            long long kept = 0;
+            for (long long k = 0; k < n; k++) {
+                const PackedPair r = src[o + k];
+                double p = exp(r.logp);
+                if (!(p >= threshold)) continue;
+                if (p > 1.0) p = 1.0;
+                t[kept * 3] = (long long) floor(p * 10000000.0);
+                t[kept * 3 + 1] = r.x;
+                t[kept * 3 + 2] = r.y;
+                lp[kept] = r.logp;
+                kept++;
+            }
+            b->hNPairs[(size_t) i] = kept;
+        }
+    };
+    const int nt = (int) std::min<int64_t>(all > 200000 ? host_threads() : 1, b->nItems);
+    if (nt <= 1) finish(0, b->nItems);
+    else {
+        /* contiguous runs of items with about the same number of candidates each */
+        std::vector<std::thread> pool;
+        int64_t i0 = 0;
+        for (int t = 0; t < nt; t++) {
+            const long long want = all * (t + 1) / nt;
+            int64_t i1 = i0;
+            while (i1 < b->nItems && (b->hPairBase[(size_t) i1 + 1] <= want || t == nt - 1)) i1++;
+            if (i1 > i0) pool.emplace_back(finish, i0, i1);
+            i0 = i1;
+        }
+        if (i0 < b->nItems) finish(i0, b->nItems);
+        for (std::thread &th : pool) th.join();
     }
     b->countsValid = true;
     return CPECAN_OK;

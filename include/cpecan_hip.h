@@ -172,6 +172,13 @@ typedef struct {
                                       (:841) instead of the posterior decode, as CPECAN_MODE_EXPECTATIONS does
                                       for the signal batches */
 
+#define CPECAN_FLAG_WORKGROUP_KERNELS 16 /* register-resident path: run this batch on the workgroup-per-alignment
+                                           kernels (cpecan_k_sy_*: 1..4 waves share an alignment through LDS) instead
+                                           of the wave-per-alignment ones (cpecan_k_wv_*, the default).  Same results
+                                           bit for bit; the workgroup family is the one that runs several batches at
+                                           once well (more, smaller-footprint workgroups per CU).  The environment
+                                           variable CPECAN_KERNELS=systolic asks the same for every batch. */
+
 /* Copies the inputs to HBM and builds per-item band tables.  All host pointers may be released
  * after the call returns. */
 int cpecan_hip_batch_create(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
@@ -218,6 +225,9 @@ int cpecan_hip_batch_info(cpecan_batch *batch, int32_t *kernel, int32_t *workgro
  * hold the widest band of the batch: 1 (bands up to 56 k-mers), 2 (120), 3 (184) or 4 (248).  The fewer waves an
  * alignment takes, the more alignments a CU holds (16, 8, 5, 4). */
 int cpecan_hip_batch_systolic_rows(cpecan_batch *batch, int32_t *rows);
+/* Register-resident path only: *wave = 1 if the batch runs on the wave-per-alignment kernels (rows is then the
+ * number of cells a lane holds: 2, 3 or 4), 0 on the workgroup-per-alignment ones (rows = waves per workgroup). */
+int cpecan_hip_batch_kernel_family(cpecan_batch *batch, int32_t *wave);
 /* Systolic path only: HIP-event time of the last run spent in the forward-window kernels and in
  * the backward-window kernels (each launched `launches_each` times, once per traceback window). */
 int cpecan_hip_batch_stage_ms(cpecan_batch *batch, float *ms_forward, float *ms_backward,

@@ -518,12 +518,24 @@ static int run_estep(char **a) {
 }
 
 /* ---- gpu: the exported host internals against the aligner entry points on the toy alignments ----------------- */
-static int same_pairs(stList *a, stList *b) { /* (probability, x, y), in the same order */
-    if (stList_length(a) != stList_length(b)) return 0;
-    for (int64_t i = 0; i < stList_length(a); i++)
+static int same_pairs(stList *host, stList *entry) {
+    /* (probability, x, y) for (probability, x, y); the entry point hands its list back in the order the reference's
+     * getAlignedPairsUsingAnchors does, which pops the per-region lists and so reverses the emission order
+     * (impl/pairwiseAligner.c:1447-1455) */
+    const int64_t n = stList_length(host);
+    int same = n == stList_length(entry);
+    for (int64_t i = 0; same && i < n; i++)
         for (int k = 0; k < 3; k++)
-            if (stIntTuple_get(stList_get(a, i), k) != stIntTuple_get(stList_get(b, i), k)) return 0;
-    return 1;
+            same &= stIntTuple_get(stList_get(host, i), k) == stIntTuple_get(stList_get(entry, n - 1 - i), k);
+    if (!same) {
+        for (int64_t i = 0; i < n; i++)
+            fprintf(stderr, "host  %lld %lld %lld\n", (long long) stIntTuple_get(stList_get(host, i), 0),
+                    (long long) stIntTuple_get(stList_get(host, i), 1), (long long) stIntTuple_get(stList_get(host, i), 2));
+        for (int64_t i = 0; i < stList_length(entry); i++)
+            fprintf(stderr, "entry %lld %lld %lld\n", (long long) stIntTuple_get(stList_get(entry, i), 0),
+                    (long long) stIntTuple_get(stList_get(entry, i), 1), (long long) stIntTuple_get(stList_get(entry, i), 2));
+    }
+    return same;
 }
 static void host_against_gpu(StateMachine *sM, Sequence *SsX, Sequence *SsY, Hmm *hostHmm, Hmm *gpuHmm, int nValues,
                              double (*value)(Hmm *, int), const char *name) {

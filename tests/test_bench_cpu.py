@@ -22,8 +22,36 @@ def test_all_core_cpu_baseline_counts_the_same_cells():
     assert out["cells"] == cells and out["value"] > 0
 
 
+def test_gpus_2_starts_its_own_two_ranks():
+    """`python bench.py --gpus 2` from a plain command line: the process starts two workers itself (one per rank,
+    torch.distributed.run on 127.0.0.1); --rehearse keeps them off the GPU (gloo, host band geometry as the step), so
+    the plumbing -- rendezvous, shard by rank, barrier, max-over-ranks time, summed cells, ONE JSON line from rank 0 --
+    runs here."""
+    import json
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse", "--reads", "6", "--events",
+           "400", "--kmers", "200", "--steps", "2", "--warmup", "1", "--master-port", str(29500 + os.getpid() % 2000)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["value"] is None
+    assert "REHEARSAL" in out["data"]
+    # every rank has its own reads (seeded by rank): the all-rank sum is rank 0's cells plus another rank's
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rehearse", "--reads", "6",
+                          "--events", "400", "--kmers", "200", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    solo = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][0])
+    assert solo["n_gpus"] == 1 and solo["config"]["cells_rank0"] == out["config"]["cells_rank0"]
+    assert out["config"]["cells_all_ranks"] > out["config"]["cells_rank0"] > 0
+    assert out["config"]["cells_all_ranks"] != 2 * out["config"]["cells_rank0"]
+
+
 def test_command_line_contract():
     h = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert h.returncode == 0
-    for flag in ("--gpus", "--steps", "--warmup"):
+    for flag in ("--gpus", "--steps", "--warmup", "--mode", "--inflight", "--single-steps"):
         assert flag in h.stdout
