@@ -109,6 +109,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-finalise", action="store_true",
                     help="leave the pairs as (x, y, exponent) in HBM inside the timed region instead of finishing "
                          "them on the host (GPU pass alone)")
+    ap.add_argument("--em-contexts", type=int, default=2,
+                    help="--mode em: 2 = the rank's reads as two concurrent batches on the workgroup kernels, 1 = one "
+                         "batch on the wave kernels")
     ap.add_argument("--rehearse", action="store_true", help="no GPU: gloo ranks, host band geometry as the step")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started workers")
     return ap.parse_args(argv)
@@ -497,7 +500,7 @@ def bench_em(args, cp, em, bp, rank, local_rank, world, dist, torch, synth, sync
     bt = first_batch if first_batch is not None else \
         synth.make_batch(3 + 100 * rank, args.reads, args.kmers, args.events, anchor_every=50)
     t0 = time.time()
-    ctxs = [cp.Context(local_rank), cp.Context(local_rank)]
+    ctxs = [cp.Context(local_rank) for _ in range(max(1, min(2, args.em_contexts)))]
     gap_x = np.full(4096, -2.3025850929940455)
     trans = np.array(cp.NANOPORE_TRANSITIONS, dtype=np.float64)
     e_step = em.PersistentEStep(cp, ctxs, bt, bp, range(len(bt["items"])), trans, gap_x,

@@ -308,6 +308,7 @@ struct cpecan_batch {
      * lasts as long as its slowest workgroup).  evStage: per group, one event after every kernel. */
     int nGroups = 1;
     std::vector<hipStream_t> gStream, gStreamB; /* gStreamB: the wave kernels' backward sweeps (see batch_run) */
+    bool gStreamOwned = true;
     int stateBytes = 0;
     std::vector<hipEvent_t> evStage, evJoin;
     hipEvent_t evFork = nullptr;
@@ -663,7 +664,8 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     for (hipEvent_t e : b->evStage) (void) hipEventDestroy(e);
     for (hipEvent_t e : b->evJoin) (void) hipEventDestroy(e);
     if (b->evFork) (void) hipEventDestroy(b->evFork);
-    for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
+    if (b->gStreamOwned)
+        for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
     if (b->hPacked) (void) hipHostFree(b->hPacked);
     delete b;
@@ -938,7 +940,13 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             b->nGroups = G;
             b->gStream.assign((size_t) G, nullptr);
             b->evJoin.assign((size_t) G, nullptr);
-            for (auto &st : b->gStream) B_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            /* a wave batch of one group sweeps forward on the context's own stream: two streams per batch, so that
+             * two batches in flight stay within the four hardware queues a process gets */
+            b->gStreamOwned = !(b->sy->wave && G == 1);
+            if (b->gStreamOwned)
+                for (auto &st : b->gStream) B_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            else
+                b->gStream[0] = c->stream;
             if (b->sy->wave) {
                 b->gStreamB.assign((size_t) G, nullptr);
                 for (auto &st : b->gStreamB) B_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

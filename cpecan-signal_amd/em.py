@@ -98,7 +98,7 @@ def gpu_e_step(cp, ctx, batch, bp, read_idx, transitions, gap_x, dist=None, pseu
             cx.models_clear()
             cx.models_create(models)
             b = cp.Batch(cx, items, batch["x_chars"], batch["events"], batch["anchors"], bp, cp.MODE_EXPECTATIONS,
-                         cp.KERNEL_AUTO, 0)
+                         cp.KERNEL_AUTO, cp.FLAG_WORKGROUP_KERNELS if len(ctxs) > 1 else 0)
             b.run()  # asynchronous on this context's streams: the next batch is issued before this one is waited for
             running.append(b)
         for b in running:
@@ -148,8 +148,11 @@ class PersistentEStep:
                                 it["n_anchors"], j, 1, 1, 0)
                 cx.models_clear()
                 cx.models_create(models)
+                # two batches at once: the workgroup-per-alignment kernels (smaller footprint per CU) interleave;
+                # one batch alone: the wave-per-alignment kernels overlap its own forward and backward sweeps
                 self.batches.append((cx, cp.Batch(cx, items, batch["x_chars"], batch["events"], batch["anchors"], bp,
-                                                  cp.MODE_EXPECTATIONS, cp.KERNEL_AUTO, 0)))
+                                                  cp.MODE_EXPECTATIONS, cp.KERNEL_AUTO,
+                                                  cp.FLAG_WORKGROUP_KERNELS if len(self.ctxs) > 1 else 0)))
         finally:
             if len(self.ctxs) > 1 and saved is None:
                 os.environ.pop("CPECAN_SYSTOLIC_GROUPS", None)
