@@ -366,21 +366,20 @@ def main(argv=None):
     # HBM traffic of one pass from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
     # rocprofv3 --pmc passes of this same command; summary committed under profiles/)
     traffic, traffic_note, valu = None, None, None
-    for name in ("r02_rocprofv3_pmc_summary.json", "r01_rocprofv3_pmc_summary.json"):
-        prof = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(prof) and args.reads == 1024 and args.events == 10000 and args.kmers == 5000:
-            pm = json.load(open(prof))
+    prof = os.path.join(ROOT, "profiles", "r02_rocprofv3_pmc_summary.json")
+    if os.path.exists(prof) and args.reads == 1024 and args.events == 10000 and args.kmers == 5000:
+        pm = json.load(open(prof))["families"].get(family)
+        if pm and pm.get("FETCH_SIZE_GB_per_pass"):
             # FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (the guide's rule; the
             # calibration kernels in the same profile confirm it for this path's 8-byte-per-lane loads:
             # reported/true = 0.5); WRITE_SIZE is exact
             rd = 2.0 * pm["FETCH_SIZE_GB_per_pass"] * 1e9
             wr = pm["WRITE_SIZE_GB_per_pass"] * 1e9
             traffic = rd + wr
-            traffic_note = ("HBM bytes per pass over the batch from rocprofv3 --pmc (separate passes, profiles/%s): "
-                            "2 x FETCH_SIZE = %.1f GB + WRITE_SIZE = %.1f GB; algorithmic %.1f GB"
-                            % (name, rd / 1e9, wr / 1e9, cells * 48.0 / 1e9))
+            traffic_note = ("HBM bytes per pass over the batch, %s kernels, from rocprofv3 --pmc (separate passes, "
+                            "profiles/r02_rocprofv3_pmc_summary.json): 2 x FETCH_SIZE = %.1f GB + WRITE_SIZE = %.1f GB; "
+                            "algorithmic %.1f GB" % (family, rd / 1e9, wr / 1e9, cells * 48.0 / 1e9))
             valu = {k: round(v.get("valu_busy_fraction_of_simd_time", 0.0), 3) for k, v in pm.get("SQ", {}).items()}
-            break
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_note": traffic_note,
                 "scope": "whole pass (all kernels of the path), 48 B per cell, %d batch(es) in flight, %s kernels"
