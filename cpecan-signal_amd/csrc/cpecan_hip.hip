@@ -243,6 +243,7 @@ template <typename T> struct DevBuf {
 
 struct cpecan_ctx {
     int device = 0;
+    long long modelEpoch = 0; /* counts cpecan_hip_models_clear calls */
     hipStream_t stream = nullptr;
     DevBuf<double> models; /* nModels * CP_MODEL_STRIDE */
     std::vector<double> hostModels;
@@ -309,6 +310,7 @@ struct cpecan_batch {
     int nGroups = 1;
     std::vector<hipStream_t> gStream, gStreamB; /* gStreamB: the wave kernels' backward sweeps (see batch_run) */
     bool gStreamOwned = true;
+    long long modelEpoch = 0; /* the context's when the batch was created */
     int stateBytes = 0;
     std::vector<hipEvent_t> evStage, evJoin;
     hipEvent_t evFork = nullptr;
@@ -369,6 +371,8 @@ int cpecan_hip_ctx_destroy(cpecan_ctx *c) {
     if (!c) return CPECAN_OK;
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamDestroy(c->stream);
+    for (auto *t : c->hdpTables) delete t;
+    c->hdpTables.clear();
     delete c;
     (void) hipGetLastError();
     return CPECAN_OK;
@@ -441,12 +445,13 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
 
 extern "C" __global__ void cpecan_k_set_transitions(double *models, int nModels, const double *values /* 9 + 4096 */,
                                                     int withGap) {
-    const int m = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nModels) return;
-    double *blk = models + (long long) m * CP_MODEL_STRIDE;
-    if (i < 9) blk[i] = values[i];
-    else if (withGap && i < 9 + CPECAN_NUM_KMERS)
-        blk[CP_MODEL_HEADER + (long long) (i - 9) * CP_ROW + CP_GAPX] = values[i];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int m = blockIdx.y; m < nModels; m += gridDim.y) { /* grid.y is capped at 65535 */
+        double *blk = models + (long long) m * CP_MODEL_STRIDE;
+        if (i < 9) blk[i] = values[i];
+        else if (withGap && i < 9 + CPECAN_NUM_KMERS)
+            blk[CP_MODEL_HEADER + (long long) (i - 9) * CP_ROW + CP_GAPX] = values[i];
+    }
 }
 
 int cpecan_hip_models_set_transitions(cpecan_ctx *c, const double *transitions, const double *gapX) {
@@ -465,7 +470,7 @@ int cpecan_hip_models_set_transitions(cpecan_ctx *c, const double *transitions, 
     DevBuf<double> dv;
     HIP_TRY(dv.alloc(v.size()));
     HIP_TRY(hipMemcpyAsync(dv.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(cpecan_k_set_transitions, dim3((9 + CPECAN_NUM_KMERS + 255) / 256, (unsigned) c->nModels),
+    hipLaunchKernelGGL(cpecan_k_set_transitions, dim3((9 + CPECAN_NUM_KMERS + 255) / 256, (unsigned) std::min(c->nModels, 65535)),
                        dim3(256), 0, c->stream, c->models.p, c->nModels, (const double *) dv.p, gapX ? 1 : 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream)); /* dv is released on return */
@@ -636,6 +641,7 @@ int cpecan_hip_models5_create(cpecan_ctx *c, const cpecan_sm5_model *models, int
 int cpecan_hip_models_clear(cpecan_ctx *c) {
     if (!c) return fail(CPECAN_EINVAL, "ctx is NULL");
     (void) hipSetDevice(c->device);
+    c->modelEpoch++; /* batches created before this call hold ids into tables that are gone: batch_run refuses them */
     c->models.release();
     c->hostModels.clear();
     c->nModels = 0;
@@ -807,6 +813,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     if (!b) return fail(CPECAN_EINVAL, "out of host memory");
     b->ctx = c;
     b->device = c->device;
+    b->modelEpoch = c->modelEpoch;
     b->nItems = nItems;
     b->mode = mode;
     b->flags = flags;
@@ -1043,6 +1050,9 @@ int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t
 int cpecan_hip_batch_run(cpecan_batch *b) {
     if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
     cpecan_ctx *c = b->ctx;
+    if (b->modelEpoch != c->modelEpoch)
+        return fail(CPECAN_EINVAL, "cpecan_hip_models_clear was called on the context after this batch was created: "
+                    "its model ids are gone");
     HIP_TRY(hipSetDevice(c->device));
     b->countsValid = false;
     HIP_TRY(hipEventRecord(b->ev0, c->stream));

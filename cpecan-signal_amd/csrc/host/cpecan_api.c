@@ -692,15 +692,25 @@ stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxM
 /* ------------------------------------------------------------------------------------------------ */
 /* the GPU context of this process                                                                  */
 /* ------------------------------------------------------------------------------------------------ */
-static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-static cpecan_ctx *g_ctx = NULL;
+/* One context (device tables, stream) per calling thread: the reference's callers align the template and the
+ * complement strand in two OpenMP sections (vanillaAlign.c:737-800), and the two then run side by side on the GPU
+ * instead of queueing behind a process-wide lock.  A thread's context goes with the thread. */
+static pthread_key_t g_ctx_key;
+static pthread_once_t g_ctx_once = PTHREAD_ONCE_INIT;
+static void ctx_release(void *ctx) {
+    if (ctx) cpecan_hip_ctx_destroy((cpecan_ctx *) ctx);
+}
+static void ctx_key_init(void) { pthread_key_create(&g_ctx_key, ctx_release); }
 
 static cpecan_ctx *context(void) {
-    if (!g_ctx) {
+    pthread_once(&g_ctx_once, ctx_key_init);
+    cpecan_ctx *ctx = pthread_getspecific(g_ctx_key);
+    if (!ctx) {
         const char *dev = getenv("CPECAN_DEVICE");
-        CHECK(cpecan_hip_ctx_create(dev ? atoi(dev) : 0, &g_ctx));
+        CHECK(cpecan_hip_ctx_create(dev ? atoi(dev) : 0, &ctx));
+        pthread_setspecific(g_ctx_key, ctx);
     }
-    return g_ctx;
+    return ctx;
 }
 
 /* returns 1 for the DNA-against-DNA combination (5-state machine, sequence_getBase on both sides),
@@ -745,7 +755,6 @@ typedef struct {
 static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **sYs, stList **anchorLists,
                       PairwiseAlignmentParameters *p, bool raggedL, bool raggedR, int mode, int unbanded,
                       stList **lists, void *hmmOut) {
-    pthread_mutex_lock(&g_lock); /* one batch at a time per process; calls from several threads queue */
     cpecan_ctx *ctx = context();
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
     const int kind = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
@@ -1047,7 +1056,6 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     }
     free(chars); free(events); free(anchors); free(items); free(origin); free(firstItem);
     free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars); free(modelsV); free(modelsH);
-    pthread_mutex_unlock(&g_lock);
 }
 
 stList *getAlignedPairsUsingAnchors(StateMachine *sM, Sequence *SsX, Sequence *SsY, stList *anchorPairs,

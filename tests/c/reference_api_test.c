@@ -16,6 +16,7 @@
  *       through the aligner entry points (GPU): same pairs, same integers; expectations agree to 1e-9.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -563,6 +564,56 @@ static double bin_value(Hmm *h, int i) { return h->getTransitionsExpFcn(h, i, 0)
 static double discrete_value(Hmm *h, int i) {
     return i < 25 ? transition_value(h, i) : h->getEmissionExpFcn(h, (i - 25) / 16, ((i - 25) % 16) / 4, (i - 25) % 4);
 }
+/* template || complement as vanillaAlign's two OpenMP sections run them (vanillaAlign.c:737-800): two threads, each
+ * with a machine of its own, aligning at the same time; every result equals the one a lone caller gets */
+typedef struct {
+    const char *model;
+    int vanillaMachine, rounds, mismatches;
+    stList *expected;
+} StrandJob;
+static stList *align_toy(const char *model, int vanillaMachine) {
+    char *ref13 = "ACGATACGGACAT";
+    StateMachine *sM = vanillaMachine ? getSignalStateMachine3Vanilla(model) : getStrawManStateMachine3(model);
+    Sequence *kmers = kmer_sequence(ref13, vanillaMachine ? sequence_getKmer2 : sequence_getKmer);
+    Sequence *events7 = sequence_construct2(7, toyEvents7, sequence_getEvent, sequence_sliceEventSequence2);
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    stList *anchorPairs = stList_construct();
+    stList *pairs = getAlignedPairsUsingAnchors(sM, kmers, events7, anchorPairs, p, diagonalCalculationPosteriorMatchProbs, 1, 1);
+    stList_destruct(anchorPairs);
+    pairwiseAlignmentBandingParameters_destruct(p);
+    sequence_sequenceDestroy(kmers);
+    sequence_sequenceDestroy(events7);
+    stateMachine_destruct(sM);
+    return pairs;
+}
+static int identical_lists(stList *a, stList *b) {
+    if (stList_length(a) != stList_length(b)) return 0;
+    for (int64_t i = 0; i < stList_length(a); i++)
+        for (int k = 0; k < 3; k++)
+            if (stIntTuple_get(stList_get(a, i), k) != stIntTuple_get(stList_get(b, i), k)) return 0;
+    return 1;
+}
+static void *strand_thread(void *arg) {
+    StrandJob *job = arg;
+    for (int r = 0; r < job->rounds; r++) {
+        stList *got = align_toy(job->model, job->vanillaMachine);
+        if (!identical_lists(got, job->expected)) job->mismatches++;
+        stList_destruct(got);
+    }
+    return NULL;
+}
+static void two_strands_at_once(const char *model) {
+    StrandJob jobs[2] = { { model, 0, 25, 0, align_toy(model, 0) }, { model, 1, 25, 0, align_toy(model, 1) } };
+    CHECK(stList_length(jobs[0].expected) > 0 && stList_length(jobs[1].expected) > 0);
+    pthread_t th[2];
+    for (int i = 0; i < 2; i++) pthread_create(&th[i], NULL, strand_thread, &jobs[i]);
+    for (int i = 0; i < 2; i++) pthread_join(th[i], NULL);
+    CHECK(jobs[0].mismatches == 0 && jobs[1].mismatches == 0);
+    stList_destruct(jobs[0].expected);
+    stList_destruct(jobs[1].expected);
+    printf("%s two_threads_two_machines\n", failures ? "FAILED" : "ok");
+}
+
 static int run_gpu(const char *goldenDir) {
     char *model = path_in(goldenDir, "template_median68pA.model");
     char *ref13 = "ACGATACGGACAT";
@@ -609,6 +660,7 @@ static int run_gpu(const char *goldenDir) {
     sequence_sequenceDestroy(bY);
     stateMachine_destruct(sM);
     sequence_sequenceDestroy(events7);
+    two_strands_at_once(model);
     free(model);
     return failures;
 }

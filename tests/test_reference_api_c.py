@@ -19,7 +19,7 @@ LIBDIR = os.path.join(ROOT, "cpecan-signal_amd")
 def program(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("cprog") / "reference_api_test")
     subprocess.run(["gcc", "-O1", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
-                    SRC, "-o", exe, "-L" + LIBDIR, "-lcpecan_host", "-lcpecan_hip", "-Wl,-rpath," + LIBDIR, "-lm"],
+                    SRC, "-o", exe, "-L" + LIBDIR, "-lcpecan_host", "-lcpecan_hip", "-Wl,-rpath," + LIBDIR, "-lm", "-lpthread"],
                    check=True)
     return exe
 
@@ -173,4 +173,4 @@ def test_exported_internals_against_the_gpu_path(program, golden_dir):
     out = _run([program, "gpu", golden_dir])
     assert "FAILED" not in out
     assert [l.split()[1] for l in out.splitlines() if l.startswith("ok ")] == [
-        "strawMan_host_vs_gpu", "vanilla_host_vs_gpu", "fiveState_host_vs_gpu"]
+        "strawMan_host_vs_gpu", "vanilla_host_vs_gpu", "fiveState_host_vs_gpu", "two_threads_two_machines"]
