@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -185,6 +186,30 @@ namespace {
 
 thread_local std::string g_err;
 
+/* std::vector without the zero-fill of resize(): the big host tables here are written in full right after they are
+ * sized (by several threads, so the page faults spread too) */
+template <class T> struct NoInit : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInit<U>; };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *) p) U;
+        else ::new ((void *) p) U(std::forward<A>(a)...);
+    }
+};
+
+/* CPECAN_TIMING=1: wall-clock laps of the host-side set-up calls on stderr (where the time before the first kernel goes) */
+struct Lap {
+    const char *who;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit Lap(const char *w) : who(w), on(getenv("CPECAN_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char *what) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[cpecan timing] %s: %s %.1f ms\n", who, what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 /* worker threads for host-side table derivation: the CPUs this process may run on (its affinity mask, which is
  * what a job's CPU share shows up as), at most 32 -- a node's hardware_concurrency() is the whole machine, and
  * eight ranks of a multi-GPU job each spawning that many threads would run into the host's task limits */
@@ -246,7 +271,7 @@ struct cpecan_ctx {
     long long modelEpoch = 0; /* counts cpecan_hip_models_clear calls */
     hipStream_t stream = nullptr;
     DevBuf<double> models; /* nModels * CP_MODEL_STRIDE */
-    std::vector<double> hostModels;
+    std::vector<double, NoInit<double>> hostModels;
     int nModels = 0;
     DevBuf<double> models5; /* 5-state symbol models, nModels5 * CP_MODEL5_STRIDE */
     std::vector<double> hostModels5;
@@ -423,8 +448,10 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
         if (!models[i].match_probs || !models[i].gap_x_probs || !models[i].gap_y_probs)
             return fail(CPECAN_EINVAL, "model %d has a NULL table", i);
     HIP_TRY(hipSetDevice(c->device));
+    Lap lap("models_create");
     const size_t old = c->hostModels.size();
     c->hostModels.resize(old + (size_t) n * CP_MODEL_STRIDE);
+    lap("resize host table");
     int nt = threads > 0 ? threads : host_threads();
     nt = std::max(1, std::min(nt, (int) n));
     std::vector<std::thread> pool;
@@ -434,12 +461,15 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
                 derive_rows(&models[i], c->hostModels.data() + old + (size_t) i * CP_MODEL_STRIDE);
         });
     for (auto &t : pool) t.join();
+    lap("derive rows (threads)");
     for (int i = 0; i < n; i++) ids[i] = c->nModels + i;
     c->nModels += n;
     hipError_t e = c->models.alloc(c->hostModels.size());
     if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
+    lap("hipMalloc");
     HIP_TRY(hipMemcpy(c->models.p, c->hostModels.data(), c->hostModels.size() * sizeof(double),
                       hipMemcpyHostToDevice));
+    lap("upload");
     return CPECAN_OK;
 }
 
@@ -724,14 +754,17 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     if (unbanded && (mode != CPECAN_MODE_POSTERIOR || kernel == CPECAN_KERNEL_SYSTOLIC))
         return fail(CPECAN_EINVAL, "un-banded alignment: posterior mode on the general kernel only");
 
-    /* per-item validation + band tables (host integer work) */
+    /* per-item validation + band tables (host integer work): offsets in one serial pass, then the items are dealt
+     * to the host threads (band, cell prefix, traceback schedule: ~15 000 diagonals per C3 read) */
     std::vector<DevItem> hItems((size_t) nItems);
-    std::vector<int> hL, hR;
-    std::vector<long long> hPre;
+    std::vector<int, NoInit<int>> hL, hR;
+    std::vector<long long, NoInit<long long>> hPre;
     long long cellTotal = 0, pairTotal = 0, totTotal = 0, bwsTotal = 0, trackTotal = 0;
     int globalMaxWidth = 0, maxSpan = 1, maxLX = 0, maxWindows = 0;
     bool systolicOk = true; /* band edges move by at most one k-mer per diagonal */
     std::vector<long long> hTrackBase((size_t) nItems);
+    Lap lap("batch_create");
+    long long diagTotal = 0;
     for (int64_t i = 0; i < nItems; i++) {
         const cpecan_item &s = items[i];
         if (s.lX < 0 || s.lY < 0 || s.x_offset < 0 || s.y_offset < 0 || s.n_anchors < 0 ||
@@ -746,59 +779,96 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         d.lX = s.lX; d.lY = s.lY; d.xOff = s.x_offset; d.yOff = s.y_offset;
         d.anchorOff = s.anchor_offset; d.nAnchors = s.n_anchors;
         d.model = s.model_id; d.raggedL = s.ragged_left ? 1 : 0; d.raggedR = s.ragged_right ? 1 : 0;
-        const long long nDiag = s.lX + s.lY + 1;
-        d.diagBase = (long long) hL.size();
-        hL.resize(hL.size() + (size_t) nDiag);
-        hR.resize(hR.size() + (size_t) nDiag);
-        hPre.resize(hPre.size() + (size_t) nDiag);
-        /* getAlignedPairsWithoutBanding builds its band from no anchors, expansion 2 (:1532) */
-        int rc = cpecan_band_construct(unbanded || !anchors ? nullptr : anchors + 2 * s.anchor_offset,
-                                       unbanded ? 0 : s.n_anchors, s.lX, s.lY,
-                                       unbanded ? 2 : params->diagonalExpansion,
-                                       hL.data() + d.diagBase, hR.data() + d.diagBase);
-        if (rc != CPECAN_OK)
-            return fail(rc, "item %lld: anchors do not describe a valid band", (long long) i);
-        long long cells = 0;
-        int maxW = 0;
-        for (long long k = 0; k < nDiag; k++) {
-            hPre[(size_t) (d.diagBase + k)] = cells;
-            int w = ((hR[(size_t) (d.diagBase + k)] - hL[(size_t) (d.diagBase + k)]) >> 1) + 1;
-            cells += w;
-            maxW = std::max(maxW, w);
-        }
-        d.nCells = cells;
-        d.maxWidth = maxW;
-        {   /* traceback schedule of getPosteriorProbsWithBanding (:917-918): longest span of forward
-             * diagonals that must be resident at once, and the edge-step property the systolic
-             * kernel relies on */
-            const int *Lp = hL.data() + d.diagBase, *Rp = hR.data() + d.diagBase;
-            long long tracedBackTo = 0;
-            int windows = 0;
-            for (long long k = 1; k < nDiag; k++) {
-                const int xmn = (int) ((k + Lp[k]) / 2), xmx = (int) ((k + Rp[k]) / 2);
-                const int pmn = (int) ((k - 1 + Lp[k - 1]) / 2), pmx = (int) ((k - 1 + Rp[k - 1]) / 2);
-                if (xmn < pmn || xmn > pmn + 1 || xmx < pmx || xmx > pmx + 1) systolicOk = false;
-                const bool atEnd = k == nDiag - 1;
-                const int w = ((Rp[k] - Lp[k]) >> 1) + 1;
-                const bool tb = k >= tracedBackTo + params->minDiagsBetweenTraceBack &&
-                                w <= params->diagonalExpansion * 2 + 1;
-                if (atEnd || tb) {
-                    windows++;
-                    maxSpan = std::max<long long>(maxSpan, k - tracedBackTo + 1);
-                    tracedBackTo = k - (params->traceBackDiagonals + 1);
+        d.diagBase = diagTotal;
+        diagTotal += s.lX + s.lY + 1;
+    }
+    hL.resize((size_t) diagTotal);
+    hR.resize((size_t) diagTotal);
+    hPre.resize((size_t) diagTotal);
+    struct ItemStats {
+        int maxSpan = 1, windows = 0, badItem = -1, badRc = 0;
+        bool systolicOk = true;
+    };
+    {
+        const int nt = (int) std::min<int64_t>(diagTotal > 2000000 ? host_threads() : 1, nItems);
+        std::vector<ItemStats> stats((size_t) nt);
+        auto work = [&](int w) {
+            ItemStats &st = stats[(size_t) w];
+            for (int64_t i = w; i < nItems; i += nt) {
+                const cpecan_item &s = items[i];
+                DevItem &d = hItems[(size_t) i];
+                const long long nDiag = s.lX + s.lY + 1;
+                int *Lp = hL.data() + d.diagBase, *Rp = hR.data() + d.diagBase;
+                /* getAlignedPairsWithoutBanding builds its band from no anchors, expansion 2 (:1532) */
+                int rc = cpecan_band_construct(unbanded || !anchors ? nullptr : anchors + 2 * s.anchor_offset,
+                                               unbanded ? 0 : s.n_anchors, s.lX, s.lY,
+                                               unbanded ? 2 : params->diagonalExpansion, Lp, Rp);
+                if (rc != CPECAN_OK) {
+                    if (st.badItem < 0) { st.badItem = (int) i; st.badRc = rc; }
+                    continue;
                 }
+                long long cells = 0;
+                int maxW = 0;
+                long long *pre = hPre.data() + d.diagBase;
+                for (long long k = 0; k < nDiag; k++) {
+                    pre[k] = cells;
+                    const int wd = ((Rp[k] - Lp[k]) >> 1) + 1;
+                    cells += wd;
+                    maxW = std::max(maxW, wd);
+                }
+                d.nCells = cells;
+                d.maxWidth = maxW;
+                /* traceback schedule of getPosteriorProbsWithBanding (:917-918): longest span of forward
+                 * diagonals that must be resident at once, and the edge-step property the register-resident
+                 * kernels rely on */
+                long long tracedBackTo = 0;
+                int windows = 0;
+                for (long long k = 1; k < nDiag; k++) {
+                    const int xmn = (int) ((k + Lp[k]) / 2), xmx = (int) ((k + Rp[k]) / 2);
+                    const int pmn = (int) ((k - 1 + Lp[k - 1]) / 2), pmx = (int) ((k - 1 + Rp[k - 1]) / 2);
+                    if (xmn < pmn || xmn > pmn + 1 || xmx < pmx || xmx > pmx + 1) st.systolicOk = false;
+                    const bool atEnd = k == nDiag - 1;
+                    const int wd = ((Rp[k] - Lp[k]) >> 1) + 1;
+                    const bool tb = k >= tracedBackTo + params->minDiagsBetweenTraceBack &&
+                                    wd <= params->diagonalExpansion * 2 + 1;
+                    if (atEnd || tb) {
+                        windows++;
+                        st.maxSpan = (int) std::max<long long>(st.maxSpan, k - tracedBackTo + 1);
+                        tracedBackTo = k - (params->traceBackDiagonals + 1);
+                    }
+                }
+                st.windows = std::max(st.windows, windows);
             }
-            maxWindows = std::max(maxWindows, windows);
+        };
+        if (nt <= 1) work(0);
+        else {
+            std::vector<std::thread> pool;
+            for (int w = 0; w < nt; w++) pool.emplace_back(work, w);
+            for (auto &t : pool) t.join();
         }
+        int bad = -1, badRc = 0;
+        for (const ItemStats &st : stats) {
+            maxSpan = std::max(maxSpan, st.maxSpan);
+            maxWindows = std::max(maxWindows, st.windows);
+            systolicOk = systolicOk && st.systolicOk;
+            if (st.badItem >= 0 && (bad < 0 || st.badItem < bad)) { bad = st.badItem; badRc = st.badRc; }
+        }
+        if (bad >= 0) return fail(badRc, "item %lld: anchors do not describe a valid band", (long long) bad);
+    }
+    for (int64_t i = 0; i < nItems; i++) {
+        const cpecan_item &s = items[i];
+        DevItem &d = hItems[(size_t) i];
+        const long long nDiag = s.lX + s.lY + 1;
         hTrackBase[(size_t) i] = trackTotal;
         trackTotal += s.lX + 1;
         maxLX = std::max<int>(maxLX, (int) s.lX);
-        globalMaxWidth = std::max(globalMaxWidth, maxW);
+        globalMaxWidth = std::max(globalMaxWidth, d.maxWidth);
         d.cellBase = cellTotal;
-        cellTotal += cells;
+        cellTotal += d.nCells;
         d.pairBase = pairTotal;
         /* the HDP machine scores with linear densities (quirk Q6): its posteriors are flat and far more
-         * cells pass the threshold (2887 pairs for a ~800-event read in the reference's own test) */
+         * cells pass the threshold (2887 pairs for a ~800-event read in the reference's own test); a batch whose
+         * counts outgrow this first guess is re-run with the counted sizes (ensure_counts) */
         d.pairCap = (hdp ? 16 : 4) * (s.lX + s.lY) + 64;
         pairTotal += d.pairCap;
         d.totBase = totTotal;
@@ -806,9 +876,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                                                                      params->traceBackDiagonals - 1) + 4;
         totTotal += d.totCap;
         d.bwsBase = bwsTotal;
-        bwsTotal += 3ll * maxW * S;
+        bwsTotal += 3ll * d.maxWidth * S;
     }
 
+    lap("band construction and window schedule (host)");
     cpecan_batch *b = new (std::nothrow) cpecan_batch();
     if (!b) return fail(CPECAN_EINVAL, "out of host memory");
     b->ctx = c;
@@ -882,6 +953,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             B_TRY(hipMemcpy(b->logNoise.p, ln.data(), (size_t) nEvents * sizeof(double), hipMemcpyHostToDevice));
         }
     }
+    lap("upload sequences and events");
     B_TRY(b->anchors.alloc((size_t) 2 * nAnchorPairs + 2));
     if (nAnchorPairs > 0)
         B_TRY(hipMemcpy(b->anchors.p, anchors, (size_t) 2 * nAnchorPairs * sizeof(long long),
@@ -897,6 +969,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     B_TRY(hipMemset(b->expect.p, 0, b->expect.n * sizeof(double)));
     b->hNCells.resize((size_t) nItems);
     for (int64_t i = 0; i < nItems; i++) b->hNCells[(size_t) i] = hItems[(size_t) i].nCells;
+    lap("output buffers");
 
     if (useKernel == CPECAN_KERNEL_GENERAL) {
         B_TRY(b->bandL.alloc(hL.size()));
@@ -925,15 +998,27 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
+        lap("ring allocation");
         {   /* the band as matrix columns per diagonal, from the x-y intervals built above */
-            std::vector<int> tab(hL.size() * 2);
-            for (int64_t i = 0; i < nItems; i++) {
-                const DevItem &d = hItems[(size_t) i];
-                const long long nDiag = d.lX + d.lY + 1;
-                for (long long k = 0; k < nDiag; k++) {
-                    tab[(size_t) (d.diagBase + k) * 2] = (int) ((k + hL[(size_t) (d.diagBase + k)]) / 2);
-                    tab[(size_t) (d.diagBase + k) * 2 + 1] = (int) ((k + hR[(size_t) (d.diagBase + k)]) / 2);
+            std::vector<int, NoInit<int>> tab(hL.size() * 2);
+            const int nt = (int) std::min<int64_t>(diagTotal > 2000000 ? host_threads() : 1, nItems);
+            auto fill = [&](int w) {
+                for (int64_t i = w; i < nItems; i += nt) {
+                    const DevItem &d = hItems[(size_t) i];
+                    const long long nDiag = d.lX + d.lY + 1;
+                    const int *Lp = hL.data() + d.diagBase, *Rp = hR.data() + d.diagBase;
+                    int *t = tab.data() + d.diagBase * 2;
+                    for (long long k = 0; k < nDiag; k++) {
+                        t[k * 2] = (int) ((k + Lp[k]) / 2);
+                        t[k * 2 + 1] = (int) ((k + Rp[k]) / 2);
+                    }
                 }
+            };
+            if (nt <= 1) fill(0);
+            else {
+                std::vector<std::thread> pool;
+                for (int w = 0; w < nt; w++) pool.emplace_back(fill, w);
+                for (auto &t : pool) t.join();
             }
             B_TRY(b->bandTab.alloc(tab.size() + 2));
             B_TRY(hipMemcpy(b->bandTab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -961,6 +1046,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             for (auto &e : b->evJoin) B_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             B_TRY(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         }
+        lap("band table upload, streams");
         if (mode == CPECAN_MODE_EXPECTATIONS)
             B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) b->sy->bring_row_doubles()));
         b->stateBytes = b->sy->wave ? cpecan_wave_state_bytes() : cpecan_systolic_state_bytes();
@@ -971,6 +1057,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         B_TRY(b->trackBase.alloc((size_t) nItems));
         B_TRY(hipMemcpy(b->trackBase.p, hTrackBase.data(), (size_t) nItems * sizeof(long long),
                         hipMemcpyHostToDevice));
+        lap("state, scratch, track allocation");
     }
     B_TRY(hipEventCreate(&b->ev0));
     B_TRY(hipEventCreate(&b->ev1));
@@ -1003,6 +1090,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         B_TRY(hipGetLastError());
         B_TRY(hipStreamSynchronize(c->stream));
     }
+    lap("k-mer index kernel");
     *out = b;
     return CPECAN_OK;
 }
