@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 void cpecan_die(const char *fmt, ...) {
     va_list ap;
@@ -26,7 +27,11 @@ void cpecan_die(const char *fmt, ...) {
     vfprintf(stderr, fmt, ap);
     va_end(ap);
     fputc('\n', stderr);
-    exit(1);
+    /* st_errAbort's convention: print and leave with status 1.  Other threads of the caller may be inside the GPU
+     * runtime at this moment (the reference's callers align two strands at once), so the process leaves without
+     * running exit handlers under them */
+    fflush(NULL);
+    _exit(1);
 }
 #define die cpecan_die
 #define CHECK(call)                                                                              \
@@ -88,6 +93,19 @@ static stIntTuple *tuple4(int64_t a, int64_t b, int64_t c, int64_t d) {
     stIntTuple *t = malloc(sizeof(stIntTuple));
     t->n = 4; t->v[0] = a; t->v[1] = b; t->v[2] = c; t->v[3] = d;
     return t;
+}
+/* stList_sort hands the comparison the elements themselves (sonLib's convention), qsort pointers to them */
+static __thread int (*sort_cmp)(const void *, const void *);
+static int sort_adapter(const void *a, const void *b) { return sort_cmp(*(void *const *) a, *(void *const *) b); }
+void stList_sort(stList *l, int (*cmpFn)(const void *a, const void *b)) {
+    sort_cmp = cmpFn;
+    qsort(l->items, (size_t) l->n, sizeof(void *), sort_adapter);
+}
+int stIntTuple_cmpFn(const void *a, const void *b) { /* element by element, then by length */
+    const stIntTuple *x = a, *y = b;
+    for (int64_t i = 0; i < x->n && i < y->n; i++)
+        if (x->v[i] != y->v[i]) return x->v[i] < y->v[i] ? -1 : 1;
+    return x->n == y->n ? 0 : x->n < y->n ? -1 : 1;
 }
 int64_t stIntTuple_get(stIntTuple *t, int64_t i) { return t->v[i]; }
 int64_t stIntTuple_length(stIntTuple *t) { return t->n; }

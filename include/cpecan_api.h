@@ -34,6 +34,8 @@ void stList_destruct(stList *list);
 int64_t stList_length(stList *list);
 void *stList_get(stList *list, int64_t index);
 void stList_append(stList *list, void *item);
+void stList_sort(stList *list, int (*cmpFn)(const void *a, const void *b)); /* cmpFn gets two elements */
+int stIntTuple_cmpFn(const void *a, const void *b);
 stIntTuple *stIntTuple_construct2(int64_t a, int64_t b);
 stIntTuple *stIntTuple_construct3(int64_t a, int64_t b, int64_t c);
 int64_t stIntTuple_get(stIntTuple *t, int64_t index);

@@ -1,0 +1,182 @@
+"""cpecan-signal_amd/vanillaAlign: the reference's signal-align driver (vanillaAlign.c:361-805) rebuilt on the host
+library -- same command line, .npRead / reference / guide-CIGAR inputs, TSV and summary outputs.  Run on the
+reference's own Zymo read with a guide alignment derived from the oracle's un-banded template alignment; the rows it
+writes must equal what the same call sequence gives through the host API from Python, strand by strand."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_api as h
+import pyoracle as o
+from cpecan_load import ROOT
+
+pytestmark = pytest.mark.gpu
+
+EXE = os.path.join(ROOT, "cpecan-signal_amd", "vanillaAlign")
+TRIM = 14
+
+
+def _guide(zymo_read, template_model):
+    """(x, read position) points on the template path, every ~60 k-mers, and the exonerate cigar through them"""
+    ref, ev = zymo_read["reference"], zymo_read["template_events"]
+    om = o.Sm3Model(template_model[0], template_model[2]).scaled(*zymo_read["template_params"])
+    tri = o.aligned_pairs_without_banding(om, ref, len(ref) - 5, ev, o.default_params())["triples"]
+    tmap = zymo_read["template_map"]
+    best = {int(x): int(y) for q, x, y in tri if q > 9000000}
+    pts, px, pr = [], -1, -1
+    for x in sorted(best):
+        r = int(np.searchsorted(tmap, best[x]))
+        if r < tmap.size - 1 and tmap[r] == best[x] and x >= px + 60 and r > pr + 40:
+            pts.append((x, r))
+            px, pr = x, r
+    ops = []
+    for (x0, r0), (x1, r1) in zip(pts, pts[1:]):
+        dx, dr = x1 - x0, r1 - r0
+        ops.append(("M", min(dx, dr)))
+        if dx > dr:
+            ops.append(("D", dx - dr))
+        elif dr > dx:
+            ops.append(("I", dr - dx))
+    cigar = "cigar: read %d %d + ZYMO %d %d + 100 %s\n" % (
+        pts[0][1], pts[-1][1], pts[0][0], pts[-1][0], " ".join("%s %d" % op for op in ops))
+    return pts, ops, cigar
+
+
+def _anchors_from_ops(pts, ops):
+    """guideAlignmentToRebasedAnchorPairs: target re-based to 0, match columns trimmed by 14 at both ends"""
+    j, k, out = 0, pts[0][1], []
+    for op, n in ops:
+        if op == "M":
+            out += [(j + l, k + l) for l in range(TRIM, n - TRIM)]
+        if op != "I":
+            j += n
+        if op != "D":
+            k += n
+    return out
+
+
+def _npread_with_forward_complement(golden_dir, zymo_read, tmp_path):
+    """The shipped fixture's complement event map runs against the 2D read (664 ... 0), which the reference's driver
+    cannot take either (makeEventSequenceFromPairwiseAlignment, vanillaAlign.c:300-314, would build a Sequence of
+    negative length).  For the driver test the complement strand is given the template strand's map and events --
+    with the complement pore model and scaling parameters it is still a different alignment."""
+    lines = open(os.path.join(golden_dir, "ZymoC_ch_1_file1.npRead")).read().split("\n")
+    head = lines[0].split()
+    head[2] = head[1]
+    lines[0] = " ".join(head)
+    lines[4], lines[5] = lines[2], lines[3]
+    path = str(tmp_path / "read.npRead")
+    open(path, "w").write("\n".join(lines))
+    rd = dict(zymo_read)
+    rd["complement_map"], rd["complement_events"] = rd["template_map"], rd["template_events"]
+    return path, rd
+
+
+def test_driver_refuses_an_event_map_that_runs_backwards(golden_dir, zymo_read, template_model):
+    _, _, cigar = _guide(zymo_read, template_model)
+    r = subprocess.run([EXE, "--strawMan", "-T", os.path.join(golden_dir, "template_median68pA.model"), "-C",
+                        os.path.join(golden_dir, "complement_median68pA_pop2.model"), "-q",
+                        os.path.join(golden_dir, "ZymoC_ch_1_file1.npRead"), "-r",
+                        os.path.join(golden_dir, "ZymoRef.txt")], input=cigar, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 1 and "runs against the read" in r.stderr
+
+
+def test_cli_alignment_matches_the_host_api(golden_dir, zymo_read, template_model, tmp_path):
+    L = h.lib()
+    pts, ops, cigar = _guide(zymo_read, template_model)
+    assert len(pts) > 8
+    npread, zymo_read = _npread_with_forward_complement(golden_dir, zymo_read, tmp_path)
+    tsv = str(tmp_path / "out.tsv")
+    models = [os.path.join(golden_dir, "template_median68pA.model"),
+              os.path.join(golden_dir, "complement_median68pA_pop2.model")]
+    cmd = [EXE, "--strawMan", "-T", models[0], "-C", models[1], "-q", npread, "-r",
+           os.path.join(golden_dir, "ZymoRef.txt"), "-u", tsv, "-L", "zymo_read", "-x", "50"]
+    r = subprocess.run(cmd, input=cigar, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "SUCCESS" in r.stderr
+    summary = r.stdout.split()
+    got = [l for l in open(tsv).read().split("\n") if l]
+
+    # the same call sequence from Python
+    ref = zymo_read["reference"]
+    x0, x1, r0 = pts[0][0], pts[-1][0], pts[0][1]
+    trimmed = ref[x0:x1]
+    rc = "".join({"A": "T", "C": "G", "G": "C", "T": "A"}[c] for c in reversed(trimmed))
+    unmapped = h.make_anchor_list(_anchors_from_ops(pts, ops))
+    filtered = L.filterToRemoveOverlap(unmapped)
+    assert int(summary[1]) == L.stList_length(filtered)
+    want_tsv = str(tmp_path / "want.tsv")
+    counts = []
+    for strand, model, params, events, emap, target, rshift in (
+            (0, models[0], zymo_read["template_params"], zymo_read["template_events"], zymo_read["template_map"],
+             trimmed, x0),
+            (1, models[1], zymo_read["complement_params"], zymo_read["complement_events"],
+             zymo_read["complement_map"], rc, x1)):
+        emap = np.ascontiguousarray(emap, dtype=np.int64)
+        ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+        s, e = int(emap[pts[0][1]]), int(emap[pts[-1][1]])
+        sm = L.getStrawManStateMachine3(model.encode())
+        L.emissions_signal_scaleModel(sm, *params)
+        remapped = L.nanopore_remapAnchorPairsWithOffset(filtered, emap.ctypes.data_as(C.POINTER(C.c_int64)), r0)
+        anchors = L.filterToRemoveOverlap(remapped)
+        xbuf = C.create_string_buffer(target.encode())
+        sX = L.sequence_construct2(len(target) - 5, C.cast(xbuf, C.c_void_p), h.fn_ptr("sequence_getKmer"),
+                                   h.fn_ptr("sequence_sliceNucleotideSequence2"))
+        sub = ev[3 * s:]
+        sY = L.sequence_construct2(e - s, sub.ctypes.data_as(C.c_void_p), h.fn_ptr("sequence_getEvent"),
+                                   h.fn_ptr("sequence_sliceEventSequence2"))
+        p = L.pairwiseAlignmentBandingParameters_construct()
+        p.contents.diagonalExpansion = 50
+        pairs = L.getAlignedPairsUsingAnchors(sm, sX, sY, anchors, p,
+                                              h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), True, True)
+        counts.append(L.stList_length(pairs))
+        L.writePosteriorProbs(want_tsv.encode(), b"zymo_read", sm.contents.model.EMISSION_MATCH_PROBS, params[0],
+                              params[1], ev.ctypes.data_as(C.POINTER(C.c_double)), target.encode(), True, b"ZYMO",
+                              s, rshift, pairs, strand)
+        for lst in (pairs, anchors, remapped):
+            L.stList_destruct(lst)
+        L.sequence_sequenceDestroy(sX)
+        L.sequence_sequenceDestroy(sY)
+        L.pairwiseAlignmentBandingParameters_destruct(p)
+        L.stateMachine_destruct(sm)
+    want = [l for l in open(want_tsv).read().split("\n") if l]
+    assert counts[0] > 300 and counts[1] > 0
+    assert summary[2].startswith("%d(" % counts[0]) and summary[3].startswith("%d(" % counts[1])
+    assert len(got) == len(want) == sum(counts)
+    # the driver sorts each strand's pairs by x + y before writing; the order among equal sums is qsort's
+    for label in ("t", "c"):
+        assert sorted(l for l in got if l.split("\t")[4] == label) == \
+            sorted(l for l in want if l.split("\t")[4] == label)
+    t_rows = [l.split("\t") for l in got if l.split("\t")[4] == "t"]
+    sums = [int(r[1]) + int(r[5]) for r in t_rows]
+    assert sums == sorted(sums) and t_rows[0][0] == "ZYMO" and len(t_rows[0]) == 15
+
+
+def test_cli_expectations_files(golden_dir, zymo_read, template_model, tmp_path):
+    _, _, cigar = _guide(zymo_read, template_model)
+    npread, _ = _npread_with_forward_complement(golden_dir, zymo_read, tmp_path)
+    t_exp, c_exp = str(tmp_path / "t.expectations"), str(tmp_path / "c.expectations")
+    cmd = [EXE, "--strawMan", "-T", os.path.join(golden_dir, "template_median68pA.model"), "-C",
+           os.path.join(golden_dir, "complement_median68pA_pop2.model"), "-q", npread, "-r",
+           os.path.join(golden_dir, "ZymoRef.txt"), "-t", t_exp, "-c", c_exp, "-L", "zymo_read"]
+    r = subprocess.run(cmd, input=cigar, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for path in (t_exp, c_exp):
+        lines = open(path).read().split("\n")
+        assert lines[0].split() == ["2", "3", "4096"]
+        vals = np.array(lines[1].split(), float)
+        assert vals.size == 10 and np.isfinite(vals[:9]).all() and vals[:9].min() >= 0.0001  # the pseudocount
+        assert len(lines[2].split()) == 4096
+    t = np.array(open(t_exp).read().split("\n")[1].split(), float)
+    assert t[0] > 100 and t[9] < 0  # hundreds of match->match transitions, a log-likelihood
+    # the next iteration reads the file back: --inTemplateHmm / --inComplementHmm after normalisation upstream
+    L = h.lib()
+    sm = L.getStrawManStateMachine3(os.path.join(golden_dir, "template_median68pA.model").encode())
+    L.hmmContinuous_loadSignalHmm.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
+    L.hmmContinuous_loadSignalHmm(t_exp.encode(), sm, 2)
+    assert np.isclose(sm.contents.TRANSITION_MATCH_CONTINUE, np.log(t[0]), atol=1e-6)
+    L.stateMachine_destruct(sm)
