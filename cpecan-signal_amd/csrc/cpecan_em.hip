@@ -1,0 +1,179 @@
+/*
+ * cpecan_em.hip -- cpecan_em_run (include/cpecan_em.h): the Baum-Welch loop as a native host loop over the C-ABI,
+ * with the ranks' expectation vectors combined by one RCCL all-reduce per iteration.  Host control code plus one
+ * small reduction kernel; built into libcpecan_em.so (links libcpecan_hip.so and librccl).
+ */
+#include "cpecan_em.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define EM_HIP(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) { rc = fail(CPECAN_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+#define EM_ABI(expr)                                                                          \
+    do {                                                                                      \
+        int r_ = (expr);                                                                      \
+        if (r_ != CPECAN_OK) { rc = fail(r_, "%s: %s", #expr, cpecan_hip_last_error()); goto done; } \
+    } while (0)
+#define EM_NCCL(expr)                                                                                       \
+    do {                                                                                                    \
+        ncclResult_t n_ = (expr);                                                                           \
+        if (n_ != ncclSuccess) { rc = fail(CPECAN_EHIP, "%s: %s", #expr, ncclGetErrorString(n_)); goto done; } \
+    } while (0)
+
+/* out[i] = pseudocount + sum over the batch's models of their block's entry i (the likelihood, last entry, starts
+ * from 0): the per-read expectation blocks of an E-step, added up where they are */
+__global__ void cpecan_k_em_sum_blocks(const double *blocks, int nModels, int len, double pseudocount, double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double s = i == len - 1 ? 0.0 : pseudocount;
+    for (int m = 0; m < nModels; m++) s += blocks[(long long) m * len + i];
+    out[i] = s;
+}
+
+/* continuousPairHmm_normalize (impl/continuousHmm.c:174-191) + continuousPairHmm_loadTransitionsAndKmerGapProbs
+ * (:206-232) on one expectation vector [from * 3 + to | 4096 k-mer gaps | likelihood] */
+void m_step(const double *e, double *transitions, double *gapX) {
+    double t[9];
+    for (int from = 0; from < 3; from++) {
+        double total = 0.0;
+        for (int to = 0; to < 3; to++) total += e[from * 3 + to];
+        for (int to = 0; to < 3; to++) t[from * 3 + to] = e[from * 3 + to] / total;
+    }
+    double total = 0.0;
+    for (int k = 0; k < CPECAN_NUM_KMERS; k++) total += e[9 + k];
+    /* the C-ABI's order: MATCH_CONTINUE, MATCH_FROM_GAP_X, MATCH_FROM_GAP_Y, GAP_OPEN_X, GAP_OPEN_Y, GAP_EXTEND_X,
+     * GAP_EXTEND_Y, GAP_SWITCH_TO_X, GAP_SWITCH_TO_Y; states match 0, gapX 1, gapY 2 */
+    transitions[0] = log(t[0 * 3 + 0]);
+    transitions[1] = log(t[1 * 3 + 0]);
+    transitions[2] = log(t[2 * 3 + 0]);
+    transitions[3] = log(t[0 * 3 + 1]);
+    transitions[4] = log(t[0 * 3 + 2]);
+    transitions[5] = log(1 - t[1 * 3 + 0]); /* sic: tied to MATCH_FROM_GAP_X (:217) */
+    transitions[6] = log(t[2 * 3 + 2]);
+    transitions[7] = log(t[2 * 3 + 1]);
+    transitions[8] = -INFINITY; /* (:218) */
+    for (int k = 0; k < CPECAN_NUM_KMERS; k++) gapX[k] = log(e[9 + k] / total);
+}
+
+/* rank 0 hands RCCL's unique id to the other ranks through a file */
+int exchange_id(const char *path, int rank, ncclUniqueId *id) {
+    if (rank == 0) {
+        std::string tmp = std::string(path) + ".tmp";
+        FILE *f = fopen(tmp.c_str(), "wb");
+        if (!f) return fail(CPECAN_EINVAL, "cannot write %s", tmp.c_str());
+        const size_t n = fwrite(id, 1, sizeof *id, f);
+        fclose(f);
+        if (n != sizeof *id || rename(tmp.c_str(), path) != 0) return fail(CPECAN_EINVAL, "cannot publish %s", path);
+        return CPECAN_OK;
+    }
+    for (int tries = 0; tries < 6000; tries++) { /* up to ten minutes */
+        FILE *f = fopen(path, "rb");
+        if (f) {
+            const size_t n = fread(id, 1, sizeof *id, f);
+            fclose(f);
+            if (n == sizeof *id) return CPECAN_OK;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+    return fail(CPECAN_EINVAL, "rank %d: no RCCL id appeared at %s", rank, path);
+}
+
+} // namespace
+
+extern "C" const char *cpecan_em_last_error(void) { return g_err.c_str(); }
+
+extern "C" int cpecan_em_run(const cpecan_em_input *in, int32_t iterations, double pseudocount, double *transitions,
+                             double *gapX, double *runningLikelihood) {
+    if (!in || !transitions || !gapX || iterations < 0 || !in->items || in->n_items <= 0 || !in->match_tables ||
+        in->n_models <= 0 || !in->gap_y_table || in->world < 1 || in->rank < 0 || in->rank >= in->world ||
+        (in->world > 1 && !in->id_file))
+        return fail(CPECAN_EINVAL, "bad argument");
+    int rc = CPECAN_OK;
+    cpecan_ctx *ctx = nullptr;
+    cpecan_batch *batch = nullptr;
+    ncclComm_t comm = nullptr;
+    double *dSum = nullptr;
+    void *stream = nullptr, *dBlocks = nullptr;
+    int64_t nDoubles = 0;
+    std::vector<cpecan_sm3_model> models((size_t) in->n_models);
+    std::vector<int32_t> ids((size_t) in->n_models);
+    std::vector<double> e(CPECAN_EXPECTATION_LEN);
+    const int len = CPECAN_EXPECTATION_LEN;
+
+    EM_HIP(hipSetDevice(in->device));
+    if (in->world > 1) {
+        ncclUniqueId id;
+        if (in->rank == 0) EM_NCCL(ncclGetUniqueId(&id));
+        rc = exchange_id(in->id_file, in->rank, &id);
+        if (rc != CPECAN_OK) goto done;
+        EM_NCCL(ncclCommInitRank(&comm, in->world, id, in->rank));
+    }
+    EM_ABI(cpecan_hip_ctx_create(in->device, &ctx));
+    EM_ABI(cpecan_hip_ctx_stream(ctx, &stream));
+    for (int32_t m = 0; m < in->n_models; m++) {
+        for (int k = 0; k < 9; k++) models[(size_t) m].transitions[k] = transitions[k];
+        models[(size_t) m].match_probs = in->match_tables[m];
+        models[(size_t) m].gap_x_probs = gapX;
+        models[(size_t) m].gap_y_probs = in->gap_y_table;
+    }
+    EM_ABI(cpecan_hip_models_create(ctx, models.data(), in->n_models, 0, ids.data()));
+    EM_ABI(cpecan_hip_batch_create(ctx, in->items, in->n_items, in->x_chars, in->n_x, in->events, in->n_events,
+                                   in->anchors, in->n_anchor_pairs, &in->params, CPECAN_MODE_EXPECTATIONS,
+                                   CPECAN_KERNEL_AUTO, 0, &batch));
+    EM_ABI(cpecan_hip_batch_expectations_device_ptr(batch, &dBlocks, &nDoubles));
+    if (nDoubles != (int64_t) in->n_models * len) {
+        rc = fail(CPECAN_EINVAL, "expectation buffer holds %lld doubles, expected %lld", (long long) nDoubles,
+                  (long long) in->n_models * len);
+        goto done;
+    }
+    EM_HIP(hipMalloc((void **) &dSum, sizeof(double) * (size_t) len));
+
+    for (int32_t it = 0; it < iterations; it++) {
+        /* the model of this iteration, in place on the device; then the E-step of this rank's reads */
+        EM_ABI(cpecan_hip_models_set_transitions(ctx, transitions, gapX));
+        EM_ABI(cpecan_hip_batch_run(batch));
+        EM_ABI(cpecan_hip_batch_sync(batch));
+        hipLaunchKernelGGL(cpecan_k_em_sum_blocks, dim3((unsigned) (len + 255) / 256), dim3(256), 0, (hipStream_t) stream,
+                           (const double *) dBlocks, (int) in->n_models, len, pseudocount, dSum);
+        EM_HIP(hipGetLastError());
+        if (comm) EM_NCCL(ncclAllReduce(dSum, dSum, (size_t) len, ncclDouble, ncclSum, comm, (hipStream_t) stream));
+        EM_HIP(hipMemcpyAsync(e.data(), dSum, sizeof(double) * (size_t) len, hipMemcpyDeviceToHost, (hipStream_t) stream));
+        EM_HIP(hipStreamSynchronize((hipStream_t) stream));
+        if (runningLikelihood) runningLikelihood[it] = e[(size_t) len - 1];
+        m_step(e.data(), transitions, gapX);
+    }
+
+done:
+    if (dSum) (void) hipFree(dSum);
+    if (batch) cpecan_hip_batch_destroy(batch);
+    if (ctx) cpecan_hip_ctx_destroy(ctx);
+    if (comm) (void) ncclCommDestroy(comm);
+    return rc;
+}

@@ -1,0 +1,54 @@
+/*
+ * cpecan_em.h -- the Baum-Welch loop of the strawMan signal machine as a native host loop, one process per GPU.
+ *
+ * What it replaces in the reference: the trainer's iteration (scripts/trainModels.py:244-330) -- a pool of vanillaAlign
+ * processes writing one .expectations file each (vanillaAlign.c:680-716), the files summed in Python
+ * (scripts/trainModels.py:126-135, scripts/nanoporeLib.py:991-1028), the sum normalised
+ * (continuousPairHmm_normalize, impl/continuousHmm.c:174-191) and loaded into the next iteration's state machine
+ * (continuousPairHmm_loadTransitionsAndKmerGapProbs, :206-232).  Here every rank keeps its reads, band tables, rings
+ * and per-read scaled emission tables resident in HBM; an iteration rewrites the nine transitions and the 4096
+ * k-mer gap probabilities in place, runs the E-step kernels, sums the per-read blocks on the device, combines the
+ * ranks with ONE all-reduce of 4106 doubles over RCCL, and normalises on the host -- no files, no gather on a master.
+ */
+#ifndef CPECAN_EM_H_
+#define CPECAN_EM_H_
+
+#include "cpecan_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+    int32_t device;      /* HIP device of this process */
+    int32_t rank, world; /* world 1: no communication */
+    const char *id_file; /* world > 1: a path every rank can read; rank 0 writes RCCL's unique id there (the ranks of a
+                            torch.distributed.run launch share a file system; no second rendezvous service is needed) */
+    /* this rank's reads in the C-ABI's batch layout (cpecan_hip_batch_create); items[i].model_id indexes match_tables */
+    const cpecan_item *items;
+    int64_t n_items;
+    const char *x_chars;
+    int64_t n_x;
+    const double *events; /* [n_events][3] */
+    int64_t n_events;
+    const int64_t *anchors; /* [n_anchor_pairs][2] */
+    int64_t n_anchor_pairs;
+    const double *const *match_tables; /* n_models tables of CPECAN_MODEL_TABLE_LEN doubles, each scaled for its read
+                                          (emissions_signal_scaleModel) */
+    int32_t n_models;
+    const double *gap_y_table; /* CPECAN_MODEL_TABLE_LEN doubles (the .model file's third line; not scaled by the reference) */
+    cpecan_band_params params;
+} cpecan_em_input;
+
+/* `iterations` Baum-Welch iterations from (transitions[9] in the C-ABI's order, gap_x[4096]); both are overwritten
+ * with the final model.  `pseudocount` is added to every expectation of a rank before the ranks are combined, as each
+ * of the reference's workers starts its Hmm from it (vanillaAlign.c:668-669).  running_likelihood[i] receives the
+ * summed log-likelihood of iteration i (under the model the iteration started from).  Identical on every rank. */
+int cpecan_em_run(const cpecan_em_input *in, int32_t iterations, double pseudocount, double *transitions,
+                  double *gap_x, double *running_likelihood);
+const char *cpecan_em_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -37,3 +37,16 @@ def test_fails_loudly_without_gpu():
         cp.Context(0)
     assert ei.value.code == cp.ENODEVICE
     assert "no CPU path" in str(ei.value)
+
+
+def test_em_library_exports_declared_symbols():
+    """include/cpecan_em.h: libcpecan_em.so loads without a GPU and exports what the header declares"""
+    import ctypes as C
+    import re
+    header = open(os.path.join(ROOT, "include", "cpecan_em.h")).read()
+    names = set(re.findall(r"\b(cpecan_em_[a-z_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S)))
+    assert names == {"cpecan_em_run", "cpecan_em_last_error"}
+    lib = C.CDLL(os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_em.so"))
+    for n in names:
+        assert hasattr(lib, n)
+    assert lib.cpecan_em_run(None, 1, C.c_double(0.0), None, None, None) != 0  # argument check, no GPU touched

@@ -52,3 +52,56 @@ def test_gpu_e_step_and_loop():
     assert len(lines) == 3 and np.isneginf(r["transitions"][8])
     assert np.allclose(np.exp(r["gap_x"]).sum(), 1.0)
     ctx.close()
+
+
+def test_native_em_loop_matches_the_python_driver():
+    """cpecan_em_run (include/cpecan_em.h, libcpecan_em.so): the same three iterations as a native host loop -- models
+    resident, transitions rewritten in place, per-read blocks summed on the device, the RCCL all-reduce skipped at
+    world 1 -- against em.train over the one-shot E-step"""
+    import ctypes as C
+    import os
+    from cpecan_load import ROOT
+    L = C.CDLL(os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_em.so"))
+    L.cpecan_em_last_error.restype = C.c_char_p
+
+    class EmInput(C.Structure):
+        _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("id_file", C.c_char_p),
+                    ("items", C.c_void_p), ("n_items", C.c_int64), ("x_chars", C.c_char_p), ("n_x", C.c_int64),
+                    ("events", C.c_void_p), ("n_events", C.c_int64), ("anchors", C.c_void_p),
+                    ("n_anchor_pairs", C.c_int64), ("match_tables", C.POINTER(C.c_void_p)), ("n_models", C.c_int32),
+                    ("gap_y_table", C.c_void_p), ("params", cp.BandParams)]
+
+    batch = synth.make_batch(47, 6, 150, 310, anchor_every=30)
+    bp = band_params(0.01, 100, 20, 40)
+    n = len(batch["items"])
+    items = np.zeros(n, cp.ITEM_DTYPE)
+    for i, it in enumerate(batch["items"]):
+        items[i] = (it["x_offset"], it["lX"], it["y_offset"], it["lY"], it["anchor_offset"], it["n_anchors"],
+                    it["model"], 1, 1, 0)
+    tables = [np.ascontiguousarray(m[0], dtype=np.float64) for m in batch["models"]]
+    gap_y = np.ascontiguousarray(batch["models"][0][2], dtype=np.float64)
+    ev = np.ascontiguousarray(batch["events"], dtype=np.float64).reshape(-1)
+    an = np.ascontiguousarray(batch["anchors"], dtype=np.int64).reshape(-1)
+    ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in tables])
+    x = batch["x_chars"]
+    inp = EmInput(0, 0, 1, None, items.ctypes.data, n, x, len(x), ev.ctypes.data, ev.size // 3, an.ctypes.data,
+                  an.size // 2, ptrs, n, gap_y.ctypes.data, bp)
+    trans = np.array(cp.NANOPORE_TRANSITIONS, dtype=np.float64)
+    gap_x = np.array(batch["models"][0][1], dtype=np.float64)
+    like = np.zeros(3)
+    rc = L.cpecan_em_run(C.byref(inp), 3, C.c_double(1e-9), trans.ctypes.data_as(C.c_void_p),
+                         gap_x.ctypes.data_as(C.c_void_p), like.ctypes.data_as(C.c_void_p))
+    assert rc == 0, L.cpecan_em_last_error()
+
+    ctx = cp.Context(0)
+    r = dist_em.train(lambda t, g: dist_em.gpu_e_step(cp, ctx, batch, bp, list(range(n)), t, g, pseudocount=1e-9),
+                      cp.NANOPORE_TRANSITIONS, batch["models"][0][1], 3)
+    ctx.close()
+    assert np.allclose(like, r["running_likelihoods"], rtol=1e-10) and like[0] < like[1] < like[2]
+    assert np.allclose(trans[:8], r["transitions"][:8], rtol=1e-8) and np.isneginf(trans[8])
+    assert np.allclose(gap_x, r["gap_x"], rtol=1e-8)
+    # a world of two without a rendezvous file is refused before anything touches the GPU
+    inp.world, inp.rank = 2, 1
+    assert L.cpecan_em_run(C.byref(inp), 1, C.c_double(0.0), trans.ctypes.data_as(C.c_void_p),
+                           gap_x.ctypes.data_as(C.c_void_p), None) != 0
+    assert b"bad argument" in L.cpecan_em_last_error()
