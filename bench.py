@@ -86,7 +86,12 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=("posterior", "em"), default="posterior")
+    ap.add_argument("--mode", choices=("posterior", "em", "hdp"), default="posterior")
+    ap.add_argument("--config", type=int, default=0,
+                    help="BASELINE.json configs by number: 3 = --mode posterior (configs[2]), 4 = --mode em (configs[3]), "
+                         "5 = --mode hdp (configs[4])")
+    ap.add_argument("--hdp", default=os.path.join(ROOT, "tests", "golden", "testTemplate.nhdp"),
+                    help="--mode hdp: a serialized NanoporeHDP (default: the reference's own test fixture)")
     ap.add_argument("--reads", type=int, default=1024)
     ap.add_argument("--events", type=int, default=10000)
     ap.add_argument("--kmers", type=int, default=5000)
@@ -114,7 +119,16 @@ def parse_args(argv=None):
                          "batch on the wave kernels")
     ap.add_argument("--rehearse", action="store_true", help="no GPU: gloo ranks, host band geometry as the step")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the self-started workers")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.config:
+        args.mode = {3: "posterior", 4: "em", 5: "hdp"}.get(args.config) or sys.exit("--config takes 3, 4 or 5")
+    given = argv if argv is not None else sys.argv
+    if args.mode == "hdp":  # long reads on the general kernel (one workgroup per read): its own default sizes
+        if "--reads" not in given:
+            args.reads, args.events, args.kmers = 256, 50000, 41500
+        if "--steps" not in given:
+            args.steps, args.warmup = 4, 1
+    return args
 
 
 def launch_workers(args, argv):
@@ -226,6 +240,8 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.mode == "hdp":
+        return bench_hdp(args, cp, bp, rank, local_rank, world, dist, torch, sync_all)
     if args.mode == "em":
         return bench_em(args, cp, load_em(), bp, rank, local_rank, world, dist, torch, synth, sync_all, first_batch,
                         cpu_all)
@@ -492,6 +508,118 @@ def kernel_stage(info, stage, cells):
                 "avg_launch_ms": round(f_ms / n_l, 4),
                 "achieved": round(cells * 24.0 / (f_ms / 1e3) / 1e9, 2),
                 "frac": round(cells * 24.0 / (f_ms / 1e3) / 1e9 / 8000.0, 5)}}
+
+
+def hdp_reads(n, lX, lY, seed, desc):
+    """Synthetic reads for the HDP machine: random ACGT reference, per k-mer 0 events with p = 0.1, else 1 + stays so
+    that about lY events come out; an event's mean is drawn around the mode of its k-mer's density in the HDP (the
+    emission model the machine scores with); anchors every 50 k-mers on the true path."""
+    import ctypes as C
+    G, rows = desc.grid_length, int(desc.n_rows)
+    grid = np.ctypeslib.as_array(C.cast(desc.grid, C.POINTER(C.c_double)), (G,))
+    y = np.ctypeslib.as_array(C.cast(desc.posterior_predictive, C.POINTER(C.c_double)), (rows, G))
+    A = desc.alphabet_size
+    kmer_row = np.ctypeslib.as_array(C.cast(desc.kmer_row, C.POINTER(C.c_int32)), (A ** 6,))
+    mode = grid[np.argmax(y, axis=1)]
+    digit = {ch: desc.alphabet.decode().index(ch) for ch in "ACGT"}
+    xs, evs, ans, items = [], [], [], []
+    xo = yo = ao = 0
+    for r in range(n):
+        rng = np.random.default_rng(seed * 1000 + r)
+        seq = rng.integers(0, 4, lX + 5)
+        chars = np.frombuffer(b"ACGT", np.uint8)[seq]
+        d = np.array([digit[c] for c in "ACGT"])[seq]
+        kid = np.zeros(lX, np.int64)
+        for j in range(6):
+            kid = kid * A + d[j:j + lX]
+        stay = max(0.05, 1.0 - 0.9 * lX / max(lY, 1))
+        counts = np.where(rng.random(lX) < 0.10, 0, rng.geometric(1.0 - stay, lX))
+        ev_k = np.repeat(np.arange(lX), counts)
+        ev = np.zeros((ev_k.size, 3))
+        ev[:, 0] = mode[kmer_row[kid[ev_k]]] + rng.normal(0, 1.0, ev_k.size)
+        ev[:, 1] = np.abs(rng.normal(1.0, 0.2, ev_k.size)) + 1e-3
+        ev[:, 2] = 0.01
+        first = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        ax = np.arange(25, lX, 50)
+        ax = ax[counts[ax] > 0]
+        an = np.stack([ax, first[ax]], axis=1).astype(np.int64)
+        items.append(dict(x_offset=xo, lX=lX, y_offset=yo, lY=ev_k.size, anchor_offset=ao, n_anchors=len(an), model=0))
+        xs.append(bytes(chars)); evs.append(ev); ans.append(an)
+        xo += lX + 5; yo += ev_k.size; ao += len(an)
+    return dict(x_chars=b"".join(xs), events=np.concatenate(evs), anchors=np.concatenate(ans), items=items)
+
+
+def bench_hdp(args, cp, bp, rank, local_rank, world, dist, torch, sync_all):
+    """BASELINE configs[4]: the HDP-emission signal machine on long reads (default 64 reads/GPU x 41 500 k-mers x
+    ~50 000 events), read-sharded; the HDP comes from a serialized .nhdp through the host library's own reader."""
+    import ctypes as C
+    host = C.CDLL(os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_host.so"))
+    host.deserialize_nhdp.restype = C.c_void_p
+    host.deserialize_nhdp.argtypes = [C.c_char_p]
+    host.getHdpStateMachine3.restype = C.c_void_p
+    host.getHdpStateMachine3.argtypes = [C.c_void_p]
+    host.cpecan_hdp_machine_as_model.argtypes = [C.c_void_p, C.c_void_p]
+    nh = host.deserialize_nhdp(args.hdp.encode())
+    sm = host.getHdpStateMachine3(nh)
+    desc = cp.HdpModelDesc()
+    host.cpecan_hdp_machine_as_model(sm, C.byref(desc))
+    t0 = time.time()
+    bt = hdp_reads(args.reads, args.kmers, args.events, 5 + 100 * rank, desc)
+    t_gen = time.time() - t0
+    cx = cp.Context(local_rank)
+    ids = np.zeros(1, np.int32)
+    rc = cp.lib().cpecan_hip_modelsh_create(cx.h, C.byref(desc), 1, ids.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        sys.exit("cpecan_hip_modelsh_create: %s" % cp.lib().cpecan_hip_last_error().decode())
+    b = cp.Batch(cx, make_items(cp, bt), bt["x_chars"], bt["events"], bt["anchors"], bp, hdp=True)
+    for _ in range(max(args.warmup, 1)):
+        b.run()
+        b.sync()
+    sync_all()
+    t_start = time.perf_counter()
+    ms = []
+    for _ in range(args.steps):
+        b.run()
+        b.sync()
+        ms.append(b.elapsed_ms()[1])
+        b.counts()  # the pairs on the host as the reference's integers, inside the timed region
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    npairs, _, ncells = b.counts()
+    cells = int(ncells.sum())
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        ct = torch.tensor([cells], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ct, op=dist.ReduceOp.SUM)
+        total_cells = int(ct.item())
+    else:
+        total_cells = cells
+    if rank == 0:
+        achieved = cells * 48.0 / (elapsed / args.steps) / 1e9
+        print(json.dumps({
+            "metric": "banded fwd-bwd Gcells/s", "value": round(total_cells * args.steps / elapsed / 1e9, 4),
+            "unit": "Gcells/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "reads_per_s": round(args.reads * world * args.steps / elapsed, 2),
+            "config": {"workload": "BASELINE configs[4]: HDP-emission signal HMM (%s), %d reads/GPU x %d k-mers x ~%d "
+                                   "events, diagonalExpansion %d, posterior decode"
+                                   % (os.path.basename(args.hdp), args.reads, args.kmers,
+                                      int(np.mean([it["lY"] for it in bt["items"]])), args.band),
+                       "cells_per_gpu": cells, "pairs_per_gpu": int(npairs.sum()), "kernel": b.info(),
+                       "kernel_ms_per_step": round(float(np.mean(ms)), 3), "generate_s": round(t_gen, 2),
+                       "parallelism": "reads sharded over %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "scope": "whole pass on the general HDP kernel (forward diagonals in HBM), 48 B per cell"},
+            "cpu_baseline": None}), flush=True)
+    b.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def bench_em(args, cp, em, bp, rank, local_rank, world, dist, torch, synth, sync_all, first_batch, cpu_all):

@@ -488,6 +488,24 @@ void nanopore_nanoporeReadDestruct(NanoporeRead *r) {
     free(r->complementEventMap); free(r->complementEvents); free(r);
 }
 
+/* the C-ABI's view of an HDP state machine (cpecan_hdp_model, cpecan_hip.h): pointers into the NanoporeHDP, no copy */
+void cpecan_hdp_machine_as_model(StateMachine *sM, void *out) {
+    if (sM->type != threeStateHdp || !((StateMachine3_HDP *) sM)->hdpModel)
+        die("cpecan_hdp_machine_as_model takes a StateMachine3_HDP with its NanoporeHDP");
+    const StateMachine3_HDP *sh = (const StateMachine3_HDP *) sM;
+    const NanoporeHDP *nh = sh->hdpModel;
+    cpecan_hdp_model *m = out;
+    memcpy(m->transitions, &sh->TRANSITION_MATCH_CONTINUE, sizeof m->transitions);
+    m->alphabet = nh->alphabet;
+    m->alphabet_size = (int32_t) nh->alphabetSize;
+    m->grid_length = (int32_t) nh->gridLength;
+    m->grid = nh->grid;
+    m->n_rows = nh->nRows;
+    m->posterior_predictive = nh->y;
+    m->spline_slopes = nh->slope;
+    m->kmer_row = nh->kmerRow;
+}
+
 StateMachine *getHdpStateMachine3(NanoporeHDP *hdp) {
     StateMachine3_HDP *s = calloc(1, sizeof *s);
     s->model.type = threeStateHdp;
@@ -842,18 +860,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         for (int32_t k = 0; k < nModels && found < 0; k++)
             if (owner5[k] == sMs[i]) found = k;
         if (found < 0) {
-            const StateMachine3_HDP *sh = (const StateMachine3_HDP *) sMs[i];
-            const NanoporeHDP *nh = sh->hdpModel;
-            cpecan_hdp_model *m = &modelsH[nModels];
-            memcpy(m->transitions, &sh->TRANSITION_MATCH_CONTINUE, sizeof m->transitions);
-            m->alphabet = nh->alphabet;
-            m->alphabet_size = (int32_t) nh->alphabetSize;
-            m->grid_length = (int32_t) nh->gridLength;
-            m->grid = nh->grid;
-            m->n_rows = nh->nRows;
-            m->posterior_predictive = nh->y;
-            m->spline_slopes = nh->slope;
-            m->kmer_row = nh->kmerRow;
+            cpecan_hdp_machine_as_model(sMs[i], &modelsH[nModels]);
             owner5[nModels] = sMs[i];
             found = nModels++;
         }

@@ -250,6 +250,9 @@ typedef struct _StateMachine3_HDP {
     double (*getMatchProbFcn)(NanoporeHDP *hdp, void *x, void *y);
 } StateMachine3_HDP;
 StateMachine *getHdpStateMachine3(NanoporeHDP *hdp); /* impl/stateMachine.c:1738 */
+/* for callers that batch HDP alignments through the C-ABI themselves: fills a cpecan_hdp_model (cpecan_hip.h) with the
+ * machine's transitions and pointers into its NanoporeHDP's tables (valid while the NanoporeHDP lives) */
+void cpecan_hdp_machine_as_model(StateMachine *sM, void *cpecan_hdp_model_out);
 
 /* getStrawManStateMachine3 (impl/stateMachine.c:1725): 3-state machine with nanopore default
  * transitions (:1278), log(0.1) k-mer gap table (:1506), emission tables from a 3-line .model file */
