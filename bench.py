@@ -123,11 +123,11 @@ def parse_args(argv=None):
     if args.config:
         args.mode = {3: "posterior", 4: "em", 5: "hdp"}.get(args.config) or sys.exit("--config takes 3, 4 or 5")
     given = argv if argv is not None else sys.argv
-    if args.mode == "hdp":  # long reads on the general kernel (one workgroup per read): its own default sizes
+    if args.mode == "hdp":  # long reads: its own default sizes
         if "--reads" not in given:
-            args.reads, args.events, args.kmers = 256, 50000, 41500
+            args.reads, args.events, args.kmers = 1024, 50000, 41500
         if "--steps" not in given:
-            args.steps, args.warmup = 4, 1
+            args.steps, args.warmup = 5, 1
     return args
 
 
@@ -540,8 +540,9 @@ def hdp_reads(n, lX, lY, seed, desc):
         ev[:, 1] = np.abs(rng.normal(1.0, 0.2, ev_k.size)) + 1e-3
         ev[:, 2] = 0.01
         first = np.concatenate([[0], np.cumsum(counts)[:-1]])
-        ax = np.arange(25, lX, 50)
-        ax = ax[counts[ax] > 0]
+        emitting = np.flatnonzero(counts > 0)
+        ax = emitting[np.searchsorted(emitting, np.arange(25, lX - 1, 50))]  # the next k-mer that emitted
+        ax = np.unique(ax)
         an = np.stack([ax, first[ax]], axis=1).astype(np.int64)
         items.append(dict(x_offset=xo, lX=lX, y_offset=yo, lY=ev_k.size, anchor_offset=ao, n_anchors=len(an), model=0))
         xs.append(bytes(chars)); evs.append(ev); ans.append(an)
@@ -613,7 +614,9 @@ def bench_hdp(args, cp, bp, rank, local_rank, world, dist, torch, sync_all):
                        "parallelism": "reads sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": None,
-                         "scope": "whole pass on the general HDP kernel (forward diagonals in HBM), 48 B per cell"},
+                         "scope": "whole pass incl. the pairs on the host, 48 B per cell; kernels: %s"
+                                  % ("cpecan_k_wv_*_h%d (wave per alignment)" % b.info().get("cells_per_lane", 0)
+                                     if b.info()["kernel"] == "systolic" else "cpecan_k_generalh")},
             "cpu_baseline": None}), flush=True)
     b.close()
     if world > 1:

@@ -26,6 +26,7 @@ FLAG_UNBANDED = 2
 FLAG_SCAN_DECODE = 4
 FLAG_EXPECTATIONS = 8
 FLAG_WORKGROUP_KERNELS = 16
+FLAG_GENERAL_KERNEL = 32
 NUM_KMERS = 4096
 MODEL_TABLE_LEN = 1 + NUM_KMERS * 5
 EXPECTATION_LEN = 9 + NUM_KMERS + 1

@@ -138,4 +138,15 @@ __device__ __forceinline__ double cp_wave_seq_fold(double acc, double v, bool va
     return acc;
 }
 
+/* one HDP model on the device (cpecan_hip_modelsh_create): the 3-state transitions and the NanoporeHDP as densities
+ * need it */
+struct DevHdpModel {
+    double t[9];            /* transitions, order of struct _StateMachine3_HDP */
+    int gridLength, pad;
+    const int *kmerRow;     /* [alphabetSize^6] table row per k-mer id */
+    const double *grid;     /* [gridLength] */
+    const double *y;        /* [rows][gridLength] */
+    const double *slope;    /* [rows][gridLength] */
+};
+
 #endif

@@ -37,12 +37,6 @@ extern "C" __global__ void cpecan_k_generalv(const DevItem *, DevParams, const i
                                              const double *, const double *, double *, double *,
                                              long long *, double *, long long *, long long *, double *,
                                              long long *, double *);
-struct DevHdpModel { /* as in cpecan_kernel_generalh.hip */
-    double t[9];
-    int gridLength, pad;
-    const int *kmerRow;
-    const double *grid, *y, *slope;
-};
 extern "C" __global__ void cpecan_k_generalh(const DevItem *, DevParams, const int *, const int *,
                                              const long long *, const int *, const double *,
                                              const DevHdpModel *, double *, double *, long long *, double *,
@@ -131,6 +125,13 @@ SY_DECLARE(_r3)
 WV_DECLARE(_l2)
 WV_DECLARE(_l3)
 WV_DECLARE(_l4)
+/* ... and the same sweeps for the HDP signal machine (-DWV_HDP, symbols _h2.._h4) */
+WV_DECLARE(_h2)
+WV_DECLARE(_h3)
+WV_DECLARE(_h4)
+extern "C" int cpecan_wave_launch_track_hdp(hipStream_t stream, const DevItem *items, long long nItems,
+                                            const double *track, const long long *trackBase, const int *kid,
+                                            const void *models, void *states, int maxLX);
 extern "C" int cpecan_wave_launch_track(hipStream_t stream, const DevItem *items, long long nItems,
                                         const double *track, const long long *trackBase,
                                         const unsigned short *kidx, const double *models, void *states, int maxLX);
@@ -175,6 +176,7 @@ struct SyBuild { /* one build of the throughput kernels */
 static const SyBuild SY_BUILDS[4] = { SY_BUILD(1, _r1), SY_BUILD(2, _r2), SY_BUILD(3, _r3), SY_BUILD(4, ) };
 /* (a one-cell-per-lane build would only serve bands below 57 k-mers; the two-cell build takes those too) */
 static const SyBuild WV_BUILDS[4] = { WV_BUILD(2, _l2), WV_BUILD(2, _l2), WV_BUILD(3, _l3), WV_BUILD(4, _l4) };
+static const SyBuild HV_BUILDS[4] = { WV_BUILD(2, _h2), WV_BUILD(2, _h2), WV_BUILD(3, _h3), WV_BUILD(4, _h4) };
 /* which family a batch runs on: the wave kernels unless CPECAN_KERNELS=systolic asks for the workgroup-per-alignment ones */
 static bool use_wave_kernels() {
     const char *k = getenv("CPECAN_KERNELS");
@@ -349,7 +351,9 @@ struct cpecan_batch {
      * copied in one piece into pinned memory */
     DevBuf<long long> packBase;
     DevBuf<PackedPair> packed;
+    DevBuf<int> packedPost;
     PackedPair *hPacked = nullptr; /* hipHostMalloc */
+    int *hPost = nullptr;          /* hipHostMalloc: the device's verdict per candidate (cpecan_k_pack_pairs) */
     size_t hPackedCap = 0;
     int trackRow = CP_ROW; /* doubles per column of the track */
     bool countsValid = false, ran = false;
@@ -704,6 +708,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
         for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
     if (b->hPacked) (void) hipHostFree(b->hPacked);
+    if (b->hPost) (void) hipHostFree(b->hPost);
     delete b;
     (void) hipGetLastError(); /* a failed clean-up call must not surface as the "last error" of a later launch */
     return CPECAN_OK;
@@ -901,7 +906,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
-    int useKernel = dna || vanilla || hdp ? CPECAN_KERNEL_GENERAL : kernel;
+    /* the HDP machine's posterior decode has wave-per-alignment kernels of its own (its E-step, and the vanilla and
+     * 5-state machines, run on the general kernels); CPECAN_FLAG_GENERAL_KERNEL keeps an HDP batch on the general one */
+    const bool hdpWave = hdp && mode == CPECAN_MODE_POSTERIOR && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
+    int useKernel = dna || vanilla || (hdp && !hdpWave) ? CPECAN_KERNEL_GENERAL : hdp ? CPECAN_KERNEL_AUTO : kernel;
     b->dna = dna;
     b->vanilla = vanilla;
     b->hdp = hdp;
@@ -926,7 +934,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         const char *rows = getenv("CPECAN_SYSTOLIC_ROWS");
         int r = rows ? atoi(rows) : 1;
         r = r < 1 ? 1 : r > 4 ? 4 : r;
-        const SyBuild *fam = (use_wave_kernels() && !(flags & CPECAN_FLAG_WORKGROUP_KERNELS)) ? WV_BUILDS : SY_BUILDS;
+        const SyBuild *fam = hdp ? HV_BUILDS
+                             : (use_wave_kernels() && !(flags & CPECAN_FLAG_WORKGROUP_KERNELS)) ? WV_BUILDS : SY_BUILDS;
         while (r < 4 && globalMaxWidth > fam[r - 1].max_width()) r++;
         b->sy = &fam[r - 1];
         b->trackRow = b->sy->wave ? cpecan_wave_track_row_doubles() : CP_ROW;
@@ -1156,7 +1165,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
                            (double *) nullptr, b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
-    } else if (b->hdp) {
+    } else if (b->hdp && b->kernel == CPECAN_KERNEL_GENERAL) {
         hipLaunchKernelGGL(cpecan_k_generalh, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
                            (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
                            (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
@@ -1199,11 +1208,21 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
         /* does any model let gap Y switch to gap X?  (the nanopore default does not, stateMachine.c:1287: the
          * kernels then run the build without that term) */
         int withSwitch = 0;
-        for (int m = 0; m < c->nModels; m++)
-            if (c->hostModels[(size_t) m * CP_MODEL_STRIDE + T_GAP_SWITCH_TO_X] > -INFINITY) withSwitch = 1;
-        int rc = (b->sy->wave ? cpecan_wave_launch_track : cpecan_systolic_launch_track)(
-            c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
-            b->maxLX);
+        int rc;
+        /* the models as the sweeps read them: strawMan tables, or the HDP records of an HDP batch */
+        const double *models = b->hdp ? (const double *) c->modelsH.p : c->models.p;
+        if (b->hdp) {
+            for (const DevHdpModel &m : c->hostModelsH)
+                if (m.t[T_GAP_SWITCH_TO_X] > -INFINITY) withSwitch = 1;
+            rc = cpecan_wave_launch_track_hdp(c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p, b->kid.p,
+                                              c->modelsH.p, b->syStates.p, b->maxLX);
+        } else {
+            for (int m = 0; m < c->nModels; m++)
+                if (c->hostModels[(size_t) m * CP_MODEL_STRIDE + T_GAP_SWITCH_TO_X] > -INFINITY) withSwitch = 1;
+            rc = (b->sy->wave ? cpecan_wave_launch_track : cpecan_systolic_launch_track)(
+                c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
+                b->maxLX);
+        }
         HIP_TRY(hipEventRecord(b->evFork, c->stream));
         const long long per = (b->nItems + G - 1) / G;
         for (int gi = 0; gi < G && rc == 0; gi++) {
@@ -1221,7 +1240,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                 /* the kernels index everything per alignment by blockIdx: shift the bases */
                 if (n > 0)
                     rc = b->sy->launch_forward(sF, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
-                                               b->trackBase.p + i0, b->events.p, c->models.p,
+                                               b->trackBase.p + i0, b->events.p, models,
                                                b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles, b->ringD,
                                                b->syStates.p + i0 * b->stateBytes, w, withSwitch);
                 HIP_TRY(hipEventRecord(e4[1], sF));
@@ -1230,7 +1249,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                 static const bool fwdOnly = getenv("CPECAN_TIMING_FORWARD_ONLY") != nullptr; /* timing study: wrong results */
                 if (rc == 0 && n > 0 && !fwdOnly)
                     rc = b->sy->launch_backward(sB, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
-                                                b->trackBase.p + i0, c->models.p,
+                                                b->trackBase.p + i0, models,
                                                 b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles, b->ringD,
                                                 b->syStates.p + i0 * b->stateBytes, b->pairs.p, b->pairLogp.p,
                                                 b->totXay.p, b->totVal.p, b->syScratch.p + i0 * b->scratchBytes,
@@ -1330,8 +1349,12 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *b, float *msTotal, float *msKernel
  * floor(p * 1e7) are finished here with the host libm, the one the reference calls
  * (diagonalCalculationPosteriorMatchProbs, impl/pairwiseAligner.c:776-786). */
 /* item i's first packBase[i + 1] - packBase[i] candidates, from its own region of the pair buffers to the packed one */
+/* With every candidate goes a verdict on its integer posterior: the device's exp() and the host libm's differ by at
+ * most a few units in the last place, so wherever exp(logp) is not within a (far wider) margin of the threshold, of 1
+ * or of a multiple of 1e-7, floor(p * 1e7) is the same number on both and is taken here (post >= 0), or the pair is
+ * surely below the threshold (post -2); the few that are close (post -1) are finished by the host with its libm. */
 extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
-                                               const double *logp, PackedPair *out) {
+                                               const double *logp, double threshold, PackedPair *out, int *post) {
     const DevItem &d = items[blockIdx.x];
     const long long o = packBase[blockIdx.x], n = packBase[blockIdx.x + 1] - o;
     for (long long k = threadIdx.x; k < n; k += blockDim.x) {
@@ -1340,6 +1363,19 @@ extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long 
         r.y = (int) pairs[(d.pairBase + k) * 3 + 2];
         r.logp = logp[d.pairBase + k];
         out[o + k] = r;
+        const double p = exp(r.logp);
+        int v = -1;
+        if (p == p) {
+            if (p < threshold - (1e-9 * threshold + 1e-300)) v = -2;
+            else if (p > threshold + (1e-9 * threshold + 1e-300) || threshold == 0.0) {
+                if (p > 1.0 + 1e-9) v = 10000000;
+                else if (p < 1.0 - 1e-9) {
+                    const double q = p * 10000000.0, fl = floor(q);
+                    if (q - fl > 1e-5 && fl + 1.0 - q > 1e-5) v = (int) fl;
+                }
+            }
+        }
+        post[o + k] = v;
     }
 }
 
@@ -1395,20 +1431,28 @@ static int ensure_counts(cpecan_batch *b) {
     }
     if (all > 0) {
         if (b->packBase.n < (size_t) b->nItems + 1) HIP_TRY(b->packBase.alloc((size_t) b->nItems + 1));
-        if (b->packed.n < (size_t) all) HIP_TRY(b->packed.alloc((size_t) all + (size_t) all / 8));
+        if (b->packed.n < (size_t) all) {
+            HIP_TRY(b->packed.alloc((size_t) all + (size_t) all / 8));
+            HIP_TRY(b->packedPost.alloc((size_t) all + (size_t) all / 8));
+        }
         if (b->hPackedCap < (size_t) all) {
             if (b->hPacked) (void) hipHostFree(b->hPacked);
+            if (b->hPost) (void) hipHostFree(b->hPost);
             b->hPacked = nullptr;
+            b->hPost = nullptr;
             b->hPackedCap = (size_t) all + (size_t) all / 8;
             HIP_TRY(hipHostMalloc((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair), hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc((void **) &b->hPost, b->hPackedCap * sizeof(int), hipHostMallocDefault));
         }
         HIP_TRY(hipMemcpyAsync(b->packBase.p, b->hPairBase.data(), ((size_t) b->nItems + 1) * sizeof(long long),
                                hipMemcpyHostToDevice, b->ctx->stream));
         hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, b->ctx->stream,
                            (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
-                           (const double *) b->pairLogp.p, b->packed.p);
+                           (const double *) b->pairLogp.p, b->P.threshold, b->packed.p, b->packedPost.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(b->hPacked, b->packed.p, (size_t) all * sizeof(PackedPair), hipMemcpyDeviceToHost,
+                               b->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->hPost, b->packedPost.p, (size_t) all * sizeof(int), hipMemcpyDeviceToHost,
                                b->ctx->stream));
         HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     }
@@ -1416,7 +1460,9 @@ static int ensure_counts(cpecan_batch *b) {
      * (impl/pairwiseAligner.c:776-786); items are independent, so they are dealt to the host threads */
     const double threshold = b->P.threshold;
     const PackedPair *src = b->hPacked;
-    auto finish = [b, src, threshold](int64_t i0, int64_t i1) {
+    const int *verdict = b->hPost;
+    static const bool hostOnly = getenv("CPECAN_HOST_FINALISE") != nullptr; /* (tests: every pair through the host libm) */
+    auto finish = [b, src, verdict, threshold](int64_t i0, int64_t i1) {
         for (int64_t i = i0; i < i1; i++) {
             const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
             long long *t = b->hPairs.data() + o * 3;
@@ -1424,10 +1470,15 @@ static int ensure_counts(cpecan_batch *b) {
             long long kept = 0;
             for (long long k = 0; k < n; k++) {
                 const PackedPair r = src[o + k];
-                double p = exp(r.logp);
-                if (!(p >= threshold)) continue;
-                if (p > 1.0) p = 1.0;
-                t[kept * 3] = (long long) floor(p * 10000000.0);
+                const int v = hostOnly ? -1 : verdict[o + k];
+                if (v == -2) continue;
+                if (v >= 0) t[kept * 3] = v;
+                else {
+                    double p = exp(r.logp);
+                    if (!(p >= threshold)) continue;
+                    if (p > 1.0) p = 1.0;
+                    t[kept * 3] = (long long) floor(p * 10000000.0);
+                }
                 t[kept * 3 + 1] = r.x;
                 t[kept * 3 + 2] = r.y;
                 lp[kept] = r.logp;

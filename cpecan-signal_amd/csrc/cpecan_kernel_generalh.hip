@@ -16,15 +16,6 @@
  */
 #include "cpecan_device.h"
 
-/* one HDP model on the device */
-struct DevHdpModel {
-    double t[9];            /* transitions, order of struct _StateMachine3_HDP */
-    int gridLength, pad;
-    const int *kmerRow;     /* [alphabetSize^6] table row per k-mer id */
-    const double *grid;     /* [gridLength] */
-    const double *y;        /* [rows][gridLength] */
-    const double *slope;    /* [rows][gridLength] */
-};
 
 namespace {
 

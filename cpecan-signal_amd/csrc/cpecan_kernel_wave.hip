@@ -38,7 +38,16 @@
 #define WV_L 3 /* cells per lane: 1..4 (bands up to 56, 120, 184, 248 k-mers) */
 #endif
 #define WV_P (64 * WV_L)
-#if WV_L == 4
+/* -DWV_HDP: the same sweeps for the 3-state HDP signal machine (stateMachine3HDP_cellCalculate, impl/stateMachine.c:
+ * 1338-1370): one density of the NanoporeHDP serves as match and as gap-Y emission, the gap-X emission is a flat
+ * log(0.1); symbols suffixed _h2.._h4 */
+#if defined(WV_HDP) && WV_L == 4
+#define WV_SYM(n) n##_h4
+#elif defined(WV_HDP) && WV_L == 3
+#define WV_SYM(n) n##_h3
+#elif defined(WV_HDP)
+#define WV_SYM(n) n##_h2
+#elif WV_L == 4
 #define WV_SYM(n) n##_l4
 #elif WV_L == 3
 #define WV_SYM(n) n##_l3
@@ -46,6 +55,11 @@
 #define WV_SYM(n) n##_l2
 #else
 #define WV_SYM(n) n##_l1
+#endif
+#ifdef WV_HDP
+#define WV_MODEL_DOUBLES ((long long) (sizeof(DevHdpModel) / sizeof(double))) /* a model = one DevHdpModel record */
+#else
+#define WV_MODEL_DOUBLES ((long long) CP_MODEL_STRIDE)
 #endif
 #define WV_ROW 20            /* doubles per column of the track: 16 emission constants, gap-X sums (open, extend, switch), gap-X */
 #define WV_ROWN 32           /* LDS ring of k-mer rows (>= the feed block)                              */
@@ -274,6 +288,9 @@ __device__ __forceinline__ void load_row_all(Prm &p, unsigned rowAddr) {
                  : [sv] "=&s"(sv) OUTS                                                                             \
                  : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel), [fv] "s"(FLAGV)                            \
                  : "memory", "scc");
+#ifdef WV_HDP
+#include "cpecan_wave_slots_hdp.h"
+#else
 #if WV_L == 1
 #define WV_SLOT_BODY9(MASKOP) "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" 
 #define WV_SLOT_OUTS9 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0])
@@ -295,6 +312,7 @@ __device__ __forceinline__ void load_row_all(Prm &p, unsigned rowAddr) {
 #define WV_SLOT_BODY10(MASKOP) "s_cmp_lg_u32 %[sel], 0\n\ts_cbranch_scc1 1f\n\t" "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" "ds_read_b128 %[a2], %[a] offset:32\n\t" "ds_read_b128 %[a3], %[a] offset:48\n\t" "ds_read_b128 %[a4], %[a] offset:64\n\t" "ds_read_b128 %[a5], %[a] offset:80\n\t" "ds_read_b128 %[a6], %[a] offset:96\n\t" "ds_read_b128 %[a7], %[a] offset:112\n\t" "ds_read_b128 %[a8], %[a] offset:128\n\t" "ds_read_b128 %[a9], %[a] offset:144\n\t" MASKOP " %[k0], %[k0], %[m]\n\tv_mov_b32 %[f0], %[fv]\n\t" "s_branch 9f\n1:\n\t" "s_cmp_lg_u32 %[sel], 1\n\ts_cbranch_scc1 2f\n\t" "ds_read_b128 %[b0], %[a]\n\t" "ds_read_b128 %[b1], %[a] offset:16\n\t" "ds_read_b128 %[b2], %[a] offset:32\n\t" "ds_read_b128 %[b3], %[a] offset:48\n\t" "ds_read_b128 %[b4], %[a] offset:64\n\t" "ds_read_b128 %[b5], %[a] offset:80\n\t" "ds_read_b128 %[b6], %[a] offset:96\n\t" "ds_read_b128 %[b7], %[a] offset:112\n\t" "ds_read_b128 %[b8], %[a] offset:128\n\t" "ds_read_b128 %[b9], %[a] offset:144\n\t" MASKOP " %[k1], %[k1], %[m]\n\tv_mov_b32 %[f1], %[fv]\n\t" "s_branch 9f\n2:\n\t" "s_cmp_lg_u32 %[sel], 2\n\ts_cbranch_scc1 3f\n\t" "ds_read_b128 %[c0], %[a]\n\t" "ds_read_b128 %[c1], %[a] offset:16\n\t" "ds_read_b128 %[c2], %[a] offset:32\n\t" "ds_read_b128 %[c3], %[a] offset:48\n\t" "ds_read_b128 %[c4], %[a] offset:64\n\t" "ds_read_b128 %[c5], %[a] offset:80\n\t" "ds_read_b128 %[c6], %[a] offset:96\n\t" "ds_read_b128 %[c7], %[a] offset:112\n\t" "ds_read_b128 %[c8], %[a] offset:128\n\t" "ds_read_b128 %[c9], %[a] offset:144\n\t" MASKOP " %[k2], %[k2], %[m]\n\tv_mov_b32 %[f2], %[fv]\n\t" "s_branch 9f\n3:\n\t" "ds_read_b128 %[d0], %[a]\n\t" "ds_read_b128 %[d1], %[a] offset:16\n\t" "ds_read_b128 %[d2], %[a] offset:32\n\t" "ds_read_b128 %[d3], %[a] offset:48\n\t" "ds_read_b128 %[d4], %[a] offset:64\n\t" "ds_read_b128 %[d5], %[a] offset:80\n\t" "ds_read_b128 %[d6], %[a] offset:96\n\t" "ds_read_b128 %[d7], %[a] offset:112\n\t" "ds_read_b128 %[d8], %[a] offset:128\n\t" "ds_read_b128 %[d9], %[a] offset:144\n\t" MASKOP " %[k3], %[k3], %[m]\n\tv_mov_b32 %[f3], %[fv]\n\t" "9:\n\t" 
 #define WV_SLOT_OUTS10 , [a0] "+v"(p[0].a[0]), [a1] "+v"(p[0].a[1]), [a2] "+v"(p[0].a[2]), [a3] "+v"(p[0].a[3]), [a4] "+v"(p[0].a[4]), [a5] "+v"(p[0].a[5]), [a6] "+v"(p[0].a[6]), [a7] "+v"(p[0].a[7]), [a8] "+v"(p[0].a[8]), [a9] "+v"(p[0].a[9]), [k0] "+s"(mask[0]), [f0] "+v"(fl[0]), [b0] "+v"(p[1].a[0]), [b1] "+v"(p[1].a[1]), [b2] "+v"(p[1].a[2]), [b3] "+v"(p[1].a[3]), [b4] "+v"(p[1].a[4]), [b5] "+v"(p[1].a[5]), [b6] "+v"(p[1].a[6]), [b7] "+v"(p[1].a[7]), [b8] "+v"(p[1].a[8]), [b9] "+v"(p[1].a[9]), [k1] "+s"(mask[1]), [f1] "+v"(fl[1]), [c0] "+v"(p[2].a[0]), [c1] "+v"(p[2].a[1]), [c2] "+v"(p[2].a[2]), [c3] "+v"(p[2].a[3]), [c4] "+v"(p[2].a[4]), [c5] "+v"(p[2].a[5]), [c6] "+v"(p[2].a[6]), [c7] "+v"(p[2].a[7]), [c8] "+v"(p[2].a[8]), [c9] "+v"(p[2].a[9]), [k2] "+s"(mask[2]), [f2] "+v"(fl[2]), [d0] "+v"(p[3].a[0]), [d1] "+v"(p[3].a[1]), [d2] "+v"(p[3].a[2]), [d3] "+v"(p[3].a[3]), [d4] "+v"(p[3].a[4]), [d5] "+v"(p[3].a[5]), [d6] "+v"(p[3].a[6]), [d7] "+v"(p[3].a[7]), [d8] "+v"(p[3].a[8]), [d9] "+v"(p[3].a[9]), [k3] "+s"(mask[3]), [f3] "+v"(fl[3])
 #endif
+#endif /* WV_HDP */
 /* (the row's tenth pair -- the switch sum and the raw gap-X emission -- is only loaded by the builds that use it) */
 template <bool SW> __device__ __forceinline__ void slot_enter(Prm (&p)[WV_L], unsigned long long (&mask)[WV_L],
                                                              unsigned (&fl)[WV_L], unsigned rowAddr,
@@ -402,6 +420,14 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
     double T[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
+#ifdef WV_HDP
+    /* the NanoporeHDP as densities need it (dir_proc_density impl/hdp.c:2577-2601 -> grid_spline_interp
+     * impl/hdp_math_utils.c:471-495): an evenly spaced sampling grid, values and spline slopes per table row */
+    const DevHdpModel *hm = (const DevHdpModel *) model;
+    const double *__restrict__ hGrid = hm->grid, *__restrict__ hY = hm->y, *__restrict__ hS = hm->slope;
+    const int hN = uni(hm->gridLength) - 1;
+    const double gX0 = uni64_d(hGrid[0]), gXn = uni64_d(hGrid[hN]), gDx = uni64_d(hGrid[1] - hGrid[0]);
+#endif
     /* the feed block: events of a block are staged one block ahead of their first use, so the ring of P
      * events must hold the band's events and a block's worth more */
     int feed = WV_P - it.maxWidth;
@@ -413,8 +439,13 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
 
     /* the "not a k-mer" row: every emission -inf */
     if (lane < WV_ROW) {
+#ifdef WV_HDP
+        /* (table row offset -1: the density of a parked slot is -inf; gap-X sums -inf) */
+        sh.rows[WV_ROWN * WV_ROW + lane] = lane >= 16 ? CP_NEG_INF : lane == 0 ? -1.0 : 0.0;
+#else
         const bool inf = lane == CP_K1 || lane == CP_K2 || lane == CP_YK1 || lane == CP_YK2 || lane >= 16;
         sh.rows[WV_ROWN * WV_ROW + lane] = inf ? CP_NEG_INF : 0.0;
+#endif
     }
     for (int i = lane; i < (2 * WV_P + WV_L) * 2; i += 64) sh.ev[i] = 0.0;
 
@@ -448,6 +479,15 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             ring[WV_OFF_FM(0)] = Am[0]; ring[WV_OFF_PM(0)] = 0.0; ring[WV_OFF_PY(0)] = 0.0;
             ring[WV_OFF_FX(0)] = Ax[0]; ring[WV_OFF_FY(0)] = Ay[0];
         }
+#ifdef WV_HDP
+        /* matrix column 0 scores the FIRST k-mer under this machine (sequence_getKmer3, :327-331: index -1 reads
+         * element 0), not a sentinel: its slot starts with that row */
+        if (lane == 0) {
+            const d2 *src = (const d2 *) track;
+#pragma unroll
+            for (int k = 0; k < WV_ROW / 2; k++) prm[0].a[k] = src[k];
+        }
+#endif
         /* the dummy row the sweep back reads for lanes without a cell: -inf everywhere */
         for (int i = lane; i < WV_ROW_DOUBLES; i += 64) ring[(long long) ringD * WV_ROW_DOUBLES + i] = CP_NEG_INF;
         RBm = RBx = RBy = CP_NEG_INF;
@@ -569,6 +609,33 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
          * the same additions by the track kernel).  The L cells of a lane are independent: their logAdds are
          * taken stage by stage, so that the L table reads of a stage are in flight together. */
         double pm[L], py[L], nm[L], nx[L], ny[L], t1[L];
+#ifdef WV_HDP
+        /* get_nanopore_kmer_density (impl/nanopore_hdp.c:390): the spline of the slot's table row at the cell's event,
+         * clamped at zero -- a linear density where a log-probability belongs (quirk Q1), match and gap-Y emission
+         * alike.  The event's grid cell and its offset in it were taken when the event was staged. */
+        double hYl[L], hYr[L], hSl[L], hSr[L];
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const double ro = prm[j].a[0].x, ex = e[j].x;
+            const unsigned base = ro < 0.0 ? 0u : (unsigned) ro;
+            const unsigned il = ex < 0.0 ? (ex == -2.0 ? (unsigned) hN : 0u) : (unsigned) ex;
+            const unsigned ir = ex < 0.0 ? il : il + 1u;
+            hYl[j] = hY[base + il]; hYr[j] = hY[base + ir];
+            hSl[j] = hS[base + il]; hSr[j] = hS[base + ir];
+        }
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const double ex = e[j].x, w = e[j].y;
+            const double dy = hYr[j] - hYl[j];
+            const double ca = hSl[j] * gDx - dy, cb = dy - hSr[j] * gDx;
+            const double tl = w, tr = 1.0 - tl;
+            const double inside = tr * hYl[j] + tl * hYr[j] + tl * tr * (ca * tr + cb * tl);
+            const double edge = ex == -1.0 ? hYl[j] - hSl[j] * w : hYl[j] + hSl[j] * w;
+            double r = ex < 0.0 ? edge : inside;
+            r = r > 0.0 ? r : 0.0;
+            pm[j] = py[j] = prm[j].a[0].x < 0.0 ? CP_NEG_INF : r;
+        }
+#else
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const Prm &p = prm[j];
@@ -582,6 +649,7 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
                     + lgauss(e[j].y, p.a[6].x, p.a[6].y, p.a[7].x, p.a[7].y);
 #endif
         }
+#endif /* WV_HDP */
         double t2[L], t3[L], t4[L];
         LaddPending<L> pa, pb;
 #pragma unroll
@@ -697,8 +765,26 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
                 if (e < evTo) {
                     const bool ok = e >= 0 && e < lY; /* index -1 is NULLEVENT (:261): it only ever meets -inf cells */
                     d2 v;
+#ifdef WV_HDP
+                    /* (grid cell, offset in it) of the event's mean, as grid_spline_interp takes them; -1 / -2 with the
+                     * distance to the grid's end for a mean below / above the grid.  An event that does not exist
+                     * stays at (0, 0): it only ever meets -inf cells and must score something finite */
+                    v.x = 0.0;
+                    v.y = 0.0;
+                    if (ok) {
+                        const double q = ev[3 * (long long) e];
+                        if (q <= gX0) { v.x = -1.0; v.y = gX0 - q; }
+                        else if (q >= gXn) { v.x = -2.0; v.y = q - gXn; }
+                        else {
+                            const long long il = (long long) ((q - gX0) / gDx);
+                            v.x = (double) il;
+                            v.y = (q - hGrid[il]) / gDx;
+                        }
+                    }
+#else
                     v.x = ok ? ev[3 * (long long) e] : 0.0;
                     v.y = ok ? ev[3 * (long long) e + 1] : 0.0;
+#endif
                     d2 *dst = (d2 *) sh.ev;
                     dst[pos] = v;
                     dst[pos + WV_P] = v;
@@ -1336,7 +1422,7 @@ template <bool SW> __device__ __forceinline__ void wv_forward_kernel(
     if (state->finished || it.lX + it.lY == 0) return;
     init_coef(sh.coef);
     forward_window<SW>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW, events,
-                       models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, state, window,
+                       models + (long long) it.model * WV_MODEL_DOUBLES, Fring + idx * ringDoubles, ringD, state, window,
                        sh);
 }
 extern "C" __global__ __launch_bounds__(64 * WV_WPB) void WV_SYM(cpecan_k_wv_forward)(
@@ -1399,7 +1485,7 @@ template <bool SW, int KIND> __device__ __forceinline__ void wv_backward_kernel(
     double *candFb = (double *) ((char *) candKx + (long long) WV_L * WV_CAND_PER_DIAG * ringD * sizeof(int2));
     int nTot = 0, nCand = 0;
     backward_window<SW, KIND>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW,
-                              models + (long long) it.model * CP_MODEL_STRIDE, Fring + idx * ringDoubles, ringD, win,
+                              models + (long long) it.model * WV_MODEL_DOUBLES, Fring + idx * ringDoubles, ringD, win,
                               out, sh, wtot, vw, rf, candKx, candFb,
                               Bring ? Bring + idx * ((long long) ringD * WV_L * 3 * 64) : nullptr, nTot, nCand);
     if ((threadIdx.x & 63) == 0) {
@@ -1428,8 +1514,10 @@ WV_BACKWARD_KERNEL(cpecan_k_wv_backward, false, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_sw, true, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep, false, WV_KIND_REDO)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep_sw, true, WV_KIND_REDO)
+#ifndef WV_HDP /* (the HDP machine's E-step stays on the general kernel) */
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em, false, WV_KIND_EXPECT)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em_sw, true, WV_KIND_EXPECT)
+#endif
 
 /*
  * What follows a sweep back, one 256-thread workgroup per alignment (none of it is a recurrence along the
@@ -1625,6 +1713,7 @@ extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
     }
 }
 
+#ifndef WV_HDP
 /*
  * Baum-Welch expectations of the traceback window the backward kernel just swept
  * (diagonalCalculation_Expectations :841-863 with cell_signal_updateTransAndKmerSkipExpectations :426-443).
@@ -1752,7 +1841,9 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     if (threadIdx.x == 0) atomicAdd(dst + 9 + 4096, lik);
 }
 
-#if WV_L == 4
+#endif /* !WV_HDP */
+
+#if WV_L == 4 && !defined(WV_HDP)
 /* per-item track of emission constants, wave layout: column x (0..lX) = the 16 emission constants of the k-mer
  * that matrix column x scores (column 0 = the "not a k-mer" sentinel, sequence_getKmer index -1, :314-318),
  * its gap-X emission plus each of the three transitions into gap X (the eP + tP of cell_calculate*), and the
@@ -1812,6 +1903,48 @@ extern "C" int cpecan_wave_launch_counts(hipStream_t stream, const void *states,
 }
 #endif
 
+#if WV_L == 4 && defined(WV_HDP)
+/* the HDP machine's track: column x (0..lX) = the offset (in doubles) of the table row of the k-mer that matrix
+ * column x scores -- sequence_getKmer3 (:327-331): column 0 (index -1) reads the first k-mer, like column 1 -- and
+ * the flat gap-X emission log(0.1) (stateMachine.c:1347) plus each of the three transitions into gap X */
+extern "C" __global__ void cpecan_k_wv_track_hdp(const DevItem *__restrict__ items, long long nItems,
+                                                 const long long *__restrict__ trackBase,
+                                                 const int *__restrict__ kid, const DevHdpModel *__restrict__ models,
+                                                 double *track) {
+    const long long item = blockIdx.y;
+    if (item >= nItems) return;
+    const DevItem it = items[item];
+    const DevHdpModel &m = models[it.model];
+    const long long n = (it.lX + 1) * WV_ROW;
+    double *dst = track + trackBase[item] * WV_ROW;
+    const double px = -2.3025850929940455;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long) gridDim.x * blockDim.x) {
+        const long long x = i / WV_ROW;
+        const int jj = (int) (i - x * WV_ROW);
+        double v = 0.0;
+        if (jj == 0) {
+            const int id = kid[it.xOff + (x > 0 ? x - 1 : 0)];
+            v = id < 0 ? -1.0 : (double) ((long long) m.kmerRow[id] * m.gridLength);
+        } else if (jj == 16) v = px + m.t[T_GAP_OPEN_X];
+        else if (jj == 17) v = px + m.t[T_GAP_EXTEND_X];
+        else if (jj == 18) v = px + m.t[T_GAP_SWITCH_TO_X];
+        else if (jj == 19) v = px;
+        dst[i] = v;
+    }
+}
+extern "C" int cpecan_wave_launch_track_hdp(hipStream_t stream, const DevItem *items, long long nItems,
+                                            const double *track, const long long *trackBase, const int *kid,
+                                            const void *models, void *states, int maxLX) {
+    int bx = (int) ((((long long) maxLX + 1) * WV_ROW + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(cpecan_k_wv_track_hdp, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items, nItems,
+                       trackBase, kid, (const DevHdpModel *) models, (double *) track);
+    if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(WvState), stream) != hipSuccess) return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int WV_SYM(cpecan_wave_max_width)(void) { return WV_P - 8; }
 extern "C" int WV_SYM(cpecan_wave_rows)(void) { return WV_L; }
 extern "C" int WV_SYM(cpecan_wave_ring_row_doubles)(void) { return WV_ROW_DOUBLES; }
@@ -1852,9 +1985,13 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
                        (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD,                \
                        (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, window)
     if (P.mode != 0) {
+#ifdef WV_HDP
+        return -1;
+#else
         if (withSwitch) WV_LAUNCH_B(cpecan_k_wv_backward_em_sw);
         else WV_LAUNCH_B(cpecan_k_wv_backward_em);
         WV_LAUNCH_POST;
+#endif
     } else {
         /* the sweep with decode candidates, the window's totals and decode, then the kernel that sweeps once more
          * the windows whose candidates could not be trusted (it returns at once for the others) */
@@ -1874,8 +2011,12 @@ extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevIt
                                                  const double *models, const double *Fring, long long ringDoubles,
                                                  const double *Bring, int ringD, void *states, const char *scratch,
                                                  long long scratchBytes, double *expect, int window) {
+#ifdef WV_HDP
+    return -1;
+#else
     hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_expect), dim3((unsigned) nItems, WV_EXPECT_CHUNKS), dim3(WV_P), 0, stream,
                        items, nItems, P, (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles,
                        Bring, ringD, (WvState *) states, scratch, scratchBytes, expect, window);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+#endif
 }

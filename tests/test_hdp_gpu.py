@@ -57,18 +57,26 @@ def hdp_batch(seed, n, lX, every, nhdp):
     return dict(x_chars=xs, events=np.concatenate(evs), anchors=np.concatenate(ans), items=items), model
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
 @pytest.mark.parametrize("case", [
     dict(n=3, lX=100, e=20, md=60, tb=10, every=25, ragged=(0, 0)),
     dict(n=2, lX=300, e=40, md=100, tb=40, every=40, ragged=(1, 1)),
+    dict(n=2, lX=700, e=100, md=200, tb=40, every=50, ragged=(1, 1)),   # three cells per lane, several windows
+    dict(n=1, lX=400, e=160, md=150, tb=40, every=80, ragged=(1, 0)),   # four cells per lane
 ])
-def test_hdp_matches_oracle(ctx, nhdp, case):
+def test_hdp_matches_oracle(ctx, nhdp, case, general):
+    """the wave-per-alignment HDP kernels (the default for the posterior decode) and the general kernel
+    (CPECAN_FLAG_GENERAL_KERNEL) against the oracle: totals, exponents, pairs and their order identical"""
     batch, model = hdp_batch(61, case["n"], case["lX"], case["every"], nhdp)
     ctx.models_clear()
     ctx.modelsh_create([(cp.NANOPORE_TRANSITIONS, nhdp["alphabet"], nhdp["grid"], nhdp["y"], nhdp["slope"],
                          nhdp["kmer_row"])])
     bp = band_params(0.01, case["md"], case["tb"], case["e"])
     b = cp.Batch(ctx, make_items(batch, case["ragged"]), batch["x_chars"], batch["events"], batch["anchors"], bp,
-                 hdp=True)
+                 flags=cp.FLAG_GENERAL_KERNEL if general else 0, hdp=True)
+    assert b.info()["kernel"] == ("general" if general else "systolic")
+    if not general:
+        assert b.info()["family"] == "wave"
     b.run()
     b.sync()
     npairs, ntot, _ = b.counts()
