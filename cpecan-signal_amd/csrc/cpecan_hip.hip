@@ -1411,9 +1411,9 @@ static int ensure_counts(cpecan_batch *b) {
     for (int64_t i = 0; i < b->nItems; i++)
         b->hPairBase[(size_t) i + 1] = b->hPairBase[(size_t) i] + std::min(b->hNPairs[(size_t) i], b->hItems[(size_t) i].pairCap);
     const long long all = b->hPairBase[(size_t) b->nItems];
-    b->hPairs.resize((size_t) all * 3);
-    b->hLogp.resize((size_t) all);
     if (b->mode != CPECAN_MODE_POSTERIOR) {
+        b->hPairs.resize((size_t) all * 3);
+        b->hLogp.resize((size_t) all);
         /* (in expectation mode the HDP machine's pair buffer carries event-to-k-mer assignments, not posteriors:
          * short lists, copied as they are) */
         for (int64_t i = 0; i < b->nItems; i++) {
@@ -1456,33 +1456,30 @@ static int ensure_counts(cpecan_batch *b) {
                                b->ctx->stream));
         HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     }
-    /* exp(), the threshold test and floor(p * 1e7) with the host's libm, the one the reference calls
-     * (impl/pairwiseAligner.c:776-786); items are independent, so they are dealt to the host threads */
+    /* The close calls: exp(), the threshold test and floor(p * 1e7) with the host's libm, the one the reference calls
+     * (impl/pairwiseAligner.c:776-786), written back over the device's "undecided" verdict; and the number of pairs
+     * every item keeps.  The records stay packed in pinned memory; cpecan_hip_batch_fetch_pairs expands an item's
+     * pairs into the reference's triples when they are asked for.  Items are independent: dealt to the host threads. */
     const double threshold = b->P.threshold;
     const PackedPair *src = b->hPacked;
-    const int *verdict = b->hPost;
+    int *verdict = b->hPost;
     static const bool hostOnly = getenv("CPECAN_HOST_FINALISE") != nullptr; /* (tests: every pair through the host libm) */
     auto finish = [b, src, verdict, threshold](int64_t i0, int64_t i1) {
         for (int64_t i = i0; i < i1; i++) {
             const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
-            long long *t = b->hPairs.data() + o * 3;
-            double *lp = b->hLogp.data() + o;
             long long kept = 0;
             for (long long k = 0; k < n; k++) {
-                const PackedPair r = src[o + k];
-                const int v = hostOnly ? -1 : verdict[o + k];
-                if (v == -2) continue;
-                if (v >= 0) t[kept * 3] = v;
-                else {
-                    double p = exp(r.logp);
-                    if (!(p >= threshold)) continue;
-                    if (p > 1.0) p = 1.0;
-                    t[kept * 3] = (long long) floor(p * 10000000.0);
+                int v = hostOnly ? -1 : verdict[o + k];
+                if (v == -1) {
+                    double p = exp(src[o + k].logp);
+                    if (!(p >= threshold)) v = -2;
+                    else {
+                        if (p > 1.0) p = 1.0;
+                        v = (int) floor(p * 10000000.0);
+                    }
+                    verdict[o + k] = v;
                 }
-                t[kept * 3 + 1] = r.x;
-                t[kept * 3 + 2] = r.y;
-                lp[kept] = r.logp;
-                kept++;
+                kept += v >= 0;
             }
             b->hNPairs[(size_t) i] = kept;
         }
@@ -1527,8 +1524,23 @@ int cpecan_hip_batch_fetch_pairs(cpecan_batch *b, int64_t item, int64_t *triples
     const long long n = b->hNPairs[(size_t) item], o = b->hPairBase[(size_t) item];
     if (n > cap) return fail(CPECAN_EOVERFLOW, "need room for %lld triples", n);
     if (n == 0) return CPECAN_OK;
-    memcpy(triples, b->hPairs.data() + o * 3, (size_t) n * 3 * sizeof(long long));
-    if (logp) memcpy(logp, b->hLogp.data() + o, (size_t) n * sizeof(double));
+    if (b->mode != CPECAN_MODE_POSTERIOR) {
+        memcpy(triples, b->hPairs.data() + o * 3, (size_t) n * 3 * sizeof(long long));
+        if (logp) memcpy(logp, b->hLogp.data() + o, (size_t) n * sizeof(double));
+        return CPECAN_OK;
+    }
+    /* the item's packed candidates with their settled verdicts -> (floor(p * 1e7), x, y), emission order */
+    const long long cand = b->hPairBase[(size_t) item + 1] - o;
+    long long kept = 0;
+    for (long long k = 0; k < cand; k++) {
+        const int v = b->hPost[o + k];
+        if (v < 0) continue;
+        triples[kept * 3] = v;
+        triples[kept * 3 + 1] = b->hPacked[o + k].x;
+        triples[kept * 3 + 2] = b->hPacked[o + k].y;
+        if (logp) logp[kept] = b->hPacked[o + k].logp;
+        kept++;
+    }
     return CPECAN_OK;
 }
 
