@@ -187,9 +187,15 @@ template <int N> __device__ __forceinline__ void ladd_issue(LaddPending<N> &p, c
         int n;
         asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(p.d[k] + p.d[k])));
         n = n < 15 ? n : 15;
+#ifdef WV_ABL_COEFREG /* timing study: the first piece's coefficients for every d, no table read */
+        (void) coefAddr;
+        p.c32[k].x = -0.009350833524763f; p.c32[k].y = 0.130659527668286f;
+        p.c10[k].x = 0.498799810682272f + 1e-300 * n; p.c10[k].y = 0.693203116424741f;
+#else
         const lds_d2p c = lds_d2p_cast(coefAddr + (unsigned) n * 32u);
         p.c32[k] = c[0];
         p.c10[k] = c[1];
+#endif
     }
 }
 template <int N> __device__ __forceinline__ void ladd_finish(const LaddPending<N> &p, double (&acc)[N]) {
