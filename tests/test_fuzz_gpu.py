@@ -71,3 +71,43 @@ def test_random_case_dna(ctx, case):
         a = pairs[3::max(2, min(case["every"], 60))] if case["every"] < 10 ** 6 else np.zeros((0, 2), np.int64)
         seqs.append((x, y, a))
     td.run_case(ctx, seqs, band_params(case["thr"], case["md"], case["tb"], case["e"]), case["ragged"])
+
+
+@pytest.mark.parametrize("case", cases(14, 4242), ids=lambda c: "h%d" % c["seed"])
+def test_random_case_hdp(ctx, case, golden_dir):
+    """the HDP machine over the same random shapes: the wave-per-alignment HDP kernels where the band fits (two,
+    three or four cells per lane), the general kernel where it does not -- totals, exponents and pairs identical to
+    the oracle either way"""
+    import os
+    import pyoracle as o
+    import test_hdp_gpu as th
+    from harness import make_items, orc_params
+    nhdp = o.load_nhdp(os.path.join(golden_dir, "testTemplate.nhdp"))
+    every = min(case["every"], 200)
+    batch, model = th.hdp_batch(case["seed"], 2, min(case["lX"], 450), every, nhdp)
+    ctx.models_clear()
+    ctx.modelsh_create([(cp.NANOPORE_TRANSITIONS, nhdp["alphabet"], nhdp["grid"], nhdp["y"], nhdp["slope"],
+                         nhdp["kmer_row"])])
+    bp = band_params(case["thr"], case["md"], case["tb"], case["e"])
+    b = cp.Batch(ctx, make_items(batch, case["ragged"]), batch["x_chars"], batch["events"], batch["anchors"], bp,
+                 hdp=True)
+    info = b.info()
+    if info["max_band_width"] <= 248:
+        assert info["kernel"] == "systolic" and info["family"] == "wave"
+    b.run()
+    b.sync()
+    npairs, ntot, ncells = b.counts()
+    p = orc_params(bp, split=1 << 60)
+    for i, it in enumerate(batch["items"]):
+        x = batch["x_chars"][it["x_offset"]: it["x_offset"] + it["lX"] + 5]
+        ev = batch["events"][it["y_offset"]: it["y_offset"] + it["lY"]]
+        an = batch["anchors"][it["anchor_offset"]: it["anchor_offset"] + it["n_anchors"]]
+        tri, lp = b.pairs(i, npairs[i])
+        xay, tot = b.totals(i, ntot[i])
+        ref = o.aligned_pairs_using_anchors(model, x, it["lX"], ev, an, p, case["ragged"][0], case["ragged"][1])
+        ref["triples"], ref["logp"] = ref["triples"][::-1], ref["logp"][::-1]
+        assert int(ncells[i]) == ref["cells"]
+        assert np.array_equal(xay, ref["totals_xay"])
+        assert np.array_equal(tot, ref["totals"])
+        assert_same_pairs(dict(triples=tri, logp=lp), ref)
+    b.close()
