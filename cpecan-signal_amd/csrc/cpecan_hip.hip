@@ -129,6 +129,15 @@ WV_DECLARE(_l4)
 WV_DECLARE(_h2)
 WV_DECLARE(_h3)
 WV_DECLARE(_h4)
+/* ... and for the vanilla signal machine (-DWV_VANILLA, symbols _v2, _v3; its four-cell build does not fit the
+ * register file and is not linked: bands above 184 k-mers run on the general kernel) */
+WV_DECLARE(_v2)
+WV_DECLARE(_v3)
+extern "C" int cpecan_wave_launch_track_vanilla(hipStream_t stream, const DevItem *items, long long nItems,
+                                                const double *track, const long long *trackBase,
+                                                const unsigned short *kidx, const double *models, void *states,
+                                                int maxLX);
+extern "C" int cpecan_wave_track_row_doubles_vanilla(void);
 extern "C" int cpecan_wave_launch_track_hdp(hipStream_t stream, const DevItem *items, long long nItems,
                                             const double *track, const long long *trackBase, const int *kid,
                                             const void *models, void *states, int maxLX);
@@ -177,6 +186,7 @@ static const SyBuild SY_BUILDS[4] = { SY_BUILD(1, _r1), SY_BUILD(2, _r2), SY_BUI
 /* (a one-cell-per-lane build would only serve bands below 57 k-mers; the two-cell build takes those too) */
 static const SyBuild WV_BUILDS[4] = { WV_BUILD(2, _l2), WV_BUILD(2, _l2), WV_BUILD(3, _l3), WV_BUILD(4, _l4) };
 static const SyBuild HV_BUILDS[4] = { WV_BUILD(2, _h2), WV_BUILD(2, _h2), WV_BUILD(3, _h3), WV_BUILD(4, _h4) };
+static const SyBuild VV_BUILDS[4] = { WV_BUILD(2, _v2), WV_BUILD(2, _v2), WV_BUILD(3, _v3), WV_BUILD(3, _v3) };
 /* which family a batch runs on: the wave kernels unless CPECAN_KERNELS=systolic asks for the workgroup-per-alignment ones */
 static bool use_wave_kernels() {
     const char *k = getenv("CPECAN_KERNELS");
@@ -908,19 +918,23 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
 
     /* the HDP machine's posterior decode has wave-per-alignment kernels of its own (its E-step, and the vanilla and
      * 5-state machines, run on the general kernels); CPECAN_FLAG_GENERAL_KERNEL keeps an HDP batch on the general one */
-    const bool hdpWave = hdp && mode == CPECAN_MODE_POSTERIOR && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
-    int useKernel = dna || vanilla || (hdp && !hdpWave) ? CPECAN_KERNEL_GENERAL : hdp ? CPECAN_KERNEL_AUTO : kernel;
+    const bool machineWave = (hdp || vanilla) && mode == CPECAN_MODE_POSTERIOR && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
+    int useKernel = dna || ((hdp || vanilla) && !machineWave) ? CPECAN_KERNEL_GENERAL
+                    : hdp || vanilla ? CPECAN_KERNEL_AUTO : kernel;
+    /* the builds of the register-resident kernels this batch would run on, and the widest band they take */
+    const SyBuild *fam = hdp ? HV_BUILDS : vanilla ? VV_BUILDS
+                         : (use_wave_kernels() && !(flags & CPECAN_FLAG_WORKGROUP_KERNELS)) ? WV_BUILDS : SY_BUILDS;
+    const int famMaxWidth = fam[3].max_width();
     b->dna = dna;
     b->vanilla = vanilla;
     b->hdp = hdp;
     if (useKernel == CPECAN_KERNEL_AUTO)
-        useKernel = (globalMaxWidth <= cpecan_systolic_max_width() && systolicOk && !b->P.debug && !unbanded)
+        useKernel = (globalMaxWidth <= famMaxWidth && systolicOk && !b->P.debug && !unbanded)
                         ? CPECAN_KERNEL_SYSTOLIC : CPECAN_KERNEL_GENERAL;
-    if (useKernel == CPECAN_KERNEL_SYSTOLIC &&
-        (globalMaxWidth > cpecan_systolic_max_width() || !systolicOk)) {
+    if (useKernel == CPECAN_KERNEL_SYSTOLIC && (globalMaxWidth > famMaxWidth || !systolicOk)) {
         delete b;
         return fail(CPECAN_EINVAL, "band is %d cells wide (systolic kernel: at most %d, edges moving "
-                    "one k-mer per diagonal)", globalMaxWidth, cpecan_systolic_max_width());
+                    "one k-mer per diagonal)", globalMaxWidth, famMaxWidth);
     }
     if (useKernel == CPECAN_KERNEL_SYSTOLIC && b->P.debug) {
         delete b;
@@ -934,11 +948,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         const char *rows = getenv("CPECAN_SYSTOLIC_ROWS");
         int r = rows ? atoi(rows) : 1;
         r = r < 1 ? 1 : r > 4 ? 4 : r;
-        const SyBuild *fam = hdp ? HV_BUILDS
-                             : (use_wave_kernels() && !(flags & CPECAN_FLAG_WORKGROUP_KERNELS)) ? WV_BUILDS : SY_BUILDS;
         while (r < 4 && globalMaxWidth > fam[r - 1].max_width()) r++;
         b->sy = &fam[r - 1];
-        b->trackRow = b->sy->wave ? cpecan_wave_track_row_doubles() : CP_ROW;
+        b->trackRow = vanilla ? cpecan_wave_track_row_doubles_vanilla()
+                      : b->sy->wave ? cpecan_wave_track_row_doubles() : CP_ROW;
     }
     b->hItems = hItems;
 
@@ -954,7 +967,18 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         B_TRY(hipMemcpy(b->charsY.p, yChars, (size_t) nEvents, hipMemcpyHostToDevice));
     } else {
         B_TRY(b->events.alloc((size_t) 3 * nEvents + 8));
-        B_TRY(hipMemcpy(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+        if (vanilla) {
+            /* the batch's own copy of the events carries log(noise) (host libm, :325) in place of the duration, which
+             * nothing on the device reads: the wave kernels stage events from this one array */
+            std::vector<double, NoInit<double>> ev3((size_t) 3 * nEvents);
+            for (int64_t i = 0; i < nEvents; i++) {
+                ev3[(size_t) 3 * i] = events[3 * i];
+                ev3[(size_t) 3 * i + 1] = events[3 * i + 1];
+                ev3[(size_t) 3 * i + 2] = log(events[3 * i + 1]);
+            }
+            B_TRY(hipMemcpy(b->events.p, ev3.data(), (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+        } else
+            B_TRY(hipMemcpy(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
         if (vanilla) { /* emissions_signal_logInvGaussPdf takes log(eventNoise) per cell (:325) */
             std::vector<double> ln((size_t) nEvents + 1);
             for (int64_t i = 0; i < nEvents; i++) ln[(size_t) i] = log(events[3 * i + 1]);
@@ -1174,7 +1198,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                            b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
                            b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
-    } else if (b->vanilla) {
+    } else if (b->vanilla && b->kernel == CPECAN_KERNEL_GENERAL) {
         hipLaunchKernelGGL(cpecan_k_generalv, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
                            (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
                            (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
@@ -1210,8 +1234,11 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
         int withSwitch = 0;
         int rc;
         /* the models as the sweeps read them: strawMan tables, or the HDP records of an HDP batch */
-        const double *models = b->hdp ? (const double *) c->modelsH.p : c->models.p;
-        if (b->hdp) {
+        const double *models = b->hdp ? (const double *) c->modelsH.p : b->vanilla ? c->modelsV.p : c->models.p;
+        if (b->vanilla) { /* (no gap Y -> gap X transition in this machine) */
+            rc = cpecan_wave_launch_track_vanilla(c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p,
+                                                  b->kidx.p, c->modelsV.p, b->syStates.p, b->maxLX);
+        } else if (b->hdp) {
             for (const DevHdpModel &m : c->hostModelsH)
                 if (m.t[T_GAP_SWITCH_TO_X] > -INFINITY) withSwitch = 1;
             rc = cpecan_wave_launch_track_hdp(c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p, b->kid.p,

@@ -41,7 +41,16 @@
 /* -DWV_HDP: the same sweeps for the 3-state HDP signal machine (stateMachine3HDP_cellCalculate, impl/stateMachine.c:
  * 1338-1370): one density of the NanoporeHDP serves as match and as gap-Y emission, the gap-X emission is a flat
  * log(0.1); symbols suffixed _h2.._h4 */
-#if defined(WV_HDP) && WV_L == 4
+/* -DWV_VANILLA: the 3-state vanilla signal machine (stateMachine3Vanilla_cellCalculate, impl/stateMachine.c:1368-1409):
+ * transition probabilities per reference position (30 skip bins of the k-mer pair sequence_getKmer2 exposes), a
+ * Gaussian level term plus an inverse-Gaussian noise term per emission; symbols suffixed _v2.._v4 */
+#if defined(WV_VANILLA) && WV_L == 4
+#define WV_SYM(n) n##_v4
+#elif defined(WV_VANILLA) && WV_L == 3
+#define WV_SYM(n) n##_v3
+#elif defined(WV_VANILLA)
+#define WV_SYM(n) n##_v2
+#elif defined(WV_HDP) && WV_L == 4
 #define WV_SYM(n) n##_h4
 #elif defined(WV_HDP) && WV_L == 3
 #define WV_SYM(n) n##_h3
@@ -56,12 +65,23 @@
 #else
 #define WV_SYM(n) n##_l1
 #endif
-#ifdef WV_HDP
+#if defined(WV_VANILLA)
+#define WV_MODEL_DOUBLES ((long long) CP_VMODEL_STRIDE)
+#elif defined(WV_HDP)
 #define WV_MODEL_DOUBLES ((long long) (sizeof(DevHdpModel) / sizeof(double))) /* a model = one DevHdpModel record */
 #else
 #define WV_MODEL_DOUBLES ((long long) CP_MODEL_STRIDE)
 #endif
+#ifdef WV_VANILLA
+/* doubles per column of the track: per table (match, extra event) level mu, sd, 1/sd, K and noise mean, 1/mean, lambda,
+ * log(lambda) - log(2 pi); then the five log transition probabilities of the column's skip bin: into gap X from match
+ * and from gap X, into match from match and from gap X, into gap Y from match */
+#define WV_ROW 22
+#define WV_PXW 6             /* of which the sweep back keeps the last six (three pairs) per slot */
+#else
 #define WV_ROW 20            /* doubles per column of the track: 16 emission constants, gap-X sums (open, extend, switch), gap-X */
+#define WV_PXW 4
+#endif
 #define WV_ROWN 32           /* LDS ring of k-mer rows (>= the feed block)                              */
 #define WV_FEED_MAX 32       /* diagonals per feed block of the forward sweep                            */
 #define WV_BITWORDS 256      /* band edge steps kept in LDS: 32 diagonals per word, circular, re-staged in halves */
@@ -294,7 +314,9 @@ __device__ __forceinline__ void load_row_all(Prm &p, unsigned rowAddr) {
                  : [sv] "=&s"(sv) OUTS                                                                             \
                  : [a] "v"(rowAddr), [m] "s"(laneMask), [sel] "s"(sel), [fv] "s"(FLAGV)                            \
                  : "memory", "scc");
-#ifdef WV_HDP
+#if defined(WV_VANILLA)
+#include "cpecan_wave_slots_vanilla.h"
+#elif defined(WV_HDP)
 #include "cpecan_wave_slots_hdp.h"
 #else
 #if WV_L == 1
@@ -404,6 +426,9 @@ __device__ int next_traceback_point(const int2 *__restrict__ tab, int D, int dAf
 struct FwdShared {
     double coef[64];
     double ev[(2 * WV_P + WV_L) * 2];       /* events (mean, noise) by index mod P, mirrored */
+#ifdef WV_VANILLA
+    double ev2[(2 * WV_P + WV_L) * 2];      /* ... and (1 / noise, log noise), same indexing */
+#endif
     double rows[(WV_ROWN + 1) * WV_ROW];    /* k-mer rows by column mod WV_ROWN; row WV_ROWN = "not a k-mer" */
     unsigned bits[2][WV_BITWORDS];
 };
@@ -426,6 +451,12 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
     double T[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) T[i] = model[i];
+#ifdef WV_VANILLA
+    /* the position-independent part of the machine: a_ym, a_yy and the end vector (cpecan_hip.hip: derive_vanilla) */
+    const double lYM = uni64_d(model[CP_VHDR_LOG_YM]), lYY = uni64_d(model[CP_VHDR_LOG_YY]);
+    const double endM = uni64_d(model[CP_VHDR_END_M]), endX = uni64_d(model[CP_VHDR_END_X]),
+                 endY = uni64_d(model[CP_VHDR_END_Y]);
+#endif
 #ifdef WV_HDP
     /* the NanoporeHDP as densities need it (dir_proc_density impl/hdp.c:2577-2601 -> grid_spline_interp
      * impl/hdp_math_utils.c:471-495): an evenly spaced sampling grid, values and spline slopes per table row */
@@ -445,7 +476,11 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
 
     /* the "not a k-mer" row: every emission -inf */
     if (lane < WV_ROW) {
-#ifdef WV_HDP
+#if defined(WV_VANILLA)
+        /* (level K -inf; the noise term kept finite: mean 1, 1/mean 1, lambda 1, c1 0; log transitions -inf) */
+        sh.rows[WV_ROWN * WV_ROW + lane] = lane >= 16 || lane == 3 || lane == 11 ? CP_NEG_INF
+                                           : (lane & 7) == 4 || (lane & 7) == 5 || (lane & 7) == 6 ? 1.0 : 0.0;
+#elif defined(WV_HDP)
         /* (table row offset -1: the density of a parked slot is -inf; gap-X sums -inf) */
         sh.rows[WV_ROWN * WV_ROW + lane] = lane >= 16 ? CP_NEG_INF : lane == 0 ? -1.0 : 0.0;
 #else
@@ -453,7 +488,16 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
         sh.rows[WV_ROWN * WV_ROW + lane] = inf ? CP_NEG_INF : 0.0;
 #endif
     }
+#ifdef WV_VANILLA
+    /* an event that does not exist scores as (mean 0, noise 1): finite, and it only ever meets -inf cells */
+    for (int i = lane; i < (2 * WV_P + WV_L) * 2; i += 64) {
+        sh.ev[i] = (i & 1) ? 1.0 : 0.0;
+        sh.ev2[i] = (i & 1) ? 0.0 : 1.0;
+    }
+    const unsigned ev2Delta = lds_addr(sh.ev2) - lds_addr(sh.ev);
+#else
     for (int i = lane; i < (2 * WV_P + WV_L) * 2; i += 64) sh.ev[i] = 0.0;
+#endif
 
     /* ---- per-slot state: layer j of this lane is slot lane * L + j ---- */
     Prm prm[L];
@@ -485,9 +529,9 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             ring[WV_OFF_FM(0)] = Am[0]; ring[WV_OFF_PM(0)] = 0.0; ring[WV_OFF_PY(0)] = 0.0;
             ring[WV_OFF_FX(0)] = Ax[0]; ring[WV_OFF_FY(0)] = Ay[0];
         }
-#ifdef WV_HDP
-        /* matrix column 0 scores the FIRST k-mer under this machine (sequence_getKmer3, :327-331: index -1 reads
-         * element 0), not a sentinel: its slot starts with that row */
+#if defined(WV_HDP) || defined(WV_VANILLA)
+        /* matrix column 0 scores the FIRST k-mer (pair) under this machine (sequence_getKmer3 / sequence_getKmer2,
+         * :320-331: index -1 reads element 0), not a sentinel: its slot starts with that row */
         if (lane == 0) {
             const d2 *src = (const d2 *) track;
 #pragma unroll
@@ -615,7 +659,34 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
          * the same additions by the track kernel).  The L cells of a lane are independent: their logAdds are
          * taken stage by stage, so that the L table reads of a stage are in flight together. */
         double pm[L], py[L], nm[L], nx[L], ny[L], t1[L];
-#ifdef WV_HDP
+#if defined(WV_VANILLA)
+        /* emissions_signal_getEventMatchProbWithTwoDists (impl/stateMachine.c:499-528) on the match table and on the
+         * extra-event table: logGaussPdf of the mean (:333-343) + logInvGaussPdf of the noise (:322-331),
+         * ((log(lambda) - log(2 pi) - 3 log(noise)) - lambda a a / noise) / 2 with a = (noise - mu) / mu; both
+         * divisions as Markstein-corrected multiplies by host-/device-rounded reciprocals, log(noise) from the host */
+        d2 e2[L];
+#pragma unroll
+        for (int j = 0; j < L; j++) e2[j] = *lds_d2p_cast(ea + ev2Delta + 16u * (unsigned) (L - 1 - j));
+#pragma unroll
+        for (int j = 0; j < L; j++) {
+            const Prm &p = prm[j];
+            const double c3 = 3 * e2[j].y;
+#pragma unroll
+            for (int tb = 0; tb < 2; tb++) {
+                const d2 g0 = p.a[4 * tb], g1 = p.a[4 * tb + 1], n0 = p.a[4 * tb + 2], n1 = p.a[4 * tb + 3];
+                const double level = lgauss(e[j].x, g0.x, g0.y, g1.x, g1.y);
+                const double u = e[j].y - n0.x;
+                const double q1 = u * n0.y;
+                const double a = __fma_rn(__fma_rn(-q1, n0.x, u), n0.y, q1); /* (noise - mu) / mu */
+                const double w = n1.x * a * a;
+                const double q2 = w * e2[j].x;
+                const double dv = __fma_rn(__fma_rn(-q2, e[j].y, w), e2[j].x, q2); /* lambda a a / noise */
+                const double nz = (n1.y - c3 - dv) / 2;
+                if (tb == 0) pm[j] = level + nz;
+                else py[j] = level + nz;
+            }
+        }
+#elif defined(WV_HDP)
         /* get_nanopore_kmer_density (impl/nanopore_hdp.c:390): the spline of the slot's table row at the cell's event,
          * clamped at zero -- a linear density where a log-probability belongs (quirk Q1), match and gap-Y emission
          * alike.  The event's grid cell and its offset in it were taken when the event was staged. */
@@ -666,20 +737,34 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
         ladd_issue<L>(pa, nx, t1, cf);
 #pragma unroll
         for (int j = 0; j < L; j++) { /* match from the middle cell: (x-1, y-1) on the diagonal before */
+#ifdef WV_VANILLA
+            nm[j] = (j ? qm[j ? j - 1 : 0] : rmm) + (pm[j] + prm[j].a[9].x);
+            t2[j] = (j ? qx[j ? j - 1 : 0] : rmx) + (pm[j] + prm[j].a[9].y);
+#else
             nm[j] = (j ? qm[j ? j - 1 : 0] : rmm) + (pm[j] + T[T_MATCH_CONTINUE]);
             t2[j] = (j ? qx[j ? j - 1 : 0] : rmx) + (pm[j] + T[T_MATCH_FROM_GAP_X]);
+#endif
         }
         ladd_issue<L>(pb, nm, t2, cf);
         ladd_finish<L>(pa, nx);
 #pragma unroll
         for (int j = 0; j < L; j++) { /* gap Y from the upper cell: (x, y-1) on the last diagonal */
+#ifdef WV_VANILLA
+            ny[j] = cm[j] + (py[j] + prm[j].a[10].x);
+            t3[j] = cy[j] + (py[j] + lYY);
+#else
             ny[j] = cm[j] + (py[j] + T[T_GAP_OPEN_Y]);
             t3[j] = cy[j] + (py[j] + T[T_GAP_EXTEND_Y]);
+#endif
         }
         ladd_issue<L>(pa, ny, t3, cf);
         ladd_finish<L>(pb, nm);
 #pragma unroll
+#ifdef WV_VANILLA
+        for (int j = 0; j < L; j++) t4[j] = (j ? qy[j ? j - 1 : 0] : rmy) + (pm[j] + lYM);
+#else
         for (int j = 0; j < L; j++) t4[j] = (j ? qy[j ? j - 1 : 0] : rmy) + (pm[j] + T[T_MATCH_FROM_GAP_Y]);
+#endif
         ladd_issue<L>(pb, nm, t4, cf);
         ladd_finish<L>(pa, ny);
         if (SW) {
@@ -723,6 +808,12 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
         /* what the sweep back will find as totalProbability, near enough: the cells of this diagonal dotted with
          * the end vector it starts from (stateMachine.c:1179-1207); cells outside the band are -inf by themselves */
         double e0, e1, e2;
+#ifdef WV_VANILLA
+        /* stateMachine3Vanilla_endStateProb / _raggedEndStateProb (stateMachine.c:1209-1236) */
+        e0 = atEnd && it.raggedR ? (endX + endY) / 2.0 : endM;
+        e1 = endX;
+        e2 = endY;
+#else
         if (atEnd && it.raggedR) {
             e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
             e1 = T[T_GAP_EXTEND_X];
@@ -732,6 +823,7 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             e1 = T[T_MATCH_FROM_GAP_X];
             e2 = T[T_MATCH_FROM_GAP_Y];
         }
+#endif
         double est = CP_NEG_INF;
 #pragma unroll
         for (int j = 0; j < L; j++) est = wave_fold(est, ladd(ladd(fm[j] + e0, fx[j] + e1, cf), fy[j] + e2, cf), cf);
@@ -787,6 +879,17 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
                             v.y = (q - hGrid[il]) / gDx;
                         }
                     }
+#elif defined(WV_VANILLA)
+                    v.x = ok ? ev[3 * (long long) e] : 0.0;
+                    v.y = ok ? ev[3 * (long long) e + 1] : 1.0;
+                    d2 v2;
+                    v2.x = ok ? 1.0 / v.y : 1.0;
+                    v2.y = ok ? ev[3 * (long long) e + 2] : 0.0; /* log(noise), host libm (the batch's own copy of the
+                                                                   events carries it in place of the duration) */
+                    d2 *dst2 = (d2 *) sh.ev2;
+                    dst2[pos] = v2;
+                    dst2[pos + WV_P] = v2;
+                    if (pos < L) dst2[pos + 2 * WV_P] = v2;
 #else
                     v.x = ok ? ev[3 * (long long) e] : 0.0;
                     v.y = ok ? ev[3 * (long long) e + 1] : 0.0;
@@ -835,10 +938,19 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
  * ------------------------------------------------------------------------------------------------------ */
 
 /* a slot's gap-X sums (eP + tP for the three transitions into gap X) and its gap-X emission */
+#ifdef WV_VANILLA
+/* ... under the vanilla machine: the log transition probabilities of the slot's k-mer pair */
+struct Px {
+    d2 a, b, c; /* (match -> gap X, gap X -> gap X) (match -> match, gap X -> match) (match -> gap Y, -) */
+};
+#else
 struct Px {
     d2 a, b; /* (open, extend) (switch, emission) */
 };
-#if WV_L == 1
+#endif
+#if defined(WV_VANILLA)
+/* (WV_PX_BODY* / WV_PX_OUTS*: cpecan_wave_slots_vanilla.h) */
+#elif WV_L == 1
 #define WV_PX_BODY1 "ds_read_b128 %[a0], %[a]\n\t" 
 #define WV_PX_OUTS1 , [a0] "+v"(p[0].a)
 #define WV_PX_BODY2 "ds_read_b128 %[a0], %[a]\n\t" "ds_read_b128 %[a1], %[a] offset:16\n\t" 
@@ -912,7 +1024,7 @@ struct ItemOut {
 #define WV_PXN 64 /* LDS ring of gap-X rows, by column */
 struct BwdShared {
     double coef[64];
-    double pxr[(WV_PXN + 1) * 4]; /* gap-X rows by column mod WV_PXN; row WV_PXN = -inf */
+    double pxr[(WV_PXN + 1) * WV_PXW]; /* gap-X rows by column mod WV_PXN; row WV_PXN = -inf */
     unsigned bits[2][WV_BITWORDS];
     int rec[128][8]; /* phase T0: a refresh's diagonal, its band and the bands of its neighbours */
 };
@@ -961,7 +1073,12 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
     const int lane = threadIdx.x & 63;
     const int D = (int) (it.lX + it.lY);
     const unsigned cf = lds_addr(sh.coef);
-    const unsigned pxAddr = lds_addr(sh.pxr), pxPark = pxAddr + WV_PXN * 32;
+    const unsigned pxAddr = lds_addr(sh.pxr), pxPark = pxAddr + WV_PXN * (WV_PXW * 8);
+#ifdef WV_VANILLA
+    const double lYM = uni64_d(model[CP_VHDR_LOG_YM]), lYY = uni64_d(model[CP_VHDR_LOG_YY]);
+    const double endM = uni64_d(model[CP_VHDR_END_M]), endX = uni64_d(model[CP_VHDR_END_X]),
+                 endY = uni64_d(model[CP_VHDR_END_Y]);
+#endif
     const int ringMask = ringD - 1;
     double T[9];
 #pragma unroll
@@ -971,7 +1088,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
     const bool atEnd = uni(win.atEnd) != 0;
     const int tPost0 = dTop < tracedBackFrom ? dTop : tracedBackFrom; /* first decoded diagonal */
     const int candCap = WV_CAND_PER_DIAG * WV_L * ringD;
-    if (lane < 4) sh.pxr[WV_PXN * 4 + lane] = CP_NEG_INF;
+    if (lane < WV_PXW) sh.pxr[WV_PXN * WV_PXW + lane] = CP_NEG_INF;
 
     unsigned voffA[L], voffB[L]; /* byte offsets of this lane's (Fm, pm) pair and of its py inside a ring row */
 #pragma unroll
@@ -1002,9 +1119,17 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
         double Bm[L], Bx[L], By[L]; /* backward cells of the diagonal above (t+1) */
         double Um[L], Uy[L];        /* upper-block sums of t+1: By + (gap-Y emission + tP)          */
         double hB[L], hP[L];        /* B.match and match emission of t+2 (the middle block's source) */
+#ifdef WV_VANILLA
+        double hTm[L], hTx[L];      /* ... and that cell's log a_mm, log a_xm (its slot may change hands before they are used) */
+#endif
         double pm1[L];              /* match emission of t+1 */
         {
-            double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207) */
+            double e0, e1, e2; /* end state vector (stateMachine.c:1179-1207; vanilla :1209-1236) */
+#ifdef WV_VANILLA
+            e0 = atEnd && it.raggedR ? (endX + endY) / 2.0 : endM;
+            e1 = endX;
+            e2 = endY;
+#else
             if (atEnd && it.raggedR) {
                 e0 = (T[T_GAP_OPEN_X] + T[T_GAP_OPEN_Y]) / 2.0;
                 e1 = T[T_GAP_EXTEND_X];
@@ -1014,6 +1139,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 e1 = T[T_MATCH_FROM_GAP_X];
                 e2 = T[T_MATCH_FROM_GAP_Y];
             }
+#endif
 #pragma unroll
             for (int j = 0; j < L; j++) {
                 const int sl = lane * L + j;
@@ -1028,11 +1154,19 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 const d2 ninf = { CP_NEG_INF, CP_NEG_INF };
                 px[j].a = v ? src[0] : ninf;
                 px[j].b = v ? src[1] : ninf;
+#ifdef WV_VANILLA
+                px[j].c = v ? src[2] : ninf;
+#endif
                 Um[j] = Uy[j] = hB[j] = CP_NEG_INF;
                 hP[j] = pm1[j] = CP_NEG_INF;
+#ifdef WV_VANILLA
+                hTm[j] = hTx[j] = CP_NEG_INF;
+#endif
             }
         }
         double rpo = rol1(px[0].a.x), rpe = rol1(px[0].a.y), rps = SW ? rol1(px[0].b.x) : 0.0;
+#ifdef WV_VANILLA
+#endif
 
         /* the fetch cursor: band, lane masks and slot counters of the diagonal whose ring row is fetched next.
          * A diagonal's forward match cell and two emissions are fetched WV_PREFETCH diagonals before the sweep
@@ -1132,6 +1266,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 /* of slot+1: B.match and match emission of t+2 (middle block), B.gapX of t+1 with its k-mer's
                  * gap-X sums (lower block of t+1); layer L-1 takes them from layer 0 of the lane above */
                 const double rhB = rol1(hB[0]), rhP = rol1(hP[0]), rBx = rol1(Bx[0]);
+#ifdef WV_VANILLA
+                const double rtm = rol1(hTm[0]), rtx = rol1(hTx[0]);
+#endif
                 /* gather form of cell_calculateBackward (:378-389): (t+2) middle block, then (t+1, smaller x-y)
                  * upper block, then (t+1, larger x-y) lower block -- the reference's scatter order per state */
                 double bm[L], bx[L], by[L], y1[L], sBx[L];
@@ -1139,9 +1276,16 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 for (int j = 0; j < L; j++) {
                     const double sB = j < L - 1 ? hB[j < L - 1 ? j + 1 : 0] : rhB, sP = j < L - 1 ? hP[j < L - 1 ? j + 1 : 0] : rhP;
                     sBx[j] = j < L - 1 ? Bx[j < L - 1 ? j + 1 : 0] : rBx;
+#ifdef WV_VANILLA
+                    /* the transitions are those of the cell the step goes TO: slot+1's k-mer pair */
+                    bm[j] = sB + (sP + (j < L - 1 ? hTm[j < L - 1 ? j + 1 : 0] : rtm));
+                    bx[j] = sB + (sP + (j < L - 1 ? hTx[j < L - 1 ? j + 1 : 0] : rtx));
+                    by[j] = sB + (sP + lYM);
+#else
                     bm[j] = sB + (sP + T[T_MATCH_CONTINUE]);
                     bx[j] = sB + (sP + T[T_MATCH_FROM_GAP_X]);
                     by[j] = sB + (sP + T[T_MATCH_FROM_GAP_Y]);
+#endif
                 }
                 double y2[L];
                 LaddPending<L> pa, pb;
@@ -1166,6 +1310,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
 #pragma unroll
                 for (int j = 0; j < L; j++) {
                     hB[j] = Bm[j]; hP[j] = pm1[j];
+#ifdef WV_VANILLA
+                    hTm[j] = px[j].b.x; hTx[j] = px[j].b.y; /* (before the installs below: the k-mer pairs of t+1) */
+#endif
                     Bm[j] = bm[j]; Bx[j] = bx[j]; By[j] = by[j];
                 }
                 /* the gap-X sums above belong to the cells of t+1, the senders of the lower block: the slots of the
@@ -1178,21 +1325,27 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                         touch0 = ((ev >> 8) & 3u) == 0u;
                     }
                     if (ev & 2u) {
-                        px_install<SW>(px, pxAddr + ((ev >> 18) & 63u) * 32u, 1ull << ((ev >> 10) & 63u), (int) ((ev >> 16) & 3u));
+                        px_install<SW>(px, pxAddr + ((ev >> 18) & 63u) * (WV_PXW * 8u), 1ull << ((ev >> 10) & 63u), (int) ((ev >> 16) & 3u));
                         touch0 = touch0 || ((ev >> 16) & 3u) == 0u;
                     }
                     if (touch0) {
                         rpo = rol1(px[0].a.x);
                         rpe = rol1(px[0].a.y);
                         if (SW) rps = rol1(px[0].b.x);
+
                     }
                 }
             }
             /* what this diagonal hands down: the upper-block sums stay in the slot */
 #pragma unroll
             for (int j = 0; j < L; j++) {
+#ifdef WV_VANILLA
+                Um[j] = By[j] + (qPy[j] + px[j].c.x); /* (the cell above shares this slot's k-mer pair) */
+                Uy[j] = By[j] + (qPy[j] + lYY);
+#else
                 Um[j] = By[j] + (qPy[j] + T[T_GAP_OPEN_Y]);
                 Uy[j] = By[j] + (qPy[j] + T[T_GAP_EXTEND_Y]);
+#endif
             }
             if (t <= tracedBackFrom) {
                 double fb[L];
@@ -1298,9 +1451,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             if ((dTop - t) % 30 == 0) {
 #endif
                 /* gap-X rows of the k-mers that can enter during the next 30 diagonals */
-                for (int i = lane; i < 32 * 4; i += 64) {
-                    const int x = bxmin - 1 - (i >> 2);
-                    if (x >= 0) sh.pxr[(x & (WV_PXN - 1)) * 4 + (i & 3)] = track[(long long) x * WV_ROW + 16 + (i & 3)];
+                for (int i = lane; i < 32 * WV_PXW; i += 64) {
+                    const int x = bxmin - 1 - i / WV_PXW, k = i % WV_PXW;
+                    if (x >= 0) sh.pxr[(x & (WV_PXN - 1)) * WV_PXW + k] = track[(long long) x * WV_ROW + 16 + k];
                 }
             }
             if (t - 64 < bitsLo && bitsLo > tracedBackTo + 1) {
@@ -1330,6 +1483,9 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                                                                    write back the whole L2, the forward kernel's ring included) */
     struct Ops {
         double fm, fx, fy, s0, s1, s2, bm, bx, by, hb, hp;
+#ifdef WV_VANILLA
+        double tm, tx; /* log a_mm, log a_xm of the cell on t+1 */
+#endif
     };
 #pragma unroll 1
     for (int base = 0; base < nTotWin; base += 128) {
@@ -1342,6 +1498,13 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             sh.rec[i][3] = ld_agent(&w->nxmin); sh.rec[i][4] = ld_agent(&w->nxmax); sh.rec[i][5] = ld_agent(&w->second);
             sh.rec[i][6] = b.x; sh.rec[i][7] = b.y;
         }
+#ifdef WV_VANILLA
+        auto column_above = [&](const int i, const int j) __attribute__((always_inline)) { /* this slot's k-mer on t+1 */
+            const int nmn = uni(sh.rec[i][3]);
+            const int sl = lane * L + j, sMinN = nmn % WV_P;
+            return nmn + (sl - sMinN + (sl < sMinN ? WV_P : 0));
+        };
+#endif
         auto flags = [&](const int i, const int j, bool &tv, bool &nv, bool &below) __attribute__((always_inline)) {
             const int xmn = uni(sh.rec[i][1]), xmx = uni(sh.rec[i][2]), nmn = uni(sh.rec[i][3]), nmx = uni(sh.rec[i][4]);
             const bool second = uni(sh.rec[i][5]) != 0;
@@ -1374,6 +1537,11 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 o[j].by = src[(2 * L + j) * 64];
                 o[j].hb = src[(3 * L + j) * 64];
                 o[j].hp = src[(4 * L + j) * 64];
+#ifdef WV_VANILLA
+                const double *tr = track + (long long) (nv ? column_above(i, j) : 0) * WV_ROW;
+                o[j].tm = tr[18];
+                o[j].tx = tr[19];
+#endif
             }
         };
         auto work = [&](const int i, const Ops (&o)[L]) __attribute__((always_inline)) {
@@ -1390,9 +1558,15 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
                 if (nv) {
                     const double s0 = below ? o[j].s0 : CP_NEG_INF, s1 = below ? o[j].s1 : CP_NEG_INF,
                                  s2 = below ? o[j].s2 : CP_NEG_INF;
+#ifdef WV_VANILLA
+                    double mm = s0 + (o[j].hp + o[j].tm);
+                    mm = ladd(mm, s1 + (o[j].hp + o[j].tx), cf);
+                    mm = ladd(mm, s2 + (o[j].hp + lYM), cf);
+#else
                     double mm = s0 + (o[j].hp + T[T_MATCH_CONTINUE]);
                     mm = ladd(mm, s1 + (o[j].hp + T[T_MATCH_FROM_GAP_X]), cf);
                     mm = ladd(mm, s2 + (o[j].hp + T[T_MATCH_FROM_GAP_Y]), cf);
+#endif
                     vw[((long long) (base + i) * 2 + 1) * WV_P + lane * L + j] = mm + o[j].hb;
                 }
             }
@@ -1520,7 +1694,7 @@ WV_BACKWARD_KERNEL(cpecan_k_wv_backward, false, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_sw, true, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep, false, WV_KIND_REDO)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep_sw, true, WV_KIND_REDO)
-#ifndef WV_HDP /* (the HDP machine's E-step stays on the general kernel) */
+#if !defined(WV_HDP) && !defined(WV_VANILLA) /* (the HDP and vanilla machines' E-steps stay on the general kernels) */
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em, false, WV_KIND_EXPECT)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em_sw, true, WV_KIND_EXPECT)
 #endif
@@ -1719,7 +1893,7 @@ extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
     }
 }
 
-#ifndef WV_HDP
+#if !defined(WV_HDP) && !defined(WV_VANILLA)
 /*
  * Baum-Welch expectations of the traceback window the backward kernel just swept
  * (diagonalCalculation_Expectations :841-863 with cell_signal_updateTransAndKmerSkipExpectations :426-443).
@@ -1847,9 +2021,9 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     if (threadIdx.x == 0) atomicAdd(dst + 9 + 4096, lik);
 }
 
-#endif /* !WV_HDP */
+#endif /* strawMan builds */
 
-#if WV_L == 4 && !defined(WV_HDP)
+#if WV_L == 4 && !defined(WV_HDP) && !defined(WV_VANILLA)
 /* per-item track of emission constants, wave layout: column x (0..lX) = the 16 emission constants of the k-mer
  * that matrix column x scores (column 0 = the "not a k-mer" sentinel, sequence_getKmer index -1, :314-318),
  * its gap-X emission plus each of the three transitions into gap X (the eP + tP of cell_calculate*), and the
@@ -1907,6 +2081,66 @@ extern "C" int cpecan_wave_launch_counts(hipStream_t stream, const void *states,
                        (const WvState *) states, nItems, nPairs, nTot, nCells);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+#endif
+
+#if WV_L == 4 && defined(WV_VANILLA)
+/* the vanilla machine's track: matrix column x scores the k-mer pair sequence_getKmer2 (impl/pairwiseAligner.c:320-325)
+ * exposes for sequence index x - 1 -- a pointer to character max(x - 2, 0): the skip bin looks at the k-mers there
+ * and one further, the emissions at the one further (columns 0, 1 and 2 all score k-mers 0 and 1, as in the
+ * reference).  Row: per table (match, extra event) mu, sd, 1/sd, K, noise mean, 1/mean, lambda,
+ * log(lambda) - log(2 pi); then the bin's five log transition probabilities (cpecan_hip.hip: derive_vanilla) */
+extern "C" __global__ void cpecan_k_wv_track_vanilla(const DevItem *__restrict__ items, long long nItems,
+                                                     const long long *__restrict__ trackBase,
+                                                     const unsigned short *__restrict__ kidx,
+                                                     const double *__restrict__ models, double *track) {
+    const long long item = blockIdx.y;
+    if (item >= nItems) return;
+    const DevItem it = items[item];
+    const double *hdr = models + (long long) it.model * CP_VMODEL_STRIDE;
+    const double *rows = hdr + CP_VHDR;
+    const long long n = (it.lX + 1) * WV_ROW;
+    double *dst = track + trackBase[item] * WV_ROW;
+    for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long) gridDim.x * blockDim.x) {
+        const long long x = i / WV_ROW;
+        const int jj = (int) (i - x * WV_ROW);
+        const long long p = x > 2 ? x - 2 : 0;
+        const int kPrev = kidx[it.xOff + p], kCur = kidx[it.xOff + p + 1];
+        const double *r = rows + (long long) kCur * CP_VROW;
+        double v = 0.0;
+        if (jj < 16) {
+            const double *q = r + 6 * (jj >> 3);
+            switch (jj & 7) {
+            case 0: v = q[CP_V_MU]; break;
+            case 1: v = q[CP_V_SD]; break;
+            case 2: v = q[CP_V_SD] == 0.0 ? 0.0 : 1.0 / q[CP_V_SD]; break;
+            case 3: v = q[CP_V_K]; break;
+            case 4: v = q[CP_V_NMU]; break;
+            case 5: v = 1.0 / q[CP_V_NMU]; break;
+            case 6: v = q[CP_V_LAMBDA]; break;
+            default: v = q[CP_V_LLAMBDA] - 1.8378770664093453; break;
+            }
+        } else if (jj < 21) {
+            const double d = fabs(r[CP_V_MU] - rows[(long long) kPrev * CP_VROW + CP_V_MU]);
+            long long bin = (long long) (d / 0.5);
+            if (bin >= 30) bin = 29;
+            v = hdr[CP_VHDR_BINS + bin * 5 + (jj - 16)];
+        }
+        dst[i] = v;
+    }
+}
+extern "C" int cpecan_wave_launch_track_vanilla(hipStream_t stream, const DevItem *items, long long nItems,
+                                                const double *track, const long long *trackBase,
+                                                const unsigned short *kidx, const double *models, void *states,
+                                                int maxLX) {
+    int bx = (int) ((((long long) maxLX + 1) * WV_ROW + 255) / 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(cpecan_k_wv_track_vanilla, dim3(bx, (unsigned) nItems), dim3(256), 0, stream, items, nItems,
+                       trackBase, kidx, models, (double *) track);
+    if (hipMemsetAsync(states, 0, (size_t) nItems * sizeof(WvState), stream) != hipSuccess) return -1;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+extern "C" int cpecan_wave_track_row_doubles_vanilla(void) { return WV_ROW; }
 #endif
 
 #if WV_L == 4 && defined(WV_HDP)
@@ -1991,7 +2225,7 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
                        (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD,                \
                        (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, window)
     if (P.mode != 0) {
-#ifdef WV_HDP
+#if defined(WV_HDP) || defined(WV_VANILLA)
         return -1;
 #else
         if (withSwitch) WV_LAUNCH_B(cpecan_k_wv_backward_em_sw);
@@ -2017,7 +2251,7 @@ extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevIt
                                                  const double *models, const double *Fring, long long ringDoubles,
                                                  const double *Bring, int ringD, void *states, const char *scratch,
                                                  long long scratchBytes, double *expect, int window) {
-#ifdef WV_HDP
+#if defined(WV_HDP) || defined(WV_VANILLA)
     return -1;
 #else
     hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_expect), dim3((unsigned) nItems, WV_EXPECT_CHUNKS), dim3(WV_P), 0, stream,

@@ -27,12 +27,16 @@ def skip_bins(seed):
     return np.sort(rng.uniform(0.05, 0.4, 30))[::-1].copy()  # larger level difference, fewer skips
 
 
-def run(ctx, batch, models, bp, ragged, unbanded=False):
+def run(ctx, batch, models, bp, ragged, unbanded=False, general=False):
     """batch as made by synth.make_batch; models: one pyoracle.VanillaModel per batch model"""
     ctx.models_clear()
     ctx.modelsv_create([(m.scalars, m.match, m.skip, m.gap_y) for m in models])
     b = cp.Batch(ctx, make_items(batch, ragged), batch["x_chars"], batch["events"], batch["anchors"], bp,
-                 flags=cp.FLAG_UNBANDED if unbanded else 0, vanilla=True)
+                 flags=(cp.FLAG_UNBANDED if unbanded else 0) | (cp.FLAG_GENERAL_KERNEL if general else 0), vanilla=True)
+    if general or unbanded:
+        assert b.info()["kernel"] == "general"
+    elif b.info()["max_band_width"] <= 184:
+        assert b.info()["kernel"] == "systolic" and b.info()["family"] == "wave"
     b.run()
     b.sync()
     npairs, ntot, ncells = b.counts()
@@ -78,19 +82,20 @@ def test_toy_known_answer(ctx, template_model):
     run(ctx, batch, [m], band_params(0.5), (0, 0), unbanded=True)
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
 @pytest.mark.parametrize("case", [
     dict(n=3, lX=120, lY=250, e=20, md=60, tb=10, every=25, ragged=(0, 0)),
     dict(n=3, lX=300, lY=610, e=40, md=100, tb=40, every=50, ragged=(1, 1)),
     dict(n=2, lX=400, lY=800, e=100, md=300, tb=40, every=50, ragged=(1, 0)),
 ])
-def test_vanilla_matches_oracle(ctx, case):
+def test_vanilla_matches_oracle(ctx, case, general):
     batch = synth.make_batch(51, case["n"], case["lX"], case["lY"], anchor_every=case["every"])
     models = []
     for i, (match, _, gapy) in enumerate(batch["models"]):
         # strand-specific fudge factors as stateMachine3Vanilla_setStrandTransitionsToDefaults sets them
         strand = (np.float32(0.17), np.float32(0.55)) if i % 2 == 0 else (np.float32(0.14), np.float32(0.49))
         models.append(o.VanillaModel(match, skip_bins(i), gapy, float(strand[0]), float(strand[1])))
-    run(ctx, batch, models, band_params(0.01, case["md"], case["tb"], case["e"]), case["ragged"])
+    run(ctx, batch, models, band_params(0.01, case["md"], case["tb"], case["e"]), case["ragged"], general=general)
 
 
 def test_vanilla_expectations_match_oracle(ctx):
