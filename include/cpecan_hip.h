@@ -179,9 +179,10 @@ typedef struct {
                                            once well (more, smaller-footprint workgroups per CU).  The environment
                                            variable CPECAN_KERNELS=systolic asks the same for every batch. */
 
-#define CPECAN_FLAG_GENERAL_KERNEL 32 /* cpecan_hip_batch_create_hdp: keep the batch on the general kernel (any band
-                                         width) instead of the wave-per-alignment HDP kernels (bands <= 248 k-mers,
-                                         posterior decode); same results bit for bit */
+#define CPECAN_FLAG_GENERAL_KERNEL 32 /* cpecan_hip_batch_create_hdp / _vanilla: keep the batch on the general kernel
+                                         (any band width) instead of the wave-per-alignment kernels of that machine
+                                         (posterior decode; bands <= 248 k-mers for the HDP machine, <= 184 for the
+                                         vanilla one); same results bit for bit */
 
 /* Copies the inputs to HBM and builds per-item band tables.  All host pointers may be released
  * after the call returns. */

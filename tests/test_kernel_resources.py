@@ -37,7 +37,7 @@ def test_systolic_kernels_fit_four_waves_per_simd(tmp_path, rows, suffix):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
-@pytest.mark.parametrize("cells,hdp", [(3, False), (2, False), (3, True)])
+@pytest.mark.parametrize("cells,hdp", [(3, False), (2, False), (3, True), (2, "vanilla")])
 def test_wave_kernels_fit_two_waves_per_simd(tmp_path, cells, hdp):
     """The wave-per-alignment sweeps run as one forward and one backward wave per SIMD (the forward sweep of window
     w+1 beside the backward sweep of window w): each must stay within 256 VGPRs -- beyond that the compiler moves
@@ -47,17 +47,17 @@ def test_wave_kernels_fit_two_waves_per_simd(tmp_path, cells, hdp):
     out = str(tmp_path / "wv.s")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                            "-fno-fast-math", "-Wno-unused-function", "-DWV_L=%d" % cells] +
-                          (["-DWV_HDP"] if hdp else []) +
+                          (["-DWV_VANILLA"] if hdp == "vanilla" else ["-DWV_HDP"] if hdp else []) +
                           ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-S",
                            "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     text = open(out).read()
-    sfx = "_%s%d" % ("h" if hdp else "l", cells)
+    sfx = "_%s%d" % ("v" if hdp == "vanilla" else "h" if hdp else "l", cells)
     for name in ("cpecan_k_wv_forward" + sfx, "cpecan_k_wv_backward" + sfx, "cpecan_k_wv_resweep" + sfx):
         meta = text[text.index(".name:           " + name + "\n"):]
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
         assert vgpr <= 256, "%s uses %d VGPRs: a forward and a backward wave no longer share a SIMD" % (name, vgpr)
         assert spill == 0, "%s spills %d VGPRs to scratch" % (name, spill)
-    if hdp:  # three register pairs per slot instead of ten: the forward sweep is the light one
+    if hdp is True:  # three register pairs per slot instead of ten: the forward sweep is the light one
         meta = text[text.index(".name:           cpecan_k_wv_forward" + sfx + "\n"):]
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 192
