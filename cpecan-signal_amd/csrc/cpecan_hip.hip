@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <sched.h>
@@ -259,6 +260,72 @@ struct PackedPair {
     double logp;
 };
 
+/* Device memory of batches and model tables goes through a small caching allocator: hipMalloc and hipFree wait for
+ * the device, so a host thread that prepares the next batch while the GPU works on the current one (one-shot
+ * alignment of a stream of batches) would otherwise stall on every buffer.  A released block is kept (per device, up
+ * to CPECAN_ALLOC_CACHE_GB, default 96) and handed to the next request it fits within 25 %. */
+struct DevCache {
+    struct Block { void *p; size_t bytes; int device; };
+    std::mutex lock;
+    std::vector<Block> blocks;
+    size_t held = 0;
+    size_t cap() const {
+        static const size_t c = [] {
+            const char *e = getenv("CPECAN_ALLOC_CACHE_GB");
+            return (size_t) (e ? atof(e) : 96.0) * (1ull << 30);
+        }();
+        return c;
+    }
+    hipError_t get(void **out, size_t bytes) {
+        int device = 0;
+        (void) hipGetDevice(&device);
+        {
+            std::lock_guard<std::mutex> g(lock);
+            size_t best = blocks.size();
+            for (size_t i = 0; i < blocks.size(); i++)
+                if (blocks[i].device == device && blocks[i].bytes >= bytes && blocks[i].bytes <= bytes + bytes / 4 + 4096 &&
+                    (best == blocks.size() || blocks[i].bytes < blocks[best].bytes))
+                    best = i;
+            if (best != blocks.size()) {
+                *out = blocks[best].p;
+                held -= blocks[best].bytes;
+                blocks.erase(blocks.begin() + (long) best);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) { /* out of memory with blocks in the cache: give them back and try once more */
+            trim(0);
+            (void) hipGetLastError();
+            e = hipMalloc(out, bytes);
+        }
+        return e;
+    }
+    void put(void *p, size_t bytes) {
+        int device = 0;
+        (void) hipGetDevice(&device);
+        std::lock_guard<std::mutex> g(lock);
+        if (bytes < (1u << 20) || held + bytes > cap()) { /* small blocks are cheap to re-create; the cache is bounded */
+            (void) hipFree(p);
+            return;
+        }
+        blocks.push_back({ p, bytes, device });
+        held += bytes;
+    }
+    void trim(size_t keep) {
+        std::lock_guard<std::mutex> g(lock);
+        while (!blocks.empty() && held > keep) {
+            (void) hipFree(blocks.back().p);
+            held -= blocks.back().bytes;
+            blocks.pop_back();
+        }
+    }
+};
+DevCache &dev_cache() {
+    static DevCache *c = new DevCache(); /* (never destroyed: the runtime may be gone by the time statics are) */
+    return *c;
+}
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
@@ -266,10 +333,10 @@ template <typename T> struct DevBuf {
         release();
         n = count;
         if (count == 0) return hipSuccess;
-        return hipMalloc((void **) &p, count * sizeof(T));
+        return dev_cache().get((void **) &p, count * sizeof(T));
     }
     void release() {
-        if (p) (void) hipFree(p);
+        if (p) dev_cache().put(p, n * sizeof(T));
         p = nullptr;
         n = 0;
     }
@@ -478,6 +545,7 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
     lap("derive rows (threads)");
     for (int i = 0; i < n; i++) ids[i] = c->nModels + i;
     c->nModels += n;
+    if (c->stream) (void) hipStreamSynchronize(c->stream); /* (the old table goes back to the allocator's cache) */
     hipError_t e = c->models.alloc(c->hostModels.size());
     if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
     lap("hipMalloc");
@@ -604,6 +672,7 @@ int cpecan_hip_modelsv_create(cpecan_ctx *c, const cpecan_vanilla_model *models,
     for (auto &t : pool) t.join();
     for (int i = 0; i < n; i++) ids[i] = c->nModelsV + i;
     c->nModelsV += n;
+    if (c->stream) (void) hipStreamSynchronize(c->stream); /* (the old table goes back to the allocator's cache) */
     hipError_t e = c->modelsV.alloc(c->hostModelsV.size());
     if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpy(c->modelsV.p, c->hostModelsV.data(), c->hostModelsV.size() * sizeof(double),
@@ -655,6 +724,7 @@ int cpecan_hip_modelsh_create(cpecan_ctx *c, const cpecan_hdp_model *models, int
         ids[i] = (int32_t) c->hostModelsH.size();
         c->hostModelsH.push_back(d);
     }
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
     HIP_TRY(c->modelsH.alloc(c->hostModelsH.size()));
     HIP_TRY(hipMemcpy(c->modelsH.p, c->hostModelsH.data(), c->hostModelsH.size() * sizeof(DevHdpModel),
                       hipMemcpyHostToDevice));
@@ -675,6 +745,7 @@ int cpecan_hip_models5_create(cpecan_ctx *c, const cpecan_sm5_model *models, int
         ids[i] = c->nModels5 + i;
     }
     c->nModels5 += n;
+    if (c->stream) (void) hipStreamSynchronize(c->stream); /* (the old table goes back to the allocator's cache) */
     hipError_t e = c->models5.alloc(c->hostModels5.size());
     if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
     HIP_TRY(hipMemcpy(c->models5.p, c->hostModels5.data(), c->hostModels5.size() * sizeof(double),
@@ -685,6 +756,7 @@ int cpecan_hip_models5_create(cpecan_ctx *c, const cpecan_sm5_model *models, int
 int cpecan_hip_models_clear(cpecan_ctx *c) {
     if (!c) return fail(CPECAN_EINVAL, "ctx is NULL");
     (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream); /* the tables go back to the allocator's cache: no reader may be left */
     c->modelEpoch++; /* batches created before this call hold ids into tables that are gone: batch_run refuses them */
     c->models.release();
     c->hostModels.clear();
@@ -708,6 +780,9 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     /* the batch keeps its own device id: a caller (a garbage collector, say) may destroy the context first, and
      * nothing here may depend on it then */
     (void) hipSetDevice(b->device);
+    /* the batch's device memory goes back to the allocator's cache, not to the driver (which would wait for the
+     * device): nothing of this batch may still be running when another batch is handed the blocks */
+    if (b->ev2 && b->ran) (void) hipEventSynchronize(b->ev2);
     if (b->ev0) (void) hipEventDestroy(b->ev0);
     if (b->ev1) (void) hipEventDestroy(b->ev1);
     if (b->ev2) (void) hipEventDestroy(b->ev2);
