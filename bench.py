@@ -114,6 +114,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-finalise", action="store_true",
                     help="leave the pairs as (x, y, exponent) in HBM inside the timed region instead of finishing "
                          "them on the host (GPU pass alone)")
+    ap.add_argument("--host-tables", action="store_true",
+                    help="--mode service: every read's scaled model table comes from the caller (cpecan_hip_models_create) "
+                         "instead of one pore model + per-read scaling parameters (cpecan_hip_models_create_scaled)")
     ap.add_argument("--em-contexts", type=int, default=2,
                     help="--mode em: 2 = the rank's reads as two concurrent batches on the workgroup kernels, 1 = one "
                          "batch on the wave kernels")
@@ -524,15 +527,22 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
     data = [synth.make_batch(3 + 10 * k, args.reads, args.kmers, args.events, anchor_every=50) for k in range(min(n, 4))]
     ctxs = [cp.Context(local_rank), cp.Context(local_rank)]
     slot = [None, None]
-    t_prep = []
+    t_prep, t_models, t_batch = [], [], []
+    items = [make_items(cp, bt) for bt in data]
 
     def prepare(k):
         t0 = time.perf_counter()
         bt, cx = data[k % len(data)], ctxs[k % 2]
         cx.models_clear()
-        cx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in bt["models"]])
-        slot[k % 2] = cp.Batch(cx, make_items(cp, bt), bt["x_chars"], bt["events"], bt["anchors"], bp,
+        if args.host_tables:  # the caller scaled every read's table itself (604 MB up per batch)
+            cx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in bt["models"]])
+        else:  # one pore model + five scaling parameters per read; rows assembled on the device
+            cx.models_create_scaled((cp.NANOPORE_TRANSITIONS,) + bt["base_model"], bt["scalings"])
+        t_models.append(time.perf_counter() - t0)
+        t1 = time.perf_counter()
+        slot[k % 2] = cp.Batch(cx, items[k % len(data)], bt["x_chars"], bt["events"], bt["anchors"], bp,
                                cp.MODE_POSTERIOR, args.kernel, 0)
+        t_batch.append(time.perf_counter() - t1)
         t_prep.append(time.perf_counter() - t0)
 
     prepare(0)
@@ -563,7 +573,10 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
         "gcells_per_s": round(cells / elapsed / 1e9, 3),
         "config": {"workload": "a stream of BASELINE configs[2] batches (%d reads x %d events x %d k-mers), each prepared "
                                "from host buffers, aligned once, pairs finished on the host" % (args.reads, args.events, args.kmers),
+                   "model_tables": "scaled by the caller, derived on the host" if args.host_tables else "scaled and assembled on the device (cpecan_hip_models_create_scaled)",
                    "host_prepare_ms_per_batch": round(1e3 * float(np.mean(t_prep[args.warmup:])), 1),
+                   "of_which_model_tables_ms": round(1e3 * float(np.mean(t_models[args.warmup:])), 1),
+                   "of_which_batch_create_ms": round(1e3 * float(np.mean(t_batch[args.warmup:])), 1),
                    "pairs": pairs}}), flush=True)
     return 0
 

@@ -38,7 +38,7 @@ EXPECTATIONH_LEN = 9 + 1
 EXPORTS = [
     "cpecan_hip_device_count", "cpecan_hip_ctx_create", "cpecan_hip_ctx_destroy",
     "cpecan_hip_last_error", "cpecan_hip_version", "cpecan_hip_models_create",
-    "cpecan_hip_models_clear", "cpecan_band_construct", "cpecan_split_points",
+    "cpecan_hip_models_clear", "cpecan_hip_models_create_scaled", "cpecan_hip_models_download", "cpecan_band_construct", "cpecan_split_points",
     "cpecan_hip_batch_create", "cpecan_hip_batch_run", "cpecan_hip_batch_sync",
     "cpecan_hip_batch_elapsed_ms", "cpecan_hip_batch_counts", "cpecan_hip_batch_fetch_pairs",
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
@@ -135,6 +135,8 @@ def lib():
         L.cpecan_hip_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.cpecan_hip_models_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.cpecan_hip_models_clear.argtypes = [C.c_void_p]
+        L.cpecan_hip_models_create_scaled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.cpecan_hip_models_download.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.cpecan_hip_models_set_transitions.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cpecan_hip_selftest_division.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.POINTER(C.c_int64)]
         L.cpecan_hip_batch_create.argtypes = [
@@ -254,6 +256,32 @@ class Context:
         ids = np.zeros(n, np.int32)
         _check(lib().cpecan_hip_models_create(self.h, C.cast(descs, C.c_void_p), n, threads, _ptr(ids)))
         return ids
+
+    def models_create_scaled(self, base, scalings, threads=0):
+        """base: (transitions[9], match[20481], gap_x[4096], gap_y[20481]) of the unscaled pore model; scalings:
+        [n, 5] (scale, shift, var, scale_sd, var_sd) per read -> ids.  emissions_signal_scaleModel per read, the
+        rows assembled on the device."""
+        t, match, gx, gy = base
+        match = np.ascontiguousarray(match, dtype=np.float64)
+        gx = np.ascontiguousarray(gx, dtype=np.float64)
+        gy = np.ascontiguousarray(gy, dtype=np.float64)
+        assert match.size == MODEL_TABLE_LEN and gy.size == MODEL_TABLE_LEN and gx.size == NUM_KMERS
+        sc = np.ascontiguousarray(scalings, dtype=np.float64).reshape(-1, 5)
+        desc = Sm3ModelDesc()
+        for j in range(9):
+            desc.transitions[j] = t[j]
+        desc.match_probs, desc.gap_x_probs, desc.gap_y_probs = match.ctypes.data, gx.ctypes.data, gy.ctypes.data
+        ids = np.zeros(len(sc), np.int32)
+        _check(lib().cpecan_hip_models_create_scaled(self.h, C.byref(desc), _ptr(sc), len(sc), threads, _ptr(ids)))
+        return ids
+
+    def models_download(self, model_id):
+        """the derived device table of one strawMan model (test aid)"""
+        n = C.c_int64(0)
+        _check(lib().cpecan_hip_models_download(self.h, 0, None, 0, C.byref(n)))
+        out = np.zeros(n.value)
+        _check(lib().cpecan_hip_models_download(self.h, int(model_id), _ptr(out), out.size, C.byref(n)))
+        return out
 
     def models5_create(self, models):
         """models: list of (transitions[17], match[16], gap_x[4], gap_y[4]) -> ids (5-state symbol machine)"""

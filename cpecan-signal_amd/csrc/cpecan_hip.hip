@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -213,8 +214,13 @@ template <class T> struct NoInit : std::allocator<T> {
 struct Lap {
     const char *who;
     bool on;
-    std::chrono::steady_clock::time_point t;
-    explicit Lap(const char *w) : who(w), on(getenv("CPECAN_TIMING") != nullptr), t(std::chrono::steady_clock::now()) {}
+    std::chrono::steady_clock::time_point t, t0;
+    explicit Lap(const char *w) : who(w), on(getenv("CPECAN_TIMING") != nullptr), t(std::chrono::steady_clock::now()), t0(t) {}
+    ~Lap() {
+        if (on)
+            fprintf(stderr, "[cpecan timing] %s: TOTAL %.1f ms\n", who,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
     void operator()(const char *what) {
         if (!on) return;
         const auto n = std::chrono::steady_clock::now();
@@ -269,13 +275,17 @@ struct DevCache {
     std::mutex lock;
     std::vector<Block> blocks;
     size_t held = 0;
-    size_t cap() const {
-        static const size_t c = [] {
-            const char *e = getenv("CPECAN_ALLOC_CACHE_GB");
-            return (size_t) (e ? atof(e) : 96.0) * (1ull << 30);
-        }();
-        return c;
-    }
+    const bool pinnedHost; /* the same for pinned host memory (the packed pairs of a batch): pinning and unpinning
+                              150 MB per batch costs tens of milliseconds; up to CPECAN_PINNED_CACHE_GB, default 8 */
+    const size_t capBytes;
+    explicit DevCache(bool host)
+        : pinnedHost(host), capBytes([host] {
+              const char *e = getenv(host ? "CPECAN_PINNED_CACHE_GB" : "CPECAN_ALLOC_CACHE_GB");
+              return (size_t) ((e ? atof(e) : host ? 8.0 : 96.0) * (double) (1ull << 30));
+          }()) {}
+    size_t cap() const { return capBytes; }
+    hipError_t raw_alloc(void **out, size_t bytes) { return pinnedHost ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes); }
+    void raw_free(void *p) { (void) (pinnedHost ? hipHostFree(p) : hipFree(p)); }
     hipError_t get(void **out, size_t bytes) {
         int device = 0;
         (void) hipGetDevice(&device);
@@ -293,11 +303,11 @@ struct DevCache {
                 return hipSuccess;
             }
         }
-        hipError_t e = hipMalloc(out, bytes);
+        hipError_t e = raw_alloc(out, bytes);
         if (e != hipSuccess) { /* out of memory with blocks in the cache: give them back and try once more */
             trim(0);
             (void) hipGetLastError();
-            e = hipMalloc(out, bytes);
+            e = raw_alloc(out, bytes);
         }
         return e;
     }
@@ -305,8 +315,9 @@ struct DevCache {
         int device = 0;
         (void) hipGetDevice(&device);
         std::lock_guard<std::mutex> g(lock);
-        if (bytes < (1u << 20) || held + bytes > cap()) { /* small blocks are cheap to re-create; the cache is bounded */
-            (void) hipFree(p);
+        if (held + bytes > cap()) { /* the cache is bounded (small blocks are kept too: hipFree waits for the device
+                                       whatever the size, and the device is busy with the previous batch) */
+            raw_free(p);
             return;
         }
         blocks.push_back({ p, bytes, device });
@@ -315,16 +326,38 @@ struct DevCache {
     void trim(size_t keep) {
         std::lock_guard<std::mutex> g(lock);
         while (!blocks.empty() && held > keep) {
-            (void) hipFree(blocks.back().p);
+            raw_free(blocks.back().p);
             held -= blocks.back().bytes;
             blocks.pop_back();
         }
     }
 };
 DevCache &dev_cache() {
-    static DevCache *c = new DevCache(); /* (never destroyed: the runtime may be gone by the time statics are) */
+    static DevCache *c = new DevCache(false); /* (never destroyed: the runtime may be gone by the time statics are) */
     return *c;
 }
+DevCache &pinned_cache() {
+    static DevCache *c = new DevCache(true);
+    return *c;
+}
+
+/* a block of pinned host memory from the cache (host-built tables on their way to the device) */
+template <typename T> struct PinnedBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return pinned_cache().get((void **) &p, count * sizeof(T));
+    }
+    void release() {
+        if (p) pinned_cache().put(p, n * sizeof(T));
+        p = nullptr;
+        n = 0;
+    }
+    ~PinnedBuf() { release(); }
+};
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -350,7 +383,9 @@ struct cpecan_ctx {
     long long modelEpoch = 0; /* counts cpecan_hip_models_clear calls */
     hipStream_t stream = nullptr;
     DevBuf<double> models; /* nModels * CP_MODEL_STRIDE */
-    std::vector<double, NoInit<double>> hostModels;
+    void *pinned = nullptr; /* staging slots of cpecan_hip_models_create */
+    size_t pinnedBytes = 0;
+    std::vector<double> switchToX; /* per strawMan model: its GAP_SWITCH_TO_X (the tables themselves live on the device only) */
     int nModels = 0;
     DevBuf<double> models5; /* 5-state symbol models, nModels5 * CP_MODEL5_STRIDE */
     std::vector<double> hostModels5;
@@ -477,6 +512,7 @@ int cpecan_hip_ctx_destroy(cpecan_ctx *c) {
     if (!c) return CPECAN_OK;
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->pinned) (void) hipHostFree(c->pinned);
     for (auto *t : c->hdpTables) delete t;
     c->hdpTables.clear();
     delete c;
@@ -522,6 +558,21 @@ static void derive_rows(const cpecan_sm3_model *m, double *dst) {
     }
 }
 
+/* Room for n more strawMan models at the end of the device table: a new block, the old rows copied across on the
+ * device (no host mirror of the tables is kept).  *fresh receives the device address of the first new model. */
+static int grow_models(cpecan_ctx *c, int32_t n, double **fresh) {
+    const size_t old = (size_t) c->nModels * CP_MODEL_STRIDE, total = old + (size_t) n * CP_MODEL_STRIDE;
+    if (c->stream) (void) hipStreamSynchronize(c->stream); /* (the old table goes back to the allocator's cache) */
+    DevBuf<double> grown;
+    hipError_t e = grown.alloc(total);
+    if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
+    if (old) HIP_TRY(hipMemcpy(grown.p, c->models.p, old * sizeof(double), hipMemcpyDeviceToDevice));
+    std::swap(grown.p, c->models.p);
+    std::swap(grown.n, c->models.n);
+    *fresh = c->models.p + old;
+    return CPECAN_OK;
+}
+
 int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int32_t n,
                              int32_t threads, int32_t *ids) {
     if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
@@ -530,28 +581,158 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
             return fail(CPECAN_EINVAL, "model %d has a NULL table", i);
     HIP_TRY(hipSetDevice(c->device));
     Lap lap("models_create");
-    const size_t old = c->hostModels.size();
-    c->hostModels.resize(old + (size_t) n * CP_MODEL_STRIDE);
-    lap("resize host table");
+    int nt = threads > 0 ? threads : host_threads();
+    nt = std::max(1, std::min(nt, (int) n));
+    double *fresh = nullptr;
+    int rc = grow_models(c, n, &fresh);
+    if (rc != CPECAN_OK) return rc;
+    /* every host thread derives a model into one of its two pinned slots and sends it on its way; the slot is
+     * written again once its copy has gone (no host copy of the whole table exists at any time) */
+    const size_t slotBytes = CP_MODEL_STRIDE * sizeof(double), want = slotBytes * 2 * (size_t) nt;
+    if (c->pinnedBytes < want) {
+        if (c->pinned) (void) hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinnedBytes = 0;
+        HIP_TRY(hipHostMalloc(&c->pinned, want, hipHostMallocDefault));
+        c->pinnedBytes = want;
+    }
+    std::vector<hipEvent_t> gone(2 * (size_t) nt, nullptr);
+    for (auto &ev : gone) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    lap("device table, pinned slots");
+    std::atomic<int> bad{0};
+    std::vector<std::thread> pool;
+    for (int w = 0; w < nt; w++)
+        pool.emplace_back([&, w]() {
+            if (hipSetDevice(c->device) != hipSuccess) { bad = 1; return; }
+            int turn = 0;
+            for (int i = w; i < n; i += nt, turn++) {
+                const size_t slot = 2 * (size_t) w + (turn & 1);
+                double *dst = (double *) ((char *) c->pinned + slot * slotBytes);
+                if (turn >= 2 && hipEventSynchronize(gone[slot]) != hipSuccess) { bad = 1; return; }
+                derive_rows(&models[i], dst);
+                if (hipMemcpyAsync(fresh + (size_t) i * CP_MODEL_STRIDE, dst, slotBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipEventRecord(gone[slot], c->stream) != hipSuccess) { bad = 1; return; }
+            }
+        });
+    for (auto &t : pool) t.join();
+    hipError_t se = hipStreamSynchronize(c->stream);
+    for (auto &ev : gone) (void) hipEventDestroy(ev);
+    if (bad || se != hipSuccess) {
+        c->models.release(); /* the table is in an unknown state: the context's strawMan models are gone */
+        c->switchToX.clear();
+        c->nModels = 0;
+        c->modelEpoch++;
+        return fail(CPECAN_EHIP, "model table upload failed: %s", hipGetErrorString(se != hipSuccess ? se : hipGetLastError()));
+    }
+    lap("derive rows (threads) || upload");
+    for (int i = 0; i < n; i++) {
+        ids[i] = c->nModels + i;
+        c->switchToX.push_back(models[i].transitions[T_GAP_SWITCH_TO_X]);
+    }
+    c->nModels += n;
+    return CPECAN_OK;
+}
+
+/* One element of one read's derived table from the base model's derived table, the read's scaling parameters
+ * (emissions_signal_scaleModel impl/stateMachine.c:631-651) and the three values per k-mer the host took with its
+ * libm (K1, the scaled noise sd, K2): every other entry is one IEEE multiply, add or divide, rounded as on the host. */
+extern "C" __global__ void cpecan_k_scale_models(const double *base, const double *scalings /* n x 5 */,
+                                                 const double *hostPart /* n x 4096 x 3 */, int n, double *out) {
+    const long long e = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= CP_MODEL_STRIDE) return;
+    const double b = base[e];
+    const long long r = e - CP_MODEL_HEADER;
+    const int k = r >= 0 ? (int) (r / CP_ROW) : -1, j = r >= 0 ? (int) (r % CP_ROW) : -1;
+    const bool plain = k < 0 || k >= CPECAN_NUM_KMERS || j >= 8;
+    /* the neighbours a derived entry needs: the level sd (j 1, 2), the noise mean's row mates */
+    const double sd = plain ? 0.0 : base[CP_MODEL_HEADER + (long long) k * CP_ROW + 1];
+    for (int m = blockIdx.y; m < n; m += gridDim.y) {
+        double v = b;
+        if (!plain) {
+            const double *sc = scalings + 5 * (long long) m;
+            const double *h = hostPart + ((long long) m * CPECAN_NUM_KMERS + k) * 3;
+            switch (j) {
+            case 0: v = __dadd_rn(__dmul_rn(b, sc[0]), sc[1]); break;
+            case 1: v = __dmul_rn(b, sc[2]); break;
+            case 2: { const double s = __dmul_rn(sd, sc[2]); v = s == 0.0 ? 0.0 : __ddiv_rn(1.0, s); break; }
+            case 3: v = h[0]; break;
+            case 4: v = __dmul_rn(b, sc[3]); break;
+            case 5: v = h[1]; break;
+            case 6: v = h[1] == 0.0 ? 0.0 : __ddiv_rn(1.0, h[1]); break;
+            default: v = h[2]; break;
+            }
+        }
+        out[(long long) m * CP_MODEL_STRIDE + e] = v;
+    }
+}
+
+int cpecan_hip_models_create_scaled(cpecan_ctx *c, const cpecan_sm3_model *base, const cpecan_read_scaling *scalings,
+                                    int32_t n, int32_t threads, int32_t *ids) {
+    if (!c || !base || !scalings || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
+    if (!base->match_probs || !base->gap_x_probs || !base->gap_y_probs) return fail(CPECAN_EINVAL, "the base model has a NULL table");
+    HIP_TRY(hipSetDevice(c->device));
+    Lap lap("models_create_scaled");
+    std::vector<double> baseRows(CP_MODEL_STRIDE);
+    derive_rows(base, baseRows.data());
+    PinnedBuf<double> part; /* (recycled pinned memory: no page faults, and the copy engine reads it directly) */
+    HIP_TRY(part.alloc((size_t) n * CPECAN_NUM_KMERS * 3));
     int nt = threads > 0 ? threads : host_threads();
     nt = std::max(1, std::min(nt, (int) n));
     std::vector<std::thread> pool;
     for (int w = 0; w < nt; w++)
         pool.emplace_back([&, w]() {
-            for (int i = w; i < n; i += nt)
-                derive_rows(&models[i], c->hostModels.data() + old + (size_t) i * CP_MODEL_STRIDE);
+            const double lg = -0.91893853320467267;
+            for (int i = w; i < n; i += nt) {
+                const cpecan_read_scaling &s = scalings[i];
+                double *dst = part.p + (size_t) i * CPECAN_NUM_KMERS * 3;
+                for (int k = 0; k < CPECAN_NUM_KMERS; k++) {
+                    const double *a = base->match_probs + 1 + (size_t) k * CPECAN_MODEL_PARAMS;
+                    const double sd = a[1] * s.var;
+                    const double nmu = a[2] * s.scale_sd, lambda = a[4] * s.var_sd;
+                    const double nsd = sqrt(pow(nmu, 3.0) / lambda);
+                    dst[3 * k] = sd == 0.0 ? -INFINITY : lg - log(sd);
+                    dst[3 * k + 1] = nsd;
+                    dst[3 * k + 2] = nsd == 0.0 ? -INFINITY : lg - log(nsd);
+                }
+            }
         });
     for (auto &t : pool) t.join();
-    lap("derive rows (threads)");
-    for (int i = 0; i < n; i++) ids[i] = c->nModels + i;
+    lap("host libm part (threads)");
+    double *fresh = nullptr;
+    int rc = grow_models(c, n, &fresh);
+    if (rc != CPECAN_OK) return rc;
+    DevBuf<double> dBase, dScal, dPart;
+    HIP_TRY(dBase.alloc(baseRows.size()));
+    HIP_TRY(dScal.alloc((size_t) n * 5));
+    HIP_TRY(dPart.alloc(part.n));
+    lap("device table");
+    static_assert(sizeof(cpecan_read_scaling) == 5 * sizeof(double), "cpecan_read_scaling is five doubles");
+    HIP_TRY(hipMemcpyAsync(dBase.p, baseRows.data(), baseRows.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dScal.p, scalings, (size_t) n * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dPart.p, part.p, part.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(cpecan_k_scale_models, dim3((unsigned) ((CP_MODEL_STRIDE + 255) / 256), (unsigned) std::min(n, 65535)),
+                       dim3(256), 0, c->stream, (const double *) dBase.p, (const double *) dScal.p, (const double *) dPart.p,
+                       (int) n, fresh);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream)); /* the staging blocks are released on return */
+    lap("upload + assemble");
+    for (int i = 0; i < n; i++) {
+        ids[i] = c->nModels + i;
+        c->switchToX.push_back(base->transitions[T_GAP_SWITCH_TO_X]);
+    }
     c->nModels += n;
-    if (c->stream) (void) hipStreamSynchronize(c->stream); /* (the old table goes back to the allocator's cache) */
-    hipError_t e = c->models.alloc(c->hostModels.size());
-    if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
-    lap("hipMalloc");
-    HIP_TRY(hipMemcpy(c->models.p, c->hostModels.data(), c->hostModels.size() * sizeof(double),
-                      hipMemcpyHostToDevice));
-    lap("upload");
+    return CPECAN_OK;
+}
+
+int cpecan_hip_models_download(cpecan_ctx *c, int32_t id, double *out, int64_t capacity, int64_t *nDoubles) {
+    if (!c || !nDoubles) return fail(CPECAN_EINVAL, "bad argument");
+    *nDoubles = CP_MODEL_STRIDE;
+    if (!out) return CPECAN_OK;
+    if (id < 0 || id >= c->nModels) return fail(CPECAN_EINVAL, "model id %d out of range (%d)", id, c->nModels);
+    if (capacity < CP_MODEL_STRIDE) return fail(CPECAN_EINVAL, "capacity %lld < %d doubles", (long long) capacity, (int) CP_MODEL_STRIDE);
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->models.p + (size_t) id * CP_MODEL_STRIDE, CP_MODEL_STRIDE * sizeof(double), hipMemcpyDeviceToHost));
     return CPECAN_OK;
 }
 
@@ -573,12 +754,7 @@ int cpecan_hip_models_set_transitions(cpecan_ctx *c, const double *transitions, 
     std::vector<double> v(9 + CPECAN_NUM_KMERS, 0.0);
     for (int i = 0; i < 9; i++) v[(size_t) i] = transitions[i];
     if (gapX) std::copy(gapX, gapX + CPECAN_NUM_KMERS, v.begin() + 9);
-    for (int m = 0; m < c->nModels; m++) { /* the host copy stays the truth for later appends */
-        double *blk = c->hostModels.data() + (size_t) m * CP_MODEL_STRIDE;
-        for (int i = 0; i < 9; i++) blk[i] = transitions[i];
-        if (gapX)
-            for (int k = 0; k < CPECAN_NUM_KMERS; k++) blk[CP_MODEL_HEADER + (size_t) k * CP_ROW + CP_GAPX] = gapX[k];
-    }
+    for (double &t : c->switchToX) t = transitions[T_GAP_SWITCH_TO_X];
     DevBuf<double> dv;
     HIP_TRY(dv.alloc(v.size()));
     HIP_TRY(hipMemcpyAsync(dv.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -759,7 +935,7 @@ int cpecan_hip_models_clear(cpecan_ctx *c) {
     if (c->stream) (void) hipStreamSynchronize(c->stream); /* the tables go back to the allocator's cache: no reader may be left */
     c->modelEpoch++; /* batches created before this call hold ids into tables that are gone: batch_run refuses them */
     c->models.release();
-    c->hostModels.clear();
+    c->switchToX.clear();
     c->nModels = 0;
     c->models5.release();
     c->hostModels5.clear();
@@ -780,6 +956,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     /* the batch keeps its own device id: a caller (a garbage collector, say) may destroy the context first, and
      * nothing here may depend on it then */
     (void) hipSetDevice(b->device);
+    Lap lap("batch_destroy");
     /* the batch's device memory goes back to the allocator's cache, not to the driver (which would wait for the
      * device): nothing of this batch may still be running when another batch is handed the blocks */
     if (b->ev2 && b->ran) (void) hipEventSynchronize(b->ev2);
@@ -792,8 +969,8 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (b->gStreamOwned)
         for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
-    if (b->hPacked) (void) hipHostFree(b->hPacked);
-    if (b->hPost) (void) hipHostFree(b->hPost);
+    if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedCap * sizeof(PackedPair));
+    if (b->hPost) pinned_cache().put(b->hPost, b->hPackedCap * sizeof(int));
     delete b;
     (void) hipGetLastError(); /* a failed clean-up call must not surface as the "last error" of a later launch */
     return CPECAN_OK;
@@ -872,23 +1049,39 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         d.diagBase = diagTotal;
         diagTotal += s.lX + s.lY + 1;
     }
-    hL.resize((size_t) diagTotal);
-    hR.resize((size_t) diagTotal);
-    hPre.resize((size_t) diagTotal);
     struct ItemStats {
         int maxSpan = 1, windows = 0, badItem = -1, badRc = 0;
         bool systolicOk = true;
     };
-    {
+    /* The band of every item: as matrix columns (first, last) per diagonal -- what the register-resident kernels
+     * read -- written straight into a pinned block; the x-y intervals and the cell prefix sums of the general kernel
+     * only when the batch will (or, on the second call, turns out to) run on it.  A thread's working copy of one
+     * item's intervals stays in its cache. */
+    PinnedBuf<int> hTab;
+    bool keptGeneral = false;
+    long long maxDiags = 0;
+    for (int64_t i = 0; i < nItems; i++) maxDiags = std::max<long long>(maxDiags, items[i].lX + items[i].lY + 1);
+    auto build_bands = [&](bool general) -> int {
+        if (general) {
+            hL.resize((size_t) diagTotal);
+            hR.resize((size_t) diagTotal);
+            hPre.resize((size_t) diagTotal);
+            keptGeneral = true;
+        }
+        maxSpan = 1;
+        maxWindows = 0;
+        systolicOk = true;
         const int nt = (int) std::min<int64_t>(diagTotal > 2000000 ? host_threads() : 1, nItems);
         std::vector<ItemStats> stats((size_t) nt);
         auto work = [&](int w) {
             ItemStats &st = stats[(size_t) w];
+            std::vector<int, NoInit<int>> own(general ? 0 : 2 * (size_t) maxDiags);
             for (int64_t i = w; i < nItems; i += nt) {
                 const cpecan_item &s = items[i];
                 DevItem &d = hItems[(size_t) i];
                 const long long nDiag = s.lX + s.lY + 1;
-                int *Lp = hL.data() + d.diagBase, *Rp = hR.data() + d.diagBase;
+                int *Lp = general ? hL.data() + d.diagBase : own.data();
+                int *Rp = general ? hR.data() + d.diagBase : own.data() + maxDiags;
                 /* getAlignedPairsWithoutBanding builds its band from no anchors, expansion 2 (:1532) */
                 int rc = cpecan_band_construct(unbanded || !anchors ? nullptr : anchors + 2 * s.anchor_offset,
                                                unbanded ? 0 : s.n_anchors, s.lX, s.lY,
@@ -899,34 +1092,37 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                 }
                 long long cells = 0;
                 int maxW = 0;
-                long long *pre = hPre.data() + d.diagBase;
-                for (long long k = 0; k < nDiag; k++) {
-                    pre[k] = cells;
-                    const int wd = ((Rp[k] - Lp[k]) >> 1) + 1;
-                    cells += wd;
-                    maxW = std::max(maxW, wd);
-                }
-                d.nCells = cells;
-                d.maxWidth = maxW;
+                long long *pre = general ? hPre.data() + d.diagBase : nullptr;
+                int *tab = hTab.p + d.diagBase * 2;
                 /* traceback schedule of getPosteriorProbsWithBanding (:917-918): longest span of forward
                  * diagonals that must be resident at once, and the edge-step property the register-resident
                  * kernels rely on */
                 long long tracedBackTo = 0;
-                int windows = 0;
-                for (long long k = 1; k < nDiag; k++) {
-                    const int xmn = (int) ((k + Lp[k]) / 2), xmx = (int) ((k + Rp[k]) / 2);
-                    const int pmn = (int) ((k - 1 + Lp[k - 1]) / 2), pmx = (int) ((k - 1 + Rp[k - 1]) / 2);
-                    if (xmn < pmn || xmn > pmn + 1 || xmx < pmx || xmx > pmx + 1) st.systolicOk = false;
-                    const bool atEnd = k == nDiag - 1;
+                int windows = 0, pmn = 0, pmx = 0;
+                for (long long k = 0; k < nDiag; k++) {
+                    if (pre) pre[k] = cells;
                     const int wd = ((Rp[k] - Lp[k]) >> 1) + 1;
-                    const bool tb = k >= tracedBackTo + params->minDiagsBetweenTraceBack &&
-                                    wd <= params->diagonalExpansion * 2 + 1;
-                    if (atEnd || tb) {
-                        windows++;
-                        st.maxSpan = (int) std::max<long long>(st.maxSpan, k - tracedBackTo + 1);
-                        tracedBackTo = k - (params->traceBackDiagonals + 1);
+                    cells += wd;
+                    maxW = std::max(maxW, wd);
+                    const int xmn = (int) ((k + Lp[k]) / 2), xmx = (int) ((k + Rp[k]) / 2);
+                    tab[k * 2] = xmn;
+                    tab[k * 2 + 1] = xmx;
+                    if (k >= 1) {
+                        if (xmn < pmn || xmn > pmn + 1 || xmx < pmx || xmx > pmx + 1) st.systolicOk = false;
+                        const bool atEnd = k == nDiag - 1;
+                        const bool tb = k >= tracedBackTo + params->minDiagsBetweenTraceBack &&
+                                        wd <= params->diagonalExpansion * 2 + 1;
+                        if (atEnd || tb) {
+                            windows++;
+                            st.maxSpan = (int) std::max<long long>(st.maxSpan, k - tracedBackTo + 1);
+                            tracedBackTo = k - (params->traceBackDiagonals + 1);
+                        }
                     }
+                    pmn = xmn;
+                    pmx = xmx;
                 }
+                d.nCells = cells;
+                d.maxWidth = maxW;
                 st.windows = std::max(st.windows, windows);
             }
         };
@@ -944,6 +1140,15 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             if (st.badItem >= 0 && (bad < 0 || st.badItem < bad)) { bad = st.badItem; badRc = st.badRc; }
         }
         if (bad >= 0) return fail(badRc, "item %lld: anchors do not describe a valid band", (long long) bad);
+        return CPECAN_OK;
+    };
+    /* (what the kernel choice below will come to, as far as it is known before the bands are) */
+    const bool surelyGeneral = dna || kernel == CPECAN_KERNEL_GENERAL || unbanded || (flags & CPECAN_FLAG_DEBUG_DUMP) ||
+                               ((hdp || vanilla) && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_GENERAL_KERNEL)));
+    HIP_TRY(hTab.alloc((size_t) diagTotal * 2 + 2));
+    {
+        int rc = build_bands(surelyGeneral);
+        if (rc != CPECAN_OK) return rc;
     }
     for (int64_t i = 0; i < nItems; i++) {
         const cpecan_item &s = items[i];
@@ -1080,6 +1285,13 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     lap("output buffers");
 
     if (useKernel == CPECAN_KERNEL_GENERAL) {
+        if (!keptGeneral) { /* the band turned out too wide (or too ragged) for the register-resident kernels */
+            int rc = build_bands(true);
+            if (rc != CPECAN_OK) {
+                cpecan_hip_batch_destroy(b);
+                return rc;
+            }
+        }
         B_TRY(b->bandL.alloc(hL.size()));
         B_TRY(b->bandR.alloc(hR.size()));
         B_TRY(b->cellPrefix.alloc(hPre.size()));
@@ -1107,30 +1319,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         b->maxLX = maxLX;
         B_TRY(b->Fstore.alloc((size_t) nItems * (size_t) b->ringDoubles));
         lap("ring allocation");
-        {   /* the band as matrix columns per diagonal, from the x-y intervals built above */
-            std::vector<int, NoInit<int>> tab(hL.size() * 2);
-            const int nt = (int) std::min<int64_t>(diagTotal > 2000000 ? host_threads() : 1, nItems);
-            auto fill = [&](int w) {
-                for (int64_t i = w; i < nItems; i += nt) {
-                    const DevItem &d = hItems[(size_t) i];
-                    const long long nDiag = d.lX + d.lY + 1;
-                    const int *Lp = hL.data() + d.diagBase, *Rp = hR.data() + d.diagBase;
-                    int *t = tab.data() + d.diagBase * 2;
-                    for (long long k = 0; k < nDiag; k++) {
-                        t[k * 2] = (int) ((k + Lp[k]) / 2);
-                        t[k * 2 + 1] = (int) ((k + Rp[k]) / 2);
-                    }
-                }
-            };
-            if (nt <= 1) fill(0);
-            else {
-                std::vector<std::thread> pool;
-                for (int w = 0; w < nt; w++) pool.emplace_back(fill, w);
-                for (auto &t : pool) t.join();
-            }
-            B_TRY(b->bandTab.alloc(tab.size() + 2));
-            B_TRY(hipMemcpy(b->bandTab.p, tab.data(), tab.size() * sizeof(int), hipMemcpyHostToDevice));
-        }
+        /* the band as matrix columns per diagonal */
+        B_TRY(b->bandTab.alloc((size_t) diagTotal * 2 + 2));
+        B_TRY(hipMemcpy(b->bandTab.p, hTab.p, (size_t) diagTotal * 2 * sizeof(int), hipMemcpyHostToDevice));
         {
             const char *g = getenv("CPECAN_SYSTOLIC_GROUPS");
             int G = g ? atoi(g) : b->sy->wave ? 1 : 2;
@@ -1320,7 +1511,7 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
                                               c->modelsH.p, b->syStates.p, b->maxLX);
         } else {
             for (int m = 0; m < c->nModels; m++)
-                if (c->hostModels[(size_t) m * CP_MODEL_STRIDE + T_GAP_SWITCH_TO_X] > -INFINITY) withSwitch = 1;
+                if (c->switchToX[(size_t) m] > -INFINITY) withSwitch = 1;
             rc = (b->sy->wave ? cpecan_wave_launch_track : cpecan_systolic_launch_track)(
                 c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
                 b->maxLX);
@@ -1485,6 +1676,7 @@ static int ensure_counts(cpecan_batch *b) {
     if (!b->ran) return fail(CPECAN_EINVAL, "batch has not run");
     if (b->countsValid) return CPECAN_OK;
     HIP_TRY(hipSetDevice(b->ctx->device));
+    Lap lap("ensure_counts");
     b->hNPairs.resize((size_t) b->nItems);
     b->hNTot.resize((size_t) b->nItems);
     for (int attempt = 0;; attempt++) {
@@ -1538,13 +1730,13 @@ static int ensure_counts(cpecan_batch *b) {
             HIP_TRY(b->packedPost.alloc((size_t) all + (size_t) all / 8));
         }
         if (b->hPackedCap < (size_t) all) {
-            if (b->hPacked) (void) hipHostFree(b->hPacked);
-            if (b->hPost) (void) hipHostFree(b->hPost);
+            if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedCap * sizeof(PackedPair));
+            if (b->hPost) pinned_cache().put(b->hPost, b->hPackedCap * sizeof(int));
             b->hPacked = nullptr;
             b->hPost = nullptr;
             b->hPackedCap = (size_t) all + (size_t) all / 8;
-            HIP_TRY(hipHostMalloc((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair), hipHostMallocDefault));
-            HIP_TRY(hipHostMalloc((void **) &b->hPost, b->hPackedCap * sizeof(int), hipHostMallocDefault));
+            HIP_TRY(pinned_cache().get((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair)));
+            HIP_TRY(pinned_cache().get((void **) &b->hPost, b->hPackedCap * sizeof(int)));
         }
         HIP_TRY(hipMemcpyAsync(b->packBase.p, b->hPairBase.data(), ((size_t) b->nItems + 1) * sizeof(long long),
                                hipMemcpyHostToDevice, b->ctx->stream));

@@ -60,6 +60,21 @@ typedef struct {
  * ids[i] receives the handle of models[i]. */
 int cpecan_hip_models_create(cpecan_ctx *ctx, const cpecan_sm3_model *models, int32_t n,
                              int32_t threads, int32_t *ids);
+/* The same for n reads that share one pore model and differ by their scaling parameters only -- what
+ * emissions_signal_scaleModel (impl/stateMachine.c:631-651) does to a read's copy of EMISSION_MATCH_PROBS before the
+ * alignment (vanillaAlign.c:624-640): level_mean * scale + shift, level_sd * var, noise_mean * scale_sd,
+ * noise_lambda * var_sd, noise_sd = sqrt(noise_mean^3 / noise_lambda).  The host takes only what needs its libm
+ * (pow, sqrt and the two logs per k-mer) and uploads three doubles per k-mer per read; the device assembles the rows
+ * with single IEEE operations.  The resulting device tables are bit-identical to cpecan_hip_models_create() on the
+ * n host-scaled tables (tests/test_scaled_models_gpu.py), at a sixth of the upload. */
+typedef struct {
+    double scale, shift, var, scale_sd, var_sd;
+} cpecan_read_scaling;
+int cpecan_hip_models_create_scaled(cpecan_ctx *ctx, const cpecan_sm3_model *base, const cpecan_read_scaling *scalings,
+                                    int32_t n, int32_t threads, int32_t *ids);
+/* Test aid: copies the derived device table of strawMan model `id` to out (n_doubles receives its length; out may be
+ * NULL to query the length only). */
+int cpecan_hip_models_download(cpecan_ctx *ctx, int32_t id, double *out, int64_t capacity, int64_t *n_doubles);
 int cpecan_hip_models_clear(cpecan_ctx *ctx);
 /* The M-step of Baum-Welch changes the nine transitions and the k-mer gap probabilities only
  * (continuousPairHmm_loadTransitionsAndKmerGapProbs impl/continuousHmm.c:206-232); the per-read scaled emission

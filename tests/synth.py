@@ -105,10 +105,11 @@ def make_batch(config_id, n_reads, lX, lY, anchor_every=50, model_seed=SEED0, di
 
     Returns dict with x_chars (bytes), events [N,3], anchors [A,2], items (list of dicts with
     x_offset,lX,y_offset,lY,anchor_offset,n_anchors,model) and models (list of
-    (match, gap_x, gap_y)) -- one scaled model per read when distinct_models, else one shared.
+    (match, gap_x, gap_y)) -- one scaled model per read when distinct_models, else one shared; base_model (the
+    unscaled pore model) and scalings [n_reads, 5] (every read's scale, shift, var, scale_sd, var_sd).
     """
     match, gap_x, gap_y = synthetic_pore_model(model_seed)
-    xs, evs, ans, items, models = [], [], [], [], []
+    xs, evs, ans, items, models, scalings = [], [], [], [], [], []
     xo = yo = ao = 0
     for r in range(n_reads):
         rng = np.random.default_rng(SEED0 + config_id * 1000 + r)
@@ -121,6 +122,7 @@ def make_batch(config_id, n_reads, lX, lY, anchor_every=50, model_seed=SEED0, di
         xs.append(rd["seq"])
         evs.append(rd["events"])
         ans.append(rd["anchors"])
+        scalings.append(rd["scale_params"])
         if distinct_models:
             models.append((rd["scaled_match"], gap_x, gap_y))
         items.append(dict(x_offset=xo, lX=lx, y_offset=yo, lY=ly, anchor_offset=ao,
@@ -131,4 +133,4 @@ def make_batch(config_id, n_reads, lX, lY, anchor_every=50, model_seed=SEED0, di
     if not distinct_models:
         models.append((match, gap_x, gap_y))
     return dict(x_chars=b"".join(xs), events=np.concatenate(evs), anchors=np.concatenate(ans),
-                items=items, models=models)
+                items=items, models=models, base_model=(match, gap_x, gap_y), scalings=np.array(scalings))
