@@ -1602,6 +1602,16 @@ int cpecan_hip_batch_stage_ms(cpecan_batch *b, float *msForward, float *msBackwa
             f += a;
             k += c2;
         }
+    static const bool timeline = getenv("CPECAN_TIMELINE") != nullptr; /* timing study: when every stage began and ended */
+    if (timeline) {
+        const hipEvent_t *ev = b->evStage.data();
+        for (int w = 0; w < b->nWindows; w++) {
+            float t[4] = { 0, 0, 0, 0 };
+            for (int q = 0; q < 4; q++) (void) hipEventElapsedTime(&t[q], ev[0], ev[1 + 4 * w + q]);
+            fprintf(stderr, "[cpecan timeline] window %2d: forward %7.3f .. %7.3f   backward+post %7.3f .. %7.3f\n", w, t[0], t[1],
+                    t[2], t[3]);
+        }
+    }
     if (msForward) *msForward = f;
     if (msBackward) *msBackward = k;
     if (launchesEach) *launchesEach = b->nWindows * b->nGroups;

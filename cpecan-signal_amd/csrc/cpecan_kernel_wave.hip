@@ -100,6 +100,9 @@
 #define WV_CAND_SLACK 0.25   /* candidates: cells within this (log units) below the posterior threshold */
 #define WV_CAND_PER_DIAG 4   /* candidate capacity, in records per ring diagonal and layer */
 #define WV_EXPECT_CHUNKS 8   /* workgroups that share one window's diagonals in the expectation pass */
+#ifndef WV_BACKWARD_PRIO
+#define WV_BACKWARD_PRIO 2
+#endif
 #define WV_WPB 1             /* alignments (waves) per workgroup of the sweeps: a workgroup's four waves are placed on the
                                 four SIMDs of a CU, which single-wave workgroups are not promised */
 
@@ -1105,8 +1108,10 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
 
     /* ------------------------------ phase S: the sweep back ------------------------------ */
     {
-#ifdef WV_ABL_PRIOB
-        __builtin_amdgcn_s_setprio(2);
+        /* the windows' sweeps back are the longer chain of the two that share a SIMD: they go first when both waves
+         * have an instruction ready (-DWV_ABL_NOPRIOB: timing study; 45.7 -> 43.9 ms per pass) */
+#ifndef WV_ABL_NOPRIOB
+        __builtin_amdgcn_s_setprio(WV_BACKWARD_PRIO);
 #endif
         int bxmin, bxmax; /* band of the diagonal being computed */
         band_load(bandTab, dTop, bxmin, bxmax);
