@@ -282,12 +282,16 @@ def main(argv=None):
     batch, b = batches[0], bs[0]
     finalise = not args.no_finalise
 
-    kernel_ms, stage, fin_s = [], [], []
+    kernel_ms, stage, fin_s, clock_mhz = [], [], [], []
+    chained = family == "wave"
 
     def wait_for(j, record):
         bs[j].sync()
         if record:
             kernel_ms.append(bs[j].elapsed_ms()[1])
+            mhz = bs[j].shader_clock_mhz()  # from the sweeps' own counters (wave kernels): boxes differ under this load
+            if mhz > 0:
+                clock_mhz.append(mhz)
             if bs[j].info()["kernel"] == "systolic":
                 stage.append(bs[j].stage_ms())
         if finalise:  # D2H of the candidates + exp/threshold/floor on the host threads; the GPU works on the other batch
@@ -303,7 +307,10 @@ def main(argv=None):
             j = s_ % inflight
             if pending[j]:
                 wait_for(j, record)
-            bs[j].run()
+            # wave kernels: one pass at a time on the device (a batch fills the register files); the batch's kernels
+            # are ordered behind the previous batch's on the device, the host meanwhile finishes that one's pairs
+            prev = bs[(s_ - 1) % inflight] if (chained and inflight > 1 and s_ > 0) else None
+            bs[j].run(after=prev)
             pending[j] = True
         for k in range(inflight):  # the oldest first
             j = (n + k) % inflight
@@ -382,6 +389,9 @@ def main(argv=None):
                            "frac": round(cells_of[0] * bytes_per_cell / (ms / 1e3) / 1e9 / 8000.0, 5),
                            "host_finalise_ms": round(1e3 * t_fin, 2), "kernel": sb.info(),
                            "stage": kernel_stage(sb.info(), st, cells_of[0])}
+            mhz = sb.shader_clock_mhz()
+            if mhz > 0:  # the sweeps' own cycle counters over their 100 MHz reference counters (wave kernels)
+                single[fam]["shader_clock_mhz"] = round(mhz, 0)
             sb.close()
 
     # HBM traffic of one pass from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
@@ -463,6 +473,7 @@ def main(argv=None):
                    "cells_per_gpu": cells, "pairs_per_gpu": int(npairs.sum()),
                    "kernel": info,
                    "batches_in_flight": inflight,
+                   "shader_clock_mhz_in_timed_region": round(float(np.mean(clock_mhz)), 0) if clock_mhz else None,
                    "pairs_finished_on_host_inside_timed_region": finalise,
                    "host_finalise_ms_per_step": round(1e3 * float(np.mean(fin_s)), 2) if fin_s else None,
                    "step_latency_ms": round(float(np.mean(kernel_ms)), 3),
@@ -525,14 +536,15 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
         sys.exit("--mode service is a one-GPU measurement")
     n = args.warmup + args.steps
     data = [synth.make_batch(3 + 10 * k, args.reads, args.kmers, args.events, anchor_every=50) for k in range(min(n, 4))]
-    ctxs = [cp.Context(local_rank), cp.Context(local_rank)]
-    slot = [None, None]
+    NSLOT = 3  # one batch running, one queued behind it on the device, one being prepared / finished by the host
+    ctxs = [cp.Context(local_rank) for _ in range(NSLOT)]
+    slot = [None] * NSLOT
     t_prep, t_models, t_batch = [], [], []
     items = [make_items(cp, bt) for bt in data]
 
     def prepare(k):
         t0 = time.perf_counter()
-        bt, cx = data[k % len(data)], ctxs[k % 2]
+        bt, cx = data[k % len(data)], ctxs[k % NSLOT]
         cx.models_clear()
         if args.host_tables:  # the caller scaled every read's table itself (604 MB up per batch)
             cx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in bt["models"]])
@@ -540,30 +552,38 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
             cx.models_create_scaled((cp.NANOPORE_TRANSITIONS,) + bt["base_model"], bt["scalings"])
         t_models.append(time.perf_counter() - t0)
         t1 = time.perf_counter()
-        slot[k % 2] = cp.Batch(cx, items[k % len(data)], bt["x_chars"], bt["events"], bt["anchors"], bp,
+        slot[k % NSLOT] = cp.Batch(cx, items[k % len(data)], bt["x_chars"], bt["events"], bt["anchors"], bp,
                                cp.MODE_POSTERIOR, args.kernel, 0)
         t_batch.append(time.perf_counter() - t1)
         t_prep.append(time.perf_counter() - t0)
 
-    prepare(0)
+    def prepare_and_queue(k):
+        prepare(k)
+        slot[k % NSLOT].run(after=slot[(k - 1) % NSLOT] if k > 0 else None)  # ordered on the device, no host round trip
+
+    prepare_and_queue(0)
+    if n > 1:
+        prepare_and_queue(1)
     pairs = cells = 0
     t_start = None
     for k in range(n):
         if k == args.warmup:
             t_start = time.perf_counter()
             pairs = cells = 0
-        b = slot[k % 2]
-        th = threading.Thread(target=prepare, args=(k + 1,)) if k + 1 < n else None
-        b.run()  # asynchronous: the kernels run while the thread below prepares the next batch
+        # batch k is running or done, batch k + 1 is queued behind it: the device goes from one pass to the next
+        # without waiting for the host, which meanwhile prepares and queues batch k + 2 (one thread) and fetches and
+        # finishes batch k's pairs (this thread and the library's)
+        b = slot[k % NSLOT]
+        th = threading.Thread(target=prepare_and_queue, args=(k + 2,)) if k + 2 < n else None
         if th:
             th.start()
         b.sync()
         npairs, _, ncells = b.counts()
         pairs += int(npairs.sum())
         cells += int(ncells.sum())
+        b.close()
         if th:
             th.join()
-        b.close()
     elapsed = time.perf_counter() - t_start
     print(json.dumps({
         "metric": "end-to-end reads/s (one-shot alignment, host preparation overlapped)", "value": round(args.reads * args.steps / elapsed, 1),

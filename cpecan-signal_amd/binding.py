@@ -39,7 +39,7 @@ EXPORTS = [
     "cpecan_hip_device_count", "cpecan_hip_ctx_create", "cpecan_hip_ctx_destroy",
     "cpecan_hip_last_error", "cpecan_hip_version", "cpecan_hip_models_create",
     "cpecan_hip_models_clear", "cpecan_hip_models_create_scaled", "cpecan_hip_models_download", "cpecan_band_construct", "cpecan_split_points",
-    "cpecan_hip_batch_create", "cpecan_hip_batch_run", "cpecan_hip_batch_sync",
+    "cpecan_hip_batch_create", "cpecan_hip_batch_run", "cpecan_hip_batch_run_after", "cpecan_hip_batch_shader_clock_mhz", "cpecan_hip_batch_sync",
     "cpecan_hip_batch_elapsed_ms", "cpecan_hip_batch_counts", "cpecan_hip_batch_fetch_pairs",
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
@@ -155,6 +155,8 @@ def lib():
         L.cpecan_hip_batch_create_dna.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
             C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
+        L.cpecan_hip_batch_run_after.argtypes = [C.c_void_p, C.c_void_p]
+        L.cpecan_hip_batch_shader_clock_mhz.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         for name in ("run", "sync", "destroy"):
             getattr(L, "cpecan_hip_batch_" + name).argtypes = [C.c_void_p]
         L.cpecan_hip_batch_elapsed_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -396,11 +398,21 @@ class Batch:
         self.vanilla = bool(vanilla) and not self.dna
         self.hdp = bool(hdp) and not self.dna
 
-    def run(self):
-        _check(lib().cpecan_hip_batch_run(self.h))
+    def run(self, after=None):
+        """after: a Batch of another context -- this batch's kernels start when that one's last run has finished"""
+        if after is None:
+            _check(lib().cpecan_hip_batch_run(self.h))
+        else:
+            _check(lib().cpecan_hip_batch_run_after(self.h, after.h))
 
     def sync(self):
         _check(lib().cpecan_hip_batch_sync(self.h))
+
+    def shader_clock_mhz(self):
+        """MHz during the last run's forward sweeps (wave kernels; 0.0 otherwise)"""
+        v = C.c_double(0.0)
+        _check(lib().cpecan_hip_batch_shader_clock_mhz(self.h, C.byref(v)))
+        return v.value
 
     def elapsed_ms(self):
         a, k = C.c_float(), C.c_float()

@@ -148,6 +148,7 @@ extern "C" int cpecan_wave_launch_track(hipStream_t stream, const DevItem *items
                                         const unsigned short *kidx, const double *models, void *states, int maxLX);
 extern "C" int cpecan_wave_track_row_doubles(void);
 extern "C" int cpecan_wave_state_bytes(void);
+extern "C" int cpecan_wave_shader_clock_mhz(hipStream_t stream, const void *states, long long nItems, double *mhz);
 extern "C" int cpecan_wave_launch_counts(hipStream_t stream, const void *states, long long nItems, long long *nPairs,
                                          long long *nTot, long long *nCells);
 
@@ -469,7 +470,14 @@ struct cpecan_batch {
     size_t hPackedCap = 0;
     int trackRow = CP_ROW; /* doubles per column of the track */
     bool countsValid = false, ran = false;
+    bool packedInRun = false; /* the last run ended with cpecan_k_pack_base + cpecan_k_pack_pairs */
 };
+
+extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
+                                               const double *logp, double threshold, long long capacity,
+                                               PackedPair *out, int *post);
+extern "C" __global__ void cpecan_k_pack_base(const DevItem *items, const long long *nPairs, long long nItems,
+                                              long long *packBase);
 
 extern "C" {
 
@@ -1434,13 +1442,17 @@ int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t
                              CPECAN_KERNEL_GENERAL, flags & ~CPECAN_FLAG_EXPECTATIONS, out);
 }
 
-int cpecan_hip_batch_run(cpecan_batch *b) {
+int cpecan_hip_batch_run(cpecan_batch *b) { return cpecan_hip_batch_run_after(b, nullptr); }
+
+int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
     if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
     cpecan_ctx *c = b->ctx;
     if (b->modelEpoch != c->modelEpoch)
         return fail(CPECAN_EINVAL, "cpecan_hip_models_clear was called on the context after this batch was created: "
                     "its model ids are gone");
+    if (after && after->device != b->device) return fail(CPECAN_EINVAL, "the two batches live on different devices");
     HIP_TRY(hipSetDevice(c->device));
+    if (after && after != b && after->ran) HIP_TRY(hipStreamWaitEvent(c->stream, after->ev2, 0));
     b->countsValid = false;
     HIP_TRY(hipEventRecord(b->ev0, c->stream));
     if (b->mode == CPECAN_MODE_EXPECTATIONS)
@@ -1567,6 +1579,29 @@ int cpecan_hip_batch_run(cpecan_batch *b) {
         if (rc != 0) return fail(CPECAN_EHIP, "throughput kernel launch failed: %s",
                                  hipGetErrorString(hipGetLastError()));
     }
+    /* posterior decode: the run ends with its candidates packed for the host (16-byte records + the device's verdict),
+     * into a buffer sized by a guess the first time (about one candidate per diagonal) and by the last run's count
+     * afterwards; ensure_counts packs again if the guess was short.  Done here, inside the pass, because a kernel
+     * launched later would wait for wave slots behind the next batch's sweeps. */
+    b->packedInRun = false;
+    static const bool packInRun = getenv("CPECAN_PACK_LATER") == nullptr;
+    if (packInRun && b->mode == CPECAN_MODE_POSTERIOR && !b->P.debug) {
+        if (b->packed.n == 0) {
+            long long guess = 0;
+            for (const DevItem &d : b->hItems) guess += std::min<long long>(d.pairCap, d.lX + d.lY + 64);
+            HIP_TRY(b->packed.alloc((size_t) guess));
+            HIP_TRY(b->packedPost.alloc((size_t) guess));
+        }
+        if (b->packBase.n < (size_t) b->nItems + 1) HIP_TRY(b->packBase.alloc((size_t) b->nItems + 1));
+        hipLaunchKernelGGL(cpecan_k_pack_base, dim3(1), dim3(256), 0, c->stream, (const DevItem *) b->items.p,
+                           (const long long *) b->nPairs.p, (long long) b->nItems, b->packBase.p);
+        hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
+                           (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
+                           (const double *) b->pairLogp.p, b->P.threshold, (long long) b->packed.n, b->packed.p,
+                           b->packedPost.p);
+        HIP_TRY(hipGetLastError());
+        b->packedInRun = true;
+    }
     HIP_TRY(hipEventRecord(b->ev2, c->stream));
     b->ran = true;
     return CPECAN_OK;
@@ -1618,6 +1653,16 @@ int cpecan_hip_batch_stage_ms(cpecan_batch *b, float *msForward, float *msBackwa
     return CPECAN_OK;
 }
 
+int cpecan_hip_batch_shader_clock_mhz(cpecan_batch *b, double *mhz) {
+    if (!b || !mhz) return fail(CPECAN_EINVAL, "bad argument");
+    *mhz = 0.0;
+    if (!b->ran || b->kernel != CPECAN_KERNEL_SYSTOLIC || !b->sy->wave) return CPECAN_OK; /* not measured on this path */
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    if (cpecan_wave_shader_clock_mhz(b->ctx->stream, b->syStates.p, b->nItems, mhz) != 0)
+        return fail(CPECAN_EHIP, "reading the sweeps' clock counters failed");
+    return CPECAN_OK;
+}
+
 int cpecan_hip_batch_info(cpecan_batch *b, int32_t *kernel, int32_t *workgroups, int32_t *maxWidth) {
     if (!b) return fail(CPECAN_EINVAL, "batch is NULL");
     if (kernel) *kernel = b->kernel;
@@ -1657,8 +1702,11 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *b, float *msTotal, float *msKernel
  * or of a multiple of 1e-7, floor(p * 1e7) is the same number on both and is taken here (post >= 0), or the pair is
  * surely below the threshold (post -2); the few that are close (post -1) are finished by the host with its libm. */
 extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
-                                               const double *logp, double threshold, PackedPair *out, int *post) {
+                                               const double *logp, double threshold, long long capacity,
+                                               PackedPair *out, int *post) {
     const DevItem &d = items[blockIdx.x];
+    if (packBase[gridDim.x] > capacity) return; /* (packed at the end of a run into a buffer sized by a guess: the host
+                                                   sees the same total and packs again into one that fits) */
     const long long o = packBase[blockIdx.x], n = packBase[blockIdx.x + 1] - o;
     for (long long k = threadIdx.x; k < n; k += blockDim.x) {
         PackedPair r;
@@ -1679,6 +1727,34 @@ extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long 
             }
         }
         post[o + k] = v;
+    }
+}
+
+/* packBase[i] = candidates of the items before i (each item's count capped at its capacity), packBase[n] = all of
+ * them: the offsets cpecan_k_pack_pairs writes to, formed on the device so that a run can end with its candidates
+ * packed (the host forms the same sums from the counts it fetches) */
+extern "C" __global__ __launch_bounds__(256) void cpecan_k_pack_base(const DevItem *items, const long long *nPairs,
+                                                                     long long nItems, long long *packBase) {
+    __shared__ long long part[256];
+    const long long per = (nItems + 255) / 256, i0 = threadIdx.x * per, i1 = i0 + per < nItems ? i0 + per : nItems;
+    long long sum = 0;
+    for (long long i = i0; i < i1; i++) sum += nPairs[i] < items[i].pairCap ? nPairs[i] : items[i].pairCap;
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int t = 0; t < 256; t++) {
+            const long long v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        packBase[nItems] = run;
+    }
+    __syncthreads();
+    long long run = part[threadIdx.x];
+    for (long long i = i0; i < i1; i++) {
+        packBase[i] = run;
+        run += nPairs[i] < items[i].pairCap ? nPairs[i] : items[i].pairCap;
     }
 }
 
@@ -1734,6 +1810,7 @@ static int ensure_counts(cpecan_batch *b) {
         return CPECAN_OK;
     }
     if (all > 0) {
+        const bool packedAlready = b->packedInRun && (size_t) all <= b->packed.n; /* the run ended with them packed */
         if (b->packBase.n < (size_t) b->nItems + 1) HIP_TRY(b->packBase.alloc((size_t) b->nItems + 1));
         if (b->packed.n < (size_t) all) {
             HIP_TRY(b->packed.alloc((size_t) all + (size_t) all / 8));
@@ -1748,12 +1825,15 @@ static int ensure_counts(cpecan_batch *b) {
             HIP_TRY(pinned_cache().get((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair)));
             HIP_TRY(pinned_cache().get((void **) &b->hPost, b->hPackedCap * sizeof(int)));
         }
+        if (!packedAlready) {
         HIP_TRY(hipMemcpyAsync(b->packBase.p, b->hPairBase.data(), ((size_t) b->nItems + 1) * sizeof(long long),
                                hipMemcpyHostToDevice, b->ctx->stream));
         hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, b->ctx->stream,
                            (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
-                           (const double *) b->pairLogp.p, b->P.threshold, b->packed.p, b->packedPost.p);
+                           (const double *) b->pairLogp.p, b->P.threshold, (long long) b->packed.n, b->packed.p,
+                           b->packedPost.p);
         HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipMemcpyAsync(b->hPacked, b->packed.p, (size_t) all * sizeof(PackedPair), hipMemcpyDeviceToHost,
                                b->ctx->stream));
         HIP_TRY(hipMemcpyAsync(b->hPost, b->packedPost.p, (size_t) all * sizeof(int), hipMemcpyDeviceToHost,

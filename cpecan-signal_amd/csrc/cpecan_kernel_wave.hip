@@ -34,6 +34,8 @@
 #include "cpecan_device.h"
 #include "cpecan_sweep.h"
 
+#include <vector>
+
 #ifndef WV_L
 #define WV_L 3 /* cells per lane: 1..4 (bands up to 56, 120, 184, 248 k-mers) */
 #endif
@@ -1605,10 +1607,16 @@ template <bool SW> __device__ __forceinline__ void wv_forward_kernel(
     WvState *state = states + idx;
     const DevItem it = uniform_item(items[idx]);
     if (state->finished || it.lX + it.lY == 0) return;
+    const unsigned long long c0 = __builtin_readcyclecounter(), r0 = __builtin_amdgcn_s_memrealtime();
     init_coef(sh.coef);
     forward_window<SW>(it, P, bandTab + it.diagBase, track + trackBase[idx] * WV_ROW, events,
                        models + (long long) it.model * WV_MODEL_DOUBLES, Fring + idx * ringDoubles, ringD, state, window,
                        sh);
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = __builtin_amdgcn_s_memrealtime();
+    if ((threadIdx.x & 63) == 0) {
+        state->clkShader += (long long) (c1 - c0);
+        state->clkRef += (long long) (r1 - r0);
+    }
 }
 extern "C" __global__ __launch_bounds__(64 * WV_WPB) void WV_SYM(cpecan_k_wv_forward)(
     const DevItem *__restrict__ items, long long nItems, DevParams P,
@@ -2071,6 +2079,22 @@ extern "C" int cpecan_wave_launch_track(hipStream_t stream, const DevItem *items
 }
 extern "C" int cpecan_wave_track_row_doubles(void) { return WV_ROW; }
 extern "C" int cpecan_wave_state_bytes(void) { return (int) sizeof(WvState); }
+/* the shader clock the forward sweeps of the last run saw, in MHz (s_memtime ticks over 100 MHz s_memrealtime ticks,
+ * summed over the first alignments of the batch); 0 when nothing ran */
+extern "C" int cpecan_wave_shader_clock_mhz(hipStream_t stream, const void *states, long long nItems, double *mhz) {
+    const long long n = nItems < 64 ? nItems : 64;
+    std::vector<WvState> h((size_t) n);
+    if (hipMemcpyAsync(h.data(), states, (size_t) n * sizeof(WvState), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        return -1;
+    double c = 0, r = 0;
+    for (const WvState &s : h) {
+        c += (double) s.clkShader;
+        r += (double) s.clkRef;
+    }
+    *mhz = r > 0 ? 100.0 * c / r : 0.0;
+    return 0;
+}
 /* results of the per-alignment states into the batch's count arrays */
 extern "C" __global__ void cpecan_k_wv_counts(const WvState *states, long long nItems, long long *nPairs,
                                               long long *nTot, long long *nCells) {

@@ -14,6 +14,8 @@ struct SyState {
     int winValid, winTop, winFrom, winTo, winAtEnd; /* traceback window for the backward kernel */
     int expectPending; /* Baum-Welch: the window's backward cells are in the B ring, not yet summed */
     long long nPairs, nTot, cells;
+    long long clkShader, clkRef; /* shader-clock and 100 MHz reference ticks the alignment's forward sweeps took (the
+                                    ratio is the clock the chip ran at under this load) */
 };
 
 /* The wave kernels' record: the forward kernel of launch w describes its window in win[w & 1] while the backward
@@ -33,6 +35,8 @@ struct WvState {
     int expectPending; /* Baum-Welch: the window's backward cells are in the B ring, not yet summed */
     WvWindow win[2];
     long long nPairs, nTot, cells;
+    long long clkShader, clkRef; /* shader-clock and 100 MHz reference ticks the alignment's forward sweeps took (the
+                                    ratio is the clock the chip ran at under this load) */
 };
 
 /* per-window bookkeeping of one totalProbability refresh, kept in HBM scratch (private to the alignment) */

@@ -235,9 +235,18 @@ int cpecan_hip_batch_create_hdp(cpecan_ctx *ctx, const cpecan_item *items, int64
                                 const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
 
 int cpecan_hip_batch_run(cpecan_batch *batch);
+/* The same, but the batch's kernels start when the last run of `after` (a batch of another context on the same device;
+ * NULL: no condition) has finished -- ordered on the device, no host round trip.  A stream of batches then keeps the
+ * device busy with one pass at a time (the wave-per-alignment kernels fill the register files with one batch) while
+ * the host fetches and finishes the previous batch's pairs and prepares the next one. */
+int cpecan_hip_batch_run_after(cpecan_batch *batch, cpecan_batch *after);
 int cpecan_hip_batch_sync(cpecan_batch *batch);
 /* HIP-event time of the last run's kernels, in ms (after sync). */
 int cpecan_hip_batch_elapsed_ms(cpecan_batch *batch, float *ms_total, float *ms_dp_kernel);
+/* The shader clock (MHz) the chip ran at during the forward sweeps of the batch's last run, from the sweeps' own cycle
+ * and 100 MHz reference counters (wave-per-alignment kernels; 0 on the other kernels).  The sweeps are bound by
+ * instruction issue, so their time follows this clock, and it differs between machines under this fp64 load. */
+int cpecan_hip_batch_shader_clock_mhz(cpecan_batch *batch, double *mhz);
 /* Which kernel the batch uses (CPECAN_KERNEL_GENERAL / _SYSTOLIC after AUTO is resolved), how many
  * workgroups it launches and the widest band (cells) among its items. */
 int cpecan_hip_batch_info(cpecan_batch *batch, int32_t *kernel, int32_t *workgroups, int32_t *max_width);
