@@ -17,6 +17,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 namespace {
 
 thread_local std::string g_err;
@@ -176,4 +178,74 @@ done:
     if (ctx) cpecan_hip_ctx_destroy(ctx);
     if (comm) (void) ncclCommDestroy(comm);
     return rc;
+}
+
+/* ---- the communicator on its own (for cpecan_trainModels of the host library) ---- */
+struct cpecan_em_comm {
+    int device = 0, world = 1;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    double *buf = nullptr;
+    size_t cap = 0;
+};
+
+extern "C" int cpecan_em_comm_create(int device, int rank, int world, const char *idFile, cpecan_em_comm **out) {
+    if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && !idFile)) return fail(CPECAN_EINVAL, "bad argument");
+    *out = nullptr;
+    int rc = CPECAN_OK;
+    cpecan_em_comm *c = new cpecan_em_comm();
+    c->device = device;
+    c->world = world;
+    {
+        ncclUniqueId id;
+        EM_HIP(hipSetDevice(device));
+        EM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        if (rank == 0) EM_NCCL(ncclGetUniqueId(&id));
+        if (world > 1) {
+            rc = exchange_id(idFile, rank, &id);
+            if (rc != CPECAN_OK) goto done;
+        }
+        EM_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+    }
+done:
+    if (rc != CPECAN_OK) {
+        cpecan_em_comm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return CPECAN_OK;
+}
+
+extern "C" void cpecan_em_comm_reduce(void *arg, double *values, int64_t n) {
+    cpecan_em_comm *c = (cpecan_em_comm *) arg;
+    int rc = CPECAN_OK;
+    if (!c || !values || n <= 0) return;
+    EM_HIP(hipSetDevice(c->device));
+    if (c->cap < (size_t) n) {
+        if (c->buf) (void) hipFree(c->buf);
+        c->buf = nullptr;
+        c->cap = 0;
+        EM_HIP(hipMalloc((void **) &c->buf, sizeof(double) * (size_t) n));
+        c->cap = (size_t) n;
+    }
+    EM_HIP(hipMemcpyAsync(c->buf, values, sizeof(double) * (size_t) n, hipMemcpyHostToDevice, c->stream));
+    EM_NCCL(ncclAllReduce(c->buf, c->buf, (size_t) n, ncclDouble, ncclSum, c->comm, c->stream));
+    EM_HIP(hipMemcpyAsync(values, c->buf, sizeof(double) * (size_t) n, hipMemcpyDeviceToHost, c->stream));
+    EM_HIP(hipStreamSynchronize(c->stream));
+done:
+    if (rc != CPECAN_OK) { /* a training loop cannot continue with half a sum: say why and stop, as the host library does */
+        fprintf(stderr, "cpecan_em_comm_reduce: %s\n", g_err.c_str());
+        fflush(nullptr);
+        _exit(1);
+    }
+}
+
+extern "C" int cpecan_em_comm_destroy(cpecan_em_comm *c) {
+    if (!c) return CPECAN_OK;
+    (void) hipSetDevice(c->device);
+    if (c->comm) (void) ncclCommDestroy(c->comm);
+    if (c->buf) (void) hipFree(c->buf);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+    return CPECAN_OK;
 }

@@ -1044,10 +1044,11 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
                             hmm->capacity = hmm->capacity ? 2 * hmm->capacity : 1024;
                             hmm->eventAssignments = realloc(hmm->eventAssignments, sizeof(double) * (size_t) hmm->capacity);
                             hmm->kmerAssignments = realloc(hmm->kmerAssignments, (size_t) hmm->capacity * (KMER_LENGTH + 1));
-                            hmm->assignmentXY = realloc(hmm->assignmentXY, sizeof(int64_t) * 2 * (size_t) hmm->capacity);
+                            hmm->assignmentXY = realloc(hmm->assignmentXY, sizeof(int64_t) * 3 * (size_t) hmm->capacity);
                         }
-                        hmm->assignmentXY[2 * hmm->numberOfAssignments] = x >= 0 ? x : 0;
-                        hmm->assignmentXY[2 * hmm->numberOfAssignments + 1] = y;
+                        hmm->assignmentXY[3 * hmm->numberOfAssignments] = x >= 0 ? x : 0;
+                        hmm->assignmentXY[3 * hmm->numberOfAssignments + 1] = y;
+                        hmm->assignmentXY[3 * hmm->numberOfAssignments + 2] = i;
                         char *dst = hmm->kmerAssignments + hmm->numberOfAssignments * (KMER_LENGTH + 1);
                         memcpy(dst, (const char *) sXs[i]->elements + (x >= 0 ? x : 0), KMER_LENGTH);
                         dst[KMER_LENGTH] = 0;
@@ -1448,64 +1449,157 @@ StateMachine *getStateMachine5(Hmm *hmmD, StateMachineFunctions *sMfs) {
     return (StateMachine *) s;
 }
 
-void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, Sequence *SsX, Sequence *SsY,
-                                 stList *anchorPairs, PairwiseAlignmentParameters *p,
-                                 DiagonalPosteriorProbFn fn, bool raggedL, bool raggedR) {
-    if (fn != diagonalCalculation_Expectations)
-        die("cpecan: the GPU path implements diagonalCalculation_Expectations only");
-    if (hmmExpectations->type != sM->type && !(sM->type == fiveState && hmmExpectations->type == fiveStateAsymmetric))
-        die("cpecan: getExpectationsUsingAnchors: the Hmm (type %d) does not belong to the state machine (type %d)",
-            (int) hmmExpectations->type, (int) sM->type);
-    switch (sM->type) {
+/* The E-step of n reads as ONE batch on the GPU, added to the Hmm through its own add functions -- what
+ * cell_updateExpectations (:407-424) and cell_signal_updateTransAndKmerSkipExpectations(2) (:426-476) do one exp() at
+ * a time.  Every read's state machine must be of the Hmm's type. */
+static void e_step_into_hmm(int64_t n, StateMachine **sMs, Hmm *hmm, Sequence **sXs, Sequence **sYs, stList **anchors,
+                            PairwiseAlignmentParameters *p, bool raggedL, bool raggedR) {
+    if (n <= 0) return;
+    for (int64_t i = 0; i < n; i++)
+        if (hmm->type != sMs[i]->type && !(sMs[i]->type == fiveState && hmm->type == fiveStateAsymmetric))
+            die("cpecan: getExpectationsUsingAnchors: the Hmm (type %d) does not belong to the state machine (type %d)",
+                (int) hmm->type, (int) sMs[i]->type);
+    switch (sMs[0]->type) {
     case fiveState:
     case fiveStateAsymmetric:
-        if (hmmExpectations->stateNumber != 5 || hmmExpectations->symbolSetSize != SYMBOL_NUMBER_NO_N)
+        if (hmm->stateNumber != 5 || hmm->symbolSetSize != SYMBOL_NUMBER_NO_N)
             die("cpecan: the 5-state E-step takes a 5-state, 4-symbol Hmm");
-        run_reads(1, &sM, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR, 1, 0, NULL, hmmExpectations);
+        run_reads(n, sMs, sXs, sYs, anchors, p, raggedL, raggedR, 1, 0, NULL, hmm);
         return;
     case threeState: {
-        /* the sums the reference's cell_signal_updateTransAndKmerSkipExpectations (:426-443) makes one exp() at a
-         * time, taken on the GPU and handed to the Hmm through its own add functions */
         ContinuousPairHmmExpectations *e = calloc(1, sizeof *e);
-        cpecan_getSignalExpectationsUsingAnchors(sM, e, SsX, SsY, anchorPairs, p, raggedL, raggedR);
-        hmmExpectations->likelihood += e->likelihood;
+        run_reads(n, sMs, sXs, sYs, anchors, p, raggedL, raggedR, 1, 0, NULL, e);
+        hmm->likelihood += e->likelihood;
         for (int64_t from = 0; from < 3; from++)
             for (int64_t to = 0; to < 3; to++)
-                hmmExpectations->addToTransitionExpectationFcn(hmmExpectations, from, to, e->transitions[from * 3 + to]);
+                hmm->addToTransitionExpectationFcn(hmm, from, to, e->transitions[from * 3 + to]);
         for (int64_t k = 0; k < NUM_OF_KMERS; k++)
             if (e->individualKmerGapProbs[k] != 0.0)
-                hmmExpectations->addToEmissionExpectationFcn(hmmExpectations, 0, k, 0, e->individualKmerGapProbs[k]);
+                hmm->addToEmissionExpectationFcn(hmm, 0, k, 0, e->individualKmerGapProbs[k]);
         free(e);
         return;
     }
     case vanilla: {
         VanillaHmmExpectations e;
         memset(&e, 0, sizeof e);
-        cpecan_getVanillaExpectationsUsingAnchors(sM, &e, SsX, SsY, anchorPairs, p, raggedL, raggedR);
-        hmmExpectations->likelihood += e.likelihood;
-        for (int64_t bin = 0; bin < 60; bin++)
-            hmmExpectations->addToTransitionExpectationFcn(hmmExpectations, bin, 0, e.kmerSkipBins[bin]);
+        run_reads(n, sMs, sXs, sYs, anchors, p, raggedL, raggedR, 1, 0, NULL, &e);
+        hmm->likelihood += e.likelihood;
+        for (int64_t bin = 0; bin < 60; bin++) hmm->addToTransitionExpectationFcn(hmm, bin, 0, e.kmerSkipBins[bin]);
         return;
     }
     case threeStateHdp: {
-        HdpHmm *h = (HdpHmm *) hmmExpectations;
+        HdpHmm *h = (HdpHmm *) hmm;
         HdpHmmExpectations *e = cpecan_hdpExpectations_construct(0.0, h->threshold);
-        cpecan_getHdpExpectationsUsingAnchors(sM, e, SsX, SsY, anchorPairs, p, raggedL, raggedR);
-        hmmExpectations->likelihood += e->likelihood;
+        run_reads(n, sMs, sXs, sYs, anchors, p, raggedL, raggedR, 1, 0, NULL, e);
+        hmm->likelihood += e->likelihood;
         for (int64_t from = 0; from < 3; from++)
             for (int64_t to = 0; to < 3; to++)
-                hmmExpectations->addToTransitionExpectationFcn(hmmExpectations, from, to, e->transitions[from * 3 + to]);
+                hmm->addToTransitionExpectationFcn(hmm, from, to, e->transitions[from * 3 + to]);
         /* as the reference's cell_signal_updateTransAndKmerSkipExpectations2 does: pointers into SsX and SsY */
-        for (int64_t i = 0; i < e->numberOfAssignments; i++)
-            h->addToAssignments(hmmExpectations, (char *) SsX->elements + e->assignmentXY[2 * i],
-                                (double *) SsY->elements + NB_EVENT_PARAMS * e->assignmentXY[2 * i + 1]);
+        for (int64_t i = 0; i < e->numberOfAssignments; i++) {
+            const int64_t r = e->assignmentXY[3 * i + 2];
+            h->addToAssignments(hmm, (char *) sXs[r]->elements + e->assignmentXY[3 * i],
+                                (double *) sYs[r]->elements + NB_EVENT_PARAMS * e->assignmentXY[3 * i + 1]);
+        }
         cpecan_hdpExpectations_destruct(e);
         return;
     }
     default:
-        die("cpecan: getExpectationsUsingAnchors: no E-step for state machine type %d", (int) sM->type);
+        die("cpecan: getExpectationsUsingAnchors: no E-step for state machine type %d", (int) sMs[0]->type);
     }
 }
+void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, Sequence *SsX, Sequence *SsY,
+                                 stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                 DiagonalPosteriorProbFn fn, bool raggedL, bool raggedR) {
+    if (fn != diagonalCalculation_Expectations)
+        die("cpecan: the GPU path implements diagonalCalculation_Expectations only");
+    e_step_into_hmm(1, &sM, hmmExpectations, &SsX, &SsY, &anchorPairs, p, raggedL, raggedR);
+}
+void getExpectationsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Hmm *hmmExpectations, Sequence **sXs,
+                                      Sequence **sYs, stList **anchors, PairwiseAlignmentParameters *p,
+                                      bool raggedL, bool raggedR) {
+    e_step_into_hmm(n, sMs, hmmExpectations, sXs, sYs, anchors, p, raggedL, raggedR);
+}
+
+/* ---- the training loop (scripts/trainModels.py:244-330 for the signal machines, cPecanEm.py:107-209 for the
+ * discrete one) as one native call: per iteration an empty Hmm with pseudocounts, the E-step of this rank's reads as
+ * one GPU batch, the ranks' expectations summed (reduce), the normalisation, and the new parameters loaded into every
+ * read's state machine; the running likelihood is logged per iteration. ------------------------------------------- */
+static Hmm *empty_hmm_for(StateMachineType type, double pseudocount, double threshold) {
+    if (type == fiveState || type == fiveStateAsymmetric)
+        return hmmDiscrete_constructEmpty(pseudocount, 5, SYMBOL_NUMBER_NO_N, type, hmmDiscrete_addToTransitionExpectation,
+                                          hmmDiscrete_setTransitionExpectation, hmmDiscrete_getTransitionExpectation,
+                                          hmmDiscrete_addToEmissionExpectation, hmmDiscrete_setEmissionExpectation,
+                                          hmmDiscrete_getEmissionExpectation, emissions_discrete_getBaseIndex);
+    return hmmContinuous_getEmptyHmm(type, pseudocount, threshold);
+}
+static void destroy_hmm_of(Hmm *hmm) {
+    if (hmm->type == fiveState || hmm->type == fiveStateAsymmetric) hmmDiscrete_destruct(hmm);
+    else hmmContinuous_destruct(hmm, hmm->type);
+}
+/* the expectation values of an Hmm as one vector (for the all-reduce) and back: likelihood first, then the
+ * "transition" table (the vanilla machine keeps its 60 skip bins there), then the emission table it has */
+static int64_t hmm_vector(Hmm *hmm, double *v, bool store) {
+    int64_t k = 0;
+    if (v) { if (store) hmm->likelihood = v[k]; else v[k] = hmm->likelihood; }
+    k++;
+    if (hmm->type == vanilla) {
+        for (int64_t bin = 0; bin < 60; bin++, k++)
+            if (v) { if (store) hmm->setTransitionFcn(hmm, bin, 0, v[k]); else v[k] = hmm->getTransitionsExpFcn(hmm, bin, 0); }
+        return k;
+    }
+    for (int64_t from = 0; from < hmm->stateNumber; from++)
+        for (int64_t to = 0; to < hmm->stateNumber; to++, k++)
+            if (v) { if (store) hmm->setTransitionFcn(hmm, from, to, v[k]); else v[k] = hmm->getTransitionsExpFcn(hmm, from, to); }
+    if (hmm->type == threeState)
+        for (int64_t i = 0; i < hmm->symbolSetSize; i++, k++)
+            if (v) { if (store) hmm->setEmissionExpectationFcn(hmm, 0, i, 0, v[k]); else v[k] = hmm->getEmissionExpFcn(hmm, 0, i, 0); }
+    if (hmm->type == fiveState || hmm->type == fiveStateAsymmetric)
+        for (int64_t st = 0; st < hmm->stateNumber; st++)
+            for (int64_t x = 0; x < hmm->symbolSetSize; x++)
+                for (int64_t y = 0; y < hmm->symbolSetSize; y++, k++)
+                    if (v) { if (store) hmm->setEmissionExpectationFcn(hmm, st, x, y, v[k]); else v[k] = hmm->getEmissionExpFcn(hmm, st, x, y); }
+    return k;
+}
+Hmm *cpecan_trainModels(int64_t nReads, StateMachine **sMs, Sequence **sXs, Sequence **sYs, stList **anchorPairs,
+                        PairwiseAlignmentParameters *p, bool raggedL, bool raggedR, StateMachineType hmmType,
+                        int64_t iterations, double pseudocount, double hdpThreshold, cpecan_reduce_fn reduce,
+                        void *reduceArg, double *runningLikelihoods) {
+    if (nReads < 0 || iterations < 0 || (nReads > 0 && (!sMs || !sXs || !sYs || !anchorPairs)) || !p)
+        die("cpecan_trainModels: bad argument");
+    Hmm *hmm = NULL;
+    for (int64_t it = 0; it < iterations || !hmm; it++) {
+        if (hmm) destroy_hmm_of(hmm);
+        hmm = empty_hmm_for(hmmType, pseudocount, hdpThreshold);
+        if (iterations == 0) break;
+        e_step_into_hmm(nReads, sMs, hmm, sXs, sYs, anchorPairs, p, raggedL, raggedR);
+        if (reduce) {
+            const int64_t len = hmm_vector(hmm, NULL, false);
+            double *v = malloc(sizeof(double) * (size_t) len);
+            hmm_vector(hmm, v, false);
+            reduce(reduceArg, v, len);
+            hmm_vector(hmm, v, true);
+            free(v);
+        }
+        if (runningLikelihoods) runningLikelihoods[it] = hmm->likelihood;
+        /* the M-step, and the new parameters into every (distinct) state machine of the reads */
+        if (hmm->type == fiveState || hmm->type == fiveStateAsymmetric) hmmDiscrete_normalize2(hmm, true);
+        else if (hmm->type == threeStateHdp) hmmDiscrete_normalize2(hmm, false);
+        else hmmContinuous_normalize(hmm, hmm->type);
+        for (int64_t i = 0; i < nReads; i++) {
+            bool seen = false;
+            for (int64_t k = 0; k < i && !seen; k++) seen = sMs[k] == sMs[i];
+            if (seen) continue;
+            if (hmm->type == fiveState) sm5_load_symmetric((StateMachine5 *) sMs[i], hmm);
+            else if (hmm->type == fiveStateAsymmetric) sm5_load_asymmetric((StateMachine5 *) sMs[i], hmm);
+            else if (hmm->type == threeState) continuousPairHmm_loadTransitionsAndKmerGapProbs(sMs[i], hmm);
+            else if (hmm->type == vanilla) vanillaHmm_loadKmerSkipBinExpectations(sMs[i], hmm);
+            else hdpHmm_loadTransitions(sMs[i], hmm);
+        }
+    }
+    return hmm;
+}
+
 void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY, int64_t lX, int64_t lY,
                      PairwiseAlignmentParameters *p, void *(*getFcn)(void *, int64_t),
                      stList *(*getAnchorPairFcn)(void *, void *, PairwiseAlignmentParameters *),

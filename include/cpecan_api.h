@@ -388,8 +388,9 @@ typedef struct _hdpHmmExpectations {
     int64_t capacity;
     double *eventAssignments;  /* [numberOfAssignments] event means */
     char *kmerAssignments;     /* [numberOfAssignments][KMER_LENGTH + 1], NUL-terminated copies */
-    int64_t *assignmentXY;     /* [numberOfAssignments][2]: where the k-mer and the event sit in the caller's SsX / SsY
-                                  (E-step only; NULL on an object read from a file) */
+    int64_t *assignmentXY;     /* [numberOfAssignments][3]: where the k-mer and the event sit in the caller's SsX / SsY
+                                  and which read of the call they belong to (E-step only; NULL on an object read
+                                  from a file) */
 } HdpHmmExpectations;
 HdpHmmExpectations *cpecan_hdpExpectations_construct(double pseudocount, double threshold);
 void cpecan_hdpExpectations_destruct(HdpHmmExpectations *hmm);
@@ -501,6 +502,30 @@ stList **getAlignedPairsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Sequenc
                                           stList **anchors, PairwiseAlignmentParameters *p,
                                           bool alignmentHasRaggedLeftEnd,
                                           bool alignmentHasRaggedRightEnd);
+
+/* The E-step of n reads as one batch (getExpectationsUsingAnchors :1571 per read, summed into one Hmm of the
+ * machines' type): read i uses sMs[i] as above. */
+void getExpectationsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Hmm *hmmExpectations, Sequence **sXs,
+                                      Sequence **sYs, stList **anchors, PairwiseAlignmentParameters *p,
+                                      bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+/* The training loop as one native call -- what scripts/trainModels.py:244-330 (signal machines) and
+ * cPecanEm.py:107-209 (discrete machine) drive through files and one process per read: `iterations` times an empty
+ * Hmm of hmmType with `pseudocount` (hmmContinuous_getEmptyHmm :913 / hmmDiscrete_constructEmpty), the E-step of the
+ * nReads reads as one GPU batch, the sum over the ranks of a multi-GPU job (reduce(reduceArg, values, n) sums the
+ * vector over all ranks in place; NULL for one rank -- libcpecan_em.so's cpecan_em_comm_reduce does it with one RCCL
+ * all-reduce), the normalisation (hmmDiscrete_normalize2 / continuousPairHmm_normalize /
+ * vanillaHmm_normalizeKmerSkipBins), and the new parameters loaded into every read's state machine
+ * (hmmDiscrete loaders of getStateMachine5 / continuousPairHmm_loadTransitionsAndKmerGapProbs /
+ * vanillaHmm_loadKmerSkipBinExpectations / hdpHmm_loadTransitions -- the HDP machine's emission update is the Gibbs
+ * sampler, out of scope: its Hmm returns with the event assignments of the last iteration).
+ * runningLikelihoods[iteration] receives the summed log-likelihood the iteration started from.  Returns the
+ * normalised Hmm of the last iteration (caller destructs it with hmmDiscrete_destruct / hmmContinuous_destruct). */
+typedef void (*cpecan_reduce_fn)(void *arg, double *values, int64_t n);
+Hmm *cpecan_trainModels(int64_t nReads, StateMachine **sMs, Sequence **sXs, Sequence **sYs, stList **anchorPairs,
+                        PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,
+                        bool alignmentHasRaggedRightEnd, StateMachineType hmmType, int64_t iterations,
+                        double pseudocount, double hdpThreshold, cpecan_reduce_fn reduce, void *reduceArg,
+                        double *runningLikelihoods);
 
 /* ---- the reference's own signal-EM interface (inc/continuousHmm.h:7-124): Hmm subclasses and their functions,
  * same structs, names and signatures.  getExpectationsUsingAnchors (below, with the 5-state entry) dispatches on

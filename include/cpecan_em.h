@@ -48,6 +48,15 @@ int cpecan_em_run(const cpecan_em_input *in, int32_t iterations, double pseudoco
                   double *gap_x, double *running_likelihood);
 const char *cpecan_em_last_error(void);
 
+/* The ranks' communicator on its own, for the host library's training loop (cpecan_trainModels, include/cpecan_api.h:
+ * any of the four machines): create once per process, hand cpecan_em_comm_reduce and the communicator to
+ * cpecan_trainModels as its `reduce` / `reduceArg`.  The vector goes to the device, through ONE ncclAllReduce (sum)
+ * and back; world = 1 needs no id file. */
+typedef struct cpecan_em_comm cpecan_em_comm;
+int cpecan_em_comm_create(int device, int rank, int world, const char *id_file, cpecan_em_comm **out);
+void cpecan_em_comm_reduce(void *comm /* cpecan_em_comm* */, double *values, int64_t n);
+int cpecan_em_comm_destroy(cpecan_em_comm *comm);
+
 #ifdef __cplusplus
 }
 #endif
