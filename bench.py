@@ -536,6 +536,10 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
         sys.exit("--mode service is a one-GPU measurement")
     n = args.warmup + args.steps
     data = [synth.make_batch(3 + 10 * k, args.reads, args.kmers, args.events, anchor_every=50) for k in range(min(n, 4))]
+    family = "workgroup" if args.family == "auto" else args.family
+    flags = cp.FLAG_WORKGROUP_KERNELS if family == "workgroup" else 0
+    if family == "workgroup" and "CPECAN_SYSTOLIC_GROUPS" not in os.environ:
+        os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"  # one stream group per batch: two batches' kernels overlap
     NSLOT = 3  # one batch running, one queued behind it on the device, one being prepared / finished by the host
     ctxs = [cp.Context(local_rank) for _ in range(NSLOT)]
     slot = [None] * NSLOT
@@ -553,13 +557,15 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
         t_models.append(time.perf_counter() - t0)
         t1 = time.perf_counter()
         slot[k % NSLOT] = cp.Batch(cx, items[k % len(data)], bt["x_chars"], bt["events"], bt["anchors"], bp,
-                               cp.MODE_POSTERIOR, args.kernel, 0)
+                               cp.MODE_POSTERIOR, args.kernel, flags)
         t_batch.append(time.perf_counter() - t1)
         t_prep.append(time.perf_counter() - t0)
 
     def prepare_and_queue(k):
         prepare(k)
-        slot[k % NSLOT].run(after=slot[(k - 1) % NSLOT] if k > 0 else None)  # ordered on the device, no host round trip
+        # wave kernels: one pass at a time, ordered on the device (no host round trip); workgroup kernels: the queued
+        # batch's kernels overlap the running one's
+        slot[k % NSLOT].run(after=slot[(k - 1) % NSLOT] if (k > 0 and family == "wave") else None)
 
     prepare_and_queue(0)
     if n > 1:
@@ -593,6 +599,7 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
         "gcells_per_s": round(cells / elapsed / 1e9, 3),
         "config": {"workload": "a stream of BASELINE configs[2] batches (%d reads x %d events x %d k-mers), each prepared "
                                "from host buffers, aligned once, pairs finished on the host" % (args.reads, args.events, args.kmers),
+                   "kernels": family + "-per-alignment",
                    "model_tables": "scaled by the caller, derived on the host" if args.host_tables else "scaled and assembled on the device (cpecan_hip_models_create_scaled)",
                    "host_prepare_ms_per_batch": round(1e3 * float(np.mean(t_prep[args.warmup:])), 1),
                    "of_which_model_tables_ms": round(1e3 * float(np.mean(t_models[args.warmup:])), 1),

@@ -13,6 +13,7 @@
 
 #include "cpecan_hip.h"
 
+#include <ctype.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdarg.h>
@@ -1612,6 +1613,125 @@ void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY,
     sequence_sequenceDestroy(SsX);
     sequence_sequenceDestroy(SsY);
     stList_destruct(anchorPairs);
+}
+
+/* ---- anchor generation (impl/pairwiseAligner.c:1065-1281): host code around an EXTERNAL aligner.  As in the
+ * reference, the anchors come from lastz run through a pipe (the reference calls "./cPecanLastz", built from its
+ * externalTools/; CPECAN_LASTZ names another executable) and read back in exonerate CIGAR format; nothing of this
+ * runs on the GPU.  Callers that bring a guide alignment (vanillaAlign) never come here. -------------------------- */
+static int cmp_by_x_plus_y(const void *a, const void *b) { /* sortByXPlusYCoordinate on (x, y) pairs (:1011-1015) */
+    const int64_t k = stIntTuple_get((stIntTuple *) a, 0) + stIntTuple_get((stIntTuple *) a, 1);
+    const int64_t l = stIntTuple_get((stIntTuple *) b, 0) + stIntTuple_get((stIntTuple *) b, 1);
+    return k > l ? 1 : (k < l ? -1 : 0);
+}
+static char *temp_fasta(const char *name, const char *seq, bool upper) {
+    char *path = malloc(64);
+    strcpy(path, "/tmp/cpecan_lastz_XXXXXX");
+    const int fd = mkstemp(path);
+    if (fd < 0) die("cpecan: getBlastPairs: cannot create a temporary file");
+    FILE *f = fdopen(fd, "w");
+    fprintf(f, ">%s\n", name);
+    for (const char *c = seq; *c; c++) fputc(upper ? toupper((unsigned char) *c) : *c, f);
+    fputc('\n', f);
+    fclose(f);
+    return path;
+}
+/* one "cigar: <seq2> s e strand <seq1> s e strand score (op length)*" line into anchor pairs: the columns of its
+ * match operations, trimmed by `trim` at both ends (convertPairwiseForwardStrandAlignmentToAnchorPairs :1036-1063) */
+static void cigar_line_to_anchor_pairs(char *line, int64_t trim, stList *out) {
+    char c2[256], c1[256], st2, st1;
+    long long s2, e2, s1, e1;
+    double score;
+    int used = 0;
+    if (sscanf(line, "cigar: %255s %lld %lld %c %255s %lld %lld %c %lf%n", c2, &s2, &e2, &st2, c1, &s1, &e1, &st1, &score,
+               &used) != 9)
+        return;
+    if (strcmp(c1, "a") != 0 || strcmp(c2, "b") != 0 || st1 != '+' || st2 != '+')
+        die("cpecan: getBlastPairs: unexpected alignment line from lastz: %s", line);
+    int64_t j = s1, k = s2;
+    char *q = line + used;
+    for (;;) {
+        char op;
+        long long len;
+        int n = 0;
+        if (sscanf(q, " %c %lld%n", &op, &len, &n) != 2) break;
+        q += n;
+        if (op == 'M')
+            for (int64_t l = trim; l < len - trim; l++) stList_append(out, stIntTuple_construct2(j + l, k + l));
+        if (op != 'I') j += len; /* 'I': sequence 2 only (PAIRWISE_INDEL_Y) */
+        if (op != 'D') k += len; /* 'D': sequence 1 only (PAIRWISE_INDEL_X) */
+    }
+    if (j != e1 || k != e2) die("cpecan: getBlastPairs: the operations of an alignment line do not add up: %s", line);
+}
+stList *getBlastPairs(const char *sX, const char *sY, int64_t trim, bool repeatMask) {
+    stList *pairs = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    const size_t lX = strlen(sX), lY = strlen(sY);
+    if (lX == 0 || lY == 0) return pairs;
+    const char *lastz = getenv("CPECAN_LASTZ") ? getenv("CPECAN_LASTZ") : "./cPecanLastz";
+    /* (the reference pipes a short Y through echo; two files either way here: same sequences, same options) */
+    char *fa = temp_fasta("a", sX, !repeatMask), *fb = temp_fasta("b", sY, !repeatMask);
+    const size_t room = strlen(lastz) + 256 + 2 * 64;
+    char *command = malloc(room);
+    snprintf(command, room, "%s --hspthresh=1800 --chain --strand=plus --gapped --format=cigar --gap=100,100 "
+                            "--ambiguous=iupac,100,100 %s %s", lastz, fa, fb);
+    FILE *fh = popen(command, "r");
+    if (!fh) die("cpecan: getBlastPairs: problems with the lastz pipe (%s)", command);
+    char *line = NULL;
+    size_t cap = 0;
+    while (getline(&line, &cap, fh) >= 0) cigar_line_to_anchor_pairs(line, trim, pairs);
+    free(line);
+    const int status = pclose(fh);
+    remove(fa);
+    remove(fb);
+    if (status != 0) die("cpecan: getBlastPairs: '%s' ended with status %d", command, status);
+    free(command);
+    free(fa);
+    free(fb);
+    stList_sort(pairs, cmp_by_x_plus_y); /* increasing coordinates */
+    return pairs;
+}
+/* anchors inside a gap between top-level anchors that is still too large, without repeat masking (:1201-1226) */
+static void blast_pairs_in_gap(const char *sX, const char *sY, int64_t pX, int64_t pY, int64_t x, int64_t y,
+                               PairwiseAlignmentParameters *p, stList *combined) {
+    const int64_t lX2 = x - pX, lY2 = y - pY;
+    if (lX2 * lY2 <= p->repeatMaskMatrixBiggerThanThis) return;
+    char *sX2 = malloc((size_t) lX2 + 1), *sY2 = malloc((size_t) lY2 + 1);
+    memcpy(sX2, sX + pX, (size_t) lX2); sX2[lX2] = 0;
+    memcpy(sY2, sY + pY, (size_t) lY2); sY2[lY2] = 0;
+    stList *unfiltered = getBlastPairs(sX2, sY2, p->constraintDiagonalTrim, 0);
+    stList_sort(unfiltered, stIntTuple_cmpFn);
+    stList *bottom = filterToRemoveOverlap(unfiltered);
+    stList_destruct(unfiltered);
+    for (int64_t k = 0; k < stList_length(bottom); k++) {
+        stIntTuple *t = stList_get(bottom, k);
+        stList_append(combined, stIntTuple_construct2(stIntTuple_get(t, 0) + pX, stIntTuple_get(t, 1) + pY));
+    }
+    stList_destruct(bottom);
+    free(sX2);
+    free(sY2);
+}
+stList *getBlastPairsForPairwiseAlignmentParameters(void *sX, void *sY, PairwiseAlignmentParameters *p) {
+    const char *cX = sX, *cY = sY;
+    const int64_t lX = (int64_t) strlen(cX), lY = (int64_t) strlen(cY);
+    if (lX * lY <= p->anchorMatrixBiggerThanThis) return stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    stList *unfiltered = getBlastPairs(cX, cY, p->constraintDiagonalTrim, 1);
+    stList_sort(unfiltered, stIntTuple_cmpFn);
+    stList *top = filterToRemoveOverlap(unfiltered);
+    stList_destruct(unfiltered);
+    stList *combined = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    int64_t pX = 0, pY = 0;
+    for (int64_t i = 0; i < stList_length(top); i++) {
+        stIntTuple *t = stList_get(top, i);
+        const int64_t x = stIntTuple_get(t, 0), y = stIntTuple_get(t, 1);
+        if (x < pX || y < pY || x >= lX || y >= lY) die("cpecan: getBlastPairs: anchors out of order or out of range");
+        blast_pairs_in_gap(cX, cY, pX, pY, x, y, p, combined);
+        stList_append(combined, stIntTuple_construct2(x, y));
+        pX = x + 1;
+        pY = y + 1;
+    }
+    blast_pairs_in_gap(cX, cY, pX, pY, lX, lY, p, combined);
+    stList_destruct(top);
+    return combined;
 }
 
 /* ---- re-weighting (impl/pairwiseAligner.c:1619-1667) -------------------------------------------------- */

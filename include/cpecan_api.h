@@ -503,6 +503,15 @@ stList **getAlignedPairsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Sequenc
                                           bool alignmentHasRaggedLeftEnd,
                                           bool alignmentHasRaggedRightEnd);
 
+/* Anchor generation (impl/pairwiseAligner.c:1065-1281, inc/pairwiseAligner.h:320-322): host code around the external
+ * lastz executable, exactly as in the reference ("./cPecanLastz" in the working directory, or the executable the
+ * environment variable CPECAN_LASTZ names), read back as exonerate CIGAR lines; match columns trimmed by `trim`,
+ * sorted by x + y.  getBlastPairsForPairwiseAlignmentParameters adds the reference's filtering and its second,
+ * un-masked pass inside gaps larger than repeatMaskMatrixBiggerThanThis; it is the getAnchorPairFcn the reference
+ * hands to getAlignedPairs / getExpectations. */
+stList *getBlastPairs(const char *sX, const char *sY, int64_t trim, bool repeatMask);
+stList *getBlastPairsForPairwiseAlignmentParameters(void *sX, void *sY, PairwiseAlignmentParameters *p);
+
 /* The E-step of n reads as one batch (getExpectationsUsingAnchors :1571 per read, summed into one Hmm of the
  * machines' type): read i uses sMs[i] as above. */
 void getExpectationsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Hmm *hmmExpectations, Sequence **sXs,
