@@ -2,6 +2,8 @@
 anchor spacing, band expansion (all four builds of the systolic kernels, and the general kernel where the band is
 too wide), traceback spacing and margin (including windows shorter than the margin), threshold, ragged ends.
 Same bar as everywhere: totals and posterior exponents bit-identical, pairs in the reference's order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,9 @@ import synth
 from harness import assert_same_pairs, band_params, cp, run_gpu, run_oracle_item
 
 pytestmark = pytest.mark.gpu
+
+# CPECAN_FUZZ_SCALE=N runs N times as many cases of every kind (the first ones are the default run's)
+SCALE = max(1, int(os.environ.get("CPECAN_FUZZ_SCALE", "1")))
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +39,7 @@ def cases(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", cases(40, 20251004), ids=lambda c: "s%d" % c["seed"])
+@pytest.mark.parametrize("case", cases(40 * SCALE, 20251004), ids=lambda c: "s%d" % c["seed"])
 def test_random_case(ctx, case):
     batch = synth.make_batch(case["seed"], 2, case["lX"], case["lY"], anchor_every=case["every"])
     bp = band_params(case["thr"], case["md"], case["tb"], case["e"])
@@ -52,7 +57,7 @@ def test_random_case(ctx, case):
         assert_same_pairs(res[i], ref)
 
 
-@pytest.mark.parametrize("case", cases(10, 77), ids=lambda c: "v%d" % c["seed"])
+@pytest.mark.parametrize("case", cases(10 * SCALE, 77), ids=lambda c: "v%d" % c["seed"])
 def test_random_case_vanilla(ctx, case):
     import pyoracle as o
     import test_vanilla_gpu as tv
@@ -61,7 +66,7 @@ def test_random_case_vanilla(ctx, case):
     tv.run(ctx, batch, models, band_params(case["thr"], case["md"], case["tb"], case["e"]), case["ragged"])
 
 
-@pytest.mark.parametrize("case", cases(10, 99), ids=lambda c: "d%d" % c["seed"])
+@pytest.mark.parametrize("case", cases(10 * SCALE, 99), ids=lambda c: "d%d" % c["seed"])
 def test_random_case_dna(ctx, case):
     import test_dna5_gpu as td
     rng = np.random.default_rng(case["seed"])
@@ -73,7 +78,7 @@ def test_random_case_dna(ctx, case):
     td.run_case(ctx, seqs, band_params(case["thr"], case["md"], case["tb"], case["e"]), case["ragged"])
 
 
-@pytest.mark.parametrize("case", cases(14, 4242), ids=lambda c: "h%d" % c["seed"])
+@pytest.mark.parametrize("case", cases(14 * SCALE, 4242), ids=lambda c: "h%d" % c["seed"])
 def test_random_case_hdp(ctx, case, golden_dir):
     """the HDP machine over the same random shapes: the wave-per-alignment HDP kernels where the band fits (two,
     three or four cells per lane), the general kernel where it does not -- totals, exponents and pairs identical to
