@@ -1619,11 +1619,6 @@ void getExpectations(StateMachine *sM, Hmm *hmmExpectations, void *sX, void *sY,
  * reference, the anchors come from lastz run through a pipe (the reference calls "./cPecanLastz", built from its
  * externalTools/; CPECAN_LASTZ names another executable) and read back in exonerate CIGAR format; nothing of this
  * runs on the GPU.  Callers that bring a guide alignment (vanillaAlign) never come here. -------------------------- */
-static int cmp_by_x_plus_y(const void *a, const void *b) { /* sortByXPlusYCoordinate on (x, y) pairs (:1011-1015) */
-    const int64_t k = stIntTuple_get((stIntTuple *) a, 0) + stIntTuple_get((stIntTuple *) a, 1);
-    const int64_t l = stIntTuple_get((stIntTuple *) b, 0) + stIntTuple_get((stIntTuple *) b, 1);
-    return k > l ? 1 : (k < l ? -1 : 0);
-}
 static char *temp_fasta(const char *name, const char *seq, bool upper) {
     char *path = malloc(64);
     strcpy(path, "/tmp/cpecan_lastz_XXXXXX");
@@ -1687,7 +1682,7 @@ stList *getBlastPairs(const char *sX, const char *sY, int64_t trim, bool repeatM
     free(command);
     free(fa);
     free(fb);
-    stList_sort(pairs, cmp_by_x_plus_y); /* increasing coordinates */
+    stList_sort(pairs, sortByXPlusYCoordinate); /* increasing coordinates */
     return pairs;
 }
 /* anchors inside a gap between top-level anchors that is still too large, without repeat masking (:1201-1226) */

@@ -60,6 +60,98 @@ double emissions_signal_getEventMatchProbWithTwoDists(const double *eventModel, 
     const double noise = log_inverse_gaussian(e[1], model_entry(eventModel, k, 2), model_entry(eventModel, k, 4));
     return level + noise;
 }
+int64_t emissions_signal_getKmerSkipBin(double *matchModel, void *kmers);
+/* ---- small emission helpers the reference exports beside the ones its machines use (impl/stateMachine.c,
+ * impl/emissionMatrix.c): host functions for callers that assemble machines of their own from them ---- */
+/* the 25 x 25 match table of two-base "k-mers" over ACGTN (impl/emissionMatrix.c:11-53): the sum of the two bases'
+ * log-probabilities -- identical, transition (A<->G, C<->T), transversion, or N */
+void emissions_kmer_setMatchProbsToDefaults(double *emissionMatchProbs) {
+    const double M = -2.1149196655034745, V = -4.5691014376830479, S = -3.9833860032220842, N = -2.772588722;
+    for (int a = 0; a < 25; a++)
+        for (int b = 0; b < 25; b++) {
+            double e[2];
+            for (int pos = 0; pos < 2; pos++) {
+                const int x = pos == 0 ? a / 5 : a % 5, y = pos == 0 ? b / 5 : b % 5;
+                e[pos] = x == 4 || y == 4 ? N : x == y ? M : (x ^ y) == 2 ? S : V;
+            }
+            emissionMatchProbs[a * 25 + b] = e[0] + e[1];
+        }
+}
+void emissions_kmer_setGapProbsToDefaults(double *emissionGapProbs) { /* :55-69: log(0.2) + log(0.2) */
+    for (int i = 0; i < 25; i++) emissionGapProbs[i] = -3.2188758248682006;
+}
+void emissions_discrete_initEmissionsToZero(StateMachine *sM) { /* :94-102 */
+    const size_t n = (size_t) sM->parameterSetSize;
+    sM->EMISSION_GAP_X_PROBS = calloc(n, sizeof(double));
+    sM->EMISSION_GAP_Y_PROBS = calloc(n, sizeof(double));
+    sM->EMISSION_MATCH_PROBS = calloc(n * n, sizeof(double));
+}
+double emissions_kmer_getMatchProb(const double *emissionMatchProbs, void *x, void *y) { /* :189-194 */
+    return emissionMatchProbs[emissions_discrete_getKmerIndex(x) * NUM_OF_KMERS + emissions_discrete_getKmerIndex(y)];
+}
+double emissions_signal_logGaussMatchProb(const double *eventModel, void *kmer, void *event) { /* :473-497 */
+    const int64_t k = emissions_discrete_getKmerIndex((char *) kmer + 1);
+    const double sd = model_entry(eventModel, k, 1), a = (*(double *) event - model_entry(eventModel, k, 0)) / sd;
+    return log(0.3989422804014327) - log(sd) + (-0.5 * a * a);
+}
+double emissions_signal_getBivariateGaussPdfMatchProb(const double *eventModel, void *kmer, void *event) { /* :556-593 */
+    const double *e = event;
+    const double rho = eventModel[0], rhoSq = rho * rho;
+    const int64_t k = emissions_discrete_getKmerIndex((char *) kmer + 1);
+    const double levelMean = model_entry(eventModel, k, 0), levelSd = model_entry(eventModel, k, 1);
+    const double noiseMean = model_entry(eventModel, k, 2), noiseSd = model_entry(eventModel, k, 3);
+    const double expC = -1 / (2 * (1 - rhoSq));
+    const double xu = (e[0] - levelMean) / levelSd, yu = (e[1] - noiseMean) / noiseSd;
+    const double a = expC * ((xu * xu) + (yu * yu) - (2 * rho * xu * yu));
+    return (-1.8378770664093453 - log(levelSd * noiseSd * sqrt(1 - rhoSq))) + a;
+}
+/* the posterior of n k-mers given the event's duration under a Poisson model (:345-370, :551-554) */
+double emissions_signal_getDurationProb(void *event, int64_t n) {
+    static const double logFactorial[6] = { 0.0, 0.0, 0.69314718056, 1.79175946923, 3.17805383035, 4.78749174278 };
+    if (n < 0 || n > 5) die("emissions_signal_getDurationProb: n = %lld (at most 5)", (long long) n);
+    const double lambda = ((double *) event)[2] / 0.00332005312085;
+    return (n + 1) * 0.1397619423751586 + n * log(lambda) - logFactorial[n] - 2 * lambda;
+}
+/* the skip probability of the bin the two k-mers' level difference falls in -- NOT in log space (:429-471) */
+double emissions_signal_getKmerSkipProb(StateMachine *sM, void *kmers) {
+    return sM->EMISSION_GAP_X_PROBS[emissions_signal_getKmerSkipBin(sM->EMISSION_MATCH_PROBS, kmers)];
+}
+void emissions_signal_scaleModelNoiseOnly(StateMachine *sM, double scale, double shift, double var, double scale_sd,
+                                          double var_sd) { /* :653-672: emissions_signal_scaleModel without the level mean */
+    (void) scale; (void) shift;
+    double *m = sM->EMISSION_MATCH_PROBS;
+    for (int64_t i = 1; i < (sM->parameterSetSize * MODEL_PARAMS) + 1; i += MODEL_PARAMS) {
+        m[i + 1] = m[i + 1] * var;
+        m[i + 2] = m[i + 2] * scale_sd;
+        m[i + 4] = m[i + 4] * var_sd;
+        m[i + 3] = sqrt(pow(m[i + 2], 3.0) / m[i + 4]);
+    }
+}
+void stateMachine3_setTransitionsToNucleotideDefaults(StateMachine *sM) { /* :1265-1276 */
+    StateMachine3 *s = (StateMachine3 *) sM;
+    s->TRANSITION_MATCH_CONTINUE = -0.030064059121770816;
+    s->TRANSITION_MATCH_FROM_GAP_X = s->TRANSITION_MATCH_FROM_GAP_Y = -1.272871422049609;
+    s->TRANSITION_GAP_OPEN_X = s->TRANSITION_GAP_OPEN_Y = -4.21256642;
+    s->TRANSITION_GAP_EXTEND_X = s->TRANSITION_GAP_EXTEND_Y = -0.3388262689231553;
+    s->TRANSITION_GAP_SWITCH_TO_X = s->TRANSITION_GAP_SWITCH_TO_Y = -4.910694825551255;
+}
+char *diagonal_getString(Diagonal diagonal) { /* impl/pairwiseAligner.c:81-84; the caller frees */
+    char *out = malloc(128);
+    snprintf(out, 128, "Diagonal, xay: %lld xmyL %lld, xmyR: %lld", (long long) diagonal.xay, (long long) diagonal.xmyL,
+             (long long) diagonal.xmyR);
+    return out;
+}
+int sortByXPlusYCoordinate(const void *i, const void *j) { /* :1011-1015: (x, y) pairs */
+    const int64_t k = stIntTuple_get((stIntTuple *) i, 0) + stIntTuple_get((stIntTuple *) i, 1);
+    const int64_t l = stIntTuple_get((stIntTuple *) j, 0) + stIntTuple_get((stIntTuple *) j, 1);
+    return k > l ? 1 : (k < l ? -1 : 0);
+}
+int sortByXPlusYCoordinate2(const void *i, const void *j) { /* :1019-1023: (score, x, y) triples */
+    const int64_t k = stIntTuple_get((stIntTuple *) i, 1) + stIntTuple_get((stIntTuple *) i, 2);
+    const int64_t l = stIntTuple_get((stIntTuple *) j, 1) + stIntTuple_get((stIntTuple *) j, 2);
+    return k > l ? 1 : (k < l ? -1 : 0);
+}
+
 int64_t emissions_signal_getKmerSkipBin(double *matchModel, void *kmers) {
     const int64_t before = emissions_discrete_getKmerIndex(kmers);
     const int64_t here = emissions_discrete_getKmerIndex((char *) kmers + 1);
@@ -630,6 +722,28 @@ void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMat
         if (posterior < p->threshold) continue;
         if (posterior > 1.0) posterior = 1.0;
         stList_append(alignedPairs, stIntTuple_construct3((int64_t) floor(posterior * PAIR_ALIGNMENT_PROB_1), x - 1, y - 1));
+    }
+}
+/* the echelon machine's decode (:797-839): states matchState .. 5 of a cell, state s standing for s k-mers.  Host
+ * only, like every function of this block; the echelon machine itself is not built (the reference marks it broken). */
+void diagonalCalculationMultiPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,
+                                                 DpMatrix *backwardDpMatrix, Sequence *sX, Sequence *sY,
+                                                 double totalProbability, PairwiseAlignmentParameters *p,
+                                                 void *extraArgs) {
+    (void) sX; (void) sY;
+    stList *alignedPairs = ((void **) extraArgs)[0];
+    DpDiagonal *f = dpMatrix_getDiagonal(forwardDpMatrix, xay), *b = dpMatrix_getDiagonal(backwardDpMatrix, xay);
+    for (int64_t xmy = f->diagonal.xmyL; xmy <= f->diagonal.xmyR; xmy += 2) {
+        const int64_t x = diagonal_getXCoordinate(xay, xmy), y = diagonal_getYCoordinate(xay, xmy);
+        if (x <= 0 || y <= 0) continue;
+        for (int64_t s = sM->matchState; s < 6 && s < sM->stateNumber; s++) {
+            double posterior = exp(dpDiagonal_getCell(f, xmy)[s] + dpDiagonal_getCell(b, xmy)[s] - totalProbability);
+            if (posterior < p->threshold) continue;
+            if (posterior > 1.0) posterior = 1.0;
+            for (int64_t n = 0; n < s; n++)
+                stList_append(alignedPairs,
+                              stIntTuple_construct3((int64_t) floor(posterior * PAIR_ALIGNMENT_PROB_1), x + n - 1, y - 1));
+        }
     }
 }
 void diagonalCalculation_Expectations(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,

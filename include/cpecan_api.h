@@ -503,6 +503,27 @@ stList **getAlignedPairsUsingAnchorsBatch(int64_t n, StateMachine **sMs, Sequenc
                                           bool alignmentHasRaggedLeftEnd,
                                           bool alignmentHasRaggedRightEnd);
 
+/* Small exported helpers of the reference that none of its four GPU-backed machines calls (inc/stateMachine.h,
+ * inc/emissionMatrix.h, inc/pairwiseAligner.h): plain host functions, same names, signatures and arithmetic. */
+void emissions_kmer_setMatchProbsToDefaults(double *emissionMatchProbs);  /* [625] impl/emissionMatrix.c:11 */
+void emissions_kmer_setGapProbsToDefaults(double *emissionGapProbs);      /* [25]  impl/emissionMatrix.c:55 */
+void emissions_discrete_initEmissionsToZero(StateMachine *sM);            /* impl/stateMachine.c:94 */
+double emissions_kmer_getMatchProb(const double *emissionMatchProbs, void *x, void *y);               /* :189 */
+double emissions_signal_logGaussMatchProb(const double *eventModel, void *kmer, void *event);         /* :473 */
+double emissions_signal_getBivariateGaussPdfMatchProb(const double *eventModel, void *kmer, void *event); /* :556 */
+double emissions_signal_getDurationProb(void *event, int64_t n);                                      /* :551 */
+double emissions_signal_getKmerSkipProb(StateMachine *sM, void *kmers);                               /* :429 */
+void emissions_signal_scaleModelNoiseOnly(StateMachine *sM, double scale, double shift, double var, double scale_sd,
+                                          double var_sd);                                             /* :653 */
+void stateMachine3_setTransitionsToNucleotideDefaults(StateMachine *sM);                              /* :1265 */
+char *diagonal_getString(Diagonal diagonal);                              /* impl/pairwiseAligner.c:81; caller frees */
+int sortByXPlusYCoordinate(const void *i, const void *j);                 /* :1011 */
+int sortByXPlusYCoordinate2(const void *i, const void *j);                /* :1019 */
+void diagonalCalculationMultiPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix,
+                                                 DpMatrix *backwardDpMatrix, Sequence *sX, Sequence *sY,
+                                                 double totalProbability, PairwiseAlignmentParameters *p,
+                                                 void *extraArgs);        /* :797 */
+
 /* Anchor generation (impl/pairwiseAligner.c:1065-1281, inc/pairwiseAligner.h:320-322): host code around the external
  * lastz executable, exactly as in the reference ("./cPecanLastz" in the working directory, or the executable the
  * environment variable CPECAN_LASTZ names), read back as exonerate CIGAR lines; match columns trimmed by `trim`,

@@ -299,6 +299,138 @@ static Sequence *kmer_sequence(char *chars, void *(*get)(void *, int64_t)) {
                                sequence_sliceNucleotideSequence2);
 }
 
+/* the small exported helpers none of the four GPU-backed machines calls (include/cpecan_api.h, "Small exported
+ * helpers"): values against the reference's literal tables and formulas */
+static void test_small_helpers(const char *model) {
+    const double M = -2.1149196655034745, V = -4.5691014376830479, S = -3.9833860032220842, N = -2.772588722;
+    double mm[625], gg[25];
+    emissions_kmer_setMatchProbsToDefaults(mm);
+    emissions_kmer_setGapProbsToDefaults(gg);
+    /* rows AA, AC, CA, NA of impl/emissionMatrix.c:22-47 */
+    CHECK(mm[0] == M + M && mm[1] == M + V && mm[2] == M + S && mm[3] == M + V && mm[4] == M + N && mm[5] == V + M);
+    CHECK(mm[25 + 0] == M + V && mm[25 + 1] == M + M && mm[25 + 3] == M + S && mm[25 + 9] == V + N);
+    CHECK(mm[5 * 25 + 0] == V + M && mm[5 * 25 + 5] == M + M && mm[5 * 25 + 12] == V + S);
+    CHECK(mm[20 * 25 + 0] == N + M && mm[20 * 25 + 2] == N + S && mm[24 * 25 + 24] == N + N);
+    for (int a = 0; a < 25; a++)
+        for (int b = 0; b < 25; b++) CHECK(mm[a * 25 + b] == mm[b * 25 + a]);
+    for (int i = 0; i < 25; i++) CHECK(gg[i] == -3.2188758248682006);
+
+    StateMachine *sMv = getSignalStateMachine3Vanilla(model);
+    char *ref = "ATGACACATT";
+    Sequence *kmers = sequence_construct(sequence_correctSeqLength(10, event), ref, sequence_getKmer2);
+    void *k1 = kmers->get(kmers->elements, 1);
+    const double *tab = sMv->EMISSION_MATCH_PROBS;
+    const int64_t ki = emissions_discrete_getKmerIndex((char *) k1 + 1), kb = emissions_discrete_getKmerIndex(k1);
+    const double mu = tab[1 + ki * MODEL_PARAMS], sd = tab[1 + ki * MODEL_PARAMS + 1], nmu = tab[1 + ki * MODEL_PARAMS + 2],
+                 nsd = tab[1 + ki * MODEL_PARAMS + 3];
+    double ev[3] = { 60.3, 0.9, 0.004 };
+    const double a = (ev[0] - mu) / sd;
+    CLOSE(emissions_signal_logGaussMatchProb(tab, k1, ev), log(0.3989422804014327) - log(sd) + (-0.5 * a * a), 1e-12);
+    const double rho = tab[0], xu = (ev[0] - mu) / sd, yu = (ev[1] - nmu) / nsd;
+    CLOSE(emissions_signal_getBivariateGaussPdfMatchProb(tab, k1, ev),
+          -1.8378770664093453 - log(sd * nsd * sqrt(1 - rho * rho)) +
+              (-1 / (2 * (1 - rho * rho))) * (xu * xu + yu * yu - 2 * rho * xu * yu), 1e-12);
+    const double lambda = ev[2] / 0.00332005312085;
+    CLOSE(emissions_signal_getDurationProb(ev, 2), 3 * 0.1397619423751586 + 2 * log(lambda) - 0.69314718056 - 2 * lambda, 1e-12);
+    int64_t bin = (int64_t) (fabs(mu - tab[1 + kb * MODEL_PARAMS]) / 0.5);
+    bin = bin >= 30 ? 29 : bin;
+    CHECK(emissions_signal_getKmerSkipProb(sMv, k1) == sMv->EMISSION_GAP_X_PROBS[bin]);
+    CHECK(emissions_signal_getKmerSkipProb(sMv, k1) == emissions_signal_getBetaOrAlphaSkipProb(sMv, k1, 0));
+    /* scaleModelNoiseOnly = scaleModel without the level mean */
+    StateMachine *sA = getStrawManStateMachine3(model), *sB = getStrawManStateMachine3(model);
+    emissions_signal_scaleModel(sA, 1.03, 4.0, 1.1, 0.9, 1.2);
+    emissions_signal_scaleModelNoiseOnly(sB, 1.03, 4.0, 1.1, 0.9, 1.2);
+    for (int64_t k = 0; k < NUM_OF_KMERS; k += 97) {
+        const double *x = sA->EMISSION_MATCH_PROBS + 1 + k * MODEL_PARAMS, *y = sB->EMISSION_MATCH_PROBS + 1 + k * MODEL_PARAMS;
+        CHECK(x[1] == y[1] && x[2] == y[2] && x[3] == y[3] && x[4] == y[4]);
+        CHECK(y[0] == tab[1 + k * MODEL_PARAMS] && x[0] == y[0] * 1.03 + 4.0);
+    }
+    stateMachine3_setTransitionsToNucleotideDefaults(sA);
+    StateMachine3 *s3 = (StateMachine3 *) sA;
+    CHECK(s3->TRANSITION_MATCH_CONTINUE == -0.030064059121770816 && s3->TRANSITION_GAP_SWITCH_TO_Y == -4.910694825551255);
+    CLOSE(exp(s3->TRANSITION_MATCH_CONTINUE) + exp(s3->TRANSITION_GAP_OPEN_X) + exp(s3->TRANSITION_GAP_OPEN_Y), 1.0, 0.01);
+    CLOSE(exp(s3->TRANSITION_MATCH_FROM_GAP_X) + exp(s3->TRANSITION_GAP_EXTEND_X) + exp(s3->TRANSITION_GAP_SWITCH_TO_Y), 1.0, 0.01);
+
+    Diagonal d = diagonal_construct(7, -3, 5);
+    char *txt = diagonal_getString(d);
+    CHECK(strcmp(txt, "Diagonal, xay: 7 xmyL -3, xmyR: 5") == 0);
+    free(txt);
+    stList *pairs = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    stList_append(pairs, stIntTuple_construct2(5, 9));
+    stList_append(pairs, stIntTuple_construct2(1, 2));
+    stList_append(pairs, stIntTuple_construct2(4, 4));
+    stList_sort(pairs, sortByXPlusYCoordinate);
+    CHECK(stIntTuple_get(stList_get(pairs, 0), 0) == 1 && stIntTuple_get(stList_get(pairs, 1), 0) == 4 &&
+          stIntTuple_get(stList_get(pairs, 2), 0) == 5);
+    stList_destruct(pairs);
+    stList *triples = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    stList_append(triples, stIntTuple_construct3(100, 5, 9));
+    stList_append(triples, stIntTuple_construct3(900, 1, 2));
+    stList_sort(triples, sortByXPlusYCoordinate2);
+    CHECK(stIntTuple_get(stList_get(triples, 0), 0) == 900);
+    stList_destruct(triples);
+
+    /* the echelon decode on the strawMan toy matrices: state s of a cell stands for s k-mers -- gap X (1) gives one
+     * pair, gap Y (2) two; counted here from the same cells */
+    {
+        Sequence *events7 = sequence_construct(7, toyEvents7, sequence_getEvent);
+        char *ref13 = "ACGATACGGACAT";
+        Sequence *kx = sequence_construct(sequence_correctSeqLength(13, event), ref13, sequence_getKmer);
+        StateMachine *sM = getStrawManStateMachine3(model);
+        const int64_t lX = kx->length, lY = events7->length;
+        DpMatrix *F = dpMatrix_construct(lX + lY, 3), *B = dpMatrix_construct(lX + lY, 3);
+        stList *none = stList_construct();
+        Band *band = band_construct(none, lX, lY, 2);
+        BandIterator *it = bandIterator_construct(band);
+        Diagonal diags[64];
+        for (int64_t i = 0; i <= lX + lY; i++) {
+            Diagonal di = bandIterator_getNext(it);
+            diags[i] = di;
+            dpDiagonal_zeroValues(dpMatrix_createDiagonal(B, di));
+            dpDiagonal_zeroValues(dpMatrix_createDiagonal(F, di));
+        }
+        dpDiagonal_initialiseValues(dpMatrix_getDiagonal(F, 0), sM, sM->startStateProb);
+        dpDiagonal_initialiseValues(dpMatrix_getDiagonal(B, lX + lY), sM, sM->endStateProb);
+        for (int64_t i = 1; i <= lX + lY; i++) diagonalCalculationForward(sM, i, F, kx, events7);
+        for (int64_t i = lX + lY; i > 0; i--) diagonalCalculationBackward(sM, i, B, kx, events7);
+        const double total = cell_dotProduct2(dpDiagonal_getCell(dpMatrix_getDiagonal(F, lX + lY), lX - lY), sM, sM->endStateProb);
+        PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+        p->threshold = 0.05;
+        stList *got = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+        void *extraArgs[1] = { got };
+        int64_t want = 0;
+        for (int64_t i = 1; i <= lX + lY; i++) {
+            diagonalCalculationMultiPosteriorMatchProbs(sM, i, F, B, kx, events7, total, p, extraArgs);
+            DpDiagonal *f = dpMatrix_getDiagonal(F, i), *b = dpMatrix_getDiagonal(B, i);
+            for (int64_t xmy = diagonal_getMinXmy(diags[i]); xmy <= diagonal_getMaxXmy(diags[i]); xmy += 2) {
+                if (diagonal_getXCoordinate(i, xmy) <= 0 || diagonal_getYCoordinate(i, xmy) <= 0) continue;
+                for (int st = 1; st < 3; st++)
+                    if (exp(dpDiagonal_getCell(f, xmy)[st] + dpDiagonal_getCell(b, xmy)[st] - total) >= p->threshold) want += st;
+            }
+        }
+        CHECK(want > 0 && stList_length(got) == want);
+        stList_destruct(got);
+        pairwiseAlignmentBandingParameters_destruct(p);
+        for (int64_t i = 0; i <= lX + lY; i++) {
+            dpMatrix_deleteDiagonal(F, i);
+            dpMatrix_deleteDiagonal(B, i);
+        }
+        dpMatrix_destruct(F);
+        dpMatrix_destruct(B);
+        bandIterator_destruct(it);
+        band_destruct(band);
+        stList_destruct(none);
+        stateMachine_destruct(sM);
+        sequence_sequenceDestroy(kx);
+        sequence_sequenceDestroy(events7);
+    }
+    sequence_sequenceDestroy(kmers);
+    stateMachine_destruct(sMv);
+    stateMachine_destruct(sA);
+    stateMachine_destruct(sB);
+    printf("%s small_helpers\n", failures ? "FAILED" : "ok");
+}
+
 static int run_cpu(const char *goldenDir) {
     char *model = path_in(goldenDir, "template_median68pA.model"), *nhdpFile = path_in(goldenDir, "testTemplate.nhdp");
     /* the struct members of the reference's headers are there and filled */
@@ -313,6 +445,7 @@ static int run_cpu(const char *goldenDir) {
     CHECK(sM->endStateProb(sM, shortGapX) == sM3->TRANSITION_MATCH_FROM_GAP_X);
     CHECK(sM->raggedEndStateProb(sM, match) == (sM3->TRANSITION_GAP_OPEN_X + sM3->TRANSITION_GAP_OPEN_Y) / 2.0);
     printf("%s stateMachine_members\n", failures ? "FAILED" : "ok");
+    test_small_helpers(model);
 
     char *ref10 = "ATGACACATT";
     Sequence *events5 = sequence_construct(5, toyEvents5, sequence_getEvent);

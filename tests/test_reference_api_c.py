@@ -34,7 +34,7 @@ def test_reference_shaped_api_on_the_host(program, golden_dir):
     out = _run([program, "cpu", golden_dir])
     names = [l.split()[1] for l in out.splitlines() if l.startswith("ok ")]
     assert "FAILED" not in out
-    assert names == ["stateMachine_members", "strawMan_cell", "vanilla_cell", "fiveState_cell", "hdp_density",
+    assert names == ["stateMachine_members", "small_helpers", "strawMan_cell", "vanilla_cell", "fiveState_cell", "hdp_density",
                      "dpDiagonal_dpMatrix", "fiveState_diagonalDPCalculations", "strawMan_diagonalDPCalculations",
                      "vanilla_diagonalDPCalculations", "plugin_constructors", "continuousPairHmm", "vanillaHmm",
                      "hdpHmm"]
