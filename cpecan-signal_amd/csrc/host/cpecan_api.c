@@ -507,21 +507,13 @@ void cpecan_hdp_machine_as_model(StateMachine *sM, void *out) {
     m->kmer_row = nh->kmerRow;
 }
 
-StateMachine *getHdpStateMachine3(NanoporeHDP *hdp) {
-    StateMachine3_HDP *s = calloc(1, sizeof *s);
-    s->model.type = threeStateHdp;
-    s->model.stateNumber = 3;
-    s->model.matchState = match;
-    s->model.parameterSetSize = NUM_OF_KMERS;
-    s->hdpModel = hdp;
-    /* StateMachine3_HDP starts with the same nine transitions as StateMachine3 */
-    stateMachine3_setTransitionsToNanoporeDefaults((StateMachine *) s);
-    s->getXGapProbFcn = emissions_kmer_getGapProb;
-    s->getYGapProbFcn = get_nanopore_kmer_density;
-    s->getMatchProbFcn = get_nanopore_kmer_density;
-    cpecan_sm3hdp_set_functions(s);
-    s->model.cellCalculateUpdateExpectations = cell_signal_updateTransAndKmerSkipExpectations2;
-    return (StateMachine *) s;
+StateMachine *getHdpStateMachine3(NanoporeHDP *hdp) { /* impl/stateMachine.c:1738-1748 */
+    /* through the plug-in constructor, as the reference does: the (zeroed) emission tables exist -- vanillaAlign hands
+     * EMISSION_MATCH_PROBS of this machine to writePosteriorProbs -- and the k-mer gap table holds log(0.1) */
+    return stateMachine3Hdp_construct(threeStateHdp, NUM_OF_KMERS, stateMachine3_setTransitionsToNanoporeDefaults,
+                                      emissions_signal_initEmissionsToZero, hdp, emissions_kmer_getGapProb,
+                                      get_nanopore_kmer_density, get_nanopore_kmer_density,
+                                      cell_signal_updateTransAndKmerSkipExpectations2);
 }
 
 StateMachine *getSignalStateMachine3Vanilla(const char *modelFile) {

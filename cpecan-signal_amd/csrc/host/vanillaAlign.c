@@ -195,11 +195,6 @@ static stList *remapped_anchor_pairs(stList *unmapped, int64_t *eventMap, int64_
 static void *(*target_getter(StateMachineType type))(void *, int64_t) {
     return type == vanilla ? sequence_getKmer2 : type == threeStateHdp ? sequence_getKmer3 : sequence_getKmer;
 }
-static int by_x_plus_y(const void *a, const void *b) { /* sortByXPlusYCoordinate2 */
-    const int64_t i = stIntTuple_get((stIntTuple *) a, 1) + stIntTuple_get((stIntTuple *) a, 2);
-    const int64_t j = stIntTuple_get((stIntTuple *) b, 1) + stIntTuple_get((stIntTuple *) b, 2);
-    return i > j ? 1 : i < j ? -1 : 0;
-}
 
 /* ---- one strand: what one OpenMP section of the reference does ----------------------------------------------- */
 typedef struct {
@@ -265,7 +260,7 @@ static void *strand_alignment(void *arg) { /* performSignalAlignment + writePost
     double total = 0.0; /* scoreByPosteriorProbabilityIgnoringGaps */
     for (int64_t i = 0; i < stList_length(j->alignedPairs); i++) total += (double) stIntTuple_get(stList_get(j->alignedPairs, i), 0);
     j->posteriorScore = 100.0 * total / ((double) stList_length(j->alignedPairs) * PAIR_ALIGNMENT_PROB_1);
-    stList_sort(j->alignedPairs, by_x_plus_y);
+    stList_sort(j->alignedPairs, sortByXPlusYCoordinate2);
     sequence_sequenceDestroy(sX);
     stList_destruct(anchors);
     j->sM = sM;

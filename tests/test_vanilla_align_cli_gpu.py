@@ -85,7 +85,10 @@ def test_driver_refuses_an_event_map_that_runs_backwards(golden_dir, zymo_read, 
     assert r.returncode == 1 and "runs against the read" in r.stderr
 
 
-def test_cli_alignment_matches_the_host_api(golden_dir, zymo_read, template_model, tmp_path):
+@pytest.mark.parametrize("machine", ["strawMan", "vanilla", "sm3Hdp"])
+def test_cli_alignment_matches_the_host_api(machine, golden_dir, zymo_read, template_model, tmp_path):
+    """the three machines the driver runs: --strawMan, the default (vanilla: sequence_getKmer2, the strand's transition
+    defaults) and --sm3Hdp (de-scaled events, sequence_getKmer3, the .nhdp files of -v / -w)"""
     L = h.lib()
     pts, ops, cigar = _guide(zymo_read, template_model)
     assert len(pts) > 8
@@ -93,8 +96,10 @@ def test_cli_alignment_matches_the_host_api(golden_dir, zymo_read, template_mode
     tsv = str(tmp_path / "out.tsv")
     models = [os.path.join(golden_dir, "template_median68pA.model"),
               os.path.join(golden_dir, "complement_median68pA_pop2.model")]
-    cmd = [EXE, "--strawMan", "-T", models[0], "-C", models[1], "-q", npread, "-r",
-           os.path.join(golden_dir, "ZymoRef.txt"), "-u", tsv, "-L", "zymo_read", "-x", "50"]
+    nhdp = os.path.join(golden_dir, "testTemplate.nhdp")
+    cmd = [EXE] + {"strawMan": ["--strawMan"], "vanilla": [], "sm3Hdp": ["--sm3Hdp", "-v", nhdp, "-w", nhdp]}[machine] + [
+        "-T", models[0], "-C", models[1], "-q", npread, "-r", os.path.join(golden_dir, "ZymoRef.txt"), "-u", tsv, "-L",
+        "zymo_read", "-x", "50"]
     r = subprocess.run(cmd, input=cigar, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "SUCCESS" in r.stderr
@@ -117,14 +122,28 @@ def test_cli_alignment_matches_the_host_api(golden_dir, zymo_read, template_mode
             (1, models[1], zymo_read["complement_params"], zymo_read["complement_events"],
              zymo_read["complement_map"], rc, x1)):
         emap = np.ascontiguousarray(emap, dtype=np.int64)
-        ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+        ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1).copy()
         s, e = int(emap[pts[0][1]]), int(emap[pts[-1][1]])
-        sm = L.getStrawManStateMachine3(model.encode())
-        L.emissions_signal_scaleModel(sm, *params)
+        nh = None
+        if machine == "strawMan":
+            sm = L.getStrawManStateMachine3(model.encode())
+            L.emissions_signal_scaleModel(sm, *params)
+        elif machine == "vanilla":
+            sm = L.getSignalStateMachine3Vanilla(model.encode())
+            L.emissions_signal_scaleModel(sm, *params)
+            L.stateMachine3Vanilla_setStrandTransitionsToDefaults(sm, strand)
+        else:
+            nh = L.deserialize_nhdp(nhdp.encode())
+            sm = L.getHdpStateMachine3(nh)
+            # nanopore_descaleNanoporeRead (impl/nanopore.c:34-38) steps by 3 over the FLAT array while i < nb_events:
+            # the means of the first third of the events are taken back to the model's scale, nothing else (kept as is)
+            idx = np.arange(0, ev.size // 3, 3)
+            ev[idx] = (ev[idx] - params[1]) / params[0]
+        getter = {"strawMan": "sequence_getKmer", "vanilla": "sequence_getKmer2", "sm3Hdp": "sequence_getKmer3"}[machine]
         remapped = L.nanopore_remapAnchorPairsWithOffset(filtered, emap.ctypes.data_as(C.POINTER(C.c_int64)), r0)
         anchors = L.filterToRemoveOverlap(remapped)
         xbuf = C.create_string_buffer(target.encode())
-        sX = L.sequence_construct2(len(target) - 5, C.cast(xbuf, C.c_void_p), h.fn_ptr("sequence_getKmer"),
+        sX = L.sequence_construct2(len(target) - 5, C.cast(xbuf, C.c_void_p), h.fn_ptr(getter),
                                    h.fn_ptr("sequence_sliceNucleotideSequence2"))
         sub = ev[3 * s:]
         sY = L.sequence_construct2(e - s, sub.ctypes.data_as(C.c_void_p), h.fn_ptr("sequence_getEvent"),
@@ -134,7 +153,8 @@ def test_cli_alignment_matches_the_host_api(golden_dir, zymo_read, template_mode
         pairs = L.getAlignedPairsUsingAnchors(sm, sX, sY, anchors, p,
                                               h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), True, True)
         counts.append(L.stList_length(pairs))
-        L.writePosteriorProbs(want_tsv.encode(), b"zymo_read", sm.contents.model.EMISSION_MATCH_PROBS, params[0],
+        L.writePosteriorProbs(want_tsv.encode(), b"zymo_read",
+                              C.cast(sm, C.POINTER(h.StateMachine3)).contents.model.EMISSION_MATCH_PROBS, params[0],
                               params[1], ev.ctypes.data_as(C.POINTER(C.c_double)), target.encode(), True, b"ZYMO",
                               s, rshift, pairs, strand)
         for lst in (pairs, anchors, remapped):
@@ -143,6 +163,8 @@ def test_cli_alignment_matches_the_host_api(golden_dir, zymo_read, template_mode
         L.sequence_sequenceDestroy(sY)
         L.pairwiseAlignmentBandingParameters_destruct(p)
         L.stateMachine_destruct(sm)
+        if nh:
+            L.destroy_nanopore_hdp(nh)
     want = [l for l in open(want_tsv).read().split("\n") if l]
     assert counts[0] > 300 and counts[1] > 0
     assert summary[2].startswith("%d(" % counts[0]) and summary[3].startswith("%d(" % counts[1])
