@@ -178,27 +178,52 @@ def test_cli_alignment_matches_the_host_api(machine, golden_dir, zymo_read, temp
     assert sums == sorted(sums) and t_rows[0][0] == "ZYMO" and len(t_rows[0]) == 15
 
 
-def test_cli_expectations_files(golden_dir, zymo_read, template_model, tmp_path):
+@pytest.mark.parametrize("machine", ["strawMan", "vanilla", "sm3Hdp"])
+def test_cli_expectations_files(machine, golden_dir, zymo_read, template_model, tmp_path):
+    """-t / -c: one E-step per strand written as the machine's .expectations file (hmmContinuous_writeToFile), the
+    file the reference's trainer sums over reads; then the next iteration's shape: the (un-normalised here) file handed
+    back through -y / -z for an alignment run"""
     _, _, cigar = _guide(zymo_read, template_model)
     npread, _ = _npread_with_forward_complement(golden_dir, zymo_read, tmp_path)
     t_exp, c_exp = str(tmp_path / "t.expectations"), str(tmp_path / "c.expectations")
-    cmd = [EXE, "--strawMan", "-T", os.path.join(golden_dir, "template_median68pA.model"), "-C",
-           os.path.join(golden_dir, "complement_median68pA_pop2.model"), "-q", npread, "-r",
-           os.path.join(golden_dir, "ZymoRef.txt"), "-t", t_exp, "-c", c_exp, "-L", "zymo_read"]
-    r = subprocess.run(cmd, input=cigar, capture_output=True, text=True, timeout=600)
+    nhdp = os.path.join(golden_dir, "testTemplate.nhdp")
+    flags = {"strawMan": ["--strawMan"], "vanilla": [], "sm3Hdp": ["--sm3Hdp", "-v", nhdp, "-w", nhdp]}[machine]
+    base = [EXE] + flags + ["-T", os.path.join(golden_dir, "template_median68pA.model"), "-C",
+                            os.path.join(golden_dir, "complement_median68pA_pop2.model"), "-q", npread, "-r",
+                            os.path.join(golden_dir, "ZymoRef.txt"), "-L", "zymo_read"]
+    r = subprocess.run(base + ["-t", t_exp, "-c", c_exp], input=cigar, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
+    L = h.lib()
+    L.hmmContinuous_loadSignalHmm.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
     for path in (t_exp, c_exp):
         lines = open(path).read().split("\n")
-        assert lines[0].split() == ["2", "3", "4096"]
-        vals = np.array(lines[1].split(), float)
-        assert vals.size == 10 and np.isfinite(vals[:9]).all() and vals[:9].min() >= 0.0001  # the pseudocount
-        assert len(lines[2].split()) == 4096
-    t = np.array(open(t_exp).read().split("\n")[1].split(), float)
-    assert t[0] > 100 and t[9] < 0  # hundreds of match->match transitions, a log-likelihood
-    # the next iteration reads the file back: --inTemplateHmm / --inComplementHmm after normalisation upstream
-    L = h.lib()
-    sm = L.getStrawManStateMachine3(os.path.join(golden_dir, "template_median68pA.model").encode())
-    L.hmmContinuous_loadSignalHmm.argtypes = [C.c_char_p, C.c_void_p, C.c_int]
-    L.hmmContinuous_loadSignalHmm(t_exp.encode(), sm, 2)
-    assert np.isclose(sm.contents.TRANSITION_MATCH_CONTINUE, np.log(t[0]), atol=1e-6)
-    L.stateMachine_destruct(sm)
+        head = lines[0].split()
+        if machine == "strawMan":
+            assert head == ["2", "3", "4096"]
+            vals = np.array(lines[1].split(), float)
+            assert vals.size == 10 and np.isfinite(vals[:9]).all() and vals[:9].min() >= 0.0001  # the pseudocount
+            assert len(lines[2].split()) == 4096
+        elif machine == "vanilla":
+            assert head[0] == "4"  # type vanilla (impl/continuousHmm.c:568-584): bins, then the two models
+            bins = np.array(lines[1].split(), float)
+            assert bins.size >= 60 and np.isfinite(bins[:60]).all() and bins[:60].min() >= 0.0001 and bins[:60].max() > 1
+        else:
+            assert head[0] == "7" and head[1] == "3" and int(head[3]) > 50  # type, states, threshold, assignments
+            assert "got %s HDP assignments" % head[3] in r.stderr
+            vals = np.array(lines[1].split(), float)
+            assert vals.size == 10 and vals[:9].min() >= 0.0001
+            assert len(lines[2].split()) == int(head[3]) == len(lines[3].split())
+    if machine == "strawMan":
+        t = np.array(open(t_exp).read().split("\n")[1].split(), float)
+        assert t[0] > 100 and t[9] < 0  # hundreds of match->match transitions, a log-likelihood
+        sm = L.getStrawManStateMachine3(os.path.join(golden_dir, "template_median68pA.model").encode())
+        L.hmmContinuous_loadSignalHmm(t_exp.encode(), sm, 2)
+        assert np.isclose(sm.contents.TRANSITION_MATCH_CONTINUE, np.log(t[0]), atol=1e-6)
+        L.stateMachine_destruct(sm)
+    # the driver itself reads them back (--inTemplateHmm / --inComplementHmm) and aligns with what they hold
+    tsv = str(tmp_path / "after.tsv")
+    r2 = subprocess.run(base + ["-y", t_exp, "-z", c_exp, "-u", tsv], input=cigar, capture_output=True, text=True,
+                        timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "loading HMM from file" in r2.stderr and "SUCCESS" in r2.stderr
+    assert len(r2.stdout.split()) == 4
