@@ -87,3 +87,48 @@ def test_two_level_anchoring_masks_then_unmasks_inside_large_gaps(lastz):
     assert _pairs(L, L.getBlastPairsForPairwiseAlignmentParameters(x.encode(), y.encode(), p)) == []
     assert len([l for l in open(log).read().split("\n") if l]) == 2
     L.pairwiseAlignmentBandingParameters_destruct(p)
+
+
+@pytest.mark.gpu
+def test_dna_realignment_end_to_end_with_the_librarys_own_anchor_function(lastz):
+    """What cPecan's realign does with one pair of sequences: getAlignedPairs(sM5, x, y, ..., getAnchorPairFcn =
+    getBlastPairsForPairwiseAlignmentParameters) -- anchors from the aligner behind the pipe (the stand-in here),
+    filtered, then the banded 5-state forward-backward on the GPU -- against the oracle given the same anchors."""
+    import pyoracle as o
+    L, _ = lastz
+    rng = np.random.default_rng(23)
+    x = "".join(rng.choice(list("ACGT"), 3000))
+    y = []
+    for i, ch in enumerate(x):  # substitutions, short deletions and insertions
+        r = rng.random()
+        if r < 0.04:
+            y.append(rng.choice(list("ACGT")))
+        elif r < 0.05:
+            continue
+        elif r < 0.06:
+            y.append(ch + rng.choice(list("ACGT")))
+        else:
+            y.append(ch)
+    y = "".join(y)
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    p.contents.anchorMatrixBiggerThanThis = 500 * 500
+    anchors_list = L.getBlastPairsForPairwiseAlignmentParameters(x.encode(), y.encode(), p)
+    anchors = h.list_to_array(anchors_list, 2)
+    L.stList_destruct(anchors_list)
+    assert len(anchors) > 500 and np.all(np.diff(anchors[:, 0]) > 0) and np.all(np.diff(anchors[:, 1]) > 0)
+    sm = L.stateMachine5_construct(0, 4, h.fn_ptr("emissions_symbol_setEmissionsToDefaults"),
+                                   h.fn_ptr("emissions_symbol_getGapProb"), h.fn_ptr("emissions_symbol_getGapProb"),
+                                   h.fn_ptr("emissions_symbol_getMatchProb"), h.fn_ptr("cell_updateExpectations"))
+    xb, yb = C.create_string_buffer(x.encode()), C.create_string_buffer(y.encode())
+    L.getAlignedPairs.restype = C.c_void_p
+    pairs = L.getAlignedPairs(sm, C.cast(xb, C.c_void_p), C.cast(yb, C.c_void_p), len(x), len(y), p,
+                              h.fn_ptr("sequence_getBase"), h.fn_ptr("sequence_getBase"),
+                              h.fn_ptr("getBlastPairsForPairwiseAlignmentParameters"), False, False)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    ref = o.aligned_pairs_using_anchors(o.Sm5Model(), x, len(x), y, [tuple(int(v) for v in a) for a in anchors],
+                                        o.default_params(), False, False)
+    assert len(got) > 2500
+    assert np.array_equal(got, ref["triples"])  # same pairs, same order, same integer posteriors
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)
