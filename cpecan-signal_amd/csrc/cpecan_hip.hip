@@ -1152,7 +1152,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     };
     /* (what the kernel choice below will come to, as far as it is known before the bands are) */
     const bool surelyGeneral = dna || kernel == CPECAN_KERNEL_GENERAL || unbanded || (flags & CPECAN_FLAG_DEBUG_DUMP) ||
-                               ((hdp || vanilla) && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_GENERAL_KERNEL)));
+                               (hdp && mode != CPECAN_MODE_POSTERIOR) ||
+                               ((hdp || vanilla) && (flags & CPECAN_FLAG_GENERAL_KERNEL));
     HIP_TRY(hTab.alloc((size_t) diagTotal * 2 + 2));
     {
         int rc = build_bands(surelyGeneral);
@@ -1204,9 +1205,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
-    /* the HDP machine's posterior decode has wave-per-alignment kernels of its own (its E-step, and the vanilla and
-     * 5-state machines, run on the general kernels); CPECAN_FLAG_GENERAL_KERNEL keeps an HDP batch on the general one */
-    const bool machineWave = (hdp || vanilla) && mode == CPECAN_MODE_POSTERIOR && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
+    /* the HDP and vanilla machines have wave-per-alignment kernels of their own: posterior decode for both, the
+     * E-step for the vanilla machine (the HDP machine's E-step and the 5-state machine run on the general kernels);
+     * CPECAN_FLAG_GENERAL_KERNEL keeps such a batch on the general kernel */
+    const bool machineWave = ((hdp && mode == CPECAN_MODE_POSTERIOR) || vanilla) && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
     int useKernel = dna || ((hdp || vanilla) && !machineWave) ? CPECAN_KERNEL_GENERAL
                     : hdp || vanilla ? CPECAN_KERNEL_AUTO : kernel;
     /* the builds of the register-resident kernels this batch would run on, and the widest band they take */
@@ -1563,7 +1565,7 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                                                 w, withSwitch);
                 if (rc == 0 && n > 0 && b->mode == CPECAN_MODE_EXPECTATIONS)
                     rc = b->sy->launch_expect(sB, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
-                                              b->trackBase.p + i0, b->kidx.p, c->models.p,
+                                              b->trackBase.p + i0, b->kidx.p, models,
                                               b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                               b->Bring.p + i0 * (long long) b->ringD * bringRow, b->ringD,
                                               b->syStates.p + i0 * b->stateBytes,

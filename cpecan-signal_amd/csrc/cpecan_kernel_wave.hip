@@ -1707,9 +1707,11 @@ WV_BACKWARD_KERNEL(cpecan_k_wv_backward, false, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_sw, true, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep, false, WV_KIND_REDO)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep_sw, true, WV_KIND_REDO)
-#if !defined(WV_HDP) && !defined(WV_VANILLA) /* (the HDP and vanilla machines' E-steps stay on the general kernels) */
+#if !defined(WV_HDP) /* (the HDP machine's E-step stays on the general kernel) */
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em, false, WV_KIND_EXPECT)
+#if !defined(WV_VANILLA) /* (no gap Y -> gap X transition in the vanilla machine) */
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em_sw, true, WV_KIND_EXPECT)
+#endif
 #endif
 
 /*
@@ -1905,6 +1907,94 @@ extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
         wp->valid = 0;
     }
 }
+
+#if defined(WV_VANILLA)
+/*
+ * The vanilla machine's expectations of the traceback window the backward kernel just swept
+ * (diagonalCalculation_Expectations :841-863 with cell_signal_updateBetaAndAlphaProb :478-498): of all transitions only
+ * match -> gap X (into the skip bin of the cell's k-mer pair) and gap X -> gap X (bin + 30) are collected, both from the
+ * cell's lower neighbour; the gap-X emission of this machine is 0.  Element-wise over the forward ring, the B ring and
+ * the window's exact totals, as the strawMan pass below: 64 * L threads, wave j takes layer j.  A thread keeps the two
+ * sums of its column in registers and adds them to the column's bin (track row entry 21) when its slot moves on.
+ */
+extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
+    const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,
+    const double *__restrict__ track, const long long *__restrict__ trackBase,
+    const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
+    long long ringDoubles, const double *Bring, int ringD, WvState *states, const char *scratch,
+    long long scratchBytes, double *expect, int window) {
+    constexpr int L = WV_L;
+    __shared__ double sBins[64];
+    (void) P; (void) kidx; (void) models;
+    const long long idx = blockIdx.x;
+    if (idx >= nItems) return;
+    const WvState *state = states + idx;
+    if (state->expectPending != window + 1) return;
+    const DevItem it = uniform_item(items[idx]);
+    const int lane = threadIdx.x & 63, j = uni(threadIdx.x >> 6);
+    const int sl = lane * L + j, sb = sl == 0 ? WV_P - 1 : sl - 1; /* this thread's slot and the one below it */
+    const int ringMask = ringD - 1;
+    const double *ring = Fring + idx * ringDoubles;
+    const double *blw = ring + (sb % L) * WV_LAYER_DOUBLES;     /* the slot below: layer sb % L, lane sb / L */
+    const int lb = sb / L;
+    const double *bown = Bring + idx * ((long long) ringD * L * 3 * 64) + j * (3 * 64) + lane;
+    const double *tr = track + trackBase[idx] * WV_ROW;
+    const int2 *tab = bandTab + it.diagBase;
+    const WinTotal *wtot = (const WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int));
+    const int dTop = uni(state->win[window & 1].top), from = uni(state->win[window & 1].from),
+              to = uni(state->win[window & 1].to);
+    const int tPost0 = dTop < from ? dTop : from;
+    double *dst = expect + (long long) it.model * (60 + 1);
+    if (threadIdx.x < 64) sBins[threadIdx.x] = 0.0;
+    __syncthreads();
+
+    double lik = 0.0, beta = 0.0, alpha = 0.0;
+    int col = -1; /* matrix column whose sums beta / alpha hold */
+    const int perChunk = (tPost0 - to + (int) gridDim.y - 1) / (int) gridDim.y;
+    const int tHi = tPost0 - (int) blockIdx.y * perChunk;             /* this workgroup: diagonals tHi .. tLo+1 */
+    const int tLo = tHi - perChunk > to ? tHi - perChunk : to;
+    if (tHi > to) {
+        int b0min, b0max, b1min, b1max;
+        band_load(tab, tHi, b0min, b0max);
+        int xs = sl + ((b0min - sl + WV_P - 1) / WV_P) * WV_P; /* this slot's k-mer: the one in (xmax-P, xmax] */
+        if (xs > b0max) xs -= WV_P;
+#pragma unroll 1
+        for (int t = tHi; t > tLo; t--) {
+            band_load(tab, t - 1, b1min, b1max);
+            if (xs > b0max) xs -= WV_P;
+            const int x = xs;
+            const double total = wtot[(tPost0 - t) / 10].total;
+            if (threadIdx.x == 0) lik += total;
+            if (x >= b0min && x - 1 >= b1min && x - 1 <= b1max) { /* the cell (t, x) and its lower neighbour exist */
+                const long long r1 = (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
+                const double Bx = bown[(long long) (t & ringMask) * (L * 3 * 64) + 64];
+                const double l0 = blw[r1 + WV_OFF_FM(lb)], l1 = blw[r1 + WV_OFF_FX(lb)];
+                const double *row = tr + (long long) x * WV_ROW;
+                if (x != col) {
+                    if (col >= 0) {
+                        const int bin = (int) tr[(long long) col * WV_ROW + 21];
+                        atomicAdd(&sBins[bin], beta);
+                        atomicAdd(&sBins[bin + 30], alpha);
+                    }
+                    col = x;
+                    beta = alpha = 0.0;
+                }
+                beta += exp(l0 + Bx + (0 + row[16]) - total);
+                alpha += exp(l1 + Bx + (0 + row[17]) - total);
+            }
+            b0min = b1min; b0max = b1max;
+        }
+        if (col >= 0) {
+            const int bin = (int) tr[(long long) col * WV_ROW + 21];
+            atomicAdd(&sBins[bin], beta);
+            atomicAdd(&sBins[bin + 30], alpha);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 60 && sBins[threadIdx.x] != 0.0) atomicAdd(dst + threadIdx.x, sBins[threadIdx.x]);
+    if (threadIdx.x == 0 && lik != 0.0) atomicAdd(dst + 60, lik);
+}
+#endif
 
 #if !defined(WV_HDP) && !defined(WV_VANILLA)
 /*
@@ -2149,11 +2239,11 @@ extern "C" __global__ void cpecan_k_wv_track_vanilla(const DevItem *__restrict__
             case 6: v = q[CP_V_LAMBDA]; break;
             default: v = q[CP_V_LLAMBDA] - 1.8378770664093453; break;
             }
-        } else if (jj < 21) {
+        } else {
             const double d = fabs(r[CP_V_MU] - rows[(long long) kPrev * CP_VROW + CP_V_MU]);
             long long bin = (long long) (d / 0.5);
             if (bin >= 30) bin = 29;
-            v = hdr[CP_VHDR_BINS + bin * 5 + (jj - 16)];
+            v = jj < 21 ? hdr[CP_VHDR_BINS + bin * 5 + (jj - 16)] : (double) bin; /* (entry 21: the bin itself, E-step) */
         }
         dst[i] = v;
     }
@@ -2254,8 +2344,12 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
                        (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD,                \
                        (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, window)
     if (P.mode != 0) {
-#if defined(WV_HDP) || defined(WV_VANILLA)
+#if defined(WV_HDP)
         return -1;
+#elif defined(WV_VANILLA)
+        if (withSwitch) return -1;
+        WV_LAUNCH_B(cpecan_k_wv_backward_em);
+        WV_LAUNCH_POST;
 #else
         if (withSwitch) WV_LAUNCH_B(cpecan_k_wv_backward_em_sw);
         else WV_LAUNCH_B(cpecan_k_wv_backward_em);
@@ -2280,7 +2374,7 @@ extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevIt
                                                  const double *models, const double *Fring, long long ringDoubles,
                                                  const double *Bring, int ringD, void *states, const char *scratch,
                                                  long long scratchBytes, double *expect, int window) {
-#if defined(WV_HDP) || defined(WV_VANILLA)
+#if defined(WV_HDP)
     return -1;
 #else
     hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_expect), dim3((unsigned) nItems, WV_EXPECT_CHUNKS), dim3(WV_P), 0, stream,

@@ -98,17 +98,26 @@ def test_vanilla_matches_oracle(ctx, case, general):
     run(ctx, batch, models, band_params(0.01, case["md"], case["tb"], case["e"]), case["ragged"], general=general)
 
 
-def test_vanilla_expectations_match_oracle(ctx):
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("shape", [
+    dict(n=4, lX=150, lY=310, every=30, md=60, tb=10, e=20),      # two cells per lane, short windows
+    dict(n=3, lX=700, lY=1500, every=50, md=300, tb=40, e=100),   # three cells per lane (band 101-156), long windows
+    dict(n=2, lX=90, lY=200, every=10 ** 6, md=40, tb=5, e=20),    # no anchors
+])
+def test_vanilla_expectations_match_oracle(ctx, shape, general):
     """Baum-Welch sums of the vanilla machine (diagonalCalculation_Expectations with
     cell_signal_updateBetaAndAlphaProb, impl/pairwiseAligner.c:478-498): 30 beta + 30 alpha skip bins and the
-    likelihood, per model.  Per-cell terms are added in another order than the host loop: 1e-9 relative."""
-    batch = synth.make_batch(57, 4, 150, 310, anchor_every=30)
+    likelihood, per model -- on the wave-per-alignment kernels (sweeps + cpecan_k_wv_expect) and on the general
+    kernel.  Per-cell terms are added in another order than the host loop: 1e-9 relative."""
+    batch = synth.make_batch(57, shape["n"], shape["lX"], shape["lY"], anchor_every=shape["every"])
     models = [o.VanillaModel(match, skip_bins(i), gapy) for i, (match, _, gapy) in enumerate(batch["models"])]
-    bp = band_params(0.01, 60, 10, 20)
+    bp = band_params(0.01, shape["md"], shape["tb"], shape["e"])
     ctx.models_clear()
     ids = ctx.modelsv_create([(m.scalars, m.match, m.skip, m.gap_y) for m in models])
     b = cp.Batch(ctx, make_items(batch, (1, 1)), batch["x_chars"], batch["events"], batch["anchors"], bp,
-                 flags=cp.FLAG_EXPECTATIONS, vanilla=True)
+                 flags=cp.FLAG_EXPECTATIONS | (cp.FLAG_GENERAL_KERNEL if general else 0), vanilla=True)
+    info = b.info()
+    assert info["kernel"] == ("general" if general else "systolic"), info
     b.run()
     b.sync()
     p = orc_params(bp, split=1 << 60)
