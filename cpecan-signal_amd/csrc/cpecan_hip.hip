@@ -76,7 +76,7 @@ extern "C" int cpecan_systolic_launch_expect(hipStream_t stream, const DevItem *
                                              const double *models, const double *Fring,
                                              long long ringDoubles, const double *Bring, int ringD,
                                              void *states, const char *scratch, long long scratchBytes,
-                                             double *expect, int window);
+                                             double *expect, int window, long long *pairs, double *pairLogp);
 extern "C" int cpecan_systolic_bring_row_doubles(void);
 extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *states, long long nItems,
                                              long long *nPairs, long long *nTot, long long *nCells);
@@ -100,7 +100,7 @@ extern "C" int cpecan_systolic_launch_counts(hipStream_t stream, const void *sta
                                                       const void *, const double *, const long long *,            \
                                                       const unsigned short *, const double *, const double *,     \
                                                       long long, const double *, int, void *, const char *,       \
-                                                      long long, double *, int);
+                                                      long long, double *, int, long long *, double *);
 SY_DECLARE(_r1)
 SY_DECLARE(_r2)
 SY_DECLARE(_r3)
@@ -123,7 +123,7 @@ SY_DECLARE(_r3)
                                                   const void *, const double *, const long long *,                \
                                                   const unsigned short *, const double *, const double *,         \
                                                   long long, const double *, int, void *, const char *,           \
-                                                  long long, double *, int);
+                                                  long long, double *, int, long long *, double *);
 WV_DECLARE(_l2)
 WV_DECLARE(_l3)
 WV_DECLARE(_l4)
@@ -1152,7 +1152,6 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     };
     /* (what the kernel choice below will come to, as far as it is known before the bands are) */
     const bool surelyGeneral = dna || kernel == CPECAN_KERNEL_GENERAL || unbanded || (flags & CPECAN_FLAG_DEBUG_DUMP) ||
-                               (hdp && mode != CPECAN_MODE_POSTERIOR) ||
                                ((hdp || vanilla) && (flags & CPECAN_FLAG_GENERAL_KERNEL));
     HIP_TRY(hTab.alloc((size_t) diagTotal * 2 + 2));
     {
@@ -1205,10 +1204,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
 
-    /* the HDP and vanilla machines have wave-per-alignment kernels of their own: posterior decode for both, the
-     * E-step for the vanilla machine (the HDP machine's E-step and the 5-state machine run on the general kernels);
-     * CPECAN_FLAG_GENERAL_KERNEL keeps such a batch on the general kernel */
-    const bool machineWave = ((hdp && mode == CPECAN_MODE_POSTERIOR) || vanilla) && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
+    /* the HDP and vanilla machines have wave-per-alignment kernels of their own, for the posterior decode and for
+     * the E-step (the 5-state machine runs on the general kernel); CPECAN_FLAG_GENERAL_KERNEL keeps such a batch on
+     * the general kernel */
+    const bool machineWave = (hdp || vanilla) && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
     int useKernel = dna || ((hdp || vanilla) && !machineWave) ? CPECAN_KERNEL_GENERAL
                     : hdp || vanilla ? CPECAN_KERNEL_AUTO : kernel;
     /* the builds of the register-resident kernels this batch would run on, and the widest band they take */
@@ -1569,7 +1568,8 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                                               b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles,
                                               b->Bring.p + i0 * (long long) b->ringD * bringRow, b->ringD,
                                               b->syStates.p + i0 * b->stateBytes,
-                                              b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes, b->expect.p, w);
+                                              b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes, b->expect.p, w,
+                                              b->pairs.p, b->pairLogp.p);
                 HIP_TRY(hipEventRecord(e4[3], sB));
             }
             HIP_TRY(hipEventRecord(b->evJoin[(size_t) gi], sB)); /* the last sweep back follows every forward sweep */
@@ -1808,6 +1808,43 @@ static int ensure_counts(cpecan_batch *b) {
                                    hipMemcpyDeviceToHost, b->ctx->stream));
         }
         HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        if (b->hdp && b->kernel == CPECAN_KERNEL_SYSTOLIC) {
+            /* the HDP machine's event assignments from the wave kernels: appended by whichever thread got there, each
+             * tagged with its traceback window (first field = from-state + 4 * window).  The reference walks windows
+             * upwards, inside a window the diagonals downwards, a diagonal by ascending x, a cell by from-state
+             * (cell_signal_updateTransAndKmerSkipExpectations2 inside diagonalCalculation_Expectations): put them so */
+            std::vector<long long> order;
+            std::vector<long long> tri;
+            std::vector<double> lp;
+            for (int64_t i = 0; i < b->nItems; i++) {
+                const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
+                if (n <= 1) {
+                    if (n == 1) b->hPairs[(size_t) o * 3] &= 3;
+                    continue;
+                }
+                long long *p3 = b->hPairs.data() + o * 3;
+                double *pl = b->hLogp.data() + o;
+                order.resize((size_t) n);
+                for (long long k = 0; k < n; k++) order[(size_t) k] = k;
+                std::sort(order.begin(), order.end(), [p3](long long a, long long c2) {
+                    const long long wa = p3[3 * a] >> 2, wc = p3[3 * c2] >> 2;
+                    if (wa != wc) return wa < wc;
+                    const long long da = p3[3 * a + 1] + p3[3 * a + 2], dc = p3[3 * c2 + 1] + p3[3 * c2 + 2];
+                    if (da != dc) return da > dc;
+                    if (p3[3 * a + 1] != p3[3 * c2 + 1]) return p3[3 * a + 1] < p3[3 * c2 + 1];
+                    return (p3[3 * a] & 3) < (p3[3 * c2] & 3);
+                });
+                tri.assign(p3, p3 + 3 * n);
+                lp.assign(pl, pl + n);
+                for (long long k = 0; k < n; k++) {
+                    const long long src = order[(size_t) k];
+                    p3[3 * k] = tri[(size_t) (3 * src)] & 3;
+                    p3[3 * k + 1] = tri[(size_t) (3 * src + 1)];
+                    p3[3 * k + 2] = tri[(size_t) (3 * src + 2)];
+                    pl[k] = lp[(size_t) src];
+                }
+            }
+        }
         b->countsValid = true;
         return CPECAN_OK;
     }

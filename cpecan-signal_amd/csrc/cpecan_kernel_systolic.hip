@@ -1549,7 +1549,8 @@ extern "C" int SY_SYM(cpecan_systolic_launch_expect)(hipStream_t stream, const D
                                              const double *models, const double *Fring,
                                              long long ringDoubles, const double *Bring, int ringD,
                                              void *states, const char *scratch, long long scratchBytes,
-                                             double *expect, int window) {
+                                             double *expect, int window, long long *pairs, double *pairLogp) {
+    (void) pairs; (void) pairLogp; /* (the HDP machine's wave kernels append event assignments there) */
     hipLaunchKernelGGL(SY_SYM(cpecan_k_sy_expect), dim3((unsigned) nItems, SY_EXPECT_CHUNKS), dim3(SY_P), 0, stream,
                        items, nItems, P, (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles,
                        Bring, ringD, (SyState *) states, scratch, scratchBytes, expect, window);

@@ -1707,11 +1707,9 @@ WV_BACKWARD_KERNEL(cpecan_k_wv_backward, false, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_sw, true, WV_KIND_POSTERIOR)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep, false, WV_KIND_REDO)
 WV_BACKWARD_KERNEL(cpecan_k_wv_resweep_sw, true, WV_KIND_REDO)
-#if !defined(WV_HDP) /* (the HDP machine's E-step stays on the general kernel) */
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em, false, WV_KIND_EXPECT)
 #if !defined(WV_VANILLA) /* (no gap Y -> gap X transition in the vanilla machine) */
 WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em_sw, true, WV_KIND_EXPECT)
-#endif
 #endif
 
 /*
@@ -1922,10 +1920,10 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const double *__restrict__ track, const long long *__restrict__ trackBase,
     const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
     long long ringDoubles, const double *Bring, int ringD, WvState *states, const char *scratch,
-    long long scratchBytes, double *expect, int window) {
+    long long scratchBytes, double *expect, int window, long long *pairs, double *pairLogp) {
     constexpr int L = WV_L;
     __shared__ double sBins[64];
-    (void) P; (void) kidx; (void) models;
+    (void) P; (void) kidx; (void) models; (void) pairs; (void) pairLogp;
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
     const WvState *state = states + idx;
@@ -1996,7 +1994,7 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
 }
 #endif
 
-#if !defined(WV_HDP) && !defined(WV_VANILLA)
+#if !defined(WV_VANILLA)
 /*
  * Baum-Welch expectations of the traceback window the backward kernel just swept
  * (diagonalCalculation_Expectations :841-863 with cell_signal_updateTransAndKmerSkipExpectations :426-443).
@@ -2006,13 +2004,19 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
  * once per window.  64 * L threads: wave j takes layer j of the ring rows, lane by lane.  A thread keeps the
  * sum of its k-mer's gap-X expectations in a register and adds it to the k-mer's bin when its slot moves to
  * another k-mer.  The match block is skipped where forward[t-2] has been freed by then, as in the reference.
+ *
+ * The HDP machine (-DWV_HDP; cell_signal_updateTransAndKmerSkipExpectations2 :445-476) collects the nine transitions
+ * and the likelihood the same way, no k-mer bins, and an ASSIGNMENT for every transition into match whose own
+ * posterior reaches the threshold: (from-state + 4 * window, x, y) with its exponent, appended to the alignment's pair
+ * list in whatever order the threads get there -- the host puts them into the reference's order (windows ascending,
+ * diagonals descending, x ascending, from-state ascending) when it fetches them.
  */
 extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTab,
     const double *__restrict__ track, const long long *__restrict__ trackBase,
     const unsigned short *__restrict__ kidx, const double *__restrict__ models, const double *Fring,
     long long ringDoubles, const double *Bring, int ringD, WvState *states, const char *scratch,
-    long long scratchBytes, double *expect, int window) {
+    long long scratchBytes, double *expect, int window, long long *pairs, double *pairLogp) {
     constexpr int L = WV_L;
     __shared__ double sExp[16];
     const long long idx = blockIdx.x;
@@ -2035,7 +2039,14 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const int dTop = uni(state->win[window & 1].top), from = uni(state->win[window & 1].from),
               to = uni(state->win[window & 1].to);
     const int tPost0 = dTop < from ? dTop : from;
+#ifdef WV_HDP
+    double *dst = expect + (long long) it.model * (9 + 1);
+    const double *tm = ((const DevHdpModel *) models)[it.model].t;
+    WvState *stateW = states + idx;
+#else
     double *dst = expect + (long long) it.model * (9 + 4096 + 1);
+    const double *tm = models + (long long) it.model * CP_MODEL_STRIDE;
+#endif
 
     double acc[8]; /* M>X X>X Y>X | M>M X>M Y>M | M>Y Y>Y */
 #pragma unroll
@@ -2076,6 +2087,7 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
                 acc[0] += p0;
                 acc[1] += p1;
                 acc[2] += p2;
+#ifndef WV_HDP
                 if (x != gapX) {
                     if (gapX > 0) {
                         const int k = kx[gapX - 1];
@@ -2087,28 +2099,52 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
                 gapSum += p0;
                 gapSum += p1;
                 gapSum += p2;
+#endif
             }
             if (vMiddle) {
                 const double m0 = blw[r2 + WV_OFF_FM(lb)], m1 = blw[r2 + WV_OFF_FX(lb)], m2 = blw[r2 + WV_OFF_FY(lb)];
                 const double eP = own[rt + WV_OFF_PM(lane)];
-                acc[3] += exp(m0 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_CONTINUE]) - total);
-                acc[4] += exp(m1 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_FROM_GAP_X]) - total);
-                acc[5] += exp(m2 + Bm + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_MATCH_FROM_GAP_Y]) - total);
+                const double e0 = m0 + Bm + (eP + tm[T_MATCH_CONTINUE]) - total;
+                const double e1 = m1 + Bm + (eP + tm[T_MATCH_FROM_GAP_X]) - total;
+                const double e2 = m2 + Bm + (eP + tm[T_MATCH_FROM_GAP_Y]) - total;
+                const double q0 = exp(e0), q1 = exp(e1), q2 = exp(e2);
+                acc[3] += q0;
+                acc[4] += q1;
+                acc[5] += q2;
+#ifdef WV_HDP
+                const double ee[3] = { e0, e1, e2 }, qq[3] = { q0, q1, q2 };
+#pragma unroll
+                for (int f = 0; f < 3; f++)
+                    if (qq[f] >= P.threshold) {
+                        const long long at = (long long) atomicAdd((unsigned long long *) &stateW->nPairs, 1ull);
+                        if (at < it.pairCap) {
+                            long long *o = pairs + (it.pairBase + at) * 3;
+                            o[0] = f + 4ll * window;
+                            o[1] = x - 1;
+                            o[2] = (t - x) - 1;
+                            pairLogp[it.pairBase + at] = ee[f];
+                        }
+                    }
+#endif
             }
             if (vUpper) {
                 const double u0 = own[r1 + WV_OFF_FM(lane)], u2 = own[r1 + WV_OFF_FY(lane)];
                 const double eP = own[rt + WV_OFF_PY(lane)];
-                acc[6] += exp(u0 + By + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_GAP_OPEN_Y]) - total);
-                acc[7] += exp(u2 + By + (eP + models[(long long) it.model * CP_MODEL_STRIDE + T_GAP_EXTEND_Y]) - total);
+                acc[6] += exp(u0 + By + (eP + tm[T_GAP_OPEN_Y]) - total);
+                acc[7] += exp(u2 + By + (eP + tm[T_GAP_EXTEND_Y]) - total);
             }
         }
         b0min = b1min; b0max = b1max;
         b1min = b2min; b1max = b2max;
     }
+#ifndef WV_HDP
     if (gapX > 0) {
         const int k = kx[gapX - 1];
         if (k < 4096) atomicAdd(dst + 9 + k, gapSum);
     }
+#else
+    (void) gapX; (void) gapSum; (void) kx;
+#endif
     /* block reduction of the per-thread sums, then one atomic per value */
     if (threadIdx.x < 16) sExp[threadIdx.x] = 0.0;
     __syncthreads();
@@ -2121,10 +2157,14 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     }
     __syncthreads();
     if (threadIdx.x < 9) atomicAdd(dst + threadIdx.x, sExp[threadIdx.x]);
+#ifdef WV_HDP
+    if (threadIdx.x == 0) atomicAdd(dst + 9, lik);
+#else
     if (threadIdx.x == 0) atomicAdd(dst + 9 + 4096, lik);
+#endif
 }
 
-#endif /* strawMan builds */
+#endif /* strawMan and HDP builds */
 
 #if WV_L == 4 && !defined(WV_HDP) && !defined(WV_VANILLA)
 /* per-item track of emission constants, wave layout: column x (0..lX) = the 16 emission constants of the k-mer
@@ -2344,9 +2384,7 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
                        (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD,                \
                        (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, window)
     if (P.mode != 0) {
-#if defined(WV_HDP)
-        return -1;
-#elif defined(WV_VANILLA)
+#if defined(WV_VANILLA)
         if (withSwitch) return -1;
         WV_LAUNCH_B(cpecan_k_wv_backward_em);
         WV_LAUNCH_POST;
@@ -2373,13 +2411,10 @@ extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevIt
                                                  const long long *trackBase, const unsigned short *kidx,
                                                  const double *models, const double *Fring, long long ringDoubles,
                                                  const double *Bring, int ringD, void *states, const char *scratch,
-                                                 long long scratchBytes, double *expect, int window) {
-#if defined(WV_HDP)
-    return -1;
-#else
+                                                 long long scratchBytes, double *expect, int window, long long *pairs,
+                                                 double *pairLogp) {
     hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_expect), dim3((unsigned) nItems, WV_EXPECT_CHUNKS), dim3(WV_P), 0, stream,
                        items, nItems, P, (const int2 *) bandTab, track, trackBase, kidx, models, Fring, ringDoubles,
-                       Bring, ringD, (WvState *) states, scratch, scratchBytes, expect, window);
+                       Bring, ringD, (WvState *) states, scratch, scratchBytes, expect, window, pairs, pairLogp);
     return hipGetLastError() == hipSuccess ? 0 : -1;
-#endif
 }

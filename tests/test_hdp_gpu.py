@@ -96,20 +96,26 @@ def test_hdp_matches_oracle(ctx, nhdp, case, general):
     b.close()
 
 
-def test_hdp_expectations_and_assignments_match_oracle(ctx, nhdp):
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("shape", [dict(seed=67, n=3, lX=120, every=25, md=60, tb=10, e=20),
+                                   dict(seed=68, n=2, lX=500, every=50, md=200, tb=40, e=100),
+                                   dict(seed=69, n=2, lX=90, every=10 ** 6, md=40, tb=5, e=20)])
+def test_hdp_expectations_and_assignments_match_oracle(ctx, nhdp, shape, general):
     """Baum-Welch sums of the HDP machine (diagonalCalculation_Expectations with
     cell_signal_updateTransAndKmerSkipExpectations2, impl/pairwiseAligner.c:445-476): 9 transitions and the
     likelihood per model (another summation order than the host loop: 1e-9 relative), and per alignment the
     event-to-k-mer assignments -- one per transition INTO match whose posterior reaches the HdpHmm's
-    threshold -- bit-identical and in the reference's order."""
-    batch, model = hdp_batch(67, 3, 120, 25, nhdp)
+    threshold -- bit-identical and in the reference's order.  On the wave-per-alignment kernels (the assignments
+    leave the device unordered, tagged with their window, and the library orders them) and on the general kernel."""
+    batch, model = hdp_batch(shape["seed"], shape["n"], shape["lX"], shape["every"], nhdp)
     ctx.models_clear()
     ids = ctx.modelsh_create([(cp.NANOPORE_TRANSITIONS, nhdp["alphabet"], nhdp["grid"], nhdp["y"],
                                nhdp["slope"], nhdp["kmer_row"])])
     threshold = 0.05  # the machine's posteriors are flat (quirk Q6): a low bar gives a few hundred assignments
-    bp = band_params(threshold, 60, 10, 20)
+    bp = band_params(threshold, shape["md"], shape["tb"], shape["e"])
     b = cp.Batch(ctx, make_items(batch, (1, 1)), batch["x_chars"], batch["events"], batch["anchors"], bp,
-                 flags=cp.FLAG_EXPECTATIONS, hdp=True)
+                 flags=cp.FLAG_EXPECTATIONS | (cp.FLAG_GENERAL_KERNEL if general else 0), hdp=True)
+    assert b.info()["kernel"] == ("general" if general else "systolic")
     b.run()
     b.sync()
     npairs, _, _ = b.counts()

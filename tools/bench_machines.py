@@ -1,5 +1,5 @@
-"""Throughput of the general kernels' machines (vanilla, HDP, 5-state DNA; posterior decode and expectations) on
-mid-size batches, for the record in DESIGN.md.  Run on the GPU box: python tools/bench_machines.py"""
+"""Throughput of the vanilla, HDP and 5-state DNA machines (posterior decode and expectations; wave-per-alignment or
+general kernels as the library picks them) on mid-size batches, for the record in DESIGN.md.  Run on the GPU box: python tools/bench_machines.py"""
 import os
 import sys
 import time
@@ -11,7 +11,6 @@ sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import pyoracle as o  # noqa: E402  (model construction only)
 import synth  # noqa: E402
 import test_dna5_gpu as td  # noqa: E402
-import test_hdp_gpu as th  # noqa: E402
 import test_vanilla_gpu as tv  # noqa: E402
 from harness import band_params, cp, make_items  # noqa: E402
 
@@ -25,7 +24,10 @@ def timed(make, label):
         b.run(); b.sync()
         t0 = time.perf_counter(); b.run(); b.sync(); dt = time.perf_counter() - t0
         cells = int(b.counts()[2].sum())
-        print("%s %s: %d items, %.1f ms, %.2f Gcells/s" % (label, what, b.n, dt * 1e3, cells / dt / 1e9), flush=True)
+        info = b.info()
+        print("%s %s: %d items, %.1f ms, %.2f Gcells/s (%s kernel, widest band %d)" % (
+            label, what, b.n, dt * 1e3, cells / dt / 1e9, info.get("family", info["kernel"]), info["max_band_width"]),
+            flush=True)
         b.close()
 
 
@@ -37,12 +39,25 @@ ctx.modelsv_create([(m.scalars, m.match, m.skip, m.gap_y) for m in models])
 timed(lambda f: cp.Batch(ctx, make_items(batch, (1, 1)), batch["x_chars"], batch["events"], batch["anchors"], bp,
                          flags=f, vanilla=True), "vanilla")
 
-nhdp = o.load_nhdp(os.path.join(ROOT, "tests", "golden", "testTemplate.nhdp"))
-hb, _ = th.hdp_batch(7, n, 2000, 50, nhdp)
+# the HDP machine: reads drawn as bench.py --config 5 draws them (anchors on k-mers that emitted), through the host
+# library's own reader of the reference's serialized HDP
+import ctypes as C  # noqa: E402
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+host = C.CDLL(os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_host.so"))
+host.deserialize_nhdp.restype = C.c_void_p
+host.deserialize_nhdp.argtypes = [C.c_char_p]
+host.getHdpStateMachine3.restype = C.c_void_p
+host.getHdpStateMachine3.argtypes = [C.c_void_p]
+host.cpecan_hdp_machine_as_model.argtypes = [C.c_void_p, C.c_void_p]
+sm = host.getHdpStateMachine3(host.deserialize_nhdp(os.path.join(ROOT, "tests", "golden", "testTemplate.nhdp").encode()))
+desc = cp.HdpModelDesc()
+host.cpecan_hdp_machine_as_model(sm, C.byref(desc))
+hb = bench.hdp_reads(n, 2000, 4000, 7, desc)
 ctx.models_clear()
-ctx.modelsh_create([(cp.NANOPORE_TRANSITIONS, nhdp["alphabet"], nhdp["grid"], nhdp["y"], nhdp["slope"],
-                     nhdp["kmer_row"])])
-timed(lambda f: cp.Batch(ctx, make_items(hb, (1, 1)), hb["x_chars"], hb["events"], hb["anchors"],
+ids = np.zeros(1, np.int32)
+assert cp.lib().cpecan_hip_modelsh_create(ctx.h, C.byref(desc), 1, ids.ctypes.data_as(C.c_void_p)) == 0
+timed(lambda f: cp.Batch(ctx, bench.make_items(cp, hb), hb["x_chars"], hb["events"], hb["anchors"],
                          band_params(0.05 if f else 0.01, 1000, 40, 100), flags=f, hdp=True), "hdp")
 
 rng = np.random.default_rng(3)
