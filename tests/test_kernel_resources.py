@@ -52,7 +52,8 @@ def test_wave_kernels_fit_two_waves_per_simd(tmp_path, cells, hdp):
                            "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     text = open(out).read()
     sfx = "_%s%d" % ("v" if hdp == "vanilla" else "h" if hdp else "l", cells)
-    for name in ("cpecan_k_wv_forward" + sfx, "cpecan_k_wv_backward" + sfx, "cpecan_k_wv_resweep" + sfx):
+    for name in ("cpecan_k_wv_forward" + sfx, "cpecan_k_wv_backward" + sfx, "cpecan_k_wv_resweep" + sfx,
+                 "cpecan_k_wv_backward_em" + sfx):  # (every machine's E-step sweeps back with this one)
         meta = text[text.index(".name:           " + name + "\n"):]
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
