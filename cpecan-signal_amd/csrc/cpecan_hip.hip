@@ -261,11 +261,13 @@ int fail(int code, const char *fmt, ...) {
                         __FILE__, __LINE__);                                                 \
     } while (0)
 
-/* one candidate pair on its way to the host: coordinates and the exponent (F + B) - totalProbability */
+/* one candidate pair on its way to the host: its coordinates.  With it goes the device's verdict (an int, see
+ * cpecan_k_pack_pairs); the exponent (F + B) - totalProbability stays in HBM and is fetched for the few candidates the
+ * host has to settle itself, and for callers that ask for it: 12 bytes per candidate cross PCIe instead of 20. */
 struct PackedPair {
     int x, y;
-    double logp;
 };
+#define CP_UNDECIDED_CAP 65536ull /* candidates per batch the host settles with its libm before it fetches exponents item by item */
 
 /* Device memory of batches and model tables goes through a small caching allocator: hipMalloc and hipFree wait for
  * the device, so a host thread that prepares the next batch while the GPU works on the current one (one-shot
@@ -465,6 +467,8 @@ struct cpecan_batch {
     DevBuf<long long> packBase;
     DevBuf<PackedPair> packed;
     DevBuf<int> packedPost;
+    DevBuf<long long> undecided;   /* cpecan_k_pack_pairs: [count | CP_UNDECIDED_CAP x (packed index, exponent bits)] */
+    long long *hUndecided = nullptr; /* its pinned copy */
     PackedPair *hPacked = nullptr; /* hipHostMalloc */
     int *hPost = nullptr;          /* hipHostMalloc: the device's verdict per candidate (cpecan_k_pack_pairs) */
     size_t hPackedCap = 0;
@@ -475,7 +479,7 @@ struct cpecan_batch {
 
 extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
                                                const double *logp, double threshold, long long capacity,
-                                               PackedPair *out, int *post);
+                                               PackedPair *out, int *post, long long *undecided);
 extern "C" __global__ void cpecan_k_pack_base(const DevItem *items, const long long *nPairs, long long nItems,
                                               long long *packBase);
 
@@ -979,6 +983,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
     if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedCap * sizeof(PackedPair));
     if (b->hPost) pinned_cache().put(b->hPost, b->hPackedCap * sizeof(int));
+    if (b->hUndecided) pinned_cache().put(b->hUndecided, (1 + 2 * CP_UNDECIDED_CAP) * sizeof(long long));
     delete b;
     (void) hipGetLastError(); /* a failed clean-up call must not surface as the "last error" of a later launch */
     return CPECAN_OK;
@@ -1595,12 +1600,14 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
             HIP_TRY(b->packedPost.alloc((size_t) guess));
         }
         if (b->packBase.n < (size_t) b->nItems + 1) HIP_TRY(b->packBase.alloc((size_t) b->nItems + 1));
+        if (b->undecided.n == 0) HIP_TRY(b->undecided.alloc(1 + 2 * CP_UNDECIDED_CAP));
+        HIP_TRY(hipMemsetAsync(b->undecided.p, 0, sizeof(long long), c->stream));
         hipLaunchKernelGGL(cpecan_k_pack_base, dim3(1), dim3(256), 0, c->stream, (const DevItem *) b->items.p,
                            (const long long *) b->nPairs.p, (long long) b->nItems, b->packBase.p);
         hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
                            (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
                            (const double *) b->pairLogp.p, b->P.threshold, (long long) b->packed.n, b->packed.p,
-                           b->packedPost.p);
+                           b->packedPost.p, b->undecided.p);
         HIP_TRY(hipGetLastError());
         b->packedInRun = true;
     }
@@ -1705,7 +1712,8 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *b, float *msTotal, float *msKernel
  * surely below the threshold (post -2); the few that are close (post -1) are finished by the host with its libm. */
 extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
                                                const double *logp, double threshold, long long capacity,
-                                               PackedPair *out, int *post) {
+                                               PackedPair *out, int *post, long long *undecided /* [0] count, then
+                                               CP_UNDECIDED_CAP x (packed index, exponent bits) */) {
     const DevItem &d = items[blockIdx.x];
     if (packBase[gridDim.x] > capacity) return; /* (packed at the end of a run into a buffer sized by a guess: the host
                                                    sees the same total and packs again into one that fits) */
@@ -1714,9 +1722,9 @@ extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long 
         PackedPair r;
         r.x = (int) pairs[(d.pairBase + k) * 3 + 1];
         r.y = (int) pairs[(d.pairBase + k) * 3 + 2];
-        r.logp = logp[d.pairBase + k];
         out[o + k] = r;
-        const double p = exp(r.logp);
+        const double e = logp[d.pairBase + k];
+        const double p = exp(e);
         int v = -1;
         if (p == p) {
             if (p < threshold - (1e-9 * threshold + 1e-300)) v = -2;
@@ -1725,10 +1733,21 @@ extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long 
                 else if (p < 1.0 - 1e-9) {
                     const double q = p * 10000000.0, fl = floor(q);
                     if (q - fl > 1e-5 && fl + 1.0 - q > 1e-5) v = (int) fl;
-                }
+                } else if (e >= 0.0) v = 10000000; /* exp(e) >= 1 on any libm: clamped to 1 */
+                else if (e <= -1e-15) v = 9999999; /* exp(e) <= 1 - 9e-16 < 1, and p * 1e7 rounds below 1e7 (its
+                                                      ulp there is 1.9e-9, the deficit at least 1e-8): a quarter of a
+                                                      C3 batch's candidates are this sure a match */
             }
         }
         post[o + k] = v;
+        if (v == -1) { /* the host settles it: its exponent goes along (a short list; a batch that overflows it has
+                          the host fetch the exponents item by item) */
+            const unsigned long long j = atomicAdd((unsigned long long *) undecided, 1ull);
+            if (j < CP_UNDECIDED_CAP) {
+                undecided[1 + 2 * j] = o + k;
+                undecided[2 + 2 * j] = __double_as_longlong(e);
+            }
+        }
     }
 }
 
@@ -1864,15 +1883,21 @@ static int ensure_counts(cpecan_batch *b) {
             HIP_TRY(pinned_cache().get((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair)));
             HIP_TRY(pinned_cache().get((void **) &b->hPost, b->hPackedCap * sizeof(int)));
         }
+        if (b->undecided.n == 0) HIP_TRY(b->undecided.alloc(1 + 2 * CP_UNDECIDED_CAP));
+        if (!b->hUndecided)
+            HIP_TRY(pinned_cache().get((void **) &b->hUndecided, (1 + 2 * CP_UNDECIDED_CAP) * sizeof(long long)));
         if (!packedAlready) {
         HIP_TRY(hipMemcpyAsync(b->packBase.p, b->hPairBase.data(), ((size_t) b->nItems + 1) * sizeof(long long),
                                hipMemcpyHostToDevice, b->ctx->stream));
+        HIP_TRY(hipMemsetAsync(b->undecided.p, 0, sizeof(long long), b->ctx->stream));
         hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, b->ctx->stream,
                            (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
                            (const double *) b->pairLogp.p, b->P.threshold, (long long) b->packed.n, b->packed.p,
-                           b->packedPost.p);
+                           b->packedPost.p, b->undecided.p);
         HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipMemcpyAsync(b->hUndecided, b->undecided.p, (1 + 2 * CP_UNDECIDED_CAP) * sizeof(long long),
+                               hipMemcpyDeviceToHost, b->ctx->stream));
         HIP_TRY(hipMemcpyAsync(b->hPacked, b->packed.p, (size_t) all * sizeof(PackedPair), hipMemcpyDeviceToHost,
                                b->ctx->stream));
         HIP_TRY(hipMemcpyAsync(b->hPost, b->packedPost.p, (size_t) all * sizeof(int), hipMemcpyDeviceToHost,
@@ -1884,45 +1909,65 @@ static int ensure_counts(cpecan_batch *b) {
      * every item keeps.  The records stay packed in pinned memory; cpecan_hip_batch_fetch_pairs expands an item's
      * pairs into the reference's triples when they are asked for.  Items are independent: dealt to the host threads. */
     const double threshold = b->P.threshold;
-    const PackedPair *src = b->hPacked;
     int *verdict = b->hPost;
     static const bool hostOnly = getenv("CPECAN_HOST_FINALISE") != nullptr; /* (tests: every pair through the host libm) */
-    auto finish = [b, src, verdict, threshold](int64_t i0, int64_t i1) {
+    const int nt = (int) std::min<int64_t>(all > 200000 ? host_threads() : 1, b->nItems);
+    /* contiguous runs of items with about the same number of candidates each */
+    std::vector<int64_t> cut(1, 0);
+    for (int t = 0; t < nt; t++) {
+        const long long want = all * (t + 1) / nt;
+        int64_t i1 = cut.back();
+        while (i1 < b->nItems && (b->hPairBase[(size_t) i1 + 1] <= want || t == nt - 1)) i1++;
+        cut.push_back(i1);
+    }
+    cut.back() = b->nItems;
+    /* what the device settled is counted by the host threads; what it left open (verdict -1) comes with its exponent
+     * in the short list the pack kernel made, and is settled here with the host libm */
+    const long long listed = all > 0 ? b->hUndecided[0] : 0;
+    const bool byList = !hostOnly && listed <= (long long) CP_UNDECIDED_CAP;
+    if (getenv("CPECAN_TIMING")) fprintf(stderr, "[cpecan timing] ensure_counts: %lld candidates, %lld left to the host\n", all, listed);
+    auto settle = [threshold](double e) {
+        double p = exp(e);
+        if (!(p >= threshold)) return -2;
+        if (p > 1.0) p = 1.0;
+        return (int) floor(p * 10000000.0);
+    };
+    if (byList)
+        for (long long j = 0; j < listed; j++) {
+            double e;
+            memcpy(&e, &b->hUndecided[2 + 2 * j], sizeof e);
+            verdict[b->hUndecided[1 + 2 * j]] = settle(e);
+        }
+    std::atomic<int> failed{0};
+    auto scan = [b, verdict, byList, &settle, &failed](int64_t i0, int64_t i1) {
+        std::vector<double> e;
         for (int64_t i = i0; i < i1; i++) {
             const long long o = b->hPairBase[(size_t) i], n = b->hPairBase[(size_t) i + 1] - o;
+            if (!byList && n > 0) { /* (tests, or more close calls than the list holds: this item's exponents from HBM) */
+                e.resize((size_t) n);
+                if (hipSetDevice(b->ctx->device) != hipSuccess ||
+                    hipMemcpy(e.data(), b->pairLogp.p + b->hItems[(size_t) i].pairBase, (size_t) n * sizeof(double),
+                              hipMemcpyDeviceToHost) != hipSuccess) {
+                    failed = 1;
+                    return;
+                }
+            }
             long long kept = 0;
             for (long long k = 0; k < n; k++) {
-                int v = hostOnly ? -1 : verdict[o + k];
-                if (v == -1) {
-                    double p = exp(src[o + k].logp);
-                    if (!(p >= threshold)) v = -2;
-                    else {
-                        if (p > 1.0) p = 1.0;
-                        v = (int) floor(p * 10000000.0);
-                    }
-                    verdict[o + k] = v;
-                }
-                kept += v >= 0;
+                if (!byList && (hostOnly || verdict[o + k] == -1)) verdict[o + k] = settle(e[(size_t) k]);
+                kept += verdict[o + k] >= 0;
             }
             b->hNPairs[(size_t) i] = kept;
         }
     };
-    const int nt = (int) std::min<int64_t>(all > 200000 ? host_threads() : 1, b->nItems);
-    if (nt <= 1) finish(0, b->nItems);
-    else {
-        /* contiguous runs of items with about the same number of candidates each */
+    {
         std::vector<std::thread> pool;
-        int64_t i0 = 0;
-        for (int t = 0; t < nt; t++) {
-            const long long want = all * (t + 1) / nt;
-            int64_t i1 = i0;
-            while (i1 < b->nItems && (b->hPairBase[(size_t) i1 + 1] <= want || t == nt - 1)) i1++;
-            if (i1 > i0) pool.emplace_back(finish, i0, i1);
-            i0 = i1;
-        }
-        if (i0 < b->nItems) finish(i0, b->nItems);
+        for (int t = 1; t < nt; t++)
+            if (cut[(size_t) t + 1] > cut[(size_t) t]) pool.emplace_back(scan, cut[(size_t) t], cut[(size_t) t + 1]);
+        scan(cut[0], cut[1]);
         for (std::thread &th : pool) th.join();
     }
+    if (failed) return fail(CPECAN_EHIP, "fetching the candidates' exponents failed: %s", hipGetErrorString(hipGetLastError()));
     b->countsValid = true;
     return CPECAN_OK;
 }
@@ -1954,6 +1999,13 @@ int cpecan_hip_batch_fetch_pairs(cpecan_batch *b, int64_t item, int64_t *triples
     }
     /* the item's packed candidates with their settled verdicts -> (floor(p * 1e7), x, y), emission order */
     const long long cand = b->hPairBase[(size_t) item + 1] - o;
+    std::vector<double> e;
+    if (logp) { /* the exponents stayed in HBM: this item's, now */
+        e.resize((size_t) cand);
+        HIP_TRY(hipSetDevice(b->ctx->device));
+        HIP_TRY(hipMemcpy(e.data(), b->pairLogp.p + b->hItems[(size_t) item].pairBase, (size_t) cand * sizeof(double),
+                          hipMemcpyDeviceToHost));
+    }
     long long kept = 0;
     for (long long k = 0; k < cand; k++) {
         const int v = b->hPost[o + k];
@@ -1961,7 +2013,7 @@ int cpecan_hip_batch_fetch_pairs(cpecan_batch *b, int64_t item, int64_t *triples
         triples[kept * 3] = v;
         triples[kept * 3 + 1] = b->hPacked[o + k].x;
         triples[kept * 3 + 2] = b->hPacked[o + k].y;
-        if (logp) logp[kept] = b->hPacked[o + k].logp;
+        if (logp) logp[kept] = e[(size_t) k];
         kept++;
     }
     return CPECAN_OK;
