@@ -87,6 +87,10 @@ struct DevParams {
     int mode, debug, unbanded;
     int scanDecode; /* systolic kernels: decode posteriors by the full scan (diagnostic) */
     double logThrSlack; /* log(threshold) minus a safety margin: cells below it skip exp() */
+    int ldsWidth; /* 5-state general kernel: cells per diagonal the workgroup's LDS holds -- the forward sweep reads its
+                     two previous diagonals from there instead of HBM (0: band too wide, through HBM).  The backward
+                     diagonals stay in HBM: with them in LDS too a CU holds three workgroups instead of five and the
+                     batch runs slower (4.1 against 6.3 Gcells/s) */
 };
 
 /* lookup(): impl/pairwiseAligner.c:238-249 -- four cubics, float literals */

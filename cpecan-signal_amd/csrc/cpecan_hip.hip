@@ -1208,6 +1208,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->P.unbanded = unbanded ? 1 : 0;
     b->P.scanDecode = (flags & CPECAN_FLAG_SCAN_DECODE) ? 1 : 0;
     b->P.logThrSlack = params->threshold > 0.0 ? log(params->threshold) - 1e-3 : -INFINITY;
+    b->P.ldsWidth = 0; /* (set per launch by the kernels that use it) */
 
     /* the HDP and vanilla machines have wave-per-alignment kernels of their own, for the posterior decode and for
      * the E-step (the 5-state machine runs on the general kernel); CPECAN_FLAG_GENERAL_KERNEL keeps such a batch on
@@ -1465,8 +1466,13 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
         HIP_TRY(hipMemsetAsync(b->expect.p, 0, b->expect.n * sizeof(double), c->stream));
     HIP_TRY(hipEventRecord(b->ev1, c->stream));
     if (b->dna) {
-        hipLaunchKernelGGL(cpecan_k_general5, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
-                           (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p,
+        /* the forward sweep's two previous diagonals live in LDS where the widest band fits (3 diagonals of 5 states:
+         * 120 bytes per cell of width); CPECAN_GENERAL_LDS=0 keeps them in HBM (timing, tests) */
+        static const bool ldsOff = getenv("CPECAN_GENERAL_LDS") != nullptr && atoi(getenv("CPECAN_GENERAL_LDS")) == 0;
+        DevParams P5 = b->P;
+        P5.ldsWidth = (!ldsOff && b->maxWidth <= 248) ? b->maxWidth : 0;
+        hipLaunchKernelGGL(cpecan_k_general5, dim3((unsigned) b->nItems), dim3(256), (size_t) P5.ldsWidth * 120, c->stream,
+                           (const DevItem *) b->items.p, P5, (const int *) b->bandL.p,
                            (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
                            (const char *) b->chars.p, (const char *) b->charsY.p,
                            (const double *) c->models5.p, b->Fstore.p, b->Bstore.p, b->pairs.p,

@@ -37,6 +37,8 @@ struct Ctx5 {
     const double *gx, *gy;  /* 4 + 4 gap emissions */
     double *F, *Bws;
     int maxWidth;
+    double *ldsF; /* the forward cells of the last three diagonals, [d % 3][cell][state]; NULL: read them from HBM */
+    int ldsW;
 };
 
 /* emissions_discrete_getBaseIndex impl/stateMachine.c:104-118: anything but upper-case ACGT is "not a
@@ -56,6 +58,14 @@ __device__ __forceinline__ const double *fcell5(const Ctx5 &c, long long d, int 
     if (d < 0) return nullptr;
     const int l = c.L[d], r = c.R[d];
     if (xmy < l || xmy > r) return nullptr;
+    return c.F + (c.pre[d] + ((xmy - l) >> 1)) * S5;
+}
+/* the same for the forward sweep's own neighbours (diagonals d - 1 and d - 2 of the diagonal being computed) */
+__device__ __forceinline__ const double *fcell5_sweep(const Ctx5 &c, long long d, int xmy) {
+    if (d < 0) return nullptr;
+    const int l = c.L[d], r = c.R[d];
+    if (xmy < l || xmy > r) return nullptr;
+    if (c.ldsF) return c.ldsF + ((d % 3) * (long long) c.ldsW + ((xmy - l) >> 1)) * S5;
     return c.F + (c.pre[d] + ((xmy - l) >> 1)) * S5;
 }
 __device__ __forceinline__ double *bslot5(const Ctx5 &c, long long d) {
@@ -86,9 +96,9 @@ __device__ __forceinline__ void forward_cell5(const Ctx5 &c, long long d, int xm
     const double *t = c.t;
 #pragma unroll
     for (int s = 0; s < S5; s++) o[s] = CP_NEG_INF;
-    const double *lower = fcell5(c, d - 1, xmy - 1);
-    const double *middle = fcell5(c, d - 2, xmy);
-    const double *upper = fcell5(c, d - 1, xmy + 1);
+    const double *lower = fcell5_sweep(c, d - 1, xmy - 1);
+    const double *middle = fcell5_sweep(c, d - 2, xmy);
+    const double *upper = fcell5_sweep(c, d - 1, xmy + 1);
     if (lower) {
         const double eP = e_gap(c.gx, bx);
         o[1] = cp_logAdd(o[1], lower[0] + (eP + t[T5_GAP_SHORT_OPEN_X]));
@@ -167,6 +177,9 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_general5(
     c.F = Fstore + it.cellBase * S5;
     c.Bws = Bstore + it.bwsBase;
     c.maxWidth = it.maxWidth;
+    extern __shared__ double ldsDiagonals[]; /* the last three forward diagonals, P.ldsWidth cells each (launch-time size) */
+    c.ldsW = P.ldsWidth;
+    c.ldsF = P.ldsWidth > 0 ? ldsDiagonals : nullptr;
     const double *t = c.t;
 
     __shared__ double sTotal;
@@ -187,6 +200,8 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_general5(
         c.F[2] = CP_NEG_INF;
         c.F[3] = it.raggedL ? 0.0 : CP_NEG_INF;
         c.F[4] = it.raggedL ? 0.0 : CP_NEG_INF;
+        if (c.ldsF)
+            for (int s = 0; s < S5; s++) c.ldsF[s] = c.F[s];
     }
     __threadfence_block();
     __syncthreads();
@@ -195,11 +210,15 @@ extern "C" __global__ __launch_bounds__(256) void cpecan_k_general5(
     for (long long d = 1; d <= D; d++) {
         const int l = c.L[d], width = ((c.R[d] - l) >> 1) + 1;
         double *fd = c.F + c.pre[d] * S5;
+        double *fl = c.ldsF ? c.ldsF + (d % 3) * (long long) c.ldsW * S5 : nullptr;
         for (int cc = tid; cc < width; cc += 256) {
             double o[S5];
             forward_cell5(c, d, l + 2 * cc, o);
 #pragma unroll
             for (int s = 0; s < S5; s++) fd[cc * S5 + s] = o[s];
+            if (fl)
+#pragma unroll
+                for (int s = 0; s < S5; s++) fl[cc * S5 + s] = o[s];
         }
         __threadfence_block();
         __syncthreads();
