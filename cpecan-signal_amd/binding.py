@@ -429,6 +429,11 @@ class Batch:
         _check(lib().cpecan_hip_batch_info(self.h, C.byref(k), C.byref(w), C.byref(m)))
         out = dict(kernel={1: "general", 2: "systolic"}.get(k.value, str(k.value)), workgroups=w.value,
                    max_band_width=m.value)
+        if self.dna:
+            f = C.c_int32()
+            _check(lib().cpecan_hip_batch_kernel_family(self.h, C.byref(f)))
+            if f.value:
+                out["family"] = "wave (5-state)"
         if k.value == KERNEL_SYSTOLIC:
             r = C.c_int32()
             _check(lib().cpecan_hip_batch_systolic_rows(self.h, C.byref(r)))

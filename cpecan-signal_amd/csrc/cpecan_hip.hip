@@ -43,6 +43,14 @@ extern "C" __global__ void cpecan_k_generalh(const DevItem *, DevParams, const i
                                              const long long *, const int *, const double *,
                                              const DevHdpModel *, double *, double *, long long *, double *,
                                              long long *, long long *, double *, long long *, double *);
+#define W5_DECLARE(L)                                                                                             \
+    extern "C" __global__ void cpecan_k_wave5_l##L(const DevItem *, DevParams, const int *, const int *,          \
+                                                   const long long *, const char *, const char *, const double *, \
+                                                   double *, long long *, double *, long long *, long long *,     \
+                                                   double *, long long *);
+W5_DECLARE(1)
+W5_DECLARE(2)
+W5_DECLARE(3)
 extern "C" __global__ void cpecan_k_hdp_kmer_id(const char *, long long, unsigned long long,
                                                 unsigned long long, int, int *);
 extern "C" __global__ void cpecan_k_kmer_index(const char *, long long, unsigned short *);
@@ -1465,7 +1473,18 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
     if (b->mode == CPECAN_MODE_EXPECTATIONS)
         HIP_TRY(hipMemsetAsync(b->expect.p, 0, b->expect.n * sizeof(double), c->stream));
     HIP_TRY(hipEventRecord(b->ev1, c->stream));
-    if (b->dna) {
+    static const bool wave5Off = getenv("CPECAN_DNA_GENERAL") != nullptr; /* (tests, timing: the general kernel) */
+    if (b->dna && b->mode == CPECAN_MODE_POSTERIOR && !b->P.debug && !b->P.unbanded && b->maxWidth <= 192 && !wave5Off &&
+        !(b->flags & CPECAN_FLAG_GENERAL_KERNEL)) {
+        /* the 5-state machine's posterior decode for bands a wave covers in one to three cells per lane: one wave per
+         * alignment, the recurrence in registers (cpecan_kernel_wave5.hip) */
+        auto kernel5 = b->maxWidth <= 64 ? cpecan_k_wave5_l1 : b->maxWidth <= 128 ? cpecan_k_wave5_l2 : cpecan_k_wave5_l3;
+        hipLaunchKernelGGL(kernel5, dim3((unsigned) b->nItems), dim3(64), 0, c->stream, (const DevItem *) b->items.p, b->P,
+                           (const int *) b->bandL.p, (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
+                           (const char *) b->chars.p, (const char *) b->charsY.p, (const double *) c->models5.p,
+                           b->Fstore.p, b->pairs.p, b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p);
+        HIP_TRY(hipGetLastError());
+    } else if (b->dna) {
         /* the forward sweep's two previous diagonals live in LDS where the widest band fits (3 diagonals of 5 states:
          * 120 bytes per cell of width); CPECAN_GENERAL_LDS=0 keeps them in HBM (timing, tests) */
         static const bool ldsOff = getenv("CPECAN_GENERAL_LDS") != nullptr && atoi(getenv("CPECAN_GENERAL_LDS")) == 0;
@@ -1631,6 +1650,12 @@ int cpecan_hip_batch_systolic_rows(cpecan_batch *b, int32_t *rows) {
 
 int cpecan_hip_batch_kernel_family(cpecan_batch *b, int32_t *wave) {
     if (!b || !wave) return fail(CPECAN_EINVAL, "bad argument");
+    if (b->dna) { /* the 5-state machine: one wave per alignment (cpecan_kernel_wave5.hip) where batch_run picks it */
+        static const bool wave5Off = getenv("CPECAN_DNA_GENERAL") != nullptr;
+        *wave = (b->mode == CPECAN_MODE_POSTERIOR && !b->P.debug && !b->P.unbanded && b->maxWidth <= 192 && !wave5Off &&
+                 !(b->flags & CPECAN_FLAG_GENERAL_KERNEL)) ? 1 : 0;
+        return CPECAN_OK;
+    }
     if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "not a register-resident batch");
     *wave = b->sy->wave ? 1 : 0;
     return CPECAN_OK;

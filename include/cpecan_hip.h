@@ -255,7 +255,9 @@ int cpecan_hip_batch_info(cpecan_batch *batch, int32_t *kernel, int32_t *workgro
  * alignment takes, the more alignments a CU holds (16, 8, 5, 4). */
 int cpecan_hip_batch_systolic_rows(cpecan_batch *batch, int32_t *rows);
 /* Register-resident path only: *wave = 1 if the batch runs on the wave-per-alignment kernels (rows is then the
- * number of cells a lane holds: 2, 3 or 4), 0 on the workgroup-per-alignment ones (rows = waves per workgroup). */
+ * number of cells a lane holds: 2, 3 or 4), 0 on the workgroup-per-alignment ones (rows = waves per workgroup).  For a
+ * DNA batch: 1 if its posterior decode runs on the one-wave-per-alignment 5-state kernel (bands up to 192 cells), 0 if
+ * on the general one. */
 int cpecan_hip_batch_kernel_family(cpecan_batch *batch, int32_t *wave);
 /* Systolic path only: HIP-event time of the last run spent in the forward-window kernels and in
  * the backward-window kernels (each launched `launches_each` times, once per traceback window). */

@@ -57,7 +57,10 @@ def run_case(ctx, seqs, bp, ragged, flags=0, unbanded=False):
     b.run()
     b.sync()
     npairs, ntot, ncells = b.counts()
-    assert b.info()["kernel"] == "general"
+    info = b.info()
+    assert info["kernel"] == "general"
+    if not unbanded and info["max_band_width"] <= 192:  # posterior decode of bands a wave covers: the 5-state wave kernel
+        assert (info.get("family") == "wave (5-state)") == (not flags & cp.FLAG_GENERAL_KERNEL)
     p = orc_params(bp, split=1 << 60)
     for i, (x, y, a) in enumerate(seqs):
         tri, lp = b.pairs(i, npairs[i])
@@ -85,12 +88,17 @@ def test_toy_known_answer(ctx):
              unbanded=True)
 
 
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
 @pytest.mark.parametrize("case", [
     dict(n=3, length=60, e=20, md=30, tb=5, ragged=(0, 0), anchored=False),
     dict(n=3, length=150, e=10, md=40, tb=8, ragged=(1, 1), anchored=True),
     dict(n=2, length=300, e=20, md=100, tb=40, ragged=(1, 0), anchored=True),
+    dict(n=2, length=700, e=50, md=150, tb=20, ragged=(0, 1), anchored=True),   # two cells per lane
+    dict(n=2, length=900, e=80, md=200, tb=40, ragged=(0, 0), anchored=True),   # three cells per lane
 ])
-def test_dna5_matches_oracle(ctx, case):
+def test_dna5_matches_oracle(ctx, case, general):
+    """the one-wave-per-alignment kernel (cpecan_kernel_wave5.hip, one to three cells per lane by band width) and the
+    general one (CPECAN_FLAG_GENERAL_KERNEL)"""
     rng = np.random.default_rng(31 + case["length"])
     seqs = []
     for _ in range(case["n"]):
@@ -98,7 +106,7 @@ def test_dna5_matches_oracle(ctx, case):
         a = pairs[5::12] if case["anchored"] else np.zeros((0, 2), np.int64)
         seqs.append((x, y, a))
     bp = band_params(0.01, case["md"], case["tb"], case["e"])
-    run_case(ctx, seqs, bp, case["ragged"])
+    run_case(ctx, seqs, bp, case["ragged"], flags=cp.FLAG_GENERAL_KERNEL if general else 0)
 
 
 def test_config1_two_1kb_sequences(ctx):

@@ -73,3 +73,9 @@ for i in range(n):
     xs += x; ys += y; an.append(a)
 anchors = np.concatenate(an)
 timed(lambda f: cp.Batch(ctx, items, xs, None, anchors, bp, flags=f, y_chars=ys), "dna5")
+# ... and with the reference's default band for DNA (diagonalExpansion 20, inc/pairwiseAligner.h defaults)
+timed(lambda f: cp.Batch(ctx, items, xs, None, anchors, band_params(0.01, 1000, 40, 20), flags=f, y_chars=ys),
+      "dna5 (expansion 20)")
+if os.environ.get("BENCH_MACHINES_NARROW"):  # per-diagonal overhead: bands a handful of cells wide
+    timed(lambda f: cp.Batch(ctx, items, xs, None, anchors, band_params(0.01, 1000, 40, 2), flags=f, y_chars=ys),
+          "dna5 (expansion 2)")
