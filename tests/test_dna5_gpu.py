@@ -151,3 +151,37 @@ def test_discrete_expectations_match_oracle(ctx):
     assert np.count_nonzero(ref[:25]) == 13  # the transitions stateMachine5_cellCalculate takes
     assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
     b.close()
+
+
+def test_degenerate_shapes_agree_between_the_two_kernels(ctx):
+    """one empty sequence, single bases, a 1 x n strip: the one-wave kernel and the general kernel give the same pairs,
+    totals and cell counts (the oracle is not asked: the reference's own entry points return before the DP there)"""
+    model = o.Sm5Model()
+    ctx.models_clear()
+    ids = ctx.models5_create([(list(model.c.t), model.match, model.gx, model.gy)])
+    seqs = [("", "ACGT"), ("ACGTAC", ""), ("A", "A"), ("A", "C"), ("G", "ACGTACGTAC"), ("ACGTACGTACGT", "T"),
+            ("ACGTACGTTGCA", "ACGTCGTTGCA")]
+    xs, ys = "", ""
+    items = np.zeros(len(seqs), cp.ITEM_DTYPE)
+    for i, (x, y) in enumerate(seqs):
+        items[i] = (len(xs), len(x), len(ys), len(y), 0, 0, ids[0], i % 2, (i // 2) % 2, 0)
+        xs += x
+        ys += y
+    out = []
+    for flags in (0, cp.FLAG_GENERAL_KERNEL):
+        b = cp.Batch(ctx, items, xs + "A", None, np.zeros((0, 2), np.int64), band_params(0.01, 4, 1, 2), flags=flags,
+                     y_chars=ys + "A")
+        b.run()
+        b.sync()
+        npairs, ntot, ncells = b.counts()
+        res = []
+        for i in range(len(seqs)):
+            tri, lp = b.pairs(i, npairs[i])
+            xay, tot = b.totals(i, ntot[i])
+            res.append((tri.copy(), lp.copy(), xay.copy(), tot.copy(), int(ncells[i])))
+        out.append(res)
+        b.close()
+    for w, g in zip(*out):
+        assert np.array_equal(w[0], g[0]) and np.array_equal(w[1].view(np.uint64), g[1].view(np.uint64))
+        assert np.array_equal(w[2], g[2]) and np.array_equal(w[3].view(np.uint64), g[3].view(np.uint64)) and w[4] == g[4]
+    assert len(out[0][-1][0]) > 5
