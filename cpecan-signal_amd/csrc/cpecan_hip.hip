@@ -47,7 +47,11 @@ extern "C" __global__ void cpecan_k_generalh(const DevItem *, DevParams, const i
     extern "C" __global__ void cpecan_k_wave5_l##L(const DevItem *, DevParams, const int *, const int *,          \
                                                    const long long *, const char *, const char *, const double *, \
                                                    double *, long long *, double *, long long *, long long *,     \
-                                                   double *, long long *);
+                                                   double *, long long *, double *);                              \
+    extern "C" __global__ void cpecan_k_wave5e_l##L(const DevItem *, DevParams, const int *, const int *,         \
+                                                    const long long *, const char *, const char *, const double *, \
+                                                    double *, long long *, double *, long long *, long long *,    \
+                                                    double *, long long *, double *);
 W5_DECLARE(1)
 W5_DECLARE(2)
 W5_DECLARE(3)
@@ -1474,15 +1478,18 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
         HIP_TRY(hipMemsetAsync(b->expect.p, 0, b->expect.n * sizeof(double), c->stream));
     HIP_TRY(hipEventRecord(b->ev1, c->stream));
     static const bool wave5Off = getenv("CPECAN_DNA_GENERAL") != nullptr; /* (tests, timing: the general kernel) */
-    if (b->dna && b->mode == CPECAN_MODE_POSTERIOR && !b->P.debug && !b->P.unbanded && b->maxWidth <= 192 && !wave5Off &&
-        !(b->flags & CPECAN_FLAG_GENERAL_KERNEL)) {
-        /* the 5-state machine's posterior decode for bands a wave covers in one to three cells per lane: one wave per
-         * alignment, the recurrence in registers (cpecan_kernel_wave5.hip) */
-        auto kernel5 = b->maxWidth <= 64 ? cpecan_k_wave5_l1 : b->maxWidth <= 128 ? cpecan_k_wave5_l2 : cpecan_k_wave5_l3;
+    if (b->dna && !b->P.debug && !b->P.unbanded && b->maxWidth <= 192 && !wave5Off && !(b->flags & CPECAN_FLAG_GENERAL_KERNEL)) {
+        /* the 5-state machine for bands a wave covers in one to three cells per lane: one wave per alignment, the
+         * recurrence in registers (cpecan_kernel_wave5.hip), posterior decode or expectations */
+        const bool em = b->mode == CPECAN_MODE_EXPECTATIONS;
+        auto kernel5 = b->maxWidth <= 64 ? (em ? cpecan_k_wave5e_l1 : cpecan_k_wave5_l1)
+                       : b->maxWidth <= 128 ? (em ? cpecan_k_wave5e_l2 : cpecan_k_wave5_l2)
+                                            : (em ? cpecan_k_wave5e_l3 : cpecan_k_wave5_l3);
         hipLaunchKernelGGL(kernel5, dim3((unsigned) b->nItems), dim3(64), 0, c->stream, (const DevItem *) b->items.p, b->P,
                            (const int *) b->bandL.p, (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
                            (const char *) b->chars.p, (const char *) b->charsY.p, (const double *) c->models5.p,
-                           b->Fstore.p, b->pairs.p, b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p);
+                           b->Fstore.p, b->pairs.p, b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
+                           em ? b->expect.p : nullptr);
         HIP_TRY(hipGetLastError());
     } else if (b->dna) {
         /* the forward sweep's two previous diagonals live in LDS where the widest band fits (3 diagonals of 5 states:
@@ -1652,8 +1659,7 @@ int cpecan_hip_batch_kernel_family(cpecan_batch *b, int32_t *wave) {
     if (!b || !wave) return fail(CPECAN_EINVAL, "bad argument");
     if (b->dna) { /* the 5-state machine: one wave per alignment (cpecan_kernel_wave5.hip) where batch_run picks it */
         static const bool wave5Off = getenv("CPECAN_DNA_GENERAL") != nullptr;
-        *wave = (b->mode == CPECAN_MODE_POSTERIOR && !b->P.debug && !b->P.unbanded && b->maxWidth <= 192 && !wave5Off &&
-                 !(b->flags & CPECAN_FLAG_GENERAL_KERNEL)) ? 1 : 0;
+        *wave = (!b->P.debug && !b->P.unbanded && b->maxWidth <= 192 && !wave5Off && !(b->flags & CPECAN_FLAG_GENERAL_KERNEL)) ? 1 : 0;
         return CPECAN_OK;
     }
     if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "not a register-resident batch");

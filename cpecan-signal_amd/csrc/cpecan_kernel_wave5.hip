@@ -93,13 +93,21 @@ template <int P> __device__ __forceinline__ int w5_column(int sl, int xmin, int 
     return x <= xmax ? x : -1;
 }
 
-template <int L> __device__ __forceinline__ void wave5_body(
+template <int L, bool EM> __device__ __forceinline__ void wave5_body(
     const DevItem &it, const DevParams &P, const int *__restrict__ bandL, const int *__restrict__ bandR,
     const long long *__restrict__ pre, const char *__restrict__ cx, const char *__restrict__ cy,
     const double *__restrict__ model, double *F, long long *pairs, double *pairLogp, long long *totXay,
     double *totVal, long long &myPairs, long long &myTot, double *stage /* LDS, 64 * L + 24 doubles */,
-    const double *coef /* LDS, the logAdd table */) {
+    const double *coef /* LDS, the logAdd table */, double *emis /* LDS, EM: the 80 emission sums */,
+    double *expect /* EM: this model's [25 transitions | 80 emissions | likelihood] */) {
     constexpr int PP = 64 * L;
+    /* EM (diagonalCalculation_Expectations :841-863 over stateMachine5_cellCalculate with cell_updateExpectations
+     * :407-424): a lane sums the thirteen kinds of transition over its cells in registers; the emission counts
+     * [to-state][x base][y base] go to the LDS table; the likelihood is added once per diagonal (quirk Q7) */
+    double trans[13];
+#pragma unroll
+    for (int k = 0; k < 13; k++) trans[k] = 0.0;
+    double lik = 0.0;
     const int lane = threadIdx.x & 63;
     /* the emission tables in LDS (a cell's lookups are on its critical path), the transitions uniform */
     if (lane < 24) stage[PP + lane] = model[24 + lane];
@@ -389,6 +397,65 @@ template <int L> __device__ __forceinline__ void wave5_body(
                     total = acc;
                 }
 
+                if (EM) {
+                    if (lane == 0) lik += total;
+                    const bool haveMiddle = d2 - 2 >= tracedBackTo; /* forward[d2-2] is freed otherwise (:982) */
+                    int e1min = 0, e1max = -1, e2min = 0, e2max = -1;
+                    long long e1pre = 0, e2pre = 0;
+                    if (d2 >= 1) {
+                        const long long dd = d2 - 1;
+                        e1min = (int) ((dd + bandL[dd]) / 2);
+                        e1max = (int) ((dd + bandR[dd]) / 2);
+                        e1pre = pre[dd];
+                    }
+                    if (d2 >= 2 && haveMiddle) {
+                        const long long dd = d2 - 2;
+                        e2min = (int) ((dd + bandL[dd]) / 2);
+                        e2max = (int) ((dd + bandR[dd]) / 2);
+                        e2pre = pre[dd];
+                    }
+#pragma unroll
+                    for (int j = 0; j < L; j++) {
+                        const int x = w5_column<PP>(lane * L + j, cxmin, cxmax);
+                        if (x < 0) continue;
+                        const long long y = d2 - x;
+                        const int bx = w5_base(cx, (long long) x - 1), by = w5_base(cy, y - 1);
+                        double into[W5S] = { 0.0, 0.0, 0.0, 0.0, 0.0 };
+                        if (x - 1 >= e1min && x - 1 <= e1max) { /* lower */
+                            const double *nb = F + (e1pre + (x - 1 - e1min)) * W5S;
+                            const double eP = w5_gap(gx, bx);
+                            double pr;
+                            pr = exp(nb[0] + cur[j][1] + (eP + t[W5_GAP_SHORT_OPEN_X]) - total); trans[0] += pr; into[1] += pr;
+                            pr = exp(nb[1] + cur[j][1] + (eP + t[W5_GAP_SHORT_EXTEND_X]) - total); trans[1] += pr; into[1] += pr;
+                            pr = exp(nb[0] + cur[j][3] + (eP + t[W5_GAP_LONG_OPEN_X]) - total); trans[2] += pr; into[3] += pr;
+                            pr = exp(nb[3] + cur[j][3] + (eP + t[W5_GAP_LONG_EXTEND_X]) - total); trans[3] += pr; into[3] += pr;
+                        }
+                        if (haveMiddle && x - 1 >= e2min && x - 1 <= e2max) { /* middle */
+                            const double *nb = F + (e2pre + (x - 1 - e2min)) * W5S;
+                            const double eP = w5_match(mm, bx, by);
+                            double pr;
+                            pr = exp(nb[0] + cur[j][0] + (eP + t[W5_MATCH_CONTINUE]) - total); trans[4] += pr; into[0] += pr;
+                            pr = exp(nb[1] + cur[j][0] + (eP + t[W5_MATCH_FROM_SHORT_GAP_X]) - total); trans[5] += pr; into[0] += pr;
+                            pr = exp(nb[2] + cur[j][0] + (eP + t[W5_MATCH_FROM_SHORT_GAP_Y]) - total); trans[6] += pr; into[0] += pr;
+                            pr = exp(nb[3] + cur[j][0] + (eP + t[W5_MATCH_FROM_LONG_GAP_X]) - total); trans[7] += pr; into[0] += pr;
+                            pr = exp(nb[4] + cur[j][0] + (eP + t[W5_MATCH_FROM_LONG_GAP_Y]) - total); trans[8] += pr; into[0] += pr;
+                        }
+                        if (x >= e1min && x <= e1max) { /* upper */
+                            const double *nb = F + (e1pre + (x - e1min)) * W5S;
+                            const double eP = w5_gap(gy, by);
+                            double pr;
+                            pr = exp(nb[0] + cur[j][2] + (eP + t[W5_GAP_SHORT_OPEN_Y]) - total); trans[9] += pr; into[2] += pr;
+                            pr = exp(nb[2] + cur[j][2] + (eP + t[W5_GAP_SHORT_EXTEND_Y]) - total); trans[10] += pr; into[2] += pr;
+                            pr = exp(nb[0] + cur[j][4] + (eP + t[W5_GAP_LONG_OPEN_Y]) - total); trans[11] += pr; into[4] += pr;
+                            pr = exp(nb[4] + cur[j][4] + (eP + t[W5_GAP_LONG_EXTEND_Y]) - total); trans[12] += pr; into[4] += pr;
+                        }
+                        if (bx < 4 && by < 4) {
+#pragma unroll
+                            for (int st = 0; st < W5S; st++)
+                                if (into[st] != 0.0) atomicAdd(&emis[st * 16 + bx * 4 + by], into[st]);
+                        }
+                    }
+                } else {
                 /* diagonalCalculationPosteriorMatchProbs :756-795, emitted in x order */
                 w5_wave_sync();
 #pragma unroll
@@ -425,6 +492,7 @@ template <int L> __device__ __forceinline__ void wave5_body(
                     }
                     myPairs += __popcll(m);
                 }
+                }
             }
 
             /* one diagonal down: the upper-slot neighbour's d2+1 becomes its d2+2, this diagonal becomes d2+1 */
@@ -443,32 +511,52 @@ template <int L> __device__ __forceinline__ void wave5_body(
         }
         tracedBackTo = tracedBackFrom;
     }
+    if (EM) {
+        /* [from * 5 + to] of the thirteen kinds, in the order they were summed above */
+        const int slot[13] = { 0 * 5 + 1, 1 * 5 + 1, 0 * 5 + 3, 3 * 5 + 3, 0 * 5 + 0, 1 * 5 + 0, 2 * 5 + 0, 3 * 5 + 0, 4 * 5 + 0,
+                               0 * 5 + 2, 2 * 5 + 2, 0 * 5 + 4, 4 * 5 + 4 };
+#pragma unroll
+        for (int k = 0; k < 13; k++) {
+            double v = trans[k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+            if (lane == 0 && v != 0.0) atomicAdd(expect + slot[k], v);
+        }
+        w5_wave_sync();
+        for (int i = lane; i < 80; i += 64)
+            if (emis[i] != 0.0) atomicAdd(expect + 25 + i, emis[i]);
+        if (lane == 0) atomicAdd(expect + CP_EXPECT5_LEN - 1, lik);
+    }
 }
 
 } // namespace
 
 /* model block: [17 transitions | pad to 24 | 16 match | 4 gapX | 4 gapY] = CP_MODEL5_STRIDE doubles */
-#define W5_KERNEL(L)                                                                                              \
-    extern "C" __global__ __launch_bounds__(64) void cpecan_k_wave5_l##L(                                         \
+#define W5_KERNEL(L, NAME, EM)                                                                                    \
+    extern "C" __global__ __launch_bounds__(64) void NAME(                                                        \
         const DevItem *items, DevParams P, const int *bandL, const int *bandR, const long long *cellPrefix,       \
         const char *xChars, const char *yChars, const double *models, double *Fstore, long long *pairs,           \
-        double *pairLogp, long long *nPairs, long long *totXay, double *totVal, long long *nTot) {                \
+        double *pairLogp, long long *nPairs, long long *totXay, double *totVal, long long *nTot, double *expect) { \
         __shared__ double stage[64 * L + 24];                                                                     \
         __shared__ double coefTable[64];                                                                          \
+        __shared__ double emis[80];                                                                               \
         w5_init_coef(coefTable);                                                                                  \
+        for (int i = threadIdx.x; i < 80; i += 64) emis[i] = 0.0;                                                 \
         w5_wave_sync();                                                                                           \
         const DevItem it = items[blockIdx.x];                                                                     \
         long long myPairs = 0, myTot = 0;                                                                         \
         if (it.lX + it.lY > 0)                                                                                    \
-            wave5_body<L>(it, P, bandL + it.diagBase, bandR + it.diagBase, cellPrefix + it.diagBase,              \
-                          xChars + it.xOff, yChars + it.yOff, models + (long long) it.model * CP_MODEL5_STRIDE,   \
-                          Fstore + it.cellBase * W5S, pairs, pairLogp, totXay, totVal, myPairs, myTot, stage,     \
-                          coefTable);                                                                             \
+            wave5_body<L, EM>(it, P, bandL + it.diagBase, bandR + it.diagBase, cellPrefix + it.diagBase,          \
+                              xChars + it.xOff, yChars + it.yOff, models + (long long) it.model * CP_MODEL5_STRIDE, \
+                              Fstore + it.cellBase * W5S, pairs, pairLogp, totXay, totVal, myPairs, myTot, stage, \
+                              coefTable, emis, EM ? expect + (long long) it.model * CP_EXPECT5_LEN : nullptr);    \
         if ((threadIdx.x & 63) == 0) {                                                                            \
             nPairs[blockIdx.x] = myPairs;                                                                         \
             nTot[blockIdx.x] = myTot;                                                                             \
         }                                                                                                         \
     }
-W5_KERNEL(1)
-W5_KERNEL(2)
-W5_KERNEL(3)
+W5_KERNEL(1, cpecan_k_wave5_l1, false)
+W5_KERNEL(2, cpecan_k_wave5_l2, false)
+W5_KERNEL(3, cpecan_k_wave5_l3, false)
+W5_KERNEL(1, cpecan_k_wave5e_l1, true)
+W5_KERNEL(2, cpecan_k_wave5e_l2, true)
+W5_KERNEL(3, cpecan_k_wave5e_l3, true)

@@ -118,7 +118,11 @@ def test_config1_two_1kb_sequences(ctx):
     run_case(ctx, [(x, y, np.zeros((0, 2), np.int64))], bp, (0, 0))
 
 
-def test_discrete_expectations_match_oracle(ctx):
+@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("shape", [dict(base=120, step=40, e=12, md=60, tb=10, every=9),
+                                   dict(base=500, step=100, e=50, md=150, tb=20, every=40),   # two cells per lane
+                                   dict(base=700, step=100, e=84, md=200, tb=40, every=60)])  # three
+def test_discrete_expectations_match_oracle(ctx, shape, general):
     """Baum-Welch sums of the 5-state machine (getExpectationsUsingAnchors with
     diagonalCalculation_Expectations and cell_updateExpectations, impl/pairwiseAligner.c:407-424,:841-863):
     25 transitions, 5 x 16 emissions and the likelihood of a batch, summed per model.  The device adds
@@ -127,19 +131,21 @@ def test_discrete_expectations_match_oracle(ctx):
     model = o.Sm5Model()
     ctx.models_clear()
     ids = ctx.models5_create([(list(model.c.t), model.match, model.gx, model.gy)])
-    bp = band_params(0.01, 60, 10, 12)
+    bp = band_params(0.01, shape["md"], shape["tb"], shape["e"])
     p = orc_params(bp, split=1 << 60)
     xs, ys, an, seqs = "", "", [], []
     items = np.zeros(4, cp.ITEM_DTYPE)
     for i in range(4):
-        x, y, pairs = evolve(rng, 120 + 40 * i)
-        a = pairs[4::9]
+        x, y, pairs = evolve(rng, shape["base"] + shape["step"] * i)
+        a = pairs[4::shape["every"]]
         items[i] = (len(xs), len(x), len(ys), len(y), sum(len(q) for q in an), len(a), ids[0], 0, 0, 0)
         xs += x
         ys += y
         an.append(a)
         seqs.append((x, y, a))
-    b = cp.Batch(ctx, items, xs, None, np.concatenate(an), bp, flags=cp.FLAG_EXPECTATIONS, y_chars=ys)
+    b = cp.Batch(ctx, items, xs, None, np.concatenate(an), bp,
+                 flags=cp.FLAG_EXPECTATIONS | (cp.FLAG_GENERAL_KERNEL if general else 0), y_chars=ys)
+    assert (b.info().get("family") == "wave (5-state)") == (not general)
     b.run()
     b.sync()
     got = b.expectations(ids[0])
