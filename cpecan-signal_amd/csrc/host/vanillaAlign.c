@@ -14,6 +14,7 @@
  * {<M|I|D> <length>}...", query = the 2D read (contig2/start2/end2 in the reference's struct), target = the
  * reference sequence (contig1/start1/end1); M advances both, D the target only, I the query only.
  */
+#include <dirent.h>
 #include <getopt.h>
 #include <math.h>
 #include <pthread.h>
@@ -267,8 +268,145 @@ static void *strand_alignment(void *arg) { /* performSignalAlignment + writePost
     return NULL;
 }
 
+/* ---- a directory of reads: what scripts/signalAlign.py does with a pool of vanillaAlign processes, one GPU batch here.
+ * Every <name>.npRead of the directory is aligned with the guide alignment in <name>.cigar (the exonerate cigar line the
+ * pipeline would pipe into the single-read driver); template and complement strands of all reads go through ONE call of
+ * getAlignedPairsUsingAnchorsBatch; posteriors are written to <outDir>/<name>.tsv, the summary lines to stdout. --------- */
+typedef struct {
+    char *name, *trimmedRefSeq, *rcTrimmedRefSeq;
+    NanoporeRead *npRead;
+    GuideAlignment *pA;
+    stList *anchorPairs;
+    Sequence *events[2];
+    int64_t nAnchors;
+} BatchRead;
+
+static int name_order(const void *a, const void *b) { return strcmp(*(char *const *) a, *(char *const *) b); }
+
+static int align_directory(const char *dir, const char *outDir, const char *referenceSequence, StateMachineType sMtype,
+                           const char *modelFiles[2], const char *hmmFiles[2], NanoporeHDP *nHdps[2],
+                           PairwiseAlignmentParameters *p, const char *substitute) {
+    DIR *d = opendir(dir);
+    if (!d) die("vanillaAlign - ERROR: cannot open the directory %s", dir);
+    char **names = NULL;
+    int64_t n = 0, cap = 0;
+    for (struct dirent *e; (e = readdir(d)) != NULL;) {
+        const size_t l = strlen(e->d_name);
+        if (l <= 7 || strcmp(e->d_name + l - 7, ".npRead") != 0) continue;
+        if (n == cap) names = realloc(names, sizeof(char *) * (size_t) (cap = cap ? 2 * cap : 64));
+        names[n] = malloc(l + 1);
+        memcpy(names[n], e->d_name, l - 7);
+        names[n++][l - 7] = 0;
+    }
+    closedir(d);
+    if (n == 0) die("vanillaAlign - ERROR: no .npRead file in %s", dir);
+    qsort(names, (size_t) n, sizeof(char *), name_order);
+    fprintf(stderr, "vanillaAlign - %lld reads in %s\n", (long long) n, dir);
+
+    BatchRead *reads = calloc((size_t) n, sizeof(BatchRead));
+    StateMachine **sMs = malloc(sizeof(StateMachine *) * 2 * (size_t) n);
+    Sequence **sXs = malloc(sizeof(Sequence *) * 2 * (size_t) n), **sYs = malloc(sizeof(Sequence *) * 2 * (size_t) n);
+    stList **anchors = malloc(sizeof(stList *) * 2 * (size_t) n);
+    char **targets = malloc(sizeof(char *) * 2 * (size_t) n);
+    for (int64_t i = 0; i < n; i++) {
+        BatchRead *r = &reads[i];
+        r->name = names[i];
+        const size_t room = strlen(dir) + strlen(names[i]) + 16;
+        char *path = malloc(room);
+        snprintf(path, room, "%s/%s.npRead", dir, names[i]);
+        r->npRead = nanopore_loadNanoporeReadFromFile(path);
+        if (sMtype == threeStateHdp) nanopore_descaleNanoporeRead(r->npRead);
+        snprintf(path, room, "%s/%s.cigar", dir, names[i]);
+        FILE *f = fopen(path, "r");
+        if (!f) die("vanillaAlign - ERROR: no guide alignment %s", path);
+        r->pA = cigar_read(f);
+        fclose(f);
+        free(path);
+        GuideAlignment *pA = r->pA;
+        r->trimmedRefSeq = pA->strand1 ? substring(referenceSequence, pA->start1, pA->end1 - pA->start1)
+                                       : substring(referenceSequence, pA->end1, pA->start1 - pA->end1);
+        if (!pA->strand1) {
+            char *rc = reverse_complement(r->trimmedRefSeq);
+            free(r->trimmedRefSeq);
+            r->trimmedRefSeq = rc;
+        }
+        r->rcTrimmedRefSeq = reverse_complement(r->trimmedRefSeq);
+        r->events[0] = event_sequence_from_guide(r->npRead->templateEvents, pA->start2, pA->end2, r->npRead->templateEventMap);
+        r->events[1] = event_sequence_from_guide(r->npRead->complementEvents, pA->start2, pA->end2, r->npRead->complementEventMap);
+        const int64_t start1 = pA->start1, end1 = pA->end1;
+        const bool forward = pA->strand1;
+        r->anchorPairs = guide_to_anchor_pairs(pA, p); /* (re-bases the target interval in pA) */
+        r->nAnchors = stList_length(r->anchorPairs);
+        pA->start1 = start1; /* the TSV rows need the original offsets */
+        pA->end1 = end1;
+        pA->strand1 = forward;
+        for (int st = 0; st < 2; st++) {
+            const int64_t k = 2 * i + st;
+            const NanoporeReadAdjustmentParameters npp = st == 0 ? r->npRead->templateParams : r->npRead->complementParams;
+            sMs[k] = build_state_machine(modelFiles[st], npp, sMtype, st == 0 ? template : complement, nHdps[st]);
+            if (hmmFiles[st]) hmmContinuous_loadSignalHmm(hmmFiles[st], sMs[k], sMs[k]->type);
+            /* (as in the single-read driver, --substitute only applies when expectations are collected) */
+            targets[k] = st == 0 ? r->trimmedRefSeq : r->rcTrimmedRefSeq;
+            sXs[k] = sequence_construct2(sequence_correctSeqLength((int64_t) strlen(targets[k]), event), targets[k],
+                                         target_getter(sMtype), sequence_sliceNucleotideSequence2);
+            sYs[k] = r->events[st];
+            anchors[k] = remapped_anchor_pairs(r->anchorPairs, st == 0 ? r->npRead->templateEventMap : r->npRead->complementEventMap,
+                                               pA->start2);
+        }
+    }
+    fprintf(stderr, "vanillaAlign - aligning %lld strands as one batch\n", (long long) (2 * n));
+    stList **pairs = getAlignedPairsUsingAnchorsBatch(2 * n, sMs, sXs, sYs, anchors, p, 1, 1);
+    for (int64_t i = 0; i < n; i++) {
+        BatchRead *r = &reads[i];
+        GuideAlignment *pA = r->pA;
+        const size_t room = strlen(outDir) + strlen(r->name) + 16;
+        char *out = malloc(room);
+        snprintf(out, room, "%s/%s.tsv", outDir, r->name);
+        remove(out); /* (writePosteriorProbs appends) */
+        double score[2];
+        for (int st = 0; st < 2; st++) {
+            const int64_t k = 2 * i + st;
+            double total = 0.0; /* scoreByPosteriorProbabilityIgnoringGaps */
+            for (int64_t q = 0; q < stList_length(pairs[k]); q++) total += (double) stIntTuple_get(stList_get(pairs[k], q), 0);
+            score[st] = 100.0 * total / ((double) stList_length(pairs[k]) * PAIR_ALIGNMENT_PROB_1);
+            stList_sort(pairs[k], sortByXPlusYCoordinate2);
+            const NanoporeReadAdjustmentParameters npp = st == 0 ? r->npRead->templateParams : r->npRead->complementParams;
+            const int64_t *map = st == 0 ? r->npRead->templateEventMap : r->npRead->complementEventMap;
+            writePosteriorProbs(out, r->name, sMs[k]->EMISSION_MATCH_PROBS, npp.scale, npp.shift,
+                                st == 0 ? r->npRead->templateEvents : r->npRead->complementEvents,
+                                st == 0 ? r->trimmedRefSeq : r->rcTrimmedRefSeq, pA->strand1, pA->contig1, map[pA->start2],
+                                st == 0 ? pA->start1 : pA->end1, pairs[k], st == 0 ? template : complement);
+        }
+        fprintf(stdout, "%s %lld\t%lld(%f)\t%lld(%f)\n", r->name, (long long) r->nAnchors, (long long) stList_length(pairs[2 * i]),
+                score[0], (long long) stList_length(pairs[2 * i + 1]), score[1]);
+        free(out);
+    }
+    for (int64_t k = 0; k < 2 * n; k++) {
+        stList_destruct(pairs[k]);
+        stList_destruct(anchors[k]);
+        sequence_sequenceDestroy(sXs[k]);
+        stateMachine_destruct(sMs[k]);
+    }
+    (void) substitute;
+    for (int64_t i = 0; i < n; i++) {
+        sequence_sequenceDestroy(reads[i].events[0]);
+        sequence_sequenceDestroy(reads[i].events[1]);
+        stList_destruct(reads[i].anchorPairs);
+        nanopore_nanoporeReadDestruct(reads[i].npRead);
+        free(reads[i].pA->ops);
+        free(reads[i].pA);
+        free(reads[i].trimmedRefSeq);
+        free(reads[i].rcTrimmedRefSeq);
+        free(reads[i].name);
+    }
+    free(pairs); free(reads); free(sMs); free(sXs); free(sYs); free(anchors); free(targets); free(names);
+    fprintf(stderr, "vanillaAlign - SUCCESS: finished alignment of %lld reads, exiting\n", (long long) n);
+    return 0;
+}
+
 int main(int argc, char *argv[]) {
     StateMachineType sMtype = vanilla;
+    const char *npReadDir = NULL, *outDir = NULL;
     int64_t diagExpansion = 50, constraintTrim = 14;
     double threshold = 0.01;
     const char *templateModelFile = "../../cPecan/models/template_median68pA.model";
@@ -287,9 +425,10 @@ int main(int argc, char *argv[]) {
         { "inComplementHmm", required_argument, 0, 'z' }, { "templateHdp", required_argument, 0, 'v' },
         { "complementHdp", required_argument, 0, 'w' }, { "templateExpectations", required_argument, 0, 't' },
         { "complementExpectations", required_argument, 0, 'c' }, { "diagonalExpansion", required_argument, 0, 'x' },
-        { "threshold", required_argument, 0, 'D' }, { "constraintTrim", required_argument, 0, 'm' }, { 0, 0, 0, 0 } };
+        { "threshold", required_argument, 0, 'D' }, { "constraintTrim", required_argument, 0, 'm' },
+        { "npReadDir", required_argument, 0, 'B' }, { "outDir", required_argument, 0, 'O' }, { 0, 0, 0, 0 } };
     int key;
-    while ((key = getopt_long(argc, argv, "hsdfeUp:M:a:T:C:L:q:r:u:y:z:v:w:t:c:x:D:m:", long_options, NULL)) != -1) {
+    while ((key = getopt_long(argc, argv, "hsdfeUp:M:a:T:C:L:q:r:u:y:z:v:w:t:c:x:D:m:B:O:", long_options, NULL)) != -1) {
         switch (key) {
         case 's': sMtype = threeState; break;
         case 'd': sMtype = threeStateHdp; break;
@@ -312,10 +451,31 @@ int main(int argc, char *argv[]) {
         case 'x': diagExpansion = atoll(optarg); break;
         case 'D': threshold = atof(optarg); break;
         case 'm': constraintTrim = atoll(optarg); break;
+        case 'B': npReadDir = optarg; break;
+        case 'O': outDir = optarg; break;
         default:
             fprintf(stderr, "vanillaAlign binary, meant to be used through the signalAlign program.\n");
             return 1;
         }
+    }
+    if (npReadDir) { /* additive: a directory of reads as one GPU batch */
+        if (!targetFile || !outDir) die("vanillaAlign - ERROR: --npReadDir needs --reference and --outDir");
+        if (templateExpectationsFile || complementExpectationsFile)
+            die("vanillaAlign - ERROR: --npReadDir aligns; expectations are collected read by read (or by cpecan_trainModels)");
+        if ((templateHdp != NULL) != (complementHdp != NULL)) die("Need to have template and complement HDPs");
+        const char *modelFiles[2] = { templateModelFile, complementModelFile }, *hmmFiles[2] = { templateHmmFile, complementHmmFile };
+        NanoporeHDP *nHdps[2] = { templateHdp ? deserialize_nhdp(templateHdp) : NULL, complementHdp ? deserialize_nhdp(complementHdp) : NULL };
+        PairwiseAlignmentParameters *bp = pairwiseAlignmentBandingParameters_construct();
+        bp->threshold = threshold;
+        bp->constraintDiagonalTrim = constraintTrim;
+        bp->diagonalExpansion = diagExpansion;
+        char *reference = first_line(targetFile);
+        const int rc = align_directory(npReadDir, outDir, reference, sMtype, modelFiles, hmmFiles, nHdps, bp, substitute);
+        free(reference);
+        pairwiseAlignmentBandingParameters_destruct(bp);
+        if (nHdps[0]) destroy_nanopore_hdp(nHdps[0]);
+        if (nHdps[1]) destroy_nanopore_hdp(nHdps[1]);
+        return rc;
     }
     if (!npReadFile || !targetFile) die("vanillaAlign - ERROR: --npRead and --reference are required");
     if (!readLabel) readLabel = npReadFile;

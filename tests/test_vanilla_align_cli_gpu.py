@@ -227,3 +227,48 @@ def test_cli_expectations_files(machine, golden_dir, zymo_read, template_model, 
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "loading HMM from file" in r2.stderr and "SUCCESS" in r2.stderr
     assert len(r2.stdout.split()) == 4
+
+
+@pytest.mark.parametrize("machine", ["strawMan", "vanilla"])
+def test_cli_directory_of_reads_as_one_batch(machine, golden_dir, zymo_read, template_model, tmp_path):
+    """--npReadDir / --outDir: every <name>.npRead of a directory with its guide in <name>.cigar, all strands through
+    ONE getAlignedPairsUsingAnchorsBatch call (what scripts/signalAlign.py does with a pool of processes); every read's
+    TSV and summary line equal what the single-read driver writes for it."""
+    pts, ops, cigar = _guide(zymo_read, template_model)
+    npread, _ = _npread_with_forward_complement(golden_dir, zymo_read, tmp_path)
+    # a second, shorter guide for the same read: another band, another set of pairs
+    short_ops, n_x, n_r = [], 0, 0
+    for op, k in ops[:len(ops) // 2]:
+        short_ops.append((op, k))
+        n_x += k if op != "I" else 0
+        n_r += k if op != "D" else 0
+    short = "cigar: read %d %d + ZYMO %d %d + 100 %s\n" % (pts[0][1], pts[0][1] + n_r, pts[0][0], pts[0][0] + n_x,
+                                                            " ".join("%s %d" % o_ for o_ in short_ops))
+    reads_dir, out_dir = tmp_path / "reads", tmp_path / "out"
+    reads_dir.mkdir()
+    out_dir.mkdir()
+    guides = {"readA": cigar, "readB": short, "readC": cigar}
+    for name, g in guides.items():
+        (reads_dir / (name + ".npRead")).write_text(open(npread).read())
+        (reads_dir / (name + ".cigar")).write_text(g)
+    (reads_dir / "notes.txt").write_text("not a read")
+    flags = ["--strawMan"] if machine == "strawMan" else []
+    common = ["-T", os.path.join(golden_dir, "template_median68pA.model"), "-C",
+              os.path.join(golden_dir, "complement_median68pA_pop2.model"), "-r", os.path.join(golden_dir, "ZymoRef.txt"),
+              "-x", "50"]
+    r = subprocess.run([EXE] + flags + common + ["--npReadDir", str(reads_dir), "--outDir", str(out_dir)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "aligning 6 strands as one batch" in r.stderr
+    summary = {l.split()[0]: l.split()[1:] for l in r.stdout.split("\n") if l}
+    assert sorted(summary) == ["readA", "readB", "readC"]
+    for name, g in guides.items():
+        tsv = str(tmp_path / (name + "_single.tsv"))
+        one = subprocess.run([EXE] + flags + common + ["-q", npread, "-u", tsv, "-L", name], input=g, capture_output=True,
+                             text=True, timeout=600)
+        assert one.returncode == 0, one.stderr[-2000:]
+        assert one.stdout.split()[1:] == summary[name]
+        want = sorted(l for l in open(tsv).read().split("\n") if l)
+        got = sorted(l for l in open(str(out_dir / (name + ".tsv"))).read().split("\n") if l)
+        assert got == want and len(got) > 100
+    assert summary["readA"] == summary["readC"] and summary["readA"] != summary["readB"]
