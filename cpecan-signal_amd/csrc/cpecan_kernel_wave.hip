@@ -105,8 +105,10 @@
 #ifndef WV_BACKWARD_PRIO
 #define WV_BACKWARD_PRIO 2
 #endif
+#ifndef WV_WPB
 #define WV_WPB 1             /* alignments (waves) per workgroup of the sweeps: a workgroup's four waves are placed on the
                                 four SIMDs of a CU, which single-wave workgroups are not promised */
+#endif
 
 /* -DWV_ABL_* are timing-study switches (tools/ablate_wave.sh): they compute wrong results by construction and are
  * never built into the product */
