@@ -28,6 +28,11 @@ def test_no_oracle_in_product():
             if f.endswith((".hip", ".h", ".c", ".cpp", ".py")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liborc" not in text and "pyoracle" not in text and "cpecan_oracle" not in text, f
+    # ... nor do the timing scripts under tools/ (those that use the checker live under tests/tools/)
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh", ".hip")):
+            text = open(os.path.join(ROOT, "tools", f)).read()
+            assert "liborc" not in text and "pyoracle" not in text and "cpecan_oracle" not in text, f
 
 
 def test_fails_loudly_without_gpu():

@@ -6,7 +6,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import pyoracle as o  # noqa: E402  (model construction only)
 import synth  # noqa: E402

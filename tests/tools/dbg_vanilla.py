@@ -1,7 +1,7 @@
 """wave-per-alignment vanilla kernels against the general kernel and the oracle on one case: where do totals / pairs part"""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import pyoracle as o, synth
 import test_vanilla_gpu as tv

@@ -1,7 +1,7 @@
 """development aid: run parity cases of tests/test_systolic_gpu.py and print where totals / pairs differ"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "oracle"))
 import numpy as np
 import synth
 from harness import band_params, cp, run_gpu, run_oracle_item

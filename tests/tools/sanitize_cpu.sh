@@ -2,7 +2,7 @@
 # AddressSanitizer + UBSan over the CPU-side code (the C host library and the oracle), through the CPU test suite.
 # GPU sanitizers are not available on this pool; the device code is covered by the parity tests instead.
 set -e
-root=$(cd "$(dirname "$0")/.." && pwd)
+root=$(cd "$(dirname "$0")/../.." && pwd)
 asan=$(gcc -print-file-name=libasan.so)
 san="-O1 -g -fPIC -ffp-contract=off -fsanitize=address,undefined -fno-omit-frame-pointer -shared"
 gcc -std=gnu99 $san -I$root/include -I$root/cpecan-signal_amd/csrc -I$root/cpecan-signal_amd/csrc/host \
