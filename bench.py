@@ -117,6 +117,10 @@ def parse_args(argv=None):
     ap.add_argument("--host-tables", action="store_true",
                     help="--mode service: every read's scaled model table comes from the caller (cpecan_hip_models_create) "
                          "instead of one pore model + per-read scaling parameters (cpecan_hip_models_create_scaled)")
+    ap.add_argument("--service-slots", type=int, default=4,
+                    help="--mode service: batches alive at once (contexts): running, queued, being prepared")
+    ap.add_argument("--service-threads", type=int, default=2,
+                    help="--mode service: host threads that prepare and queue batches")
     ap.add_argument("--em-contexts", type=int, default=2,
                     help="--mode em: 2 = the rank's reads as two concurrent batches on the workgroup kernels, 1 = one "
                          "batch on the wave kernels")
@@ -540,11 +544,15 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
     flags = cp.FLAG_WORKGROUP_KERNELS if family == "workgroup" else 0
     if family == "workgroup" and "CPECAN_SYSTOLIC_GROUPS" not in os.environ:
         os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"  # one stream group per batch: two batches' kernels overlap
-    NSLOT = 3  # one batch running, one queued behind it on the device, one being prepared / finished by the host
+    NSLOT = max(3, args.service_slots)  # one batch running, one queued behind it on the device, the others being prepared
+    NPROD = max(1, args.service_threads)  # host threads that prepare and queue batches (the consumer is this thread)
     ctxs = [cp.Context(local_rank) for _ in range(NSLOT)]
     slot = [None] * NSLOT
-    t_prep, t_models, t_batch = [], [], []
+    t_prep, t_models, t_batch = {}, {}, {}
     items = [make_items(cp, bt) for bt in data]
+    queued = [threading.Event() for _ in range(n)]   # batch k has been handed to the device
+    closed = [threading.Event() for _ in range(n)]   # batch k's results have been taken and its slot is free
+    failed = []
 
     def prepare(k):
         t0 = time.perf_counter()
@@ -554,42 +562,56 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
             cx.models_create([(cp.NANOPORE_TRANSITIONS, m, gx, gy) for (m, gx, gy) in bt["models"]])
         else:  # one pore model + five scaling parameters per read; rows assembled on the device
             cx.models_create_scaled((cp.NANOPORE_TRANSITIONS,) + bt["base_model"], bt["scalings"])
-        t_models.append(time.perf_counter() - t0)
+        t_models[k] = time.perf_counter() - t0
         t1 = time.perf_counter()
         slot[k % NSLOT] = cp.Batch(cx, items[k % len(data)], bt["x_chars"], bt["events"], bt["anchors"], bp,
                                cp.MODE_POSTERIOR, args.kernel, flags)
-        t_batch.append(time.perf_counter() - t1)
-        t_prep.append(time.perf_counter() - t0)
+        t_batch[k] = time.perf_counter() - t1
+        t_prep[k] = time.perf_counter() - t0
 
-    def prepare_and_queue(k):
-        prepare(k)
-        # wave kernels: one pass at a time, ordered on the device (no host round trip); workgroup kernels: the queued
-        # batch's kernels overlap the running one's
-        slot[k % NSLOT].run(after=slot[(k - 1) % NSLOT] if (k > 0 and family == "wave") else None)
+    def producer(first):
+        # batches first, first + NPROD, ...: each is prepared as soon as its slot is free and queued in batch order
+        try:
+            for k in range(first, n, NPROD):
+                if k >= NSLOT:
+                    closed[k - NSLOT].wait()
+                prepare(k)
+                if k > 0:
+                    queued[k - 1].wait()
+                # wave kernels: one pass at a time, ordered on the device (no host round trip); workgroup kernels: the
+                # queued batch's kernels overlap the running one's
+                slot[k % NSLOT].run(after=slot[(k - 1) % NSLOT] if (k > 0 and family == "wave") else None)
+                queued[k].set()
+        except BaseException as e:  # noqa: BLE001 -- the consumer must not wait for ever
+            failed.append(e)
+            for ev in queued + closed:
+                ev.set()
 
-    prepare_and_queue(0)
-    if n > 1:
-        prepare_and_queue(1)
+    threads = [threading.Thread(target=producer, args=(f,), daemon=True) for f in range(min(NPROD, n))]
+    for th in threads:
+        th.start()
     pairs = cells = 0
     t_start = None
     for k in range(n):
         if k == args.warmup:
             t_start = time.perf_counter()
             pairs = cells = 0
-        # batch k is running or done, batch k + 1 is queued behind it: the device goes from one pass to the next
-        # without waiting for the host, which meanwhile prepares and queues batch k + 2 (one thread) and fetches and
-        # finishes batch k's pairs (this thread and the library's)
+        # batch k is running or done and batch k + 1 queued behind it: the device goes from one pass to the next
+        # without waiting for the host, whose producer threads meanwhile prepare the batches after it while this thread
+        # (and the library's) fetches and finishes batch k's pairs
+        queued[k].wait()
+        if failed:
+            raise failed[0]
         b = slot[k % NSLOT]
-        th = threading.Thread(target=prepare_and_queue, args=(k + 2,)) if k + 2 < n else None
-        if th:
-            th.start()
         b.sync()
         npairs, _, ncells = b.counts()
         pairs += int(npairs.sum())
         cells += int(ncells.sum())
         b.close()
-        if th:
-            th.join()
+        closed[k].set()
+    for th in threads:
+        th.join()
+    t_prep, t_models, t_batch = ([d[k] for k in range(n)] for d in (t_prep, t_models, t_batch))
     elapsed = time.perf_counter() - t_start
     print(json.dumps({
         "metric": "end-to-end reads/s (one-shot alignment, host preparation overlapped)", "value": round(args.reads * args.steps / elapsed, 1),
@@ -599,7 +621,7 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
         "gcells_per_s": round(cells / elapsed / 1e9, 3),
         "config": {"workload": "a stream of BASELINE configs[2] batches (%d reads x %d events x %d k-mers), each prepared "
                                "from host buffers, aligned once, pairs finished on the host" % (args.reads, args.events, args.kmers),
-                   "kernels": family + "-per-alignment",
+                   "kernels": family + "-per-alignment", "slots": NSLOT, "producer_threads": NPROD,
                    "model_tables": "scaled by the caller, derived on the host" if args.host_tables else "scaled and assembled on the device (cpecan_hip_models_create_scaled)",
                    "host_prepare_ms_per_batch": round(1e3 * float(np.mean(t_prep[args.warmup:])), 1),
                    "of_which_model_tables_ms": round(1e3 * float(np.mean(t_models[args.warmup:])), 1),

@@ -397,6 +397,10 @@ struct cpecan_ctx {
     int device = 0;
     long long modelEpoch = 0; /* counts cpecan_hip_models_clear calls */
     hipStream_t stream = nullptr;
+    /* input preparation (uploads, table assembly, k-mer indices) goes through a stream of the highest priority: it
+     * gets a hardware queue of its own and its copies and small kernels are not held up behind the sweeps of the
+     * batches that are running while the next one is prepared; every call that uses it waits for it before it returns */
+    hipStream_t prep = nullptr;
     DevBuf<double> models; /* nModels * CP_MODEL_STRIDE */
     void *pinned = nullptr; /* staging slots of cpecan_hip_models_create */
     size_t pinnedBytes = 0;
@@ -528,6 +532,14 @@ int cpecan_hip_ctx_create(int device, cpecan_ctx **out) {
         delete c;
         return fail(CPECAN_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
+    int least = 0, greatest = 0;
+    (void) hipDeviceGetStreamPriorityRange(&least, &greatest);
+    e = hipStreamCreateWithPriority(&c->prep, hipStreamNonBlocking, greatest);
+    if (e != hipSuccess) {
+        (void) hipStreamDestroy(c->stream);
+        delete c;
+        return fail(CPECAN_EHIP, "hipStreamCreateWithPriority: %s", hipGetErrorString(e));
+    }
     *out = c;
     return CPECAN_OK;
 }
@@ -536,6 +548,7 @@ int cpecan_hip_ctx_destroy(cpecan_ctx *c) {
     if (!c) return CPECAN_OK;
     (void) hipSetDevice(c->device);
     if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->prep) (void) hipStreamDestroy(c->prep);
     if (c->pinned) (void) hipHostFree(c->pinned);
     for (auto *t : c->hdpTables) delete t;
     c->hdpTables.clear();
@@ -634,12 +647,12 @@ int cpecan_hip_models_create(cpecan_ctx *c, const cpecan_sm3_model *models, int3
                 double *dst = (double *) ((char *) c->pinned + slot * slotBytes);
                 if (turn >= 2 && hipEventSynchronize(gone[slot]) != hipSuccess) { bad = 1; return; }
                 derive_rows(&models[i], dst);
-                if (hipMemcpyAsync(fresh + (size_t) i * CP_MODEL_STRIDE, dst, slotBytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                    hipEventRecord(gone[slot], c->stream) != hipSuccess) { bad = 1; return; }
+                if (hipMemcpyAsync(fresh + (size_t) i * CP_MODEL_STRIDE, dst, slotBytes, hipMemcpyHostToDevice, c->prep) != hipSuccess ||
+                    hipEventRecord(gone[slot], c->prep) != hipSuccess) { bad = 1; return; }
             }
         });
     for (auto &t : pool) t.join();
-    hipError_t se = hipStreamSynchronize(c->stream);
+    hipError_t se = hipStreamSynchronize(c->prep);
     for (auto &ev : gone) (void) hipEventDestroy(ev);
     if (bad || se != hipSuccess) {
         c->models.release(); /* the table is in an unknown state: the context's strawMan models are gone */
@@ -731,14 +744,14 @@ int cpecan_hip_models_create_scaled(cpecan_ctx *c, const cpecan_sm3_model *base,
     HIP_TRY(dPart.alloc(part.n));
     lap("device table");
     static_assert(sizeof(cpecan_read_scaling) == 5 * sizeof(double), "cpecan_read_scaling is five doubles");
-    HIP_TRY(hipMemcpyAsync(dBase.p, baseRows.data(), baseRows.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dScal.p, scalings, (size_t) n * 5 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(dPart.p, part.p, part.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(dBase.p, baseRows.data(), baseRows.size() * sizeof(double), hipMemcpyHostToDevice, c->prep));
+    HIP_TRY(hipMemcpyAsync(dScal.p, scalings, (size_t) n * 5 * sizeof(double), hipMemcpyHostToDevice, c->prep));
+    HIP_TRY(hipMemcpyAsync(dPart.p, part.p, part.n * sizeof(double), hipMemcpyHostToDevice, c->prep));
     hipLaunchKernelGGL(cpecan_k_scale_models, dim3((unsigned) ((CP_MODEL_STRIDE + 255) / 256), (unsigned) std::min(n, 65535)),
-                       dim3(256), 0, c->stream, (const double *) dBase.p, (const double *) dScal.p, (const double *) dPart.p,
+                       dim3(256), 0, c->prep, (const double *) dBase.p, (const double *) dScal.p, (const double *) dPart.p,
                        (int) n, fresh);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream)); /* the staging blocks are released on return */
+    HIP_TRY(hipStreamSynchronize(c->prep)); /* the staging blocks are released on return */
     lap("upload + assemble");
     for (int i = 0; i < n; i++) {
         ids[i] = c->nModels + i;
@@ -1263,15 +1276,15 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->hItems = hItems;
 
     B_TRY(b->items.alloc((size_t) nItems));
-    B_TRY(hipMemcpy(b->items.p, hItems.data(), (size_t) nItems * sizeof(DevItem), hipMemcpyHostToDevice));
+    B_TRY(hipMemcpyAsync(b->items.p, hItems.data(), (size_t) nItems * sizeof(DevItem), hipMemcpyHostToDevice, c->prep));
     B_TRY(b->chars.alloc((size_t) nX + 8));
-    B_TRY(hipMemset(b->chars.p, 0, (size_t) nX + 8));
-    B_TRY(hipMemcpy(b->chars.p, xChars, (size_t) nX, hipMemcpyHostToDevice));
+    B_TRY(hipMemsetAsync(b->chars.p, 0, (size_t) nX + 8, c->prep));
+    B_TRY(hipMemcpyAsync(b->chars.p, xChars, (size_t) nX, hipMemcpyHostToDevice, c->prep));
     B_TRY(b->kidx.alloc((size_t) nX + 8));
     if (dna) {
         B_TRY(b->charsY.alloc((size_t) nEvents + 8));
-        B_TRY(hipMemset(b->charsY.p, 0, (size_t) nEvents + 8));
-        B_TRY(hipMemcpy(b->charsY.p, yChars, (size_t) nEvents, hipMemcpyHostToDevice));
+        B_TRY(hipMemsetAsync(b->charsY.p, 0, (size_t) nEvents + 8, c->prep));
+        B_TRY(hipMemcpyAsync(b->charsY.p, yChars, (size_t) nEvents, hipMemcpyHostToDevice, c->prep));
     } else {
         B_TRY(b->events.alloc((size_t) 3 * nEvents + 8));
         if (vanilla) {
@@ -1283,20 +1296,23 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                 ev3[(size_t) 3 * i + 1] = events[3 * i + 1];
                 ev3[(size_t) 3 * i + 2] = log(events[3 * i + 1]);
             }
-            B_TRY(hipMemcpy(b->events.p, ev3.data(), (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+            B_TRY(hipMemcpyAsync(b->events.p, ev3.data(), (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice, c->prep));
+            B_TRY(hipStreamSynchronize(c->prep)); /* ev3 ends here */
         } else
-            B_TRY(hipMemcpy(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice));
+            B_TRY(hipMemcpyAsync(b->events.p, events, (size_t) 3 * nEvents * sizeof(double), hipMemcpyHostToDevice, c->prep));
         if (vanilla) { /* emissions_signal_logInvGaussPdf takes log(eventNoise) per cell (:325) */
             std::vector<double> ln((size_t) nEvents + 1);
             for (int64_t i = 0; i < nEvents; i++) ln[(size_t) i] = log(events[3 * i + 1]);
             B_TRY(b->logNoise.alloc((size_t) nEvents + 8));
-            B_TRY(hipMemcpy(b->logNoise.p, ln.data(), (size_t) nEvents * sizeof(double), hipMemcpyHostToDevice));
+            B_TRY(hipMemcpyAsync(b->logNoise.p, ln.data(), (size_t) nEvents * sizeof(double), hipMemcpyHostToDevice, c->prep));
+            B_TRY(hipStreamSynchronize(c->prep)); /* ln ends here */
         }
     }
+    B_TRY(hipStreamSynchronize(c->prep));
     lap("upload sequences and events");
     B_TRY(b->anchors.alloc((size_t) 2 * nAnchorPairs + 2));
     if (nAnchorPairs > 0)
-        B_TRY(hipMemcpy(b->anchors.p, anchors, (size_t) 2 * nAnchorPairs * sizeof(long long),
+        B_TRY(hipMemcpyAsync(b->anchors.p, anchors, (size_t) 2 * nAnchorPairs * sizeof(long long),
                         hipMemcpyHostToDevice));
     B_TRY(b->pairs.alloc((size_t) pairTotal * 3));
     B_TRY(b->pairLogp.alloc((size_t) pairTotal));
@@ -1306,9 +1322,10 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     B_TRY(b->totXay.alloc((size_t) totTotal));
     B_TRY(b->totVal.alloc((size_t) totTotal));
     B_TRY(b->expect.alloc((size_t) std::max(b->nModels, 1) * b->expectLen));
-    B_TRY(hipMemset(b->expect.p, 0, b->expect.n * sizeof(double)));
+    B_TRY(hipMemsetAsync(b->expect.p, 0, b->expect.n * sizeof(double), c->prep));
     b->hNCells.resize((size_t) nItems);
     for (int64_t i = 0; i < nItems; i++) b->hNCells[(size_t) i] = hItems[(size_t) i].nCells;
+    B_TRY(hipStreamSynchronize(c->prep));
     lap("output buffers");
 
     if (useKernel == CPECAN_KERNEL_GENERAL) {
@@ -1322,14 +1339,14 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         B_TRY(b->bandL.alloc(hL.size()));
         B_TRY(b->bandR.alloc(hR.size()));
         B_TRY(b->cellPrefix.alloc(hPre.size()));
-        B_TRY(hipMemcpy(b->bandL.p, hL.data(), hL.size() * sizeof(int), hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(b->bandR.p, hR.data(), hR.size() * sizeof(int), hipMemcpyHostToDevice));
-        B_TRY(hipMemcpy(b->cellPrefix.p, hPre.data(), hPre.size() * sizeof(long long), hipMemcpyHostToDevice));
+        B_TRY(hipMemcpyAsync(b->bandL.p, hL.data(), hL.size() * sizeof(int), hipMemcpyHostToDevice, c->prep));
+        B_TRY(hipMemcpyAsync(b->bandR.p, hR.data(), hR.size() * sizeof(int), hipMemcpyHostToDevice, c->prep));
+        B_TRY(hipMemcpyAsync(b->cellPrefix.p, hPre.data(), hPre.size() * sizeof(long long), hipMemcpyHostToDevice, c->prep));
         B_TRY(b->Fstore.alloc((size_t) cellTotal * S));
         B_TRY(b->Bstore.alloc((size_t) bwsTotal));
         if (b->P.debug) {
             B_TRY(b->dbgB.alloc((size_t) cellTotal * 3));
-            B_TRY(hipMemset(b->dbgB.p, 0xff, (size_t) cellTotal * 3 * sizeof(double)));
+            B_TRY(hipMemsetAsync(b->dbgB.p, 0xff, (size_t) cellTotal * 3 * sizeof(double), c->prep));
         }
     } else {
         /* one workgroup per alignment and launch; the ring of forward diagonals lives per alignment
@@ -1348,7 +1365,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         lap("ring allocation");
         /* the band as matrix columns per diagonal */
         B_TRY(b->bandTab.alloc((size_t) diagTotal * 2 + 2));
-        B_TRY(hipMemcpy(b->bandTab.p, hTab.p, (size_t) diagTotal * 2 * sizeof(int), hipMemcpyHostToDevice));
+        B_TRY(hipMemcpyAsync(b->bandTab.p, hTab.p, (size_t) diagTotal * 2 * sizeof(int), hipMemcpyHostToDevice, c->prep));
         {
             const char *g = getenv("CPECAN_SYSTOLIC_GROUPS");
             int G = g ? atoi(g) : b->sy->wave ? 1 : 2;
@@ -1372,6 +1389,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             for (auto &e : b->evJoin) B_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             B_TRY(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         }
+        B_TRY(hipStreamSynchronize(c->prep));
         lap("band table upload, streams");
         if (mode == CPECAN_MODE_EXPECTATIONS)
             B_TRY(b->Bring.alloc((size_t) nItems * (size_t) b->ringD * (size_t) b->sy->bring_row_doubles()));
@@ -1381,8 +1399,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         B_TRY(b->syScratch.alloc((size_t) nItems * (size_t) b->scratchBytes));
         B_TRY(b->track.alloc((size_t) trackTotal * (size_t) b->trackRow));
         B_TRY(b->trackBase.alloc((size_t) nItems));
-        B_TRY(hipMemcpy(b->trackBase.p, hTrackBase.data(), (size_t) nItems * sizeof(long long),
-                        hipMemcpyHostToDevice));
+        B_TRY(hipMemcpyAsync(b->trackBase.p, hTrackBase.data(), (size_t) nItems * sizeof(long long),
+                             hipMemcpyHostToDevice, c->prep));
+        B_TRY(hipStreamSynchronize(c->prep));
         lap("state, scratch, track allocation");
     }
     B_TRY(hipEventCreate(&b->ev0));
@@ -1399,11 +1418,11 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         B_TRY(b->kid.alloc((size_t) nX + 8));
         const int blocks = (int) ((nX + 255) / 256);
         if (blocks > 0)
-            hipLaunchKernelGGL(cpecan_k_hdp_kmer_id, dim3(blocks), dim3(256), 0, c->stream,
+            hipLaunchKernelGGL(cpecan_k_hdp_kmer_id, dim3(blocks), dim3(256), 0, c->prep,
                                (const char *) b->chars.p, (long long) nX, lo, hi, (int) c->hdpAlphabet.size(),
                                b->kid.p);
         B_TRY(hipGetLastError());
-        B_TRY(hipStreamSynchronize(c->stream));
+        B_TRY(hipStreamSynchronize(c->prep));
     }
     /* k-mer indices are part of input preparation (done once, like H2D) */
     if (!dna && !hdp) {
@@ -1411,11 +1430,12 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         int threads = 256;
         int blocks = (int) ((n + threads - 1) / threads);
         if (blocks > 0)
-            hipLaunchKernelGGL(cpecan_k_kmer_index, dim3(blocks), dim3(threads), 0, c->stream,
+            hipLaunchKernelGGL(cpecan_k_kmer_index, dim3(blocks), dim3(threads), 0, c->prep,
                                (const char *) b->chars.p, n, b->kidx.p);
         B_TRY(hipGetLastError());
-        B_TRY(hipStreamSynchronize(c->stream));
+        B_TRY(hipStreamSynchronize(c->prep));
     }
+    B_TRY(hipStreamSynchronize(c->prep)); /* every upload above has landed */
     lap("k-mer index kernel");
     *out = b;
     return CPECAN_OK;
