@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -51,7 +52,15 @@ extern "C" __global__ void cpecan_k_generalh(const DevItem *, DevParams, const i
     extern "C" __global__ void cpecan_k_wave5e_l##L(const DevItem *, DevParams, const int *, const int *,         \
                                                     const long long *, const char *, const char *, const double *, \
                                                     double *, long long *, double *, long long *, long long *,    \
-                                                    double *, long long *, double *);
+                                                    double *, long long *, double *);                             \
+    extern "C" __global__ void cpecan_k_wave5p_l##L(const DevItem *, DevParams, const int *, const int *,         \
+                                                    const long long *, const char *, const char *, const double *, \
+                                                    double *, long long *, double *, long long *, long long *,    \
+                                                    double *, long long *, double *);                             \
+    extern "C" __global__ void cpecan_k_wave5pe_l##L(const DevItem *, DevParams, const int *, const int *,        \
+                                                     const long long *, const char *, const char *, const double *, \
+                                                     double *, long long *, double *, long long *, long long *,   \
+                                                     double *, long long *, double *);
 W5_DECLARE(1)
 W5_DECLARE(2)
 W5_DECLARE(3)
@@ -393,6 +402,8 @@ template <typename T> struct DevBuf {
 
 } // namespace
 
+#define CP_WAVE5_PAIRED_BELOW 1536 /* alignments: below this (fewer than 1.5 per SIMD) the 5-state machine runs on two waves
+                                    * per alignment: 1.14-1.24x at 1024 alignments, 0.8-0.9x at 4096 */
 struct cpecan_ctx {
     int device = 0;
     long long modelEpoch = 0; /* counts cpecan_hip_models_clear calls */
@@ -1502,10 +1513,17 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
         /* the 5-state machine for bands a wave covers in one to three cells per lane: one wave per alignment, the
          * recurrence in registers (cpecan_kernel_wave5.hip), posterior decode or expectations */
         const bool em = b->mode == CPECAN_MODE_EXPECTATIONS;
-        auto kernel5 = b->maxWidth <= 64 ? (em ? cpecan_k_wave5e_l1 : cpecan_k_wave5_l1)
-                       : b->maxWidth <= 128 ? (em ? cpecan_k_wave5e_l2 : cpecan_k_wave5_l2)
-                                            : (em ? cpecan_k_wave5e_l3 : cpecan_k_wave5_l3);
-        hipLaunchKernelGGL(kernel5, dim3((unsigned) b->nItems), dim3(64), 0, c->stream, (const DevItem *) b->items.p, b->P,
+        /* a batch that leaves SIMDs with fewer than two waves runs the sweeps of an alignment on a pair of waves
+         * (forward and back overlapping); CPECAN_WAVE5_PAIRED=0/1 forces either form (tests, timing) */
+        const char *pairedEnv = getenv("CPECAN_WAVE5_PAIRED");
+        const int l5 = b->maxWidth <= 64 ? 0 : b->maxWidth <= 128 ? 1 : 2;
+        /* (the one-wave E-step at three cells per lane needs more registers than two waves of a SIMD can have) */
+        const bool paired = pairedEnv ? atoi(pairedEnv) != 0 : (b->nItems < CP_WAVE5_PAIRED_BELOW || (em && l5 == 2));
+        static const auto kernels5 = std::array<decltype(&cpecan_k_wave5_l1), 12>{
+            cpecan_k_wave5_l1, cpecan_k_wave5_l2, cpecan_k_wave5_l3, cpecan_k_wave5e_l1, cpecan_k_wave5e_l2, cpecan_k_wave5e_l3,
+            cpecan_k_wave5p_l1, cpecan_k_wave5p_l2, cpecan_k_wave5p_l3, cpecan_k_wave5pe_l1, cpecan_k_wave5pe_l2, cpecan_k_wave5pe_l3 };
+        auto kernel5 = kernels5[(size_t) ((paired ? 6 : 0) + (em ? 3 : 0) + l5)];
+        hipLaunchKernelGGL(kernel5, dim3((unsigned) b->nItems), dim3(paired ? 128 : 64), 0, c->stream, (const DevItem *) b->items.p, b->P,
                            (const int *) b->bandL.p, (const int *) b->bandR.p, (const long long *) b->cellPrefix.p,
                            (const char *) b->chars.p, (const char *) b->charsY.p, (const double *) c->models5.p,
                            b->Fstore.p, b->pairs.p, b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,

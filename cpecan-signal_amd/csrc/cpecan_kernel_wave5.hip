@@ -93,14 +93,25 @@ template <int P> __device__ __forceinline__ int w5_column(int sl, int xmin, int 
     return x <= xmax ? x : -1;
 }
 
-template <int L, bool EM> __device__ __forceinline__ void wave5_body(
+/* PAIRED: the alignment has a workgroup of TWO waves -- wave 0 sweeps forward and publishes, at every traceback point,
+ * the diagonal it has reached (its cells are in HBM by then: release fence, then the LDS word); wave 1 finds the same
+ * traceback points from the band table alone, waits for the forward sweep to reach each of them and sweeps the window
+ * back.  Same arithmetic, same order, same outputs as the one-wave form: the sweep back of a window never depended on
+ * anything of the forward sweep but its cells up to the window's top.  A batch of fewer alignments than the chip has
+ * SIMDs to spare gets two waves per SIMD this way (forward and backward sweeps overlap), and each wave holds only its
+ * own half of the register state. */
+/* ROLE 0: one wave does both sweeps; 1: the forward wave of a pair; 2: the backward wave of a pair (compile-time, so
+ * that each wave of a pair is allocated the registers of its own sweep only) */
+template <int L, bool EM, int ROLE> __device__ __forceinline__ void wave5_body(
     const DevItem &it, const DevParams &P, const int *__restrict__ bandL, const int *__restrict__ bandR,
     const long long *__restrict__ pre, const char *__restrict__ cx, const char *__restrict__ cy,
     const double *__restrict__ model, double *F, long long *pairs, double *pairLogp, long long *totXay,
     double *totVal, long long &myPairs, long long &myTot, double *stage /* LDS, 64 * L + 24 doubles */,
     const double *coef /* LDS, the logAdd table */, double *emis /* LDS, EM: the 80 emission sums */,
-    double *expect /* EM: this model's [25 transitions | 80 emissions | likelihood] */) {
+    double *expect /* EM: this model's [25 transitions | 80 emissions | likelihood] */,
+    volatile long long *progress /* LDS, PAIRED: the last traceback point the forward sweep has reached */) {
     constexpr int PP = 64 * L;
+    constexpr bool PAIRED = ROLE != 0, sweepsForward = ROLE != 2, sweepsBack = ROLE != 1;
     /* EM (diagonalCalculation_Expectations :841-863 over stateMachine5_cellCalculate with cell_updateExpectations
      * :407-424): a lane sums the thirteen kinds of transition over its cells in registers; the emission counts
      * [to-state][x base][y base] go to the LDS table; the likelihood is added once per diagonal (quirk Q7) */
@@ -122,7 +133,7 @@ template <int L, bool EM> __device__ __forceinline__ void wave5_body(
 #pragma unroll
         for (int s = 0; s < W5S; s++) U[j][s] = N1[j][s] = N2[j][s] = CP_NEG_INF;
     /* diagonal 0: stateMachine5_startStateProb / raggedStartStateProb (:743-763); its only cell is column 0 = slot 0 */
-    if (lane == 0) {
+    if (lane == 0 && sweepsForward) {
         U[0][0] = it.raggedL ? CP_NEG_INF : 0.0;
         U[0][1] = CP_NEG_INF;
         U[0][2] = CP_NEG_INF;
@@ -149,9 +160,41 @@ template <int L, bool EM> __device__ __forceinline__ void wave5_body(
         nextBy[j] = x >= 0 ? w5_base(cy, (1 - (long long) x) - 1) : 4;
     }
     for (long long d = 1; d <= D; d++) {
-        const int lo = nLo, hi = nHi;
-        const long long preD = nPre;
-        const int xmin = (int) ((d + lo) / 2), xmax = (int) ((d + hi) / 2), width = xmax - xmin + 1;
+        int lo, hi, xmin, xmax, width;
+        long long preD;
+        if (PAIRED && !sweepsForward) {
+            /* the next traceback point at or after d: the last diagonal, or the first one minDiags past the previous
+             * window whose band is narrow enough (the test of the one-wave loop below), 64 diagonals per step */
+            long long from = tracedBackTo + P.minDiags;
+            if (from < d) from = d;
+            long long dTopNext = D;
+            for (long long base = from; base < D; base += 64) {
+                const long long dd = base + lane;
+                bool narrow = false;
+                if (dd < D) {
+                    const int l = bandL[dd], h = bandR[dd];
+                    narrow = (int) ((dd + h) / 2) - (int) ((dd + l) / 2) + 1 <= P.expansion * 2 + 1;
+                }
+                const unsigned long long m = __ballot(narrow);
+                if (m) {
+                    dTopNext = base + (__ffsll((long long) m) - 1);
+                    break;
+                }
+            }
+            d = dTopNext;
+            lo = bandL[d];
+            hi = bandR[d];
+            preD = pre[d];
+            xmin = (int) ((d + lo) / 2);
+            xmax = (int) ((d + hi) / 2);
+            width = xmax - xmin + 1;
+        } else {
+        lo = nLo;
+        hi = nHi;
+        preD = nPre;
+        xmin = (int) ((d + lo) / 2);
+        xmax = (int) ((d + hi) / 2);
+        width = xmax - xmin + 1;
         if (d < D) {
             nLo = bandL[d + 1];
             nHi = bandR[d + 1];
@@ -222,15 +265,26 @@ template <int L, bool EM> __device__ __forceinline__ void wave5_body(
         }
         xmin2 = xmin1; xmax2 = xmax1;
         xmin1 = xmin; xmax1 = xmax;
+        }
 
         const bool atEnd = d == D;
         const bool tb = d >= tracedBackTo + P.minDiags && width <= P.expansion * 2 + 1;
         if (!(atEnd || tb)) continue;
 
         /* ---- traceback window (:921-992) ---- */
-        __threadfence_block(); /* the window's forward cells are read back from HBM below */
         const long long dTop = d;
         const long long tracedBackFrom = dTop - (atEnd ? 0 : P.tbDiags + 1);
+        if (PAIRED) {
+            if (sweepsForward) { /* every cell up to dTop is written: say so, and go on */
+                __threadfence();
+                if (lane == 0) *progress = dTop;
+                tracedBackTo = tracedBackFrom;
+                continue;
+            }
+            while (*progress < dTop) __builtin_amdgcn_s_sleep(16);
+            __threadfence(); /* (acquire: nothing of this CU's vector cache predates the forward wave's stores) */
+        } else
+            __threadfence_block(); /* the window's forward cells are read back from HBM below */
         double e[W5S]; /* stateMachine5_endStateProb / raggedEndStateProb (:765-789) */
         if (atEnd && it.raggedR) {
             e[0] = t[W5_GAP_LONG_OPEN_X];
@@ -267,7 +321,10 @@ template <int L, bool EM> __device__ __forceinline__ void wave5_body(
             baseXb[j] = 4;
             const int x = w5_column<PP>(lane * L + j, xmin, xmax);
             nextYb[j] = x >= 0 ? w5_base(cy, dTop - (long long) x) : 4;
-            nextF0[j] = U[j][0]; /* the forward cells of dTop are still in registers */
+            if (PAIRED)
+                nextF0[j] = x >= 0 ? F[(preD + (x - xmin)) * W5S] : 0.0;
+            else
+                nextF0[j] = U[j][0]; /* the forward cells of dTop are still in registers */
         }
         for (long long d2 = dTop; d2 > tracedBackTo; d2--) {
             const int l2 = qLo, h2 = qHi;
@@ -511,7 +568,7 @@ template <int L, bool EM> __device__ __forceinline__ void wave5_body(
         }
         tracedBackTo = tracedBackFrom;
     }
-    if (EM) {
+    if (EM && sweepsBack) {
         /* [from * 5 + to] of the thirteen kinds, in the order they were summed above */
         const int slot[13] = { 0 * 5 + 1, 1 * 5 + 1, 0 * 5 + 3, 3 * 5 + 3, 0 * 5 + 0, 1 * 5 + 0, 2 * 5 + 0, 3 * 5 + 0, 4 * 5 + 0,
                                0 * 5 + 2, 2 * 5 + 2, 0 * 5 + 4, 4 * 5 + 4 };
@@ -531,32 +588,51 @@ template <int L, bool EM> __device__ __forceinline__ void wave5_body(
 } // namespace
 
 /* model block: [17 transitions | pad to 24 | 16 match | 4 gapX | 4 gapY] = CP_MODEL5_STRIDE doubles */
-#define W5_KERNEL(L, NAME, EM)                                                                                    \
-    extern "C" __global__ __launch_bounds__(64) void NAME(                                                        \
+#define W5_OCC(PAIRED) W5_OCC_##PAIRED
+#define W5_OCC_false
+#define W5_OCC_true __attribute__((amdgpu_waves_per_eu(2))) /* two waves per SIMD at least: 256 registers */
+#define W5_ARGS(EM)                                                                                               \
+    (it, P, bandL + it.diagBase, bandR + it.diagBase, cellPrefix + it.diagBase, xChars + it.xOff, yChars + it.yOff, \
+     models + (long long) it.model * CP_MODEL5_STRIDE, Fstore + it.cellBase * W5S, pairs, pairLogp, totXay, totVal, \
+     myPairs, myTot, stage, coefTable, emis, EM ? expect + (long long) it.model * CP_EXPECT5_LEN : nullptr, &progress)
+#define W5_CALL(L, EM, PAIRED)                                                                                    \
+    {                                                                                                             \
+        if (!PAIRED) wave5_body<L, EM, 0> W5_ARGS(EM);                                                            \
+        else if (__builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6) == 0) wave5_body<L, EM, 1> W5_ARGS(EM);  \
+        else wave5_body<L, EM, 2> W5_ARGS(EM);                                                                    \
+    }
+#define W5_KERNEL(L, NAME, EM, PAIRED)                                                                            \
+    extern "C" __global__ __launch_bounds__(PAIRED ? 128 : 64) W5_OCC(PAIRED) void NAME(                                         \
         const DevItem *items, DevParams P, const int *bandL, const int *bandR, const long long *cellPrefix,       \
         const char *xChars, const char *yChars, const double *models, double *Fstore, long long *pairs,           \
         double *pairLogp, long long *nPairs, long long *totXay, double *totVal, long long *nTot, double *expect) { \
         __shared__ double stage[64 * L + 24];                                                                     \
         __shared__ double coefTable[64];                                                                          \
         __shared__ double emis[80];                                                                               \
+        __shared__ long long progress;                                                                            \
         w5_init_coef(coefTable);                                                                                  \
-        for (int i = threadIdx.x; i < 80; i += 64) emis[i] = 0.0;                                                 \
-        w5_wave_sync();                                                                                           \
+        for (int i = threadIdx.x; i < 80; i += (PAIRED ? 128 : 64)) emis[i] = 0.0;                                \
+        if (threadIdx.x == 0) progress = 0;                                                                       \
+        if (PAIRED) __syncthreads();                                                                              \
+        else w5_wave_sync();                                                                                      \
         const DevItem it = items[blockIdx.x];                                                                     \
         long long myPairs = 0, myTot = 0;                                                                         \
         if (it.lX + it.lY > 0)                                                                                    \
-            wave5_body<L, EM>(it, P, bandL + it.diagBase, bandR + it.diagBase, cellPrefix + it.diagBase,          \
-                              xChars + it.xOff, yChars + it.yOff, models + (long long) it.model * CP_MODEL5_STRIDE, \
-                              Fstore + it.cellBase * W5S, pairs, pairLogp, totXay, totVal, myPairs, myTot, stage, \
-                              coefTable, emis, EM ? expect + (long long) it.model * CP_EXPECT5_LEN : nullptr);    \
-        if ((threadIdx.x & 63) == 0) {                                                                            \
+            W5_CALL(L, EM, PAIRED)                                                                                \
+        if (threadIdx.x == (PAIRED ? 64 : 0)) {                                                                   \
             nPairs[blockIdx.x] = myPairs;                                                                         \
             nTot[blockIdx.x] = myTot;                                                                             \
         }                                                                                                         \
     }
-W5_KERNEL(1, cpecan_k_wave5_l1, false)
-W5_KERNEL(2, cpecan_k_wave5_l2, false)
-W5_KERNEL(3, cpecan_k_wave5_l3, false)
-W5_KERNEL(1, cpecan_k_wave5e_l1, true)
-W5_KERNEL(2, cpecan_k_wave5e_l2, true)
-W5_KERNEL(3, cpecan_k_wave5e_l3, true)
+W5_KERNEL(1, cpecan_k_wave5_l1, false, false)
+W5_KERNEL(2, cpecan_k_wave5_l2, false, false)
+W5_KERNEL(3, cpecan_k_wave5_l3, false, false)
+W5_KERNEL(1, cpecan_k_wave5e_l1, true, false)
+W5_KERNEL(2, cpecan_k_wave5e_l2, true, false)
+W5_KERNEL(3, cpecan_k_wave5e_l3, true, false)
+W5_KERNEL(1, cpecan_k_wave5p_l1, false, true)
+W5_KERNEL(2, cpecan_k_wave5p_l2, false, true)
+W5_KERNEL(3, cpecan_k_wave5p_l3, false, true)
+W5_KERNEL(1, cpecan_k_wave5pe_l1, true, true)
+W5_KERNEL(2, cpecan_k_wave5pe_l2, true, true)
+W5_KERNEL(3, cpecan_k_wave5pe_l3, true, true)

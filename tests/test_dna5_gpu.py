@@ -88,7 +88,22 @@ def test_toy_known_answer(ctx):
              unbanded=True)
 
 
-@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+KERNEL_FORMS = [("0", False), ("1", False), (None, True)]  # (CPECAN_WAVE5_PAIRED, general kernel)
+KERNEL_IDS = ["wave", "pair", "general"]
+
+
+def pick_form(monkeypatch, form):
+    """one wave per alignment, a forward + a backward wave per alignment (what the library picks for batches that
+    leave SIMDs idle), or the general kernel"""
+    paired, general = form
+    if paired is None:
+        monkeypatch.delenv("CPECAN_WAVE5_PAIRED", raising=False)
+    else:
+        monkeypatch.setenv("CPECAN_WAVE5_PAIRED", paired)
+    return cp.FLAG_GENERAL_KERNEL if general else 0
+
+
+@pytest.mark.parametrize("form", KERNEL_FORMS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("case", [
     dict(n=3, length=60, e=20, md=30, tb=5, ragged=(0, 0), anchored=False),
     dict(n=3, length=150, e=10, md=40, tb=8, ragged=(1, 1), anchored=True),
@@ -96,9 +111,10 @@ def test_toy_known_answer(ctx):
     dict(n=2, length=700, e=50, md=150, tb=20, ragged=(0, 1), anchored=True),   # two cells per lane
     dict(n=2, length=900, e=80, md=200, tb=40, ragged=(0, 0), anchored=True),   # three cells per lane
 ])
-def test_dna5_matches_oracle(ctx, case, general):
-    """the one-wave-per-alignment kernel (cpecan_kernel_wave5.hip, one to three cells per lane by band width) and the
-    general one (CPECAN_FLAG_GENERAL_KERNEL)"""
+def test_dna5_matches_oracle(ctx, case, form, monkeypatch):
+    """the wave-per-alignment kernels (cpecan_kernel_wave5.hip, one to three cells per lane by band width; one wave
+    for both sweeps or a pair of waves) and the general one (CPECAN_FLAG_GENERAL_KERNEL)"""
+    flags = pick_form(monkeypatch, form)
     rng = np.random.default_rng(31 + case["length"])
     seqs = []
     for _ in range(case["n"]):
@@ -106,7 +122,7 @@ def test_dna5_matches_oracle(ctx, case, general):
         a = pairs[5::12] if case["anchored"] else np.zeros((0, 2), np.int64)
         seqs.append((x, y, a))
     bp = band_params(0.01, case["md"], case["tb"], case["e"])
-    run_case(ctx, seqs, bp, case["ragged"], flags=cp.FLAG_GENERAL_KERNEL if general else 0)
+    run_case(ctx, seqs, bp, case["ragged"], flags=flags)
 
 
 def test_config1_two_1kb_sequences(ctx):
@@ -118,15 +134,16 @@ def test_config1_two_1kb_sequences(ctx):
     run_case(ctx, [(x, y, np.zeros((0, 2), np.int64))], bp, (0, 0))
 
 
-@pytest.mark.parametrize("general", [False, True], ids=["wave", "general"])
+@pytest.mark.parametrize("form", KERNEL_FORMS, ids=KERNEL_IDS)
 @pytest.mark.parametrize("shape", [dict(base=120, step=40, e=12, md=60, tb=10, every=9),
                                    dict(base=500, step=100, e=50, md=150, tb=20, every=40),   # two cells per lane
                                    dict(base=700, step=100, e=84, md=200, tb=40, every=60)])  # three
-def test_discrete_expectations_match_oracle(ctx, shape, general):
+def test_discrete_expectations_match_oracle(ctx, shape, form, monkeypatch):
     """Baum-Welch sums of the 5-state machine (getExpectationsUsingAnchors with
     diagonalCalculation_Expectations and cell_updateExpectations, impl/pairwiseAligner.c:407-424,:841-863):
     25 transitions, 5 x 16 emissions and the likelihood of a batch, summed per model.  The device adds
     the per-cell terms in another order than the host loop: 1e-9 relative (north_star asks 1e-6)."""
+    general = pick_form(monkeypatch, form) != 0
     rng = np.random.default_rng(77)
     model = o.Sm5Model()
     ctx.models_clear()
@@ -159,8 +176,8 @@ def test_discrete_expectations_match_oracle(ctx, shape, general):
     b.close()
 
 
-def test_degenerate_shapes_agree_between_the_two_kernels(ctx):
-    """one empty sequence, single bases, a 1 x n strip: the one-wave kernel and the general kernel give the same pairs,
+def test_degenerate_shapes_agree_between_the_kernels(ctx, monkeypatch):
+    """one empty sequence, single bases, a 1 x n strip: the wave kernels (both forms) and the general kernel give the same pairs,
     totals and cell counts (the oracle is not asked: the reference's own entry points return before the DP there)"""
     model = o.Sm5Model()
     ctx.models_clear()
@@ -174,7 +191,8 @@ def test_degenerate_shapes_agree_between_the_two_kernels(ctx):
         xs += x
         ys += y
     out = []
-    for flags in (0, cp.FLAG_GENERAL_KERNEL):
+    for form in KERNEL_FORMS:
+        flags = pick_form(monkeypatch, form)
         b = cp.Batch(ctx, items, xs + "A", None, np.zeros((0, 2), np.int64), band_params(0.01, 4, 1, 2), flags=flags,
                      y_chars=ys + "A")
         b.run()
@@ -187,7 +205,8 @@ def test_degenerate_shapes_agree_between_the_two_kernels(ctx):
             res.append((tri.copy(), lp.copy(), xay.copy(), tot.copy(), int(ncells[i])))
         out.append(res)
         b.close()
-    for w, g in zip(*out):
-        assert np.array_equal(w[0], g[0]) and np.array_equal(w[1].view(np.uint64), g[1].view(np.uint64))
-        assert np.array_equal(w[2], g[2]) and np.array_equal(w[3].view(np.uint64), g[3].view(np.uint64)) and w[4] == g[4]
+    for res in out[:2]:
+        for w, g in zip(res, out[2]):
+            assert np.array_equal(w[0], g[0]) and np.array_equal(w[1].view(np.uint64), g[1].view(np.uint64))
+            assert np.array_equal(w[2], g[2]) and np.array_equal(w[3].view(np.uint64), g[3].view(np.uint64)) and w[4] == g[4]
     assert len(out[0][-1][0]) > 5

@@ -67,8 +67,9 @@ def test_random_case_vanilla(ctx, case):
 
 
 @pytest.mark.parametrize("case", cases(10 * SCALE, 99), ids=lambda c: "d%d" % c["seed"])
-def test_random_case_dna(ctx, case):
+def test_random_case_dna(ctx, case, monkeypatch):
     import test_dna5_gpu as td
+    monkeypatch.setenv("CPECAN_WAVE5_PAIRED", str(case["seed"] % 2))  # one wave per alignment / a forward + a backward wave
     rng = np.random.default_rng(case["seed"])
     seqs = []
     for _ in range(2):

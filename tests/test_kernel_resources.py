@@ -62,3 +62,22 @@ def test_wave_kernels_fit_two_waves_per_simd(tmp_path, cells, hdp):
     if hdp is True:  # three register pairs per slot instead of ten: the forward sweep is the light one
         meta = text[text.index(".name:           cpecan_k_wv_forward" + sfx + "\n"):]
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 192
+
+
+def test_wave5_pair_kernels_fit_two_waves_per_simd(tmp_path):
+    """The 5-state machine's two-waves-per-alignment kernels exist to put a forward and a backward wave on every SIMD
+    of a small batch: each wave is allocated the registers of its own sweep only (256 at most: two waves per SIMD,
+    nothing in scratch); with one and two cells per lane three waves fit (170 registers)."""
+    src = os.path.join(ROOT, "cpecan-signal_amd", "csrc", "cpecan_kernel_wave5.hip")
+    out = str(tmp_path / "w5.s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+                           "-fno-fast-math", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src), "-S",
+                           "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
+    text = open(out).read()
+    for name, cap in (("cpecan_k_wave5p_l1", 170), ("cpecan_k_wave5p_l2", 170), ("cpecan_k_wave5p_l3", 256),
+                      ("cpecan_k_wave5pe_l1", 256), ("cpecan_k_wave5pe_l2", 256), ("cpecan_k_wave5pe_l3", 256)):
+        meta = text[text.index(".name:           " + name + "\n"):]
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
+        assert vgpr <= cap, "%s uses %d VGPRs" % (name, vgpr)
+        assert spill == 0, "%s spills %d VGPRs to scratch" % (name, spill)
