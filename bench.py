@@ -684,30 +684,58 @@ def bench_hdp(args, cp, bp, rank, local_rank, world, dist, torch, sync_all):
     sm = host.getHdpStateMachine3(nh)
     desc = cp.HdpModelDesc()
     host.cpecan_hdp_machine_as_model(sm, C.byref(desc))
+    # as in the default mode, consecutive steps work on distinct batches of --reads reads (--inflight 2): step s + 1
+    # sweeps on the device (queued behind step s with cpecan_hip_batch_run_after: the wave kernels run one pass at a
+    # time) while the host fetches and finishes the pairs of step s -- 9 GB of packed candidates per step cross PCIe
+    nb = max(1, min(2, args.inflight, args.steps))
     t0 = time.time()
-    bt = hdp_reads(args.reads, args.kmers, args.events, 5 + 100 * rank, desc)
+    bts = [hdp_reads(args.reads, args.kmers, args.events, 5 + 100 * rank + 7 * j, desc) for j in range(nb)]
+    bt = bts[0]
     t_gen = time.time() - t0
-    cx = cp.Context(local_rank)
-    ids = np.zeros(1, np.int32)
-    rc = cp.lib().cpecan_hip_modelsh_create(cx.h, C.byref(desc), 1, ids.ctypes.data_as(C.c_void_p))
-    if rc != 0:
-        sys.exit("cpecan_hip_modelsh_create: %s" % cp.lib().cpecan_hip_last_error().decode())
-    b = cp.Batch(cx, make_items(cp, bt), bt["x_chars"], bt["events"], bt["anchors"], bp, hdp=True)
-    for _ in range(max(args.warmup, 1)):
-        b.run()
-        b.sync()
-    sync_all()
-    t_start = time.perf_counter()
+    bs = []
+    for j in range(nb):
+        cx = cp.Context(local_rank)
+        ids = np.zeros(1, np.int32)
+        rc = cp.lib().cpecan_hip_modelsh_create(cx.h, C.byref(desc), 1, ids.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            sys.exit("cpecan_hip_modelsh_create: %s" % cp.lib().cpecan_hip_last_error().decode())
+        bs.append(cp.Batch(cx, make_items(cp, bts[j]), bts[j]["x_chars"], bts[j]["events"], bts[j]["anchors"], bp, hdp=True))
+    b = bs[0]
     ms = []
-    for _ in range(args.steps):
-        b.run()
-        b.sync()
-        ms.append(b.elapsed_ms()[1])
-        b.counts()  # the pairs on the host as the reference's integers, inside the timed region
+
+    def finish(j):
+        bs[j].sync()
+        ms.append(bs[j].elapsed_ms()[1])
+        bs[j].counts()  # the pairs on the host as the reference's integers, inside the timed region
+
+    def run_steps(n):
+        pending = [False] * nb
+        for s_ in range(n):
+            j = s_ % nb
+            if pending[j]:
+                finish(j)
+            bs[j].run(after=bs[(s_ - 1) % nb] if (nb > 1 and s_ > 0) else None)
+            pending[j] = True
+        for k in range(nb):  # the oldest first
+            j = (n + k) % nb
+            if pending[j]:
+                finish(j)
+
+    run_steps(max(args.warmup, nb))
+    sync_all()
+    ms = []
+    t_start = time.perf_counter()
+    run_steps(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t_start
-    npairs, _, ncells = b.counts()
-    cells = int(ncells.sum())
+    npairs = np.zeros(0, np.int64)
+    cells_of = []
+    for bb in bs:
+        npj, _, ncj = bb.counts()
+        cells_of.append(int(ncj.sum()))
+        if bb is b:
+            npairs = npj
+    cells = int(round(sum(cells_of[s_ % nb] for s_ in range(args.steps)) / args.steps))  # per step
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -730,6 +758,7 @@ def bench_hdp(args, cp, bp, rank, local_rank, world, dist, torch, sync_all):
                                    % (os.path.basename(args.hdp), args.reads, args.kmers,
                                       int(np.mean([it["lY"] for it in bt["items"]])), args.band),
                        "cells_per_gpu": cells, "pairs_per_gpu": int(npairs.sum()), "kernel": b.info(),
+                       "batches_in_flight": nb,
                        "kernel_ms_per_step": round(float(np.mean(ms)), 3), "generate_s": round(t_gen, 2),
                        "parallelism": "reads sharded over %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
@@ -738,7 +767,8 @@ def bench_hdp(args, cp, bp, rank, local_rank, world, dist, torch, sync_all):
                                   % ("cpecan_k_wv_*_h%d (wave per alignment)" % b.info().get("cells_per_lane", 0)
                                      if b.info()["kernel"] == "systolic" else "cpecan_k_generalh")},
             "cpu_baseline": None}), flush=True)
-    b.close()
+    for bb in bs:
+        bb.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
