@@ -44,7 +44,7 @@ EXPORTS = [
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
-    "cpecan_hip_batch_systolic_rows", "cpecan_hip_batch_kernel_family", "cpecan_hip_models_set_transitions",
+    "cpecan_hip_batch_systolic_rows", "cpecan_hip_batch_kernel_family", "cpecan_hip_batch_assembly_sweeps", "cpecan_hip_models_set_transitions",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
     "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
     "cpecan_hip_modelsh_create", "cpecan_hip_batch_create_hdp",
@@ -443,6 +443,9 @@ class Batch:
             out["family"] = "wave" if f.value else "workgroup"
             if f.value:
                 out["cells_per_lane"] = r.value
+            a = C.c_int32()
+            _check(lib().cpecan_hip_batch_assembly_sweeps(self.h, C.byref(a)))
+            out["assembly_sweeps"] = a.value
         return out
 
     def counts(self):

@@ -1,0 +1,952 @@
+#!/usr/bin/env python3
+"""Generates the hand-scheduled gfx950 assembly of the sweeps of the banded pair-HMM (strawMan signal machine,
+posterior decode): cpecan_k_asm_forward_l3 and cpecan_k_asm_backward_l3.
+
+Same algorithm, same memory formats and -- bit for bit -- the same arithmetic as the compiled wave kernels
+(cpecan_kernel_wave.hip: one wave per alignment, L cells per lane, slot = matrix column mod 64 L, lane = slot / L,
+layer = slot % L); what changes is who schedules the instructions.  The compiler's sweeps spend 390 + 365 vector
+instructions and about 300 + 350 scalar / wait / branch instructions per anti-diagonal; written out by hand a
+diagonal takes about 350 + 280 vector instructions and a fifth of the others, and both sweeps leave room in a SIMD's
+register file for the post-processing wave.
+
+Everything irregular stays outside: the host plans the traceback windows and the band's edge steps per diagonal
+(cpecan_hip.hip: build_asm_plan), a forward wave carries its registers from one launch to the next through a context
+block in HBM instead of re-deriving them, and what follows a sweep back (the totals' terms, the folds, the decode) is
+the compiled post kernel's.
+
+Reference arithmetic: cell_calculateForward / Backward impl/pairwiseAligner.c:365-389, stateMachine3_cellCalculate
+impl/stateMachine.c:1305-1334, logAdd / lookup impl/pairwiseAligner.c:235-255, emissions_signal_logGaussPdf
+impl/stateMachine.c:333-343.
+
+usage: gen_sweeps.py OUT.s [OUT.h]   (OUT.h: the sizes and offsets the C++ side shares, cpecan_asm_gen.h)
+"""
+import struct
+import sys
+
+from emit import Emitter, Neg, Pool, S, V
+
+L = 3
+P = 64 * L
+
+# ---------------------------------------------------------------- memory formats shared with the C++ side (cpecan_asm.h)
+ROW_DOUBLES = L * 5 * 64                 # a ring row: per layer (Fm, pm) x 64 | py x 64 | (Fx, Fy) x 64
+ROW_BYTES = ROW_DOUBLES * 8
+LAYER_BYTES = 5 * 64 * 8
+OFF_PY = 128 * 8
+OFF_FXY = 192 * 8
+TRACK_ROW_BYTES = 20 * 8                 # a track row: 16 emission constants, gap-X sums (open, extend, switch), gap-X
+NCONST = 18                              # ... of which a slot keeps the first 18 doubles
+
+# kernel arguments: struct AsmArgs
+A_ITEMS, A_TRACKBASE, A_PLANWIN, A_PLANCTL, A_PLANOFF, A_EVENTS, A_MODELS, A_TRACK = 0, 8, 16, 24, 32, 40, 48, 56
+A_RING, A_RINGDOUBLES, A_STATES, A_CTX, A_CTXBYTES, A_COEF, A_NITEMS, A_WINDOW = 64, 72, 80, 88, 96, 104, 112, 116
+A_RINGD, A_MAXWIN, A_SCRATCH, A_SCRATCHBYTES, A_LOGTHR, A_MODELSTRIDE, ARGS_BYTES = 120, 124, 128, 136, 144, 152, 160
+# DevItem
+I_LX, I_LY, I_YOFF, I_MODEL, I_RAGGEDL, I_RAGGEDR, ITEM_BYTES = 0, 8, 24, 112, 116, 120, 128
+# AsmPlanWin: 16 dwords
+W_D0, W_TOP, W_FROM, W_TO, W_ATEND, W_XMINTOP, W_XMAXTOP, W_NWIN, W_CELLS, W_XMIN0, W_XMAX0, W_TPOST0 = \
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12
+PLANWIN_BYTES = 64
+CTL_BYTES = 32                           # per 64 diagonals: u64 stepMin, stepMax, full, spare
+# WvState / WvWindow (cpecan_sweep.h)
+ST_D, ST_TB, ST_FIN, ST_WIN, ST_CELLS, ST_CLKS, ST_CLKR, STATE_BYTES = 0, 4, 8, 16, 112, 120, 128, 136
+WIN_BYTES = 40
+# the forward sweep's context (registers of a wave between two launches)
+CTX_C = 0                                # L x 36 dwords of constants, 1024 bytes per 4 dwords
+CTX_X = L * 9 * 1024                     # per (parity, layer): m (512 bytes), (x, y) (1024 bytes)
+CTX_S = CTX_X + 2 * L * 1536             # scalars: masks, band slots
+CTX_BYTES = CTX_S + 256
+
+# LDS of the forward kernel
+LDS_COEF = 0
+LDS_EV = 512                             # events by index mod 256, mirrored: (2 * 256 + L) x 16 bytes
+EVN = 256
+LDS_ROWS = LDS_EV + ((2 * EVN + L) * 16 + 63) // 64 * 64
+ROWN = 64
+LDS_F_BYTES = LDS_ROWS + ROWN * TRACK_ROW_BYTES
+# ... and of the backward kernel
+LDS_PX = 512
+PXN = 64
+LDS_B_BYTES = LDS_PX + PXN * 16
+
+MAX_WIDTH = 158                          # band widths the staging scheme holds
+BLOCK = 64                               # diagonals per staging block
+
+LOG2E_F32 = 0x3FB8AA3B
+LN2_F32 = 0x3F317218
+
+
+def dbits(x):
+    return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+
+class Kernel(Emitter):
+    """Emitter + the idioms both sweeps share."""
+
+    def __init__(self, pool):
+        super().__init__()
+        self.pool = pool
+
+    def ror64(self, dst, src):
+        for h in (0, 1):
+            self.valu("v_mov_b32_dpp", dst.sub(h), src.sub(h), dpp="wave_ror:1 row_mask:0xf bank_mask:0xf")
+
+    def rol64(self, dst, src):
+        for h in (0, 1):
+            self.valu("v_mov_b32_dpp", dst.sub(h), src.sub(h), dpp="wave_rol:1 row_mask:0xf bank_mask:0xf")
+
+    def add(self, dst, a, b):
+        self.valu("v_add_f64", dst, a, b)
+
+    def mul(self, dst, a, b):
+        self.valu("v_mul_f64", dst, a, b)
+
+    # ---- logAdd in two halves (impl/pairwiseAligner.c:235-255; ladd() in cpecan_kernel_wave.hip): hi / lo are the
+    # operands as the reference's two branches order them, d = hi - lo, the cubic's four float-literal coefficients
+    # come from the LDS table at offset 0 indexed by ceil(2 d) (the pieces' limits are multiples of 1/2).  d >= 7.5,
+    # an infinite or a NaN d discard the cubic: the index is then anything at all -- an LDS read beyond the allocation
+    # returns zero (measured: profiles/r03_ubench2_exec_lds_branch.txt) -- so it is not clamped.
+    def ladd_front(self, x, y, free=()):
+        p = self.pool
+        hi, lo, d = p.take(2), p.take(2), p.take(2)
+        self.valu("v_max_f64", hi, x, y)
+        self.valu("v_min_f64", lo, x, y)
+        p.give(*free)
+        self.add(d, hi, Neg(lo))
+        c32, c10 = p.take(4), p.take(4)
+        t = c32.sub(0, 2)
+        self.add(t, d, d)
+        self.valu("v_ceil_f64_e32", t, t)
+        a = c10.lo
+        self.valu("v_cvt_i32_f64_e32", a, t)
+        self.valu("v_lshlrev_b32_e32", a, 5, a)
+        self.ds_read(128, c32, a)
+        self.ds_read(128, c10, a, 16)
+        return (hi, lo, d, c32, c10)
+
+    def ladd_back(self, rec, dst, s7p5):
+        hi, lo, d, c32, c10 = rec
+        r = c32.sub(0, 2)
+        self.mul(r, c32.sub(0, 2), d)
+        self.add(r, r, c32.sub(2, 2))
+        self.mul(r, r, d)
+        self.add(r, r, c10.sub(0, 2))
+        self.mul(r, r, d)
+        self.add(r, r, c10.sub(2, 2))
+        self.add(r, r, lo)
+        self.valu("v_cmp_gt_f64_e32", "vcc", s7p5, d)
+        self.valu("v_cndmask_b32_e32", dst.lo, hi.lo, r.lo, "vcc")
+        self.valu("v_cndmask_b32_e32", dst.hi, hi.hi, r.hi, "vcc")
+        self.pool.give(hi, lo, d, c32, c10)
+
+    # ---- log N(x; mu, sd) = K - (a / 2) a, a = (x - mu) / sd as a Markstein-corrected multiply by RN(1 / sd) (lgauss())
+    def gauss(self, dst, x, mu, sd, rsd, K, t0, t1):
+        self.add(t0, x, Neg(mu))
+        self.mul(t1, t0, rsd)
+        self.valu("v_fma_f64", t0, Neg(t1), sd, t0)
+        self.valu("v_fma_f64", t1, t0, rsd, t1)
+        self.mul(t0, t1, "0.5")
+        self.mul(t0, t1, t0)
+        self.add(dst, K, Neg(t0))
+
+    def s_mov64_lit(self, dst, value):
+        self.salu("s_mov_b32", dst.lo, "0x%x" % (value & 0xFFFFFFFF))
+        self.salu("s_mov_b32", dst.hi, "0x%x" % (value >> 32))
+
+    def add64(self, dst, a, b_lo, b_hi=0):
+        self.salu("s_add_u32", dst.lo, a.lo, b_lo)
+        self.salu("s_addc_u32", dst.hi, a.hi, b_hi)
+
+    def pc_of(self, dst, label):
+        """dst = address of label (which lies AFTER this point)."""
+        here = self.newlabel("pc")
+        self.salu("s_getpc_b64", dst)
+        self.label(here)
+        self.salu("s_add_u32", dst.lo, dst.lo, "%s-%s" % (label, here))
+        self.salu("s_addc_u32", dst.hi, dst.hi, 0)
+
+    def butterfly(self, op, val, tmp, vLane4, tmp2):
+        """all lanes <- op over the wave of val (32-bit), by ds_bpermute with lane ^ 1, 2, .. 32"""
+        for off in (1, 2, 4, 8, 16, 32):
+            self.valu("v_xor_b32_e32", tmp2, off * 4, vLane4)
+            self.lines.append("\tds_bpermute_b32 %s, %s, %s" % (tmp, tmp2, val))
+            self.n += 1
+            self.lgkm.append({tmp.i})
+            self.valu(op, val, val, tmp)
+
+
+# ====================================================================================================== forward
+def forward_kernel(name):
+    """The forward sweep of one traceback window, one wave per alignment (forward_window() of cpecan_kernel_wave.hip)."""
+    # ---- vector registers
+    vOff16, vOff8, vTmp = V(0), V(1), V(2 + L)
+    # a slot's event on diagonal d has index d - 1 - x; the events sit in LDS by index mod 256, mirrored, so the address is
+    # a per-slot constant (LDS_EV + 16 * ((-1 - x) mod 256), set when the slot's k-mer enters) plus 16 * (d mod 256)
+    vEvSlot = [V(2 + j) for j in range(L)]
+    e0 = (3 + L + 1) // 2 * 2
+    E = [V(e0 + 4 * j, 4) for j in range(L)]           # event (mean, noise) of the layer's cell
+    PY = [V(e0 + 4 * L + 2 * j, 2) for j in range(L)]  # gap-Y emission
+    c0 = e0 + 6 * L
+    C = [[V(c0 + 36 * j + 2 * q, 2) for q in range(NCONST)] for j in range(L)]
+    x0 = c0 + 36 * L
+    # cells of a diagonal per parity of the diagonal and layer: m | pm | x | y  ((m, pm) and (x, y) leave as pairs)
+    X = [[V(x0 + 8 * (L * p + j), 8) for j in range(L)] for p in range(2)]
+    r0 = x0 + 16 * L
+    R = [V(r0 + 6 * p, 6) for p in range(2)]           # layer L-1 of the lane below (m, x, y) per parity
+    t0 = r0 + 12
+    pool = Pool(t0, 255)
+    k = Kernel(pool)
+
+    def Xm(p, j): return X[p][j].sub(0, 2)
+    def Xpm(p, j): return X[p][j].sub(2, 2)
+    def Xx(p, j): return X[p][j].sub(4, 2)
+    def Xy(p, j): return X[p][j].sub(6, 2)
+    CMU, CSD, CRSD, CK1, CNMU, CNSD, CRNSD, CK2 = range(8)
+    CPXO, CPXE = 16, 17
+
+    # ---- scalar registers
+    sArg, sWg = S(0, 2), S(2)
+    sRing, sRow0, sRow1 = S(4, 2), S(6, 2), S(8, 2)
+    sD, sTop, sXmin, sXmax, sRingMask, sDmod = S(10), S(11), S(12), S(13), S(14), S(15)
+    sMask = [S(16 + 2 * j, 2) for j in range(L)]
+    sInL, sInJ, sOutL, sOutJ = S(22), S(23), S(24), S(25)
+    sEv, sLY, sEvHi = S(26, 2), S(28), S(29)
+    sTrack, sLX, sStop = S(30, 2), S(32), S(33)
+    sCtlPtr = S(34, 2)
+    sCtl = S(36, 8)                                     # stepMin, stepMax, full, spare
+    sStepMin, sStepMax, sFull = sCtl.sub(0, 2), sCtl.sub(2, 2), sCtl.sub(4, 2)
+    sTMM, sTXM, sTYM, sTMY, sTYY = S(44, 2), S(46, 2), S(48, 2), S(50, 2), S(52, 2)
+    s7p5, sNinf = S(54, 2), S(56, 2)
+    sBit, sRet, sStagePC = S(58, 2), S(60, 2), S(62, 2)
+    sT = [S(64 + i) for i in range(8)]
+    sP = [S(64 + 2 * i, 2) for i in range(4)]           # the same as pairs
+    sCtx, sState = S(72, 2), S(74, 2)
+    sWin = S(76, 16)                                    # the window's plan record
+    sClk0, sRt0 = S(92, 2), S(94, 2)
+    sK = S(96, 4)
+    sWindow, sCtxBytes = S(100), S(101)
+    def W(f): return sWin.sub(f)
+    lbl = lambda s: ".L_%s_%s" % (name, s)
+
+    # ------------------------------------------------------------------ prologue
+    k.label(name)
+    k.salu("s_memtime", sClk0)
+    k.salu("s_memrealtime", sRt0)
+    k.smem("s_load_dwordx4", sK, sArg, A_NITEMS)          # nItems, window, ringD, maxWindows
+    k.smem("s_load_dwordx2", sP[1], sArg, A_PLANWIN)
+    k.wait_lgkm()
+    k.salu("s_cmp_ge_u32", sWg, sK.sub(0))
+    k.branch("s_cbranch_scc1", lbl("exit"))
+    k.salu("s_mov_b32", sWindow, sK.sub(1))
+    k.salu("s_sub_u32", sRingMask, sK.sub(2), 1)
+    # the window's plan record: planWin + (wg * maxWindows + window) * 64
+    k.salu("s_mul_i32", sT[0], sWg, sK.sub(3))
+    k.salu("s_add_u32", sT[0], sT[0], sWindow)
+    k.salu("s_lshl_b32", sT[0], sT[0], 6)
+    k.add64(sP[1], sP[1], sT[0])
+    k.smem("s_load_dwordx16", sWin, sP[1], 0)
+    k.smem("s_load_dwordx2", sP[2], sArg, A_ITEMS)
+    k.wait_lgkm()
+    k.salu("s_cmp_ge_i32", sWindow, W(W_NWIN))
+    k.branch("s_cbranch_scc1", lbl("exit"))
+    # item record
+    k.salu("s_lshl_b32", sT[0], sWg, 7)
+    k.add64(sP[2], sP[2], sT[0])
+    k.smem("s_load_dword", sLX, sP[2], I_LX)
+    k.smem("s_load_dword", sLY, sP[2], I_LY)
+    k.smem("s_load_dwordx2", sP[3], sP[2], I_YOFF)
+    k.smem("s_load_dword", sT[1], sP[2], I_MODEL)
+    k.smem("s_load_dwordx2", sEv, sArg, A_EVENTS)
+    k.wait_lgkm()
+    # events of this alignment: events + 24 * yOff
+    k.salu("s_mul_i32", sT[2], sT[6], 24)
+    k.salu("s_mul_hi_u32", sT[3], sT[6], 24)
+    k.add64(sEv, sEv, sT[2], sT[3])
+    # the model's transitions: models + model * stride * 8
+    k.smem("s_load_dwordx2", sP[2], sArg, A_MODELS)
+    k.smem("s_load_dwordx2", sP[3], sArg, A_MODELSTRIDE)
+    k.wait_lgkm()
+    k.salu("s_lshl_b32", sT[6], sT[6], 3)
+    k.salu("s_mul_i32", sT[2], sT[1], sT[6])
+    k.salu("s_mul_hi_u32", sT[3], sT[1], sT[6])
+    k.add64(sP[2], sP[2], sT[2], sT[3])
+    k.smem("s_load_dwordx2", sTMM, sP[2], 0 * 8)
+    k.smem("s_load_dwordx2", sTXM, sP[2], 1 * 8)
+    k.smem("s_load_dwordx2", sTYM, sP[2], 2 * 8)
+    k.smem("s_load_dwordx2", sTMY, sP[2], 4 * 8)
+    k.smem("s_load_dwordx2", sTYY, sP[2], 6 * 8)
+    # track rows of this alignment: track + trackBase[wg] * 160
+    k.smem("s_load_dwordx2", sP[3], sArg, A_TRACKBASE)
+    k.smem("s_load_dwordx2", sTrack, sArg, A_TRACK)
+    k.wait_lgkm()
+    k.salu("s_lshl_b32", sT[0], sWg, 3)
+    k.smem("s_load_dwordx2", sP[3], sP[3], sT[0])
+    k.wait_lgkm()
+    k.salu("s_mul_i32", sT[2], sT[6], TRACK_ROW_BYTES)
+    k.salu("s_mul_hi_u32", sT[3], sT[6], TRACK_ROW_BYTES)
+    k.add64(sTrack, sTrack, sT[2], sT[3])
+    # ring of this alignment: ring + wg * ringDoubles * 8
+    k.smem("s_load_dwordx4", S(64, 4), sArg, A_RING)      # ring, ringDoubles
+    k.wait_lgkm()
+    k.salu("s_lshl_b64", sP[1], sP[1], 3)
+    k.salu("s_mul_i32", sT[4], sT[2], sWg)
+    k.salu("s_mul_hi_u32", sT[5], sT[2], sWg)
+    k.salu("s_mul_i32", sT[6], sT[3], sWg)
+    k.salu("s_add_u32", sT[5], sT[5], sT[6])
+    k.add64(sRing, sP[0], sT[4], sT[5])
+    # control words: planCtl + planOff[wg] * 32
+    k.smem("s_load_dwordx2", sP[3], sArg, A_PLANOFF)
+    k.smem("s_load_dwordx2", sCtlPtr, sArg, A_PLANCTL)
+    k.wait_lgkm()
+    k.salu("s_lshl_b32", sT[0], sWg, 3)
+    k.smem("s_load_dwordx2", sP[3], sP[3], sT[0])
+    k.wait_lgkm()
+    k.salu("s_lshl_b64", sP[3], sP[3], 5)
+    k.add64(sCtlPtr, sCtlPtr, sT[6], sT[7])
+    # state record and contexts
+    k.smem("s_load_dwordx2", sState, sArg, A_STATES)
+    k.smem("s_load_dwordx4", S(64, 4), sArg, A_CTX)       # ctx, ctxBytes (per context)
+    k.wait_lgkm()
+    k.salu("s_mul_i32", sT[4], sWg, STATE_BYTES)
+    k.add64(sState, sState, sT[4])
+    k.salu("s_mov_b32", sCtxBytes, sT[2])
+    # three contexts per alignment: [0], [1] by window parity, [2] the start of an alignment (written by the host)
+    k.salu("s_mul_i32", sT[4], sWg, 3)
+    k.salu("s_mul_i32", sT[5], sT[4], sCtxBytes)
+    k.salu("s_mul_hi_u32", sT[6], sT[4], sCtxBytes)
+    k.add64(sCtx, sP[0], sT[5], sT[6])                    # context [0]
+    # the one to load: window 0 -> [2], else [(window - 1) & 1]
+    k.salu("s_add_u32", sT[0], sWindow, 1)
+    k.salu("s_and_b32", sT[0], sT[0], 1)
+    k.salu("s_cmp_eq_u32", sWindow, 0)
+    k.salu("s_cselect_b32", sT[0], 2, sT[0])
+    k.salu("s_mul_i32", sT[1], sT[0], sCtxBytes)
+    k.add64(sP[3], sCtx, sT[1])                           # sP[3]: the context to load
+    # ... and the one to save: [window & 1]
+    k.salu("s_and_b32", sT[0], sWindow, 1)
+    k.salu("s_mul_i32", sT[1], sT[0], sCtxBytes)
+    k.add64(sCtx, sCtx, sT[1])
+
+    # lane constants (v0 = lane on entry)
+    k.valu("v_lshlrev_b32_e32", vOff8, 3, V(0))
+    # the logAdd table: 64 doubles from the library's copy, one per lane
+    k.smem("s_load_dwordx2", sP[1], sArg, A_COEF)
+    k.wait_lgkm()
+    tq = pool.take(2)
+    k.gload(2, tq, vOff8, sP[1])
+    k.valu("v_lshlrev_b32_e32", vOff16, 4, V(0))          # (v0 is vOff16 from here on)
+    k.ds_write(64, vOff8, tq, LDS_COEF)
+    pool.give(tq)
+    k.s_mov64_lit(s7p5, dbits(7.5))
+    k.s_mov64_lit(sNinf, dbits(float("-inf")))
+
+    # ---- the context: constants and the cells of the last two diagonals
+    for j in range(L):
+        for q in range(9):
+            k.gload(4, V(C[j][0].i + 4 * q, 4), vOff16, sP[3], (q % 4) * 1024)
+            if q % 4 == 3 or q == 8:
+                k.add64(sP[3], sP[3], 4096 if q % 4 == 3 else 1024)
+    for p in range(2):
+        for j in range(L):
+            k.gload(2, Xm(p, j), vOff8, sP[3], 0)
+            k.gload(4, V(Xx(p, j).i, 4), vOff16, sP[3], 512)
+            k.add64(sP[3], sP[3], 1536)
+    k.smem("s_load_dwordx8", S(16, 8), sP[3], 0)          # masks (6 dwords), in slot (lane, layer)
+    k.smem("s_load_dwordx2", S(24, 2), sP[3], 32)         # out slot (lane, layer)
+    k.wait_all()
+    k.salu("s_mov_b32", sD, W(W_D0))                      # last diagonal done
+    k.salu("s_mov_b32", sTop, W(W_TOP))
+    k.salu("s_mov_b32", sXmin, W(W_XMIN0))
+    k.salu("s_mov_b32", sXmax, W(W_XMAX0))
+    # the k-mer a slot holds: the one of (xmax - P, xmax] that is congruent to the slot; its event address constant
+    tq = pool.take(2)
+    for j in range(L):
+        k.valu("v_lshrrev_b32_e32", tq.lo, 4, vOff16)                # lane
+        k.valu("v_mul_u32_u24_e32", tq.lo, L, tq.lo)
+        k.valu("v_sub_u32_e32", tq.lo, P - j, tq.lo)                 # P - slot
+        k.valu("v_add_u32_e32", tq.lo, sXmax, tq.lo)                 # n = xmax + P - slot  (> 0)
+        k.valu("v_mov_b32_e32", tq.hi, "0x%x" % ((1 << 32) // P + 1))
+        k.valu("v_mul_hi_u32", tq.hi, tq.lo, tq.hi)                  # n / P
+        k.valu("v_mul_u32_u24_e32", tq.hi, P, tq.hi)
+        k.valu("v_sub_u32_e32", tq.lo, tq.lo, tq.hi)                 # n mod P = xmax - x
+        k.valu("v_subrev_u32_e32", tq.lo, sXmax, tq.lo)              # -x
+        k.valu("v_add_u32_e32", tq.lo, -1, tq.lo)                    # -1 - x
+        k.valu("v_and_b32_e32", tq.lo, EVN - 1, tq.lo)
+        k.valu("v_lshlrev_b32_e32", tq.lo, 4, tq.lo)
+        k.valu("v_add_u32_e32", vEvSlot[j], LDS_EV, tq.lo)
+    pool.give(tq)
+    # the rotated neighbours of both diagonals
+    for p in range(2):
+        for q, src in enumerate((Xm(p, L - 1), Xx(p, L - 1), Xy(p, L - 1))):
+            k.ror64(R[p].sub(2 * q, 2), src)
+    # stage from scratch everything the first diagonal's block can ask for
+    k.salu("s_add_u32", sD, sD, 1)
+    k.salu("s_sub_u32", sEvHi, sD, sXmax)
+    k.salu("s_sub_u32", sEvHi, sEvHi, 2)
+    k.pc_of(sStagePC, lbl("stage"))
+    k.salu("s_swappc_b64", sRet, sStagePC)
+    k.forget()
+    # the first diagonal's events
+    k.salu("s_and_b32", sDmod, sD, EVN - 1)
+    k.salu("s_lshl_b32", sDmod, sDmod, 4)
+    for j in range(L):
+        k.valu("v_add_u32_e32", E[j].lo, sDmod, vEvSlot[j])
+        k.ds_read(128, E[j], E[j].lo)
+    k.salu("s_bitcmp1_b32", sD, 0)
+    k.branch("s_cbranch_scc1", lbl("odd"))
+
+    # ------------------------------------------------------------------ one anti-diagonal
+    def step(p):
+        """Diagonal sD of parity p: X[p] holds the diagonal before last and receives this one, X[1-p] the last one."""
+        q = 1 - p
+        pend = list(k.lgkm)  # the events' reads, issued by the step before
+        # band edges: the k-mer that leaves first (its slot is parked), then the one that enters
+        k.salu("s_bitcmp1_b64", sStepMin, sD)
+        k.branch("s_cbranch_scc1", lbl("leave%d" % p))
+        k.label(lbl("left%d" % p))
+        k.salu("s_bitcmp1_b64", sStepMax, sD)
+        k.branch("s_cbranch_scc1", lbl("enter%d" % p))
+        k.label(lbl("entered%d" % p))
+        k.lgkm = pend
+        # this diagonal's ring row
+        k.salu("s_and_b32", sT[0], sD, sRingMask)
+        k.salu("s_mul_i32", sT[0], sT[0], ROW_BYTES)
+        k.add64(sRow0, sRing, sT[0])
+        k.add64(sRow1, sRow0, 4096)
+
+        def lower(j, w):   # (x-1, y) on the last diagonal: m (w = 0) or x (w = 1)
+            return (Xm(q, j - 1), Xx(q, j - 1))[w] if j else R[q].sub(2 * w, 2)
+
+        def middle(j, w):  # (x-1, y-1) on the diagonal before: m, x, y
+            return (Xm(p, j - 1), Xx(p, j - 1), Xy(p, j - 1))[w] if j else R[p].sub(2 * w, 2)
+
+        # P1: gap X from the lower cell -- needs no emission
+        recs = []
+        for j in range(L):
+            a, b = pool.take(2), pool.take(2)
+            k.add(a, lower(j, 0), C[j][CPXO])
+            k.add(b, lower(j, 1), C[j][CPXE])
+            recs.append(k.ladd_front(a, b, free=(a, b)))
+        # P2: match emissions; the sums of the middle cell's gap-X state, which the gap-X results are about to overwrite
+        g0, g1, g2 = pool.take(2), pool.take(2), pool.take(2)
+        bsum = []
+        for j in range(L):
+            c = C[j]
+            k.gauss(Xpm(p, j), E[j].sub(0, 2), c[CMU], c[CSD], c[CRSD], c[CK1], g0, g1)
+            k.gauss(g2, E[j].sub(2, 2), c[CNMU], c[CNSD], c[CRNSD], c[CK2], g0, g1)
+            k.add(Xpm(p, j), Xpm(p, j), g2)
+        for j in range(L):
+            b = pool.take(2)
+            k.add(b, Xpm(p, j), sTXM)
+            k.add(b, middle(j, 1), b)
+            bsum.append(b)
+        # P3: gap X done
+        for j in range(L):
+            k.ladd_back(recs[j], Xx(p, j), s7p5)
+        # P4: match from the middle cell, first two terms
+        recs = []
+        for j in range(L):
+            a = pool.take(2)
+            k.add(a, Xpm(p, j), sTMM)
+            k.add(a, middle(j, 0), a)
+            recs.append(k.ladd_front(a, bsum[j], free=(a, bsum[j])))
+        # P5: gap-Y emissions; the third match term (the middle cell's gap-Y state dies with this diagonal's gap-Y results)
+        csum = []
+        for j in range(L):
+            c = C[j]
+            k.gauss(PY[j], E[j].sub(0, 2), c[8 + CMU], c[8 + CSD], c[8 + CRSD], c[8 + CK1], g0, g1)
+            k.gauss(g2, E[j].sub(2, 2), c[8 + CNMU], c[8 + CNSD], c[8 + CRNSD], c[8 + CK2], g0, g1)
+            k.add(PY[j], PY[j], g2)
+        pool.give(g0, g1, g2)
+        for j in range(L):
+            cc = pool.take(2)
+            k.add(cc, Xpm(p, j), sTYM)
+            k.add(cc, middle(j, 2), cc)
+            csum.append(cc)
+        # P6
+        for j in range(L):
+            k.ladd_back(recs[j], Xm(p, j), s7p5)
+        # P7: gap Y from the upper cell
+        recs = []
+        for j in range(L):
+            a, b = pool.take(2), pool.take(2)
+            k.add(a, PY[j], sTMY)
+            k.add(a, Xm(q, j), a)
+            k.add(b, PY[j], sTYY)
+            k.add(b, Xy(q, j), b)
+            recs.append(k.ladd_front(a, b, free=(a, b)))
+        # ... while its table reads are under way: the next diagonal's events, the gap-Y emissions' stores
+        k.salu("s_add_u32", sDmod, sDmod, 16)
+        k.salu("s_and_b32", sDmod, sDmod, 16 * (EVN - 1))
+        for j in range(L):
+            k.valu("v_add_u32_e32", E[j].lo, sDmod, vEvSlot[j])
+            k.ds_read(128, E[j], E[j].lo)
+        for j in range(L):
+            k.salu("s_mov_b64", "exec", sMask[j])
+            off = j * LAYER_BYTES + OFF_PY
+            k.gstore(2, vOff8, PY[j], sRow0 if off < 4096 else sRow1, off % 4096)
+        k.salu("s_mov_b64", "exec", -1)
+        # P9
+        for j in range(L):
+            k.ladd_back(recs[j], Xy(p, j), s7p5)
+        # P10: the match cell's third term
+        recs = []
+        for j in range(L):
+            recs.append(k.ladd_front(Xm(p, j), csum[j], free=(csum[j],)))
+        # ... meanwhile the gap states leave where the sweep back reads them again, and layer L-1 is rotated up a lane
+        k.salu("s_bitcmp1_b64", sFull, sD)
+        k.branch("s_cbranch_scc1", lbl("full%d" % p))
+        k.label(lbl("fulldone%d" % p))
+        k.ror64(R[p].sub(2, 2), Xx(p, L - 1))
+        k.ror64(R[p].sub(4, 2), Xy(p, L - 1))
+        for j in range(L):
+            k.ladd_back(recs[j], Xm(p, j), s7p5)
+        # P11: (Fm, pm) leave; the match cells of layer L-1 go up a lane
+        for j in range(L):
+            k.salu("s_mov_b64", "exec", sMask[j])
+            off = j * LAYER_BYTES
+            k.gstore(4, vOff16, V(Xm(p, j).i, 4), sRow0 if off < 4096 else sRow1, off % 4096)
+        k.salu("s_mov_b64", "exec", -1)
+        k.ror64(R[p].sub(0, 2), Xm(p, L - 1))
+        k.salu("s_add_u32", sD, sD, 1)
+
+    k.label(lbl("even"))
+    step(0)
+    state_after = list(k.lgkm)
+    k.salu("s_cmp_gt_i32", sD, sTop)
+    k.branch("s_cbranch_scc1", lbl("done"))
+    k.label(lbl("odd"))
+    k.vm = []
+    k.lgkm = [set(E[j].regs()) for j in range(L)]  # (a window that starts on an odd diagonal enters here, its events in flight)
+    step(1)
+    k.salu("s_cmp_le_i32", sD, sStop)
+    k.branch("s_cbranch_scc1", lbl("even"))
+    # a staging block ends here, or the window
+    k.salu("s_cmp_gt_i32", sD, sTop)
+    k.branch("s_cbranch_scc1", lbl("done"))
+    k.salu("s_swappc_b64", sRet, sStagePC)
+    k.branch("s_branch", lbl("even"))
+
+    # ------------------------------------------------------------------ out of line: band edges, full rows
+    for p in range(2):
+        # the k-mer at the band's low end leaves: its slot scores -inf from now on (K1, K2 of both tables, the gap-X sums)
+        k.forget()
+        k.label(lbl("leave%d" % p))
+        k.salu("s_add_u32", sXmin, sXmin, 1)
+        k.salu("s_lshl_b64", sBit, 1, sOutL)
+        for j in range(L - 1):
+            k.salu("s_cmp_eq_u32", sOutJ, j)
+            k.branch("s_cbranch_scc1", lbl("leave%d_%d" % (p, j)))
+        for j in reversed(range(L)):
+            if j < L - 1:
+                k.label(lbl("leave%d_%d" % (p, j)))
+            k.salu("s_andn2_b64", sMask[j], sMask[j], sBit)
+            k.salu("s_mov_b64", "exec", sBit)
+            for q in (CK1, CK2, 8 + CK1, 8 + CK2, CPXO, CPXE):
+                k.valu("v_mov_b32_e32", C[j][q].lo, 0)
+                k.valu("v_mov_b32_e32", C[j][q].hi, sNinf.hi)
+            k.salu("s_mov_b64", "exec", -1)
+            if j < L - 1:
+                k.salu("s_add_u32", sOutJ, sOutJ, 1)
+            else:
+                k.salu("s_mov_b32", sOutJ, 0)
+                k.salu("s_add_u32", sOutL, sOutL, 1)
+                k.salu("s_and_b32", sOutL, sOutL, 63)
+            k.branch("s_branch", lbl("left%d" % p))
+        # the next k-mer enters at the band's high end: its row comes from the LDS ring of rows
+        k.forget()
+        k.label(lbl("enter%d" % p))
+        k.salu("s_add_u32", sXmax, sXmax, 1)
+        k.salu("s_and_b32", sT[0], sXmax, ROWN - 1)
+        k.salu("s_mul_i32", sT[0], sT[0], TRACK_ROW_BYTES)
+        k.salu("s_add_u32", sT[0], sT[0], LDS_ROWS)
+        k.valu("v_mov_b32_e32", vTmp, sT[0])
+        k.salu("s_sub_u32", sT[1], -1, sXmax)
+        k.salu("s_and_b32", sT[1], sT[1], EVN - 1)
+        k.salu("s_lshl_b32", sT[1], sT[1], 4)
+        k.salu("s_add_u32", sT[1], sT[1], LDS_EV)
+        k.salu("s_lshl_b64", sBit, 1, sInL)
+        for j in range(L - 1):
+            k.salu("s_cmp_eq_u32", sInJ, j)
+            k.branch("s_cbranch_scc1", lbl("enter%d_%d" % (p, j)))
+        for j in reversed(range(L)):
+            if j < L - 1:
+                k.label(lbl("enter%d_%d" % (p, j)))
+            k.salu("s_or_b64", sMask[j], sMask[j], sBit)
+            k.salu("s_mov_b64", "exec", sBit)
+            for q in range(9):
+                k.ds_read(128, V(C[j][0].i + 4 * q, 4), vTmp, 16 * q)
+            # ... and its event of this diagonal (the read the last step issued went by the slot's old constant)
+            k.valu("v_mov_b32_e32", vEvSlot[j], sT[1])
+            k.valu("v_add_u32_e32", vTmp, sDmod, vEvSlot[j])
+            k.ds_read(128, E[j], vTmp)
+            k.salu("s_mov_b64", "exec", -1)
+            if j < L - 1:
+                k.salu("s_add_u32", sInJ, sInJ, 1)
+            else:
+                k.salu("s_mov_b32", sInJ, 0)
+                k.salu("s_add_u32", sInL, sInL, 1)
+                k.salu("s_and_b32", sInL, sInL, 63)
+            k.drain_lgkm()
+            k.branch("s_branch", lbl("entered%d" % p))
+        # a diagonal the sweep back reads all three states of
+        k.forget()
+        k.label(lbl("full%d" % p))
+        for j in range(L):
+            k.salu("s_mov_b64", "exec", sMask[j])
+            off = j * LAYER_BYTES + OFF_FXY
+            k.gstore(4, vOff16, V(Xx(p, j).i, 4), sRow0 if off < 4096 else sRow1, off % 4096)
+        k.salu("s_mov_b64", "exec", -1)
+        k.branch("s_branch", lbl("fulldone%d" % p))
+
+    # ------------------------------------------------------------------ staging: control words, events, k-mer rows
+    k.forget()
+    k.label(lbl("stage"))
+    # the control words of sD's block, and where the block (or the window) ends
+    k.salu("s_lshr_b32", sT[0], sD, 6)
+    k.salu("s_lshl_b32", sT[0], sT[0], 5)
+    k.smem("s_load_dwordx8", sCtl, sCtlPtr, sT[0])
+    k.salu("s_or_b32", sStop, sD, BLOCK - 1)
+    k.salu("s_min_i32", sStop, sStop, sTop)
+    # events up to index (block end + 1) - xmin - 1: the first diagonal of the next block reads before that block is staged
+    k.salu("s_or_b32", sT[1], sD, BLOCK - 1)
+    k.salu("s_add_u32", sT[1], sT[1], 2)
+    k.salu("s_sub_u32", sT[1], sT[1], sXmin)              # sT[1]: first event index not needed yet
+    tE = pool.take(4)
+    tI, tA, tB = pool.take(2), pool.take(2), pool.take(2)
+    k.label(lbl("stage_ev"))
+    k.salu("s_cmp_ge_i32", sEvHi, sT[1])
+    k.branch("s_cbranch_scc1", lbl("stage_rows"))
+    k.valu("v_lshrrev_b32_e32", tI.lo, 4, vOff16)          # lane
+    k.valu("v_add_u32_e32", tI.lo, sEvHi, tI.lo)           # e
+    k.valu("v_mov_b32_e32", tE.sub(0), 0)
+    k.valu("v_mov_b32_e32", tE.sub(1), 0)
+    k.valu("v_mov_b32_e32", tE.sub(2), 0)
+    k.valu("v_mov_b32_e32", tE.sub(3), 0)
+    k.valu("v_cmp_le_i32_e32", "vcc", 0, tI.lo)
+    k.valu("v_cmp_gt_i32_e64", sP[1], sLY, tI.lo)
+    k.salu("s_and_b64", sP[1], sP[1], "vcc")
+    k.valu("v_cmp_gt_i32_e64", sP[2], sT[1], tI.lo)        # e below the limit: these lanes write the ring
+    k.salu("s_and_b64", sP[1], sP[1], sP[2])
+    k.valu("v_mul_u32_u24_e32", tA.lo, 24, tI.lo)
+    k.salu("s_mov_b64", "exec", sP[1])
+    k.gload(4, tE, tA.lo, sEv)
+    k.salu("s_mov_b64", "exec", sP[2])
+    k.valu("v_and_b32_e32", tB.lo, EVN - 1, tI.lo)
+    k.valu("v_lshlrev_b32_e32", tA.hi, 4, tB.lo)
+    k.valu("v_add_u32_e32", tA.hi, LDS_EV, tA.hi)
+    k.wait_vm()
+    k.ds_write(128, tA.hi, tE, 0)
+    k.ds_write(128, tA.hi, tE, 16 * EVN)
+    k.valu("v_cmp_gt_u32_e32", "vcc", L, tB.lo)
+    k.salu("s_and_b64", "exec", "exec", "vcc")
+    k.ds_write(128, tA.hi, tE, 32 * EVN)
+    k.salu("s_mov_b64", "exec", -1)
+    k.salu("s_add_u32", sEvHi, sEvHi, 64)
+    k.branch("s_branch", lbl("stage_ev"))
+    k.label(lbl("stage_rows"))
+    k.salu("s_mov_b32", sEvHi, sT[1])
+    # rows of the k-mers xmax + 1 .. xmax + 64 (one lane each; past the last column: that column's, never installed)
+    k.valu("v_lshrrev_b32_e32", tI.lo, 4, vOff16)
+    k.valu("v_add_u32_e32", tI.lo, sXmax, tI.lo)
+    k.valu("v_add_u32_e32", tI.lo, 1, tI.lo)
+    k.valu("v_min_i32_e32", tI.hi, sLX, tI.lo)
+    k.valu("v_mul_u32_u24_e32", tA.lo, TRACK_ROW_BYTES, tI.hi)
+    k.valu("v_and_b32_e32", tB.lo, ROWN - 1, tI.lo)
+    k.valu("v_mul_u32_u24_e32", tB.lo, TRACK_ROW_BYTES, tB.lo)
+    k.valu("v_add_u32_e32", tB.lo, LDS_ROWS, tB.lo)
+    rows = [pool.take(4) for _ in range(3)]
+    for base in range(0, 9, 3):
+        for q in range(3):
+            k.gload(4, rows[q], tA.lo, sTrack, 16 * (base + q))
+        for q in range(3):
+            k.ds_write(128, tB.lo, rows[q], 16 * (base + q))
+    pool.give(tE, tI, tA, tB, *rows)
+    k.wait_all()
+    k.salu("s_setpc_b64", sRet)
+
+    # ------------------------------------------------------------------ the window is swept: hand it to the sweep back
+    k.forget()
+    k.label(lbl("done"))
+    k.wait_all()
+    # an estimate of the window's totalProbability: the cells of the top diagonal dotted with the end vector the sweep
+    # back starts from (stateMachine.c:1179-1207), in any order -- it steers the candidate test, the post kernel checks
+    # every exact total against it.  log-sum-exp around the largest term, single precision past the subtraction.
+    return k, locals()
+
+
+def forward_tail(k, v):
+    """(continued: split only to keep the functions readable)"""
+    g = dict(v)
+    pool, L_, name = g["pool"], L, g["name"]
+    S_, lbl = S, g["lbl"]
+    sArg, sWg, sT, sP, sWin, sState, sCtx = g["sArg"], g["sWg"], g["sT"], g["sP"], g["sWin"], g["sState"], g["sCtx"]
+    sTop, sMask, sWindow, sNinf = g["sTop"], g["sMask"], g["sWindow"], g["sNinf"]
+    sTMM, sTXM, sTYM = g["sTMM"], g["sTXM"], g["sTYM"]
+    sInL, sInJ, sOutL, sOutJ, sClk0, sRt0 = g["sInL"], g["sInJ"], g["sOutL"], g["sOutJ"], g["sClk0"], g["sRt0"]
+    Xm, Xx, Xy, C = g["Xm"], g["Xx"], g["Xy"], g["C"]
+    vOff16, vOff8 = g["vOff16"], g["vOff8"]
+    W = g["W"]
+    # the model's record again (its transitions 3..6 for the ragged end vector): models + model * stride * 8
+    k.smem("s_load_dwordx2", sP[3], sArg, A_ITEMS)
+    k.wait_lgkm()
+    k.salu("s_lshl_b32", sT[0], sWg, 7)
+    k.add64(sP[3], sP[3], sT[0])
+    k.smem("s_load_dword", sT[0], sP[3], I_RAGGEDR)
+    k.smem("s_load_dword", sT[1], sP[3], I_MODEL)
+    k.smem("s_load_dwordx2", sP[2], sArg, A_MODELS)
+    k.smem("s_load_dwordx2", sP[3], sArg, A_MODELSTRIDE)
+    k.wait_lgkm()
+    k.salu("s_lshl_b32", sT[6], sT[6], 3)
+    k.salu("s_mul_i32", sT[2], sT[1], sT[6])
+    k.salu("s_mul_hi_u32", sT[3], sT[1], sT[6])
+    k.add64(sP[2], sP[2], sT[2], sT[3])
+    sOX, sOY, sEX, sEY = S_(36, 2), S_(38, 2), S_(40, 2), S_(42, 2)  # (the control words are done with)
+    k.smem("s_load_dwordx2", sOX, sP[2], 3 * 8)
+    k.smem("s_load_dwordx2", sOY, sP[2], 4 * 8)
+    k.smem("s_load_dwordx2", sEX, sP[2], 5 * 8)
+    k.smem("s_load_dwordx2", sEY, sP[2], 6 * 8)
+    k.wait_lgkm()
+    e0, e1, e2 = pool.take(2), pool.take(2), pool.take(2)
+    # at the end of a ragged alignment: ((open X + open Y) / 2, extend X, extend Y); otherwise the transitions into match
+    k.salu("s_cmp_lg_u32", W(W_ATEND), 0)
+    k.salu("s_cselect_b32", sT[0], sT[0], 0)
+    k.valu("v_mov_b32_e32", e0.lo, sOX.lo)
+    k.valu("v_mov_b32_e32", e0.hi, sOX.hi)
+    k.add(e0, e0, sOY)
+    k.mul(e0, e0, "0.5")
+    k.valu("v_mov_b32_e32", e1.lo, sEX.lo)
+    k.valu("v_mov_b32_e32", e1.hi, sEX.hi)
+    k.valu("v_mov_b32_e32", e2.lo, sEY.lo)
+    k.valu("v_mov_b32_e32", e2.hi, sEY.hi)
+    k.salu("s_cmp_lg_u32", sT[0], 0)
+    k.salu("s_cselect_b64", "vcc", -1, 0)
+    for e, s in ((e0, sTMM), (e1, sTXM), (e2, sTYM)):
+        t = pool.take(2)
+        k.valu("v_mov_b32_e32", t.lo, s.lo)
+        k.valu("v_mov_b32_e32", t.hi, s.hi)
+        k.valu("v_cndmask_b32_e32", e.lo, t.lo, e.lo, "vcc")
+        k.valu("v_cndmask_b32_e32", e.hi, t.hi, e.hi, "vcc")
+        pool.give(t)
+    # the top diagonal's parity
+    terms = [pool.take(2) for _ in range(3 * L_)]
+    for p in range(2):
+        k.salu("s_and_b32", sT[1], sTop, 1)
+        k.salu("s_cmp_eq_u32", sT[1], p)
+        k.branch("s_cbranch_scc0", lbl("est_p%d" % p))
+        for j in range(L_):
+            k.add(terms[3 * j + 0], Xm(p, j), e0)
+            k.add(terms[3 * j + 1], Xx(p, j), e1)
+            k.add(terms[3 * j + 2], Xy(p, j), e2)
+        k.label(lbl("est_p%d" % p))
+    pool.give(e0, e1, e2)
+    vS = [g["E"][0].sub(q) for q in range(4)] + [g["E"][1].sub(0)]  # (the events' registers are free by now)
+    # cells outside the band do not count
+    for j in range(L_):
+        for q in range(3):
+            t = terms[3 * j + q]
+            k.valu("v_mov_b32_e32", vS[0], sNinf.hi)
+            k.valu("v_cndmask_b32_e64", t.hi, vS[0], t.hi, sMask[j])
+            k.valu("v_cndmask_b32_e64", t.lo, 0, t.lo, sMask[j])
+    mx = pool.take(2)
+    k.valu("v_max_f64", mx, terms[0], terms[1])
+    for t in terms[2:]:
+        k.valu("v_max_f64", mx, mx, t)
+    vM, vTmp, vTmp2, vLane4, vSum = vS
+    k.valu("v_cvt_f32_f64_e32", vM, mx)
+    k.valu("v_lshrrev_b32_e32", vLane4, 2, vOff16)
+    k.butterfly("v_max_f32_e32", vM, vTmp, vLane4, vTmp2)
+    k.valu("v_cvt_f64_f32_e32", mx, vM)
+    k.valu("v_mov_b32_e32", vSum, 0)
+    for t in terms:
+        k.add(t, t, Neg(mx))
+        k.valu("v_cvt_f32_f64_e32", vTmp, t)
+        k.valu("v_mul_f32_e32", vTmp, "0x%x" % LOG2E_F32, vTmp)
+        k.valu("v_exp_f32_e32", vTmp, vTmp)
+        k.nop(0)
+        k.valu("v_add_f32_e32", vSum, vSum, vTmp)
+    k.butterfly("v_add_f32_e32", vSum, vTmp, vLane4, vTmp2)
+    k.valu("v_log_f32_e32", vSum, vSum)
+    k.nop(0)
+    k.valu("v_mul_f32_e32", vSum, "0x%x" % LN2_F32, vSum)
+    est = terms[0]
+    k.valu("v_cvt_f64_f32_e32", est, vSum)
+    k.add(est, est, mx)
+
+    # ---- the context for the next launch (and for the sweep back of this window)
+    k.salu("s_mov_b64", sP[3], sCtx)
+    for j in range(L_):
+        for q in range(9):
+            k.gstore(4, vOff16, V(C[j][0].i + 4 * q, 4), sP[3], (q % 4) * 1024)
+            if q % 4 == 3 or q == 8:
+                k.add64(sP[3], sP[3], 4096 if q % 4 == 3 else 1024)
+    for p in range(2):
+        for j in range(L_):
+            k.gstore(2, vOff8, Xm(p, j), sP[3], 0)
+            k.gstore(4, vOff16, V(Xx(p, j).i, 4), sP[3], 512)
+            k.add64(sP[3], sP[3], 1536)
+    # scalars and records leave through lane 0
+    k.salu("s_mov_b64", "exec", 1)
+    q4 = [pool.take(4) for _ in range(3)]
+    srcs = [sMask[0].lo, sMask[0].hi, sMask[1].lo, sMask[1].hi, sMask[2].lo, sMask[2].hi, sInL, sInJ, sOutL, sOutJ, 0, 0]
+    for i, s in enumerate(srcs):
+        k.valu("v_mov_b32_e32", q4[i // 4].sub(i % 4), s)
+    vZ = pool.take(2)
+    k.valu("v_mov_b32_e32", vZ.lo, 0)
+    for i in range(3):
+        k.gstore(4, vZ.lo, q4[i], sP[3], 16 * i)
+    # the window for the sweep back: win[window & 1] = { valid 1, top, from, to, atEnd, 0, 0, 0, est }
+    k.salu("s_and_b32", sT[0], sWindow, 1)
+    k.salu("s_mul_i32", sT[0], sT[0], WIN_BYTES)
+    k.salu("s_add_u32", sT[0], sT[0], ST_WIN)
+    k.add64(sP[2], sState, sT[0])
+    w4 = [pool.take(4) for _ in range(2)]
+    for i, s in enumerate((1, W(W_TOP), W(W_FROM), W(W_TO), W(W_ATEND), 0, 0, 0)):
+        k.valu("v_mov_b32_e32", w4[i // 4].sub(i % 4), s)
+    k.gstore(4, vZ.lo, w4[0], sP[2], 0)
+    k.gstore(4, vZ.lo, w4[1], sP[2], 16)
+    k.gstore(2, vZ.lo, est, sP[2], 32)
+    # state: d, tracedBackTo, finished; cells
+    s3 = pool.take(4)
+    k.valu("v_mov_b32_e32", s3.sub(0), W(W_TOP))
+    k.valu("v_mov_b32_e32", s3.sub(1), W(W_FROM))
+    k.valu("v_mov_b32_e32", s3.sub(2), W(W_ATEND))
+    k.lines.append("\tglobal_store_dwordx3 %s, %s, %s" % (vZ.lo, V(s3.i, 3), sState))
+    k.n += 1
+    c2 = pool.take(2)
+    k.valu("v_mov_b32_e32", c2.lo, W(W_CELLS))
+    k.valu("v_mov_b32_e32", c2.hi, W(W_CELLS + 1))
+    k.gstore(2, vZ.lo, c2, sState, ST_CELLS)
+    # the clocks this sweep took (shader clock and the 100 MHz reference)
+    clk = pool.take(4)
+    k.gload(4, clk, vZ.lo, sState, ST_CLKS)
+    k.salu("s_memtime", sP[0])
+    k.salu("s_memrealtime", sP[1])
+    k.drain_lgkm()
+    k.salu("s_sub_u32", sT[0], sT[0], sClk0.lo)
+    k.salu("s_subb_u32", sT[1], sT[1], sClk0.hi)
+    k.salu("s_sub_u32", sT[2], sT[2], sRt0.lo)
+    k.salu("s_subb_u32", sT[3], sT[3], sRt0.hi)
+    d4 = pool.take(4)
+    for i in range(4):
+        k.valu("v_mov_b32_e32", d4.sub(i), sT[i])
+    k.valu("v_add_co_u32_e32", clk.sub(0), "vcc", clk.sub(0), d4.sub(0))
+    k.valu("v_addc_co_u32_e32", clk.sub(1), "vcc", clk.sub(1), d4.sub(1), "vcc")
+    k.valu("v_add_co_u32_e32", clk.sub(2), "vcc", clk.sub(2), d4.sub(2))
+    k.valu("v_addc_co_u32_e32", clk.sub(3), "vcc", clk.sub(3), d4.sub(3), "vcc")
+    k.gstore(4, vZ.lo, clk, sState, ST_CLKS)
+    k.label(lbl("exit"))
+    k.salu("s_endpgm")
+    return k
+
+
+KERNEL_TEMPLATE = """\t.text
+\t.protected\t{name}
+\t.globl\t{name}
+\t.p2align\t8
+\t.type\t{name},@function
+{body}
+\t.section\t.rodata,"a",@progbits
+\t.p2align\t6, 0x0
+\t.amdhsa_kernel {name}
+\t\t.amdhsa_group_segment_fixed_size {lds}
+\t\t.amdhsa_private_segment_fixed_size 0
+\t\t.amdhsa_kernarg_size {kernarg}
+\t\t.amdhsa_user_sgpr_count 2
+\t\t.amdhsa_user_sgpr_dispatch_ptr 0
+\t\t.amdhsa_user_sgpr_queue_ptr 0
+\t\t.amdhsa_user_sgpr_kernarg_segment_ptr 1
+\t\t.amdhsa_user_sgpr_dispatch_id 0
+\t\t.amdhsa_user_sgpr_kernarg_preload_length 0
+\t\t.amdhsa_user_sgpr_kernarg_preload_offset 0
+\t\t.amdhsa_user_sgpr_private_segment_size 0
+\t\t.amdhsa_uses_dynamic_stack 0
+\t\t.amdhsa_enable_private_segment 0
+\t\t.amdhsa_system_sgpr_workgroup_id_x 1
+\t\t.amdhsa_system_sgpr_workgroup_id_y 0
+\t\t.amdhsa_system_sgpr_workgroup_id_z 0
+\t\t.amdhsa_system_sgpr_workgroup_info 0
+\t\t.amdhsa_system_vgpr_workitem_id 0
+\t\t.amdhsa_next_free_vgpr {vgprs}
+\t\t.amdhsa_next_free_sgpr {sgprs}
+\t\t.amdhsa_accum_offset {accum}
+\t\t.amdhsa_reserve_vcc 1
+\t\t.amdhsa_float_round_mode_32 0
+\t\t.amdhsa_float_round_mode_16_64 0
+\t\t.amdhsa_float_denorm_mode_32 3
+\t\t.amdhsa_float_denorm_mode_16_64 3
+\t\t.amdhsa_dx10_clamp 1
+\t\t.amdhsa_ieee_mode 1
+\t\t.amdhsa_fp16_overflow 0
+\t\t.amdhsa_tg_split 0
+\t\t.amdhsa_exception_fp_ieee_invalid_op 0
+\t\t.amdhsa_exception_fp_denorm_src 0
+\t\t.amdhsa_exception_fp_ieee_div_zero 0
+\t\t.amdhsa_exception_fp_ieee_overflow 0
+\t\t.amdhsa_exception_fp_ieee_underflow 0
+\t\t.amdhsa_exception_fp_ieee_inexact 0
+\t\t.amdhsa_exception_int_div_zero 0
+\t.end_amdhsa_kernel
+\t.text
+.Lend_{name}:
+\t.size\t{name}, .Lend_{name}-{name}
+"""
+
+META_TEMPLATE = """  - .agpr_count:     0
+    .args:
+      - .offset:         0
+        .size:           {kernarg}
+        .value_kind:     by_value
+    .group_segment_fixed_size: {lds}
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: {kernarg}
+    .language:       OpenCL C
+    .language_version:
+      - 2
+      - 0
+    .max_flat_workgroup_size: 64
+    .name:           {name}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     {sgprs}
+    .sgpr_spill_count: 0
+    .symbol:         {name}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     {vgprs}
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+"""
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else "/dev/stdout"
+    kernels = []
+    name = "cpecan_k_asm_forward_l%d" % L
+    k, v = forward_kernel(name)
+    forward_tail(k, v)
+    kernels.append(dict(name=name, body=k.text(), lds=LDS_F_BYTES, kernarg=ARGS_BYTES, vgprs=256, sgprs=102, accum=256,
+                        stats=k.stats))
+    text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6"]
+    for kk in kernels:
+        text.append(KERNEL_TEMPLATE.format(**kk))
+    text.append("\t.amdgpu_metadata\n---\namdhsa.kernels:")
+    for kk in kernels:
+        text.append(META_TEMPLATE.format(**kk).rstrip("\n"))
+    text.append("amdhsa.target:   amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\n\t.end_amdgpu_metadata")
+    open(out, "w").write("\n".join(text) + "\n")
+    if len(sys.argv) > 2:
+        defs = dict(ASM_L=L, ASM_ROW_BYTES=ROW_BYTES, ASM_CTX_X=CTX_X, ASM_CTX_S=CTX_S, ASM_CTX_BYTES=CTX_BYTES,
+                    ASM_MAX_WIDTH=MAX_WIDTH, ASM_PLANWIN_BYTES=PLANWIN_BYTES, ASM_CTL_BYTES=CTL_BYTES, ASM_BLOCK=BLOCK,
+                    ASM_ARGS_BYTES=ARGS_BYTES, ASM_NCONST=NCONST, ASM_LDS_F_BYTES=LDS_F_BYTES, ASM_LDS_B_BYTES=LDS_B_BYTES)
+        with open(sys.argv[2], "w") as h:
+            h.write("/* generated by asm/gen_sweeps.py: what the assembly sweeps and the C++ side agree on */\n")
+            h.write("#ifndef CPECAN_ASM_GEN_H_\n#define CPECAN_ASM_GEN_H_\n")
+            for kname, val in defs.items():
+                h.write("#define %s %d\n" % (kname, val))
+            h.write("#endif\n")
+    for kk in kernels:
+        sys.stderr.write("%s: %s\n" % (kk["name"], kk["stats"]))
+
+
+if __name__ == "__main__":
+    main()

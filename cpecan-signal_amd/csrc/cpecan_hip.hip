@@ -8,6 +8,8 @@
 #include "cpecan_hip.h"
 
 #include "cpecan_device.h"
+#include "cpecan_asm.h"
+#include "cpecan_sweep.h"
 
 #include <hip/hip_runtime.h>
 
@@ -15,6 +17,7 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -502,7 +505,73 @@ struct cpecan_batch {
     int trackRow = CP_ROW; /* doubles per column of the track */
     bool countsValid = false, ran = false;
     bool packedInRun = false; /* the last run ended with cpecan_k_pack_base + cpecan_k_pack_pairs */
+    /* the hand-scheduled assembly sweeps (cpecan_asm.h): the host's plan of windows and band steps, the forward waves'
+     * contexts */
+    bool useAsm = false, asmBackward = false;
+    int asmMaxWindows = 0;
+    DevBuf<AsmPlanWin> planWin;
+    DevBuf<AsmPlanCtl> planCtl;
+    DevBuf<long long> planOff;
+    DevBuf<char> asmCtx;
 };
+
+/* The plan of one alignment for the assembly sweeps: its traceback windows (getPosteriorProbsWithBanding's schedule,
+ * impl/pairwiseAligner.c:917-921 -- a function of the band alone; the same walk as the window count in batch_create) and,
+ * per diagonal, whether the band's edges step and whether the forward sweep keeps all three states of the diagonal
+ * (forward_window() of cpecan_kernel_wave.hip works the same rule out on the device).  tab: (first, last) column per
+ * diagonal. */
+static void build_asm_plan(const int *tab, long long nDiag, const cpecan_band_params &bp, std::vector<AsmPlanWin> &wins,
+                           AsmPlanCtl *ctl) {
+    const long long D = nDiag - 1;
+    memset(ctl, 0, (size_t) (D / ASM_BLOCK + 2) * sizeof(AsmPlanCtl));
+    wins.clear();
+    long long tracedBackTo = 0, cells = 1;
+    int d0 = 0;
+    for (long long k = 1; k <= D; k++) {
+        const int xmn = tab[2 * k], xmx = tab[2 * k + 1];
+        if (xmn != tab[2 * k - 2]) ctl[k >> 6].stepMin |= 1ull << (k & 63);
+        if (xmx != tab[2 * k - 1]) ctl[k >> 6].stepMax |= 1ull << (k & 63);
+        cells += xmx - xmn + 1;
+        const bool atEnd = k == D;
+        const bool tb = k >= tracedBackTo + bp.minDiagsBetweenTraceBack && xmx - xmn + 1 <= bp.diagonalExpansion * 2 + 1;
+        if (!(atEnd || tb)) continue;
+        AsmPlanWin w{};
+        w.d0 = d0;
+        w.top = (int) k;
+        w.from = (int) (k - (atEnd ? 0 : bp.traceBackDiagonals + 1));
+        w.to = (int) tracedBackTo;
+        w.atEnd = atEnd ? 1 : 0;
+        w.xminTop = xmn;
+        w.xmaxTop = xmx;
+        w.cells = cells;
+        w.xmin0 = tab[2 * d0];
+        w.xmax0 = tab[2 * d0 + 1];
+        w.tpost0 = std::min(w.top, w.from);
+        wins.push_back(w);
+        d0 = (int) k;
+        tracedBackTo = w.from;
+    }
+    for (size_t wi = 0; wi < wins.size(); wi++) {
+        AsmPlanWin &w = wins[wi];
+        w.nWindows = (int) wins.size();
+        /* all three states: the two diagonals a launch resumes from, every diagonal a totalProbability refresh of the
+         * window that decodes it reads (every 10th decoded diagonal, counted down from the window's first) and the one
+         * below it; everything where windows are shorter than the traceback margin */
+        const bool endW = w.atEnd != 0;
+        const int tpA = w.tpost0;
+        int tpB = tpA;
+        bool allFull = false;
+        if (!endW) {
+            tpB = wins[wi + 1].tpost0;
+            allFull = tpB < w.top;
+        }
+        for (int dj = w.d0 + 1; dj <= w.top; dj++) {
+            const int rA = ((tpA - dj) % 10 + 10) % 10, rB = endW ? 99 : ((tpB - dj) % 10 + 10) % 10;
+            const int rHere = dj <= w.from ? rA : rB, rAbove = dj + 1 <= w.from ? rA : rB;
+            if (allFull || dj >= w.top - 1 || rHere == 0 || rAbove == 1) ctl[dj >> 6].full |= 1ull << (dj & 63);
+        }
+    }
+}
 
 extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
                                                const double *logp, double threshold, long long capacity,
@@ -1107,6 +1176,21 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
      * only when the batch will (or, on the second call, turns out to) run on it.  A thread's working copy of one
      * item's intervals stays in its cache. */
     PinnedBuf<int> hTab;
+    /* the assembly sweeps' plan (build_asm_plan), for the batches that can run on them */
+    const bool wantPlan = !dna && !vanilla && !hdp && !unbanded && mode == CPECAN_MODE_POSTERIOR &&
+                          kernel != CPECAN_KERNEL_GENERAL && use_wave_kernels() && !(flags & CPECAN_FLAG_WORKGROUP_KERNELS) &&
+                          !(flags & CPECAN_FLAG_DEBUG_DUMP);
+    std::vector<std::vector<AsmPlanWin>> planWins(wantPlan ? (size_t) nItems : 0);
+    std::vector<long long> hPlanOff(wantPlan ? (size_t) nItems : 0);
+    PinnedBuf<AsmPlanCtl> hCtl;
+    long long ctlTotal = 0;
+    if (wantPlan) {
+        for (int64_t i = 0; i < nItems; i++) {
+            hPlanOff[(size_t) i] = ctlTotal;
+            ctlTotal += (items[i].lX + items[i].lY) / ASM_BLOCK + 2;
+        }
+        HIP_TRY(hCtl.alloc((size_t) ctlTotal));
+    }
     bool keptGeneral = false;
     long long maxDiags = 0;
     for (int64_t i = 0; i < nItems; i++) maxDiags = std::max<long long>(maxDiags, items[i].lX + items[i].lY + 1);
@@ -1173,6 +1257,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                 d.nCells = cells;
                 d.maxWidth = maxW;
                 st.windows = std::max(st.windows, windows);
+                if (wantPlan) build_asm_plan(tab, nDiag, *params, planWins[(size_t) i], hCtl.p + hPlanOff[(size_t) i]);
             }
         };
         if (nt <= 1) work(0);
@@ -1414,6 +1499,36 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                              hipMemcpyHostToDevice, c->prep));
         B_TRY(hipStreamSynchronize(c->prep));
         lap("state, scratch, track allocation");
+        /* the hand-scheduled assembly sweeps take the strawMan machine's posterior batches whose bands need three cells
+         * per lane and fit their staging scheme (CPECAN_ASM=0: the compiled kernels, for tests and timing) */
+        static const bool asmOff = getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 0;
+        if (wantPlan && !asmOff && b->sy->wave && b->sy->rows == ASM_L && globalMaxWidth <= ASM_MAX_WIDTH && b->nGroups == 1 &&
+            b->stateBytes == (int) sizeof(WvState) && cpecan_asm_load(c->device) == 0) {
+            b->asmMaxWindows = std::max(maxWindows, 1);
+            PinnedBuf<AsmPlanWin> hWin;
+            B_TRY(hWin.alloc((size_t) nItems * (size_t) b->asmMaxWindows));
+            memset(hWin.p, 0, (size_t) nItems * (size_t) b->asmMaxWindows * sizeof(AsmPlanWin));
+            for (int64_t i = 0; i < nItems; i++)
+                std::copy(planWins[(size_t) i].begin(), planWins[(size_t) i].end(), hWin.p + (size_t) i * (size_t) b->asmMaxWindows);
+            B_TRY(b->planWin.alloc(hWin.n));
+            B_TRY(b->planCtl.alloc((size_t) ctlTotal));
+            B_TRY(b->planOff.alloc((size_t) nItems));
+            B_TRY(b->asmCtx.alloc((size_t) nItems * 3 * ASM_CTX_BYTES));
+            B_TRY(hipMemcpyAsync(b->planWin.p, hWin.p, hWin.n * sizeof(AsmPlanWin), hipMemcpyHostToDevice, c->prep));
+            B_TRY(hipMemcpyAsync(b->planCtl.p, hCtl.p, (size_t) ctlTotal * sizeof(AsmPlanCtl), hipMemcpyHostToDevice, c->prep));
+            B_TRY(hipMemcpyAsync(b->planOff.p, hPlanOff.data(), (size_t) nItems * sizeof(long long), hipMemcpyHostToDevice, c->prep));
+            if (cpecan_asm_launch_ctx_init(c->prep, b->items.p, nItems, b->asmCtx.p, ASM_CTX_BYTES, b->Fstore.p, b->ringDoubles,
+                                           b->ringD) != 0) {
+                cpecan_hip_batch_destroy(b);
+                return fail(CPECAN_EHIP, "context kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+            }
+            B_TRY(hipStreamSynchronize(c->prep)); /* hWin ends here */
+            b->useAsm = true;
+            if (getenv("CPECAN_ASM_TRACE"))
+                fprintf(stderr, "[cpecan asm] batch of %lld alignments, widest band %d, %d windows: assembly sweeps\n",
+                        (long long) nItems, globalMaxWidth, b->asmMaxWindows);
+            lap("assembly sweeps: plan upload, contexts");
+        }
     }
     B_TRY(hipEventCreate(&b->ev0));
     B_TRY(hipEventCreate(&b->ev1));
@@ -1604,6 +1719,19 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                 c->stream, b->items.p, b->nItems, b->track.p, b->trackBase.p, b->kidx.p, c->models.p, b->syStates.p,
                 b->maxLX);
         }
+        /* the assembly sweeps (no model of the batch may let gap Y switch to gap X: they have no such term) */
+        const bool asmRun = b->useAsm && !withSwitch && rc == 0;
+        AsmArgs asmArgs{};
+        if (asmRun) {
+            asmArgs.items = b->items.p; asmArgs.trackBase = b->trackBase.p; asmArgs.planWin = b->planWin.p;
+            asmArgs.planCtl = b->planCtl.p; asmArgs.planOff = b->planOff.p; asmArgs.events = b->events.p;
+            asmArgs.models = c->models.p; asmArgs.track = b->track.p; asmArgs.ring = b->Fstore.p;
+            asmArgs.ringDoubles = b->ringDoubles; asmArgs.states = b->syStates.p; asmArgs.ctx = b->asmCtx.p;
+            asmArgs.ctxBytes = ASM_CTX_BYTES; asmArgs.coef = cpecan_asm_coef(c->device); asmArgs.nItems = (int) b->nItems;
+            asmArgs.ringD = b->ringD; asmArgs.maxWindows = b->asmMaxWindows; asmArgs.scratch = b->syScratch.p;
+            asmArgs.scratchBytes = b->scratchBytes; asmArgs.logThrSlack = b->P.logThrSlack; asmArgs.modelStride = CP_MODEL_STRIDE;
+            rc = cpecan_asm_launch_begin(c->stream, b->items.p, b->nItems, b->Fstore.p, b->ringDoubles);
+        }
         HIP_TRY(hipEventRecord(b->evFork, c->stream));
         const long long per = (b->nItems + G - 1) / G;
         for (int gi = 0; gi < G && rc == 0; gi++) {
@@ -1619,7 +1747,10 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                 if (sB != sF && w >= 2) HIP_TRY(hipStreamWaitEvent(sF, ev[1 + 4 * (w - 2) + 3], 0));
                 HIP_TRY(hipEventRecord(e4[0], sF));
                 /* the kernels index everything per alignment by blockIdx: shift the bases */
-                if (n > 0)
+                if (n > 0 && asmRun) {
+                    asmArgs.window = w;
+                    rc = cpecan_asm_launch_forward(c->device, sF, &asmArgs);
+                } else if (n > 0)
                     rc = b->sy->launch_forward(sF, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                b->trackBase.p + i0, b->events.p, models,
                                                b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles, b->ringD,
@@ -1702,6 +1833,12 @@ int cpecan_hip_batch_kernel_family(cpecan_batch *b, int32_t *wave) {
     }
     if (b->kernel != CPECAN_KERNEL_SYSTOLIC) return fail(CPECAN_EINVAL, "not a register-resident batch");
     *wave = b->sy->wave ? 1 : 0;
+    return CPECAN_OK;
+}
+
+int cpecan_hip_batch_assembly_sweeps(cpecan_batch *b, int32_t *sweeps) {
+    if (!b || !sweeps) return fail(CPECAN_EINVAL, "bad argument");
+    *sweeps = b->useAsm ? (b->asmBackward ? 2 : 1) : 0;
     return CPECAN_OK;
 }
 

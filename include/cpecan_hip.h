@@ -259,6 +259,10 @@ int cpecan_hip_batch_systolic_rows(cpecan_batch *batch, int32_t *rows);
  * DNA batch: 1 if its posterior decode runs on the one-wave-per-alignment 5-state kernel (bands up to 192 cells), 0 if
  * on the general one. */
 int cpecan_hip_batch_kernel_family(cpecan_batch *batch, int32_t *wave);
+/* *sweeps = 1 if the batch's sweeps run on the hand-scheduled assembly kernels (strawMan machine, posterior decode,
+ * bands of 121..158 k-mers: the BASELINE configs[2] shape), 2 if both the forward and the backward sweep do, 0 if on
+ * the compiled kernels.  CPECAN_ASM=0 in the environment keeps every batch on the compiled kernels. */
+int cpecan_hip_batch_assembly_sweeps(cpecan_batch *batch, int32_t *sweeps);
 /* Systolic path only: HIP-event time of the last run spent in the forward-window kernels and in
  * the backward-window kernels (each launched `launches_each` times, once per traceback window). */
 int cpecan_hip_batch_stage_ms(cpecan_batch *batch, float *ms_forward, float *ms_backward,
