@@ -99,9 +99,11 @@ class Emitter:
     def label(self, name):
         self.lines.append(name + ":")
 
+    _labels = [0]
+
     def newlabel(self, stem):
-        self.label_n += 1
-        return ".L_%s_%d" % (stem, self.label_n)
+        Emitter._labels[0] += 1
+        return ".L_%s_%d" % (stem, Emitter._labels[0])
 
     def _ins(self, text, kind):
         self.lines.append("\t" + text)
@@ -134,6 +136,10 @@ class Emitter:
         if len(self.vm) > left:
             self._ins("s_waitcnt vmcnt(%d)" % left, "wait")
             del self.vm[: len(self.vm) - left]
+
+    def raw_wait_vm(self, left):
+        """a wait for loads another copy of the loop issued: the queue here does not know them"""
+        self._ins("s_waitcnt vmcnt(%d)" % left, "wait")
 
     def drain_lgkm(self):
         """(for what the queues here do not see: s_memtime and the like)"""
@@ -254,6 +260,14 @@ class Pool:
                 k = (r - self.first) // 2
                 assert not self.free[k], "register v%d freed twice" % r
                 self.free[k] = True
+
+    def hold(self, *vs):
+        """registers that are live where the code being emitted runs, although this program has handed them back"""
+        for v in vs:
+            for r in range(v.i, v.i + v.n, 2):
+                k = (r - self.first) // 2
+                assert self.free[k], "register v%d is not free" % r
+                self.free[k] = False
 
     def in_use(self):
         return sum(1 for f in self.free if not f)

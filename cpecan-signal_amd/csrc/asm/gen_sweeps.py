@@ -40,9 +40,12 @@ NCONST = 18                              # ... of which a slot keeps the first 1
 # kernel arguments: struct AsmArgs
 A_ITEMS, A_TRACKBASE, A_PLANWIN, A_PLANCTL, A_PLANOFF, A_EVENTS, A_MODELS, A_TRACK = 0, 8, 16, 24, 32, 40, 48, 56
 A_RING, A_RINGDOUBLES, A_STATES, A_CTX, A_CTXBYTES, A_COEF, A_NITEMS, A_WINDOW = 64, 72, 80, 88, 96, 104, 112, 116
-A_RINGD, A_MAXWIN, A_SCRATCH, A_SCRATCHBYTES, A_LOGTHR, A_MODELSTRIDE, ARGS_BYTES = 120, 124, 128, 136, 144, 152, 160
+A_RINGD, A_MAXWIN, A_SCRATCH, A_SCRATCHBYTES, A_LOGTHR, A_MODELSTRIDE, ARGS_BYTES = 120, 124, 128, 136, 144, 152, 168
+A_MASKTAB = 160                          # per diagonal of every item: the band's lanes per layer (6 dwords), its first and last
+                                         # column, the lanes a ring row is stored / loaded under (6 dwords): the band and its
+                                         # two neighbour slots, whose k-mers are parked in the forward sweep: -inf emissions
 # DevItem
-I_LX, I_LY, I_YOFF, I_MODEL, I_RAGGEDL, I_RAGGEDR, ITEM_BYTES = 0, 8, 24, 112, 116, 120, 128
+I_LX, I_LY, I_YOFF, I_DIAGBASE, I_MODEL, I_RAGGEDL, I_RAGGEDR, ITEM_BYTES = 0, 8, 24, 48, 112, 116, 120, 128
 # AsmPlanWin: 16 dwords
 W_D0, W_TOP, W_FROM, W_TO, W_ATEND, W_XMINTOP, W_XMAXTOP, W_NWIN, W_CELLS, W_XMIN0, W_XMAX0, W_TPOST0 = \
     0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 12
@@ -222,31 +225,40 @@ def forward_kernel(name):
     sP = [S(64 + 2 * i, 2) for i in range(4)]           # the same as pairs
     sCtx, sState = S(72, 2), S(74, 2)
     sWin = S(76, 16)                                    # the window's plan record
-    sClk0, sRt0 = S(92, 2), S(94, 2)
-    sK = S(96, 4)
-    sWindow, sCtxBytes = S(100), S(101)
+    sClk0, sRt0 = S(92), S(93)                          # (low words: a launch is far shorter than 2^32 ticks)
+    sMaskTab = S(94, 2)
+    sK = S(96, 4)                                       # (prologue only)
+    # what a ring row's stores cover (from the mask table): the band and the two slots next to it, which are parked here --
+    # the sweep back loads a row under the same lanes and finds -inf emissions where a k-mer has just left or is about
+    # to enter, which is what keeps cells outside the band out of its recurrence
+    sMaskS = [S(96 + 2 * j, 2) for j in range(L)]
+    sCtxBytes = S(62)                                   # (prologue only: sStagePC is set after it)
     def W(f): return sWin.sub(f)
+    sWindow = W(13)                                     # (a spare word of the plan record)
     lbl = lambda s: ".L_%s_%s" % (name, s)
 
     # ------------------------------------------------------------------ prologue
     k.label(name)
-    k.salu("s_memtime", sClk0)
-    k.salu("s_memrealtime", sRt0)
+    k.salu("s_memtime", sP[0])
+    k.salu("s_memrealtime", sP[3])
     k.smem("s_load_dwordx4", sK, sArg, A_NITEMS)          # nItems, window, ringD, maxWindows
     k.smem("s_load_dwordx2", sP[1], sArg, A_PLANWIN)
     k.wait_lgkm()
+    k.salu("s_mov_b32", sClk0, sT[0])
+    k.salu("s_mov_b32", sRt0, sT[6])
     k.salu("s_cmp_ge_u32", sWg, sK.sub(0))
     k.branch("s_cbranch_scc1", lbl("exit"))
-    k.salu("s_mov_b32", sWindow, sK.sub(1))
+    k.salu("s_mov_b32", S(3), sK.sub(1))                 # window (sWindow lives in the plan record, loaded below)
     k.salu("s_sub_u32", sRingMask, sK.sub(2), 1)
     # the window's plan record: planWin + (wg * maxWindows + window) * 64
     k.salu("s_mul_i32", sT[0], sWg, sK.sub(3))
-    k.salu("s_add_u32", sT[0], sT[0], sWindow)
+    k.salu("s_add_u32", sT[0], sT[0], S(3))
     k.salu("s_lshl_b32", sT[0], sT[0], 6)
     k.add64(sP[1], sP[1], sT[0])
     k.smem("s_load_dwordx16", sWin, sP[1], 0)
     k.smem("s_load_dwordx2", sP[2], sArg, A_ITEMS)
     k.wait_lgkm()
+    k.salu("s_mov_b32", sWindow, S(3))
     k.salu("s_cmp_ge_i32", sWindow, W(W_NWIN))
     k.branch("s_cbranch_scc1", lbl("exit"))
     # item record
@@ -255,8 +267,13 @@ def forward_kernel(name):
     k.smem("s_load_dword", sLX, sP[2], I_LX)
     k.smem("s_load_dword", sLY, sP[2], I_LY)
     k.smem("s_load_dwordx2", sP[3], sP[2], I_YOFF)
-    k.smem("s_load_dword", sT[1], sP[2], I_MODEL)
     k.smem("s_load_dwordx2", sEv, sArg, A_EVENTS)
+    k.smem("s_load_dwordx2", sP[0], sP[2], I_DIAGBASE)
+    k.smem("s_load_dwordx2", sMaskTab, sArg, A_MASKTAB)
+    k.wait_lgkm()
+    k.salu("s_lshl_b64", sP[0], sP[0], 6)
+    k.add64(sMaskTab, sMaskTab, sT[0], sT[1])
+    k.smem("s_load_dword", sT[1], sP[2], I_MODEL)
     k.wait_lgkm()
     # events of this alignment: events + 24 * yOff
     k.salu("s_mul_i32", sT[2], sT[6], 24)
@@ -334,11 +351,26 @@ def forward_kernel(name):
     k.wait_lgkm()
     tq = pool.take(2)
     k.gload(2, tq, vOff8, sP[1])
+    k.valu("v_mov_b32_e32", vTmp, V(0))                   # (the lane)
     k.valu("v_lshlrev_b32_e32", vOff16, 4, V(0))          # (v0 is vOff16 from here on)
     k.ds_write(64, vOff8, tq, LDS_COEF)
     pool.give(tq)
     k.s_mov64_lit(s7p5, dbits(7.5))
     k.s_mov64_lit(sNinf, dbits(float("-inf")))
+    # every event of the LDS ring reads as (0, 0) until it is staged: a parked slot scores whatever its stale address
+    # points at, and that has to be a number
+    tz = pool.take(4)
+    for q in range(4):
+        k.valu("v_mov_b32_e32", tz.sub(q), 0)
+    for q in range(((2 * EVN + L) * 16 + 1023) // 1024):
+        if (q + 1) * 1024 <= (2 * EVN + L) * 16:
+            k.ds_write(128, vOff16, tz, LDS_EV + q * 1024)
+        else:
+            k.valu("v_cmp_gt_u32_e32", "vcc", ((2 * EVN + L) * 16 - q * 1024) // 16, vTmp)
+            k.salu("s_and_b64", "exec", "exec", "vcc")
+            k.ds_write(128, vOff16, tz, LDS_EV + q * 1024)
+            k.salu("s_mov_b64", "exec", -1)
+    pool.give(tz)
 
     # ---- the context: constants and the cells of the last two diagonals
     for j in range(L):
@@ -381,6 +413,12 @@ def forward_kernel(name):
             k.ror64(R[p].sub(2 * q, 2), src)
     # stage from scratch everything the first diagonal's block can ask for
     k.salu("s_add_u32", sD, sD, 1)
+    k.salu("s_lshl_b32", sT[0], sD, 6)
+    k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sT[0]) if False else None
+    k.salu("s_add_u32", sT[0], sT[0], 32)
+    k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sT[0])
+    k.salu("s_add_u32", sT[0], sT[0], 16)
+    k.smem("s_load_dwordx2", S(100, 2), sMaskTab, sT[0])
     k.salu("s_sub_u32", sEvHi, sD, sXmax)
     k.salu("s_sub_u32", sEvHi, sEvHi, 2)
     k.pc_of(sStagePC, lbl("stage"))
@@ -399,7 +437,8 @@ def forward_kernel(name):
     def step(p):
         """Diagonal sD of parity p: X[p] holds the diagonal before last and receives this one, X[1-p] the last one."""
         q = 1 - p
-        pend = list(k.lgkm)  # the events' reads, issued by the step before
+        k.drain_lgkm()       # this diagonal's store masks (asked for at the end of the step before); the events are in too
+        pend = []
         # band edges: the k-mer that leaves first (its slot is parked), then the one that enters
         k.salu("s_bitcmp1_b64", sStepMin, sD)
         k.branch("s_cbranch_scc1", lbl("leave%d" % p))
@@ -482,7 +521,7 @@ def forward_kernel(name):
             k.valu("v_add_u32_e32", E[j].lo, sDmod, vEvSlot[j])
             k.ds_read(128, E[j], E[j].lo)
         for j in range(L):
-            k.salu("s_mov_b64", "exec", sMask[j])
+            k.salu("s_mov_b64", "exec", sMaskS[j])
             off = j * LAYER_BYTES + OFF_PY
             k.gstore(2, vOff8, PY[j], sRow0 if off < 4096 else sRow1, off % 4096)
         k.salu("s_mov_b64", "exec", -1)
@@ -503,12 +542,18 @@ def forward_kernel(name):
             k.ladd_back(recs[j], Xm(p, j), s7p5)
         # P11: (Fm, pm) leave; the match cells of layer L-1 go up a lane
         for j in range(L):
-            k.salu("s_mov_b64", "exec", sMask[j])
+            k.salu("s_mov_b64", "exec", sMaskS[j])
             off = j * LAYER_BYTES
             k.gstore(4, vOff16, V(Xm(p, j).i, 4), sRow0 if off < 4096 else sRow1, off % 4096)
         k.salu("s_mov_b64", "exec", -1)
         k.ror64(R[p].sub(0, 2), Xm(p, L - 1))
         k.salu("s_add_u32", sD, sD, 1)
+        k.salu("s_lshl_b32", sT[0], sD, 6)
+        k.salu("s_add_u32", sT[0], sT[0], 32)
+        k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sT[0])
+        k.salu("s_add_u32", sT[0], sT[0], 16)
+        k.smem("s_load_dwordx2", S(100, 2), sMaskTab, sT[0])
+        k.lgkm = []          # (waited for at the top of the next step, where nothing else is under way)
 
     k.label(lbl("even"))
     step(0)
@@ -517,7 +562,6 @@ def forward_kernel(name):
     k.branch("s_cbranch_scc1", lbl("done"))
     k.label(lbl("odd"))
     k.vm = []
-    k.lgkm = [set(E[j].regs()) for j in range(L)]  # (a window that starts on an odd diagonal enters here, its events in flight)
     step(1)
     k.salu("s_cmp_le_i32", sD, sStop)
     k.branch("s_cbranch_scc1", lbl("even"))
@@ -593,7 +637,7 @@ def forward_kernel(name):
         k.forget()
         k.label(lbl("full%d" % p))
         for j in range(L):
-            k.salu("s_mov_b64", "exec", sMask[j])
+            k.salu("s_mov_b64", "exec", sMaskS[j])
             off = j * LAYER_BYTES + OFF_FXY
             k.gstore(4, vOff16, V(Xx(p, j).i, 4), sRow0 if off < 4096 else sRow1, off % 4096)
         k.salu("s_mov_b64", "exec", -1)
@@ -823,10 +867,10 @@ def forward_tail(k, v):
     k.salu("s_memtime", sP[0])
     k.salu("s_memrealtime", sP[1])
     k.drain_lgkm()
-    k.salu("s_sub_u32", sT[0], sT[0], sClk0.lo)
-    k.salu("s_subb_u32", sT[1], sT[1], sClk0.hi)
-    k.salu("s_sub_u32", sT[2], sT[2], sRt0.lo)
-    k.salu("s_subb_u32", sT[3], sT[3], sRt0.hi)
+    k.salu("s_sub_u32", sT[0], sT[0], sClk0)
+    k.salu("s_mov_b32", sT[1], 0)
+    k.salu("s_sub_u32", sT[2], sT[2], sRt0)
+    k.salu("s_mov_b32", sT[3], 0)
     d4 = pool.take(4)
     for i in range(4):
         k.valu("v_mov_b32_e32", d4.sub(i), sT[i])
@@ -835,6 +879,591 @@ def forward_tail(k, v):
     k.valu("v_add_co_u32_e32", clk.sub(2), "vcc", clk.sub(2), d4.sub(2))
     k.valu("v_addc_co_u32_e32", clk.sub(3), "vcc", clk.sub(3), d4.sub(3), "vcc")
     k.gstore(4, vZ.lo, clk, sState, ST_CLKS)
+    k.label(lbl("exit"))
+    k.salu("s_endpgm")
+    return k
+
+
+# ====================================================================================================== backward
+# more of the formats: the scratch of one alignment (wv_backward_kernel() of cpecan_kernel_wave.hip), the mask table
+MASK_BYTES = 64
+WINTOTAL_BYTES = 32
+CAND_PER_DIAG = 4
+CAND_SLACK = 0.25
+
+
+def backward_kernel(name):
+    """The sweep back of one traceback window, one wave per alignment (phase S of backward_window() of
+    cpecan_kernel_wave.hip): the backward cells of every diagonal from the traceback point down, the decode candidates
+    (cells whose F.match + B.match comes within CAND_SLACK of the posterior threshold against the forward kernel's
+    estimate of the window's totalProbability) and, on the diagonals where the reference refreshes totalProbability,
+    the backward operands of that sum parked for the post kernel.
+
+    Everything that lives across diagonals rotates by the diagonal mod 3, so the loop body is written three times:
+    M[q] the match cells of the diagonals = q, T[q] the ring's (Fm, pm) pairs of such a diagonal, PYB[q] its gap-Y
+    emissions, SM[q] its band (lanes per layer, first and last column) from the mask table.
+
+    A ring row is loaded under the band of the row and of the row above it: the forward sweep stores -inf emissions for
+    the slot of the k-mer that enters next, so a slot whose k-mer has just left the band (going down) reads -inf
+    emissions on that diagonal, which is what takes its cells out of the recurrence; whatever a slot further outside
+    holds (values of an earlier diagonal) only ever meets -inf cells."""
+    vOff16, vOff8, vTmp, vTmp2 = V(0), V(1), V(2), V(3)
+    vThr, vCthr = V(4, 2), V(6, 2)                     # candidate threshold in force / once decoding has begun
+    PX = [V(8 + 4 * j, 4) for j in range(L)]           # (gap-X open sum, gap-X extend sum) of the slot's k-mer
+    RP = V(8 + 4 * L, 4)                               # ... of layer 0 of the lane above
+    m0 = 8 + 4 * L + 4
+    M = [[V(m0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]
+    b0 = m0 + 6 * L
+    BX = [V(b0 + 2 * j, 2) for j in range(L)]
+    BY = [V(b0 + 2 * L + 2 * j, 2) for j in range(L)]
+    UM = [V(b0 + 4 * L + 2 * j, 2) for j in range(L)]  # upper-block sums of the diagonal above: By + (py + tP)
+    UY = [V(b0 + 6 * L + 2 * j, 2) for j in range(L)]
+    t0 = b0 + 8 * L
+    T = [[V(t0 + 4 * L * q + 4 * j, 4) for j in range(L)] for q in range(3)]
+    p0 = t0 + 12 * L
+    PYB = [[V(p0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]
+    pool0 = p0 + 6 * L
+    pool = Pool(pool0, 255)
+    k = Kernel(pool)
+    def Tf(q, j): return T[q][j].sub(0, 2)
+    def Tpm(q, j): return T[q][j].sub(2, 2)
+    def PXo(j): return PX[j].sub(0, 2)
+    def PXe(j): return PX[j].sub(2, 2)
+
+    sArg, sWg, sWindow = S(0, 2), S(2), S(3)
+    sRing0, sRing1 = S(4, 2), S(6, 2)
+    sTd, sTo, sFrom, sTop, sTpost0, sRingMask, sNCand, sNTot = [S(8 + i) for i in range(8)]
+    sCandCap, sRefCnt, sStop, sAtEnd = S(16), S(17), S(18), S(19)
+    sRow0, sRow1 = S(20, 2), S(22, 2)
+    SM = [S(24 + 8 * q, 8) for q in range(3)]
+    def SMm(q, j): return SM[q].sub(2 * j, 2)
+    def SMxmin(q): return SM[q].sub(6)
+    def SMxmax(q): return SM[q].sub(7)
+    sB = [S(24 + i) for i in range(24)]                # (the prologue's second scratch: the masks' registers)
+    def sBp(i): return S(24 + i, 2)
+    sMaskTab, sTrack = S(48, 2), S(50, 2)
+    sTMM, sTXM, sTYM, sTMY, sTYY = S(52, 2), S(54, 2), S(56, 2), S(58, 2), S(60, 2)
+    s7p5, sNinf = S(62, 2), S(64, 2)
+    sRf, sWtot, sCandKx, sCandFb, sState = S(66, 2), S(68, 2), S(70, 2), S(72, 2), S(74, 2)
+    sA = [S(76 + i) for i in range(16)]                # scratch; the window's plan record lands here first
+    def sAp(i): return S(76 + i, 2)
+    sRet, sStagePC = S(92, 2), S(94, 2)
+    sLm = [S(96 + 2 * j, 2) for j in range(L)]         # the lanes a ring row is loaded under (mask table)
+    sCmp = [S(84 + 2 * j, 2) for j in range(L)]        # candidate compares
+    lbl = lambda s: ".L_%s_%s" % (name, s)
+
+    # ------------------------------------------------------------------ prologue (common part)
+    k.label(name)
+    k.smem("s_load_dwordx4", S(24, 4), sArg, A_NITEMS)     # sB0..3: nItems, window, ringD, maxWindows
+    k.smem("s_load_dwordx2", sBp(4), sArg, A_PLANWIN)
+    k.smem("s_load_dwordx2", sBp(6), sArg, A_STATES)
+    k.smem("s_load_dwordx2", sBp(8), sArg, A_ITEMS)
+    k.smem("s_load_dwordx2", sBp(10), sArg, A_LOGTHR)
+    k.wait_lgkm()
+    k.salu("s_cmp_ge_u32", sWg, sB[0])
+    k.branch("s_cbranch_scc1", lbl("exit"))
+    k.salu("s_mov_b32", sWindow, sB[1])
+    k.salu("s_sub_u32", sRingMask, sB[2], 1)
+    k.salu("s_mul_i32", sCandCap, sB[2], CAND_PER_DIAG * L)
+    k.salu("s_mul_i32", sA[0], sWg, sB[3])
+    k.salu("s_add_u32", sA[0], sA[0], sWindow)
+    k.salu("s_lshl_b32", sA[0], sA[0], 6)
+    k.add64(sBp(4), sBp(4), sA[0])
+    k.smem("s_load_dwordx16", S(76, 16), sBp(4), 0)        # the plan record
+    k.wait_lgkm()
+    k.salu("s_cmp_ge_i32", sWindow, sA[W_NWIN])
+    k.branch("s_cbranch_scc1", lbl("exit"))
+    k.salu("s_mov_b32", sTop, sA[W_TOP])
+    k.salu("s_mov_b32", sFrom, sA[W_FROM])
+    k.salu("s_mov_b32", sTo, sA[W_TO])
+    k.salu("s_mov_b32", sAtEnd, sA[W_ATEND])
+    k.salu("s_mov_b32", sTpost0, sA[W_TPOST0])
+    # the state record; the window as the forward kernel described it
+    k.salu("s_mul_i32", sA[0], sWg, STATE_BYTES)
+    k.add64(sState, sBp(6), sA[0])
+    k.salu("s_and_b32", sA[0], sWindow, 1)
+    k.salu("s_mul_i32", sA[0], sA[0], WIN_BYTES)
+    k.salu("s_add_u32", sA[0], sA[0], ST_WIN)
+    k.add64(sAp(2), sState, sA[0])
+    k.smem("s_load_dword", sA[0], sAp(2), 0)               # valid
+    k.smem("s_load_dwordx2", sAp(4), sAp(2), 32)           # est
+    k.salu("s_lshl_b32", sA[1], sWg, 7)
+    k.add64(sBp(8), sBp(8), sA[1])                         # the item
+    k.smem("s_load_dword", sA[6], sBp(8), I_MODEL)
+    k.smem("s_load_dword", sA[7], sBp(8), I_RAGGEDR)
+    k.smem("s_load_dwordx2", sAp(8), sBp(8), I_DIAGBASE)
+    k.smem("s_load_dwordx2", sAp(10), sArg, A_MODELS)
+    k.smem("s_load_dwordx2", sAp(12), sArg, A_MODELSTRIDE)
+    k.smem("s_load_dwordx2", sMaskTab, sArg, A_MASKTAB)
+    k.wait_lgkm()
+    k.salu("s_cmp_lg_u32", sA[0], 1)
+    k.branch("s_cbranch_scc1", lbl("exit"))
+    # candidates: F.match + B.match >= est + (log threshold - margin) - slack (a threshold of 0: -inf, every cell; the
+    # lists overflow and the post kernel hands the window to the re-sweep kernel)
+    k.valu("v_mov_b32_e32", vCthr.lo, sB[10])
+    k.valu("v_mov_b32_e32", vCthr.hi, sB[11])
+    k.s_mov64_lit(sBp(12), dbits(-CAND_SLACK))
+    k.add(vCthr, vCthr, sBp(12))
+    k.add(vCthr, vCthr, sAp(4))
+    # the band table of this alignment; the model's transitions
+    k.salu("s_lshl_b64", sAp(8), sAp(8), 6)
+    k.add64(sMaskTab, sMaskTab, sA[8], sA[9])
+    k.salu("s_lshl_b32", sA[12], sA[12], 3)
+    k.salu("s_mul_i32", sA[0], sA[6], sA[12])
+    k.salu("s_mul_hi_u32", sA[1], sA[6], sA[12])
+    k.add64(sAp(10), sAp(10), sA[0], sA[1])
+    k.smem("s_load_dwordx2", sTMM, sAp(10), 0 * 8)
+    k.smem("s_load_dwordx2", sTXM, sAp(10), 1 * 8)
+    k.smem("s_load_dwordx2", sTYM, sAp(10), 2 * 8)
+    k.smem("s_load_dwordx2", sTMY, sAp(10), 4 * 8)
+    k.smem("s_load_dwordx2", sTYY, sAp(10), 6 * 8)
+    k.smem("s_load_dwordx2", sBp(12), sAp(10), 3 * 8)      # open X
+    k.smem("s_load_dwordx2", sBp(14), sAp(10), 5 * 8)      # extend X
+    k.smem("s_load_dwordx2", sBp(16), sArg, A_TRACKBASE)
+    k.smem("s_load_dwordx2", sTrack, sArg, A_TRACK)
+    k.wait_lgkm()
+    # the end vector the sweep starts from (stateMachine.c:1179-1207): at the end of a ragged alignment
+    # ((open X + open Y) / 2, extend X, extend Y), otherwise the transitions into match
+    e = [pool.take(2) for _ in range(3)]
+    k.salu("s_cmp_lg_u32", sAtEnd, 0)
+    k.salu("s_cselect_b32", sA[7], sA[7], 0)
+    k.valu("v_mov_b32_e32", e[0].lo, sB[12])
+    k.valu("v_mov_b32_e32", e[0].hi, sB[13])
+    k.add(e[0], e[0], sTMY)
+    k.mul(e[0], e[0], "0.5")
+    k.valu("v_mov_b32_e32", e[1].lo, sB[14])
+    k.valu("v_mov_b32_e32", e[1].hi, sB[15])
+    k.valu("v_mov_b32_e32", e[2].lo, sTYY.lo)
+    k.valu("v_mov_b32_e32", e[2].hi, sTYY.hi)
+    k.salu("s_cmp_lg_u32", sA[7], 0)
+    k.salu("s_cselect_b64", "vcc", -1, 0)
+    for ee, s in ((e[0], sTMM), (e[1], sTXM), (e[2], sTYM)):
+        k.valu("v_mov_b32_e32", vTmp, s.lo)
+        k.valu("v_mov_b32_e32", vTmp2, s.hi)
+        k.valu("v_cndmask_b32_e32", ee.lo, vTmp, ee.lo, "vcc")
+        k.valu("v_cndmask_b32_e32", ee.hi, vTmp2, ee.hi, "vcc")
+    # track rows of this alignment (the gap-X sums of the k-mers that enter on the way down)
+    k.salu("s_lshl_b32", sA[0], sWg, 3)
+    k.smem("s_load_dwordx2", sBp(16), sBp(16), sA[0])
+    k.smem("s_load_dwordx4", S(76 + 4, 4), sArg, A_RING)   # sA4..7: ring, ringDoubles
+    k.smem("s_load_dwordx4", S(76 + 8, 4), sArg, A_CTX)    # sA8..11: ctx, ctxBytes
+    k.smem("s_load_dwordx4", S(76 + 12, 4), sArg, A_SCRATCH)  # sA12..15: scratch, scratchBytes
+    k.wait_lgkm()
+    k.salu("s_mul_i32", sA[0], sB[16], TRACK_ROW_BYTES)
+    k.salu("s_mul_hi_u32", sA[1], sB[16], TRACK_ROW_BYTES)
+    k.add64(sTrack, sTrack, sA[0], sA[1])
+    # ring of this alignment
+    k.salu("s_lshl_b64", sAp(6), sAp(6), 3)
+    k.salu("s_mul_i32", sA[0], sA[6], sWg)
+    k.salu("s_mul_hi_u32", sA[1], sA[6], sWg)
+    k.salu("s_mul_i32", sA[2], sA[7], sWg)
+    k.salu("s_add_u32", sA[1], sA[1], sA[2])
+    k.add64(sRing0, sAp(4), sA[0], sA[1])
+    k.add64(sRing1, sRing0, 4096)
+    # the context the forward kernel saved at this traceback point: [window & 1]
+    k.salu("s_mul_i32", sA[0], sWg, 3)
+    k.salu("s_and_b32", sA[1], sWindow, 1)
+    k.salu("s_add_u32", sA[0], sA[0], sA[1])
+    k.salu("s_mul_i32", sA[1], sA[0], sA[10])
+    k.salu("s_mul_hi_u32", sA[2], sA[0], sA[10])
+    k.add64(sAp(8), sAp(8), sA[1], sA[2])                  # sA8:9: the context
+    # scratch of this alignment: [hit offsets | window totals | their terms | parked operands | hit masks | candidates]
+    k.salu("s_mul_i32", sA[0], sA[14], sWg)
+    k.salu("s_mul_hi_u32", sA[1], sA[14], sWg)
+    k.salu("s_mul_i32", sA[2], sA[15], sWg)
+    k.salu("s_add_u32", sA[1], sA[1], sA[2])
+    k.add64(sAp(12), sAp(12), sA[0], sA[1])                # sc
+    k.salu("s_lshl_b32", sA[0], sB[2], 3)                  # 2 * ringD * 4
+    k.add64(sWtot, sAp(12), sA[0])
+    k.salu("s_mul_hi_u32", sA[0], sB[2], "0xcccccccd")
+    k.salu("s_lshr_b32", sA[0], sA[0], 3)
+    k.salu("s_add_u32", sA[0], sA[0], 8)                   # nW = ringD / 10 + 8
+    k.salu("s_mul_i32", sA[1], sA[0], WINTOTAL_BYTES)
+    k.add64(sRf, sWtot, sA[1])                             # (the terms)
+    k.salu("s_mul_i32", sA[1], sA[0], 2 * P * 8)
+    k.add64(sRf, sRf, sA[1])                               # the parked operands
+    k.salu("s_mul_i32", sA[1], sA[0], 5 * P * 8)
+    k.add64(sCandKx, sRf, sA[1])                           # (the hit masks)
+    k.salu("s_lshl_b32", sA[1], sB[2], 5)                  # 4 * ringD * 8
+    k.add64(sCandKx, sCandKx, sA[1])
+    k.salu("s_mul_i32", sA[1], sB[2], L * CAND_PER_DIAG * 8)
+    k.add64(sCandFb, sCandKx, sA[1])
+    # lane constants, the logAdd table, constants
+    k.valu("v_lshlrev_b32_e32", vOff8, 3, V(0))
+    k.smem("s_load_dwordx2", sAp(0), sArg, A_COEF)
+    k.wait_lgkm()
+    tq = pool.take(2)
+    k.gload(2, tq, vOff8, sAp(0))
+    k.valu("v_lshlrev_b32_e32", vOff16, 4, V(0))
+    k.ds_write(64, vOff8, tq, LDS_COEF)
+    pool.give(tq)
+    k.s_mov64_lit(s7p5, dbits(7.5))
+    k.s_mov64_lit(sNinf, dbits(float("-inf")))
+    # the gap-X sums of the slots at the traceback point are the forward wave's (a parked slot holds -inf)
+    k.add64(sAp(8), sAp(8), 8 * 1024)
+    for j in range(L):
+        k.gload(4, PX[j], vOff16, sAp(8), 0)
+        if j < L - 1:
+            k.add64(sAp(8), sAp(8), 9 * 1024)
+    # every cell and every ring value starts as -inf
+    for r in range(m0, pool0, 2):
+        k.valu("v_mov_b32_e32", V(r), 0)
+        k.valu("v_mov_b32_e32", V(r + 1), sNinf.hi)
+    k.salu("s_mov_b32", sNCand, 0)
+    k.salu("s_mov_b32", sNTot, 0)
+    k.salu("s_mov_b32", sTd, sTop)
+    # decoding starts at tracedBackFrom: until then no cell is a candidate; the first refresh falls on the first
+    # decoded diagonal
+    k.valu("v_mov_b32_e32", vThr.lo, 0)
+    k.valu("v_mov_b32_e32", vThr.hi, "0x7ff00000")
+    k.salu("s_sub_u32", sRefCnt, sTop, sTpost0)
+    k.salu("s_cmp_le_i32", sTop, sFrom)
+    k.branch("s_cbranch_scc0", lbl("nodecode"))
+    k.valu("v_mov_b32_e32", vThr.lo, vCthr.lo)
+    k.valu("v_mov_b32_e32", vThr.hi, vCthr.hi)
+    k.label(lbl("nodecode"))
+    k.pc_of(sStagePC, lbl("stage"))
+    k.wait_all()
+    for h in range(2):
+        k.rol64(RP.sub(2 * h, 2), PX[0].sub(2 * h, 2))
+    # which third of the loop the traceback point falls in
+    k.salu("s_mul_hi_u32", sA[0], sTop, "0x55555556")
+    k.salu("s_mul_i32", sA[0], sA[0], 3)
+    k.salu("s_sub_u32", sA[0], sTop, sA[0])                # top mod 3
+    k.salu("s_cmp_eq_u32", sA[0], 1)
+    k.branch("s_cbranch_scc1", lbl("entry1"))
+    k.salu("s_cmp_eq_u32", sA[0], 2)
+    k.branch("s_cbranch_scc1", lbl("entry2"))
+
+    def row_bases(dreg):
+        """sRow0 / sRow1 <- byte address of ring row dreg (and + 4096)"""
+        k.salu("s_and_b32", sA[0], dreg, sRingMask)
+        k.salu("s_mul_i32", sA[0], sA[0], ROW_BYTES)
+        k.add64(sRow0, sRing0, sA[0])
+        k.add64(sRow1, sRing1, sA[0])
+
+    def fetch_row(q, masks):
+        """ring row at sRow0 -> T[q], PYB[q], each layer under its exec mask"""
+        for j in range(L):
+            k.salu("s_mov_b64", "exec", masks[j])
+            off = j * LAYER_BYTES
+            k.gload(4, T[q][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
+            off += OFF_PY
+            k.gload(2, PYB[q][j], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
+        k.salu("s_mov_b64", "exec", -1)
+
+    def load_masks(q, dreg):
+        """SM[q] <- band of diagonal dreg (clamped at 0) from the mask table"""
+        k.salu("s_max_i32", sA[0], dreg, 0)
+        k.salu("s_lshl_b32", sA[0], sA[0], 6)
+        k.smem("s_load_dwordx8", SM[q], sMaskTab, sA[0])
+
+    def load_row_masks(dreg):
+        """sLm <- the lanes ring row dreg is loaded under"""
+        k.salu("s_max_i32", sA[0], dreg, 0)
+        k.salu("s_lshl_b32", sA[0], sA[0], 6)
+        k.salu("s_add_u32", sA[0], sA[0], 32)
+        k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sA[0])
+        k.salu("s_add_u32", sA[0], sA[0], 16)
+        k.smem("s_load_dwordx2", S(100, 2), sMaskTab, sA[0])
+
+    # ------------------------------------------------------------------ entry: the traceback point = kk mod 3
+    for kk in (0, 1, 2):
+        k1, k2 = (kk + 1) % 3, (kk + 2) % 3
+        k.forget()
+        k.label(lbl("entry%d" % kk))
+        load_masks(kk, sTd)
+        k.salu("s_sub_u32", sA[1], sTd, 1)
+        load_masks(k2, sA[1])
+        k.salu("s_sub_u32", sA[1], sTd, 2)
+        load_masks(k1, sA[1])
+        load_row_masks(sTd)
+        k.drain_lgkm()
+        # the cells of the traceback point: the end vector wherever the band has a cell
+        for j in range(L):
+            k.salu("s_mov_b64", "exec", SMm(kk, j))
+            for dst, src in ((M[kk][j], e[0]), (BX[j], e[1]), (BY[j], e[2])):
+                k.valu("v_mov_b32_e32", dst.lo, src.lo)
+                k.valu("v_mov_b32_e32", dst.hi, src.hi)
+        k.salu("s_mov_b64", "exec", -1)
+        # its ring row, and the row below it
+        row_bases(sTd)
+        fetch_row(kk, sLm)
+        k.salu("s_sub_u32", sA[1], sTd, 1)
+        load_row_masks(sA[1])
+        k.drain_lgkm()
+        row_bases(sA[1])
+        fetch_row(k2, sLm)
+        k.salu("s_sub_u32", sA[1], sTd, 2)
+        load_row_masks(sA[1])
+        k.label(lbl("entered%d" % kk))
+        k.salu("s_mov_b64", S(90, 2), SM[kk].sub(6, 2))
+        k.salu("s_mov_b32", sA[2], SMxmin(kk))
+        k.salu("s_swappc_b64", sRet, sStagePC)
+        k.wait_all()
+        k.branch("s_branch", lbl("tail%d" % kk))
+    pool.give(*e)
+    return k, locals()
+
+
+def backward_loop(k, v):
+    g = dict(v)
+    name, pool, lbl = g["name"], g["pool"], g["lbl"]
+    M, BX, BY, UM, UY, T, PYB, PX, RP = g["M"], g["BX"], g["BY"], g["UM"], g["UY"], g["T"], g["PYB"], g["PX"], g["RP"]
+    Tf, Tpm, PXo, PXe = g["Tf"], g["Tpm"], g["PXo"], g["PXe"]
+    vOff16, vOff8, vTmp, vTmp2, vThr, vCthr = g["vOff16"], g["vOff8"], g["vTmp"], g["vTmp2"], g["vThr"], g["vCthr"]
+    SM, SMm, SMxmin, SMxmax, sLm, sA, sAp = g["SM"], g["SMm"], g["SMxmin"], g["SMxmax"], g["sLm"], g["sA"], g["sAp"]
+    sTd, sTo, sFrom, sTop, sTpost0, sNCand, sNTot, sCandCap, sRefCnt, sStop = \
+        g["sTd"], g["sTo"], g["sFrom"], g["sTop"], g["sTpost0"], g["sNCand"], g["sNTot"], g["sCandCap"], g["sRefCnt"], g["sStop"]
+    sTMM, sTXM, sTYM, sTMY, sTYY, s7p5, sNinf = g["sTMM"], g["sTXM"], g["sTYM"], g["sTMY"], g["sTYY"], g["s7p5"], g["sNinf"]
+    sRow0, sRow1, sRf, sWtot, sCandKx, sCandFb, sState = g["sRow0"], g["sRow1"], g["sRf"], g["sWtot"], g["sCandKx"], g["sCandFb"], g["sState"]
+    sRet, sStagePC, sTrack, sWindow, sMaskTab = g["sRet"], g["sStagePC"], g["sTrack"], g["sWindow"], g["sMaskTab"]
+    row_bases, fetch_row, load_masks, load_row_masks, sCmp = g["row_bases"], g["fetch_row"], g["load_masks"], g["load_row_masks"], g["sCmp"]
+    sNxt = S(90, 2)                            # band (first, last column) of the diagonal above the current one
+
+    for kk in (0, 1, 2):
+        k1, k2 = (kk + 1) % 3, (kk + 2) % 3   # the diagonals t + 1 and t + 2 (= t - 1) mod 3
+        # ------------------------------------------------------------ head: the cells of diagonal t (t = kk mod 3)
+        k.forget()
+        k.label(lbl("head%d" % kk))
+        k.drain_lgkm()                         # (the band of t - 1, asked for a diagonal ago)
+        # of slot + 1: B.match and match emission of t + 2 (middle block), B.gapX of t + 1 with its k-mer's gap-X sums
+        # (lower block); layer L-1 takes them from layer 0 of the lane above
+        rhB, rhP, rBx = pool.take(2), pool.take(2), pool.take(2)
+        k.rol64(rhB, M[k2][0])
+        k.rol64(rhP, Tpm(k2, 0))
+        k.rol64(rBx, BX[0])
+        bmin, bxin, byin, y1, y2 = [], [], [], [], []
+        w = pool.take(2)
+        for j in range(L):
+            sB_ = M[k2][j + 1] if j < L - 1 else rhB
+            sP_ = Tpm(k2, j + 1) if j < L - 1 else rhP
+            sBx_ = BX[j + 1] if j < L - 1 else rBx
+            pe = PXe(j + 1) if j < L - 1 else RP.sub(2, 2)
+            po = PXo(j + 1) if j < L - 1 else RP.sub(0, 2)
+            a, b, c, d, e = [pool.take(2) for _ in range(5)]
+            # gather form of cell_calculateBackward (:378-389): (t + 2) middle block first
+            k.add(w, sP_, sTMM)
+            k.add(a, sB_, w)
+            k.add(w, sP_, sTXM)
+            k.add(b, sB_, w)
+            k.add(w, sP_, sTYM)
+            k.add(c, sB_, w)
+            k.add(d, sBx_, pe)
+            k.add(e, sBx_, po)
+            bmin.append(a); bxin.append(b); byin.append(c); y1.append(d); y2.append(e)
+        pool.give(w, rhB, rhP, rBx)
+        # the k-mers that left / entered the band coming down to t: their slots change hands now, for the diagonals below
+        k.salu("s_cmp_lg_u64", SM[k1].sub(6, 2), SM[kk].sub(6, 2))
+        k.branch("s_cbranch_scc1", lbl("band%d" % kk))
+        k.label(lbl("banded%d" % kk))
+        # the band of t - 2 (into the registers of t + 1's, whose columns the tail still wants), then the ring row of t - 1
+        k.salu("s_mov_b64", sNxt, SM[k1].sub(6, 2))
+        k.salu("s_sub_u32", sA[1], sTd, 2)
+        load_masks(k1, sA[1])
+        k.salu("s_sub_u32", sA[1], sTd, 1)
+        row_bases(sA[1])
+        fetch_row(k2, sLm)
+        k.salu("s_sub_u32", sA[1], sTd, 2)
+        load_row_masks(sA[1])
+        # (t + 1, same slot) upper block, then (t + 1, slot + 1) lower block -- the reference's scatter order per state
+        ra = [k.ladd_front(bmin[j], UM[j], free=(bmin[j],)) for j in range(L)]
+        rb = [k.ladd_front(byin[j], UY[j], free=(byin[j],)) for j in range(L)]
+        for j in range(L):
+            k.ladd_back(ra[j], M[kk][j], s7p5)
+        rc = [k.ladd_front(bxin[j], y1[j], free=(bxin[j], y1[j])) for j in range(L)]
+        for j in range(L):
+            k.ladd_back(rb[j], BY[j], s7p5)
+        rd = [k.ladd_front(M[kk][j], y2[j], free=(y2[j],)) for j in range(L)]
+        for j in range(L):
+            k.ladd_back(rc[j], BX[j], s7p5)
+        for j in range(L):
+            k.ladd_back(rd[j], M[kk][j], s7p5)
+        # ------------------------------------------------------------ tail: what diagonal t hands down, its candidates
+        k.label(lbl("tail%d" % kk))
+        k.raw_wait_vm(2 * L)                   # this diagonal's ring row (the loads of the next one may still be under way)
+        w = pool.take(2)
+        for j in range(L):
+            k.add(w, PYB[kk][j], sTMY)
+            k.add(UM[j], BY[j], w)
+            k.add(w, PYB[kk][j], sTYY)
+            k.add(UY[j], BY[j], w)
+        pool.give(w)
+        fb = [pool.take(2) for _ in range(L)]
+        for j in range(L):
+            k.add(fb[j], Tf(kk, j), M[kk][j])
+        for j in range(L):
+            k.valu("v_cmp_ge_f64_e64", sCmp[j], fb[j], vThr)
+        k.salu("s_or_b64", sAp(2), sCmp[0], sCmp[1])
+        for j in range(2, L):
+            k.salu("s_or_b64", sAp(2), sAp(2), sCmp[j])
+        k.branch("s_cbranch_scc1", lbl("cand%d" % kk))
+        k.label(lbl("canded%d" % kk))
+        k.salu("s_sub_u32", sRefCnt, sRefCnt, 1)
+        k.salu("s_cmp_eq_u32", sRefCnt, -1)
+        k.branch("s_cbranch_scc1", lbl("refresh%d" % kk))
+        k.label(lbl("refreshed%d" % kk))
+        pool.give(*fb)
+        k.salu("s_sub_u32", sTd, sTd, 1)
+        k.salu("s_cmp_gt_i32", sTd, sStop)
+        k.branch("s_cbranch_scc1", lbl("head%d" % k2))
+        k.salu("s_mov_b32", sA[3], k2)
+        k.salu("s_mov_b32", sA[2], SMxmin(k2))
+        k.branch("s_branch", lbl("pause"))
+        g["fb%d" % kk] = fb
+
+    # ------------------------------------------------------------------ out of line
+    for kk in (0, 1, 2):
+        k1, k2 = (kk + 1) % 3, (kk + 2) % 3
+        fb = g["fb%d" % kk]
+        # band edges between t + 1 and t: the slot of a k-mer that left (at the band's high end) is parked, the one of the
+        # k-mer that entered (at the low end) gets its gap-X sums from the LDS ring of rows
+        k.forget()
+        k.label(lbl("band%d" % kk))
+        k.salu("s_and_b32", sA[0], SMxmin(kk), PXN - 1)
+        k.salu("s_lshl_b32", sA[0], sA[0], 4)
+        k.salu("s_add_u32", sA[0], sA[0], LDS_PX)
+        k.valu("v_mov_b32_e32", vTmp, sA[0])
+        for j in range(L):
+            k.salu("s_andn2_b64", "exec", SMm(k1, j), SMm(kk, j))
+            for q in range(2):
+                k.valu("v_mov_b32_e32", PX[j].sub(2 * q), 0)
+                k.valu("v_mov_b32_e32", PX[j].sub(2 * q + 1), sNinf.hi)
+            k.salu("s_andn2_b64", "exec", SMm(kk, j), SMm(k1, j))
+            k.ds_read(128, PX[j], vTmp)
+        k.salu("s_mov_b64", "exec", -1)
+        k.drain_lgkm()
+        for h in range(2):
+            k.rol64(RP.sub(2 * h, 2), PX[0].sub(2 * h, 2))
+        k.branch("s_branch", lbl("banded%d" % kk))
+        # decode candidates of diagonal t: (how far down the window, k-mer) and F.match + B.match, appended to the lists
+        k.forget()
+        k.label(lbl("cand%d" % kk))
+        k.salu("s_sub_u32", sA[4], sTpost0, sTd)            # kPost
+        # slot of the band's first k-mer: xmin mod P
+        k.salu("s_mul_hi_u32", sA[5], SMxmin(kk), "0x%x" % ((1 << 32) // P + 1))
+        k.salu("s_mul_i32", sA[5], sA[5], P)
+        k.salu("s_sub_u32", sA[5], SMxmin(kk), sA[5])
+        pool.hold(*fb)
+        ci, cx = pool.take(2), pool.take(2)
+        for j in range(L):
+            skip = lbl("cand%d_%d" % (kk, j))
+            k.salu("s_cmp_eq_u64", sCmp[j], 0)
+            k.branch("s_cbranch_scc1", skip)
+            k.valu("v_mbcnt_lo_u32_b32", ci.lo, sCmp[j].lo, 0)
+            k.valu("v_mbcnt_hi_u32_b32", ci.lo, sCmp[j].hi, ci.lo)
+            k.valu("v_add_u32_e32", ci.lo, sNCand, ci.lo)
+            # the k-mer of this slot: xmin + ((slot - slot of xmin) mod P)
+            k.valu("v_lshrrev_b32_e32", cx.lo, 4, vOff16)
+            k.valu("v_mul_u32_u24_e32", cx.lo, L, cx.lo)
+            k.valu("v_add_u32_e32", cx.lo, j, cx.lo)
+            k.valu("v_subrev_u32_e32", cx.lo, sA[5], cx.lo)
+            k.valu("v_add_u32_e32", cx.hi, P, cx.lo)
+            k.valu("v_cmp_gt_i32_e32", "vcc", 0, cx.lo)
+            k.valu("v_cndmask_b32_e32", cx.hi, cx.lo, cx.hi, "vcc")
+            k.valu("v_add_u32_e32", cx.hi, SMxmin(kk), cx.hi)
+            k.valu("v_mov_b32_e32", cx.lo, sA[4])
+            k.valu("v_cmp_gt_u32_e32", "vcc", sCandCap, ci.lo)
+            k.salu("s_and_b64", "exec", sCmp[j], "vcc")
+            k.valu("v_lshlrev_b32_e32", ci.lo, 3, ci.lo)
+            k.gstore(2, ci.lo, cx, sCandKx)
+            k.gstore(2, ci.lo, fb[j], sCandFb)
+            k.salu("s_mov_b64", "exec", -1)
+            k.salu("s_bcnt1_i32_b64", sA[6], sCmp[j])
+            k.salu("s_add_u32", sNCand, sNCand, sA[6])
+            k.label(skip)
+        pool.give(ci, cx, *fb)
+        k.branch("s_branch", lbl("canded%d" % kk))
+        # a refresh of totalProbability (:956-966) on diagonal t: the backward operands of its terms are parked -- B of this
+        # diagonal, B.match and the match emission of the one above -- with the diagonal and the two bands
+        k.forget()
+        k.label(lbl("refresh%d" % kk))
+        k.salu("s_mov_b32", sRefCnt, 9)
+        k.salu("s_mul_i32", sA[0], sNTot, 5 * P * 8)
+        k.add64(sAp(4), sRf, sA[0])
+        k.add64(sAp(6), sAp(4), 4096)
+        vals = [M[kk], BX, BY, M[k1], [Tpm(k1, j) for j in range(L)]]
+        for q in range(5):
+            for j in range(L):
+                off = (q * L + j) * 512
+                k.gstore(2, vOff8, vals[q][j], sAp(4) if off < 4096 else sAp(6), off % 4096)
+        pool.hold(*fb)
+        rec = [pool.take(4), pool.take(4)]
+        k.salu("s_mov_b64", "exec", 1)
+        k.salu("s_add_u32", sA[1], sTd, 1)
+        k.salu("s_cmp_le_i32", sA[1], sTop)
+        k.salu("s_cselect_b32", sA[1], 1, 0)
+        for i, s in enumerate((sTd, SMxmin(kk), SMxmax(kk), sNxt.lo, sNxt.hi, sA[1], 0, sNinf.hi)):
+            k.valu("v_mov_b32_e32", rec[i // 4].sub(i % 4), s)
+        k.valu("v_mov_b32_e32", vTmp, 0)
+        k.salu("s_lshl_b32", sA[0], sNTot, 5)
+        k.add64(sAp(4), sWtot, sA[0])
+        k.gstore(4, vTmp, rec[0], sAp(4), 0)
+        k.gstore(4, vTmp, rec[1], sAp(4), 16)
+        k.salu("s_mov_b64", "exec", -1)
+        k.salu("s_add_u32", sNTot, sNTot, 1)
+        pool.give(*rec)
+        pool.give(*fb)
+        k.branch("s_branch", lbl("refreshed%d" % kk))
+
+    # ------------------------------------------------------------------ the loop pauses: end of the window, the diagonal
+    # where decoding begins, or a staging block of gap-X rows
+    k.forget()
+    k.label(lbl("pause"))
+    k.salu("s_cmp_le_i32", sTd, sTo)
+    k.branch("s_cbranch_scc1", lbl("done"))
+    k.salu("s_cmp_lg_u32", sTd, sFrom)
+    k.branch("s_cbranch_scc1", lbl("pause_stage"))
+    k.valu("v_mov_b32_e32", vThr.lo, vCthr.lo)
+    k.valu("v_mov_b32_e32", vThr.hi, vCthr.hi)
+    k.label(lbl("pause_stage"))
+    k.salu("s_swappc_b64", sRet, sStagePC)
+    for q in (1, 2):
+        k.salu("s_cmp_eq_u32", sA[3], q)
+        k.branch("s_cbranch_scc1", lbl("head%d" % q))
+    k.branch("s_branch", lbl("head0"))
+
+    # ------------------------------------------------------------------ staging: gap-X rows of the k-mers that can enter
+    # before the next pause; where that is.  In: sTd the next diagonal to compute, sA[2] the band's first column there
+    k.forget()
+    k.label(lbl("stage"))
+    tx, ta = pool.take(2), pool.take(4)
+    k.valu("v_lshrrev_b32_e32", tx.lo, 4, vOff16)
+    k.valu("v_sub_u32_e32", tx.lo, sA[2], tx.lo)           # x = xmin - lane: the k-mer that may enter at the very next diagonal, and on
+    k.valu("v_cmp_le_i32_e32", "vcc", 0, tx.lo)
+    k.valu("v_mul_u32_u24_e32", tx.hi, TRACK_ROW_BYTES, tx.lo)
+    k.salu("s_and_b64", "exec", "exec", "vcc")
+    k.gload(4, ta, tx.hi, sTrack, 16 * 8)
+    k.valu("v_and_b32_e32", tx.lo, PXN - 1, tx.lo)
+    k.valu("v_lshlrev_b32_e32", tx.lo, 4, tx.lo)
+    k.ds_write(128, tx.lo, ta, LDS_PX)
+    k.salu("s_mov_b64", "exec", -1)
+    pool.give(tx, ta)
+    # the next pause: 64 diagonals on, the diagonal decoding begins at, or the end of the window
+    k.salu("s_sub_u32", sStop, sTd, BLOCK)
+    k.salu("s_cmp_gt_i32", sTd, sFrom)
+    k.salu("s_cselect_b32", sA[0], sFrom, sTo)
+    k.salu("s_max_i32", sStop, sStop, sA[0])
+    k.salu("s_max_i32", sStop, sStop, sTo)
+    k.wait_all()
+    k.salu("s_setpc_b64", sRet)
+
+    # ------------------------------------------------------------------ the window is swept: counts for the post kernel
+    k.forget()
+    k.label(lbl("done"))
+    k.salu("s_and_b32", sA[0], sWindow, 1)
+    k.salu("s_mul_i32", sA[0], sA[0], WIN_BYTES)
+    k.salu("s_add_u32", sA[0], sA[0], ST_WIN)
+    k.add64(sAp(2), sState, sA[0])
+    k.salu("s_mov_b64", "exec", 1)
+    k.valu("v_mov_b32_e32", vTmp, 0)
+    r2 = pool.take(2)
+    k.valu("v_mov_b32_e32", r2.lo, sNCand)
+    k.valu("v_mov_b32_e32", r2.hi, sNTot)
+    k.gstore(2, vTmp, r2, sAp(2), 20)                      # nCand, nRefresh
+    k.valu("v_mov_b32_e32", vTmp2, 3)
+    k.gstore(1, vTmp, vTmp2, sAp(2), 0)                    # valid = 3: swept back, the post kernel's turn
+    pool.give(r2)
     k.label(lbl("exit"))
     k.salu("s_endpgm")
     return k
@@ -926,6 +1555,12 @@ def main():
     forward_tail(k, v)
     kernels.append(dict(name=name, body=k.text(), lds=LDS_F_BYTES, kernarg=ARGS_BYTES, vgprs=256, sgprs=102, accum=256,
                         stats=k.stats))
+    name = "cpecan_k_asm_backward_l%d" % L
+    k, v = backward_kernel(name)
+    backward_loop(k, v)
+    nv = (v["pool0"] + 2 * k.pool.high + 7) // 8 * 8
+    kernels.append(dict(name=name, body=k.text(), lds=LDS_B_BYTES, kernarg=ARGS_BYTES, vgprs=nv, sgprs=102, accum=nv,
+                        stats=dict(k.stats, vgprs=nv)))
     text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6"]
     for kk in kernels:
         text.append(KERNEL_TEMPLATE.format(**kk))
@@ -937,7 +1572,7 @@ def main():
     if len(sys.argv) > 2:
         defs = dict(ASM_L=L, ASM_ROW_BYTES=ROW_BYTES, ASM_CTX_X=CTX_X, ASM_CTX_S=CTX_S, ASM_CTX_BYTES=CTX_BYTES,
                     ASM_MAX_WIDTH=MAX_WIDTH, ASM_PLANWIN_BYTES=PLANWIN_BYTES, ASM_CTL_BYTES=CTL_BYTES, ASM_BLOCK=BLOCK,
-                    ASM_ARGS_BYTES=ARGS_BYTES, ASM_NCONST=NCONST, ASM_LDS_F_BYTES=LDS_F_BYTES, ASM_LDS_B_BYTES=LDS_B_BYTES)
+                    ASM_ARGS_BYTES=ARGS_BYTES, ASM_NCONST=NCONST, ASM_MASK_BYTES=MASK_BYTES, ASM_LDS_F_BYTES=LDS_F_BYTES, ASM_LDS_B_BYTES=LDS_B_BYTES)
         with open(sys.argv[2], "w") as h:
             h.write("/* generated by asm/gen_sweeps.py: what the assembly sweeps and the C++ side agree on */\n")
             h.write("#ifndef CPECAN_ASM_GEN_H_\n#define CPECAN_ASM_GEN_H_\n")

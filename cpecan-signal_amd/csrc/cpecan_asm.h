@@ -58,6 +58,7 @@ struct AsmArgs {
     long long scratchBytes;
     double logThrSlack;
     long long modelStride;       /* doubles */
+    const unsigned *maskTab;     /* ASM_MASK_BYTES per diagonal of every item (cpecan_k_asm_masks), at the item's diagBase */
 };
 static_assert(sizeof(AsmArgs) == ASM_ARGS_BYTES, "argument block");
 
@@ -70,6 +71,10 @@ int cpecan_asm_launch_backward(int device, hipStream_t stream, const AsmArgs *ar
 /* once per batch: context [2] of every alignment (a wave that has done diagonal 0) and the ring's -inf row */
 int cpecan_asm_launch_ctx_init(hipStream_t stream, const DevItem *items, long long nItems, char *ctx, long long ctxBytes,
                                double *ring, long long ringDoubles, int ringD);
+/* once per batch: the mask table -- per diagonal the lanes of the band per layer (6 dwords), the band's first and last
+ * column, and the lanes a ring row is stored / loaded under (6 dwords: the band and the slots next to it on either side) */
+int cpecan_asm_launch_masks(hipStream_t stream, const DevItem *items, long long nItems, long long maxDiags, const int *bandTab,
+                            unsigned *maskTab);
 /* once per run: ring row 0 */
 int cpecan_asm_launch_begin(hipStream_t stream, const DevItem *items, long long nItems, double *ring, long long ringDoubles);
 }

@@ -114,6 +114,40 @@ extern "C" __global__ void cpecan_k_asm_ctx_init(const DevItem *items, long long
     for (int i = lane; i < ASM_ROW_BYTES / 8; i += 64) r[i] = ninf;
 }
 
+/* The mask table of one batch: one thread per diagonal. */
+extern "C" __global__ void cpecan_k_asm_masks(const DevItem *items, long long nItems, const int *bandTab, unsigned *maskTab) {
+    const long long idx = blockIdx.y;
+    if (idx >= nItems) return;
+    const DevItem it = items[idx];
+    const long long d = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > it.lX + it.lY) return;
+    const int lo = bandTab[2 * (it.diagBase + d)], hi = bandTab[2 * (it.diagBase + d) + 1];
+    unsigned long long m[ASM_L], g[ASM_L];
+    for (int j = 0; j < ASM_L; j++) m[j] = g[j] = 0ull;
+    for (int x = lo > 0 ? lo - 1 : 0; x <= hi + 1; x++) {
+        const int s = x % (64 * ASM_L);
+        g[s % ASM_L] |= 1ull << (s / ASM_L);
+        if (x >= lo && x <= hi) m[s % ASM_L] |= 1ull << (s / ASM_L);
+    }
+    unsigned *e = maskTab + (it.diagBase + d) * (ASM_MASK_BYTES / 4);
+    for (int j = 0; j < ASM_L; j++) {
+        e[2 * j] = (unsigned) m[j];
+        e[2 * j + 1] = (unsigned) (m[j] >> 32);
+        e[8 + 2 * j] = (unsigned) g[j];
+        e[9 + 2 * j] = (unsigned) (g[j] >> 32);
+    }
+    e[6] = (unsigned) lo;
+    e[7] = (unsigned) hi;
+    e[14] = e[15] = 0u;
+}
+
+extern "C" int cpecan_asm_launch_masks(hipStream_t stream, const DevItem *items, long long nItems, long long maxDiags,
+                                       const int *bandTab, unsigned *maskTab) {
+    hipLaunchKernelGGL(cpecan_k_asm_masks, dim3((unsigned) ((maxDiags + 255) / 256), (unsigned) nItems), dim3(256), 0, stream, items,
+                       nItems, bandTab, maskTab);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 /* Ring row 0: cell (0, 0) as the forward kernel of cpecan_kernel_wave.hip leaves it. */
 extern "C" __global__ void cpecan_k_asm_begin(const DevItem *items, long long nItems, double *ring, long long ringDoubles) {
     const long long idx = (long long) blockIdx.x * blockDim.x + threadIdx.x;

@@ -176,6 +176,12 @@ extern "C" int cpecan_wave_shader_clock_mhz(hipStream_t stream, const void *stat
 extern "C" int cpecan_wave_launch_counts(hipStream_t stream, const void *states, long long nItems, long long *nPairs,
                                          long long *nTot, long long *nCells);
 
+extern "C" int cpecan_wave_launch_post_asm_l3(hipStream_t stream, const DevItem *items, long long nItems, DevParams P,
+                                              const void *bandTab, const double *track, const long long *trackBase,
+                                              const double *models, double *Fring, long long ringDoubles, int ringD,
+                                              void *states, long long *pairs, double *pairLogp, long long *totXay,
+                                              double *totVal, char *scratch, long long scratchBytes, int window);
+
 struct SyBuild { /* one build of the throughput kernels */
     int rows;  /* waves per workgroup (systolic) or cells per lane (wave) */
     bool wave; /* one wave per alignment (cpecan_kernel_wave.hip) */
@@ -513,6 +519,7 @@ struct cpecan_batch {
     DevBuf<AsmPlanCtl> planCtl;
     DevBuf<long long> planOff;
     DevBuf<char> asmCtx;
+    DevBuf<unsigned> asmMasks;
 };
 
 /* The plan of one alignment for the assembly sweeps: its traceback windows (getPosteriorProbsWithBanding's schedule,
@@ -1514,16 +1521,21 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             B_TRY(b->planCtl.alloc((size_t) ctlTotal));
             B_TRY(b->planOff.alloc((size_t) nItems));
             B_TRY(b->asmCtx.alloc((size_t) nItems * 3 * ASM_CTX_BYTES));
+            B_TRY(b->asmMasks.alloc((size_t) (diagTotal + 2) * (ASM_MASK_BYTES / 4)));
+            B_TRY(hipMemsetAsync(b->asmMasks.p + (size_t) diagTotal * (ASM_MASK_BYTES / 4), 0, 2 * ASM_MASK_BYTES, c->prep));
             B_TRY(hipMemcpyAsync(b->planWin.p, hWin.p, hWin.n * sizeof(AsmPlanWin), hipMemcpyHostToDevice, c->prep));
             B_TRY(hipMemcpyAsync(b->planCtl.p, hCtl.p, (size_t) ctlTotal * sizeof(AsmPlanCtl), hipMemcpyHostToDevice, c->prep));
             B_TRY(hipMemcpyAsync(b->planOff.p, hPlanOff.data(), (size_t) nItems * sizeof(long long), hipMemcpyHostToDevice, c->prep));
-            if (cpecan_asm_launch_ctx_init(c->prep, b->items.p, nItems, b->asmCtx.p, ASM_CTX_BYTES, b->Fstore.p, b->ringDoubles,
+            if (cpecan_asm_launch_masks(c->prep, b->items.p, nItems, maxDiags, b->bandTab.p, b->asmMasks.p) != 0 ||
+                cpecan_asm_launch_ctx_init(c->prep, b->items.p, nItems, b->asmCtx.p, ASM_CTX_BYTES, b->Fstore.p, b->ringDoubles,
                                            b->ringD) != 0) {
                 cpecan_hip_batch_destroy(b);
                 return fail(CPECAN_EHIP, "context kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
             }
             B_TRY(hipStreamSynchronize(c->prep)); /* hWin ends here */
             b->useAsm = true;
+            /* CPECAN_ASM=1: the forward sweep only (the compiled sweep back reads what it writes: tests, timing) */
+            b->asmBackward = !(getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 1);
             if (getenv("CPECAN_ASM_TRACE"))
                 fprintf(stderr, "[cpecan asm] batch of %lld alignments, widest band %d, %d windows: assembly sweeps\n",
                         (long long) nItems, globalMaxWidth, b->asmMaxWindows);
@@ -1730,7 +1742,29 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
             asmArgs.ctxBytes = ASM_CTX_BYTES; asmArgs.coef = cpecan_asm_coef(c->device); asmArgs.nItems = (int) b->nItems;
             asmArgs.ringD = b->ringD; asmArgs.maxWindows = b->asmMaxWindows; asmArgs.scratch = b->syScratch.p;
             asmArgs.scratchBytes = b->scratchBytes; asmArgs.logThrSlack = b->P.logThrSlack; asmArgs.modelStride = CP_MODEL_STRIDE;
+            asmArgs.maskTab = b->asmMasks.p;
             rc = cpecan_asm_launch_begin(c->stream, b->items.p, b->nItems, b->Fstore.p, b->ringDoubles);
+            if (getenv("CPECAN_ASM_TRACE")) {
+                auto span = [](const char *what, const void *p, size_t bytes) {
+                    fprintf(stderr, "[cpecan asm]   %-10s %p .. %p (%zu bytes)\n", what, p, (const char *) p + bytes, bytes);
+                };
+                span("items", b->items.p, b->items.n * sizeof(DevItem));
+                span("trackBase", b->trackBase.p, b->trackBase.n * 8);
+                span("planWin", b->planWin.p, b->planWin.n * sizeof(AsmPlanWin));
+                span("planCtl", b->planCtl.p, b->planCtl.n * sizeof(AsmPlanCtl));
+                span("planOff", b->planOff.p, b->planOff.n * 8);
+                span("events", b->events.p, b->events.n * 8);
+                span("models", c->models.p, c->models.n * 8);
+                span("track", b->track.p, b->track.n * 8);
+                span("ring", b->Fstore.p, b->Fstore.n * 8);
+                span("states", b->syStates.p, b->syStates.n);
+                span("ctx", b->asmCtx.p, b->asmCtx.n);
+                span("scratch", b->syScratch.p, b->syScratch.n);
+                span("masks", b->asmMasks.p, b->asmMasks.n * 4);
+                span("coef", asmArgs.coef, 512);
+                fprintf(stderr, "[cpecan asm]   ringD %d ringDoubles %lld windows %d scratchBytes %lld\n", b->ringD, b->ringDoubles,
+                        b->asmMaxWindows, b->scratchBytes);
+            }
         }
         HIP_TRY(hipEventRecord(b->evFork, c->stream));
         const long long per = (b->nItems + G - 1) / G;
@@ -1759,7 +1793,15 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                 if (sB != sF) HIP_TRY(hipStreamWaitEvent(sB, e4[1], 0));
                 HIP_TRY(hipEventRecord(e4[2], sB));
                 static const bool fwdOnly = getenv("CPECAN_TIMING_FORWARD_ONLY") != nullptr; /* timing study: wrong results */
-                if (rc == 0 && n > 0 && !fwdOnly)
+                if (rc == 0 && n > 0 && asmRun && b->asmBackward) {
+                    asmArgs.window = w;
+                    rc = cpecan_asm_launch_backward(c->device, sB, &asmArgs);
+                    if (rc == 0)
+                        rc = cpecan_wave_launch_post_asm_l3(sB, b->items.p, n, b->P, b->bandTab.p, b->track.p, b->trackBase.p, models,
+                                                            b->Fstore.p, b->ringDoubles, b->ringD, b->syStates.p, b->pairs.p,
+                                                            b->pairLogp.p, b->totXay.p, b->totVal.p, b->syScratch.p,
+                                                            b->scratchBytes, w);
+                } else if (rc == 0 && n > 0 && !fwdOnly)
                     rc = b->sy->launch_backward(sB, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                 b->trackBase.p + i0, models,
                                                 b->Fstore.p + i0 * b->ringDoubles, b->ringDoubles, b->ringD,

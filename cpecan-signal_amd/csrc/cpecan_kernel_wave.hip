@@ -1736,7 +1736,7 @@ extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
     const DevItem *__restrict__ items, long long nItems, DevParams P, const int2 *__restrict__ bandTabAll,
     const double *__restrict__ models, const double *Fring, long long ringDoubles, int ringD, WvState *states,
     long long *pairs, double *pairLogp, long long *totXay, double *totVal, char *scratch, long long scratchBytes,
-    int window) {
+    int window, int formTerms) {
     constexpr int L = WV_L;
     __shared__ PostShared sh;
     const long long idx = blockIdx.x;
@@ -1757,7 +1757,6 @@ extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
     __syncthreads();
     const unsigned cf = lds_addr(sh.coef);
     const int2 *bandTab = bandTabAll + it.diagBase;
-    (void) models; (void) Fring; (void) ringDoubles;
     char *sc = scratch + idx * scratchBytes;
     const long long nW = (long long) ringD / 10 + 8;
     int *offBuf = (int *) sc;
@@ -1768,6 +1767,61 @@ extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
     const int2 *candKx = (const int2 *) ((char *) msk + 4ll * ringD * sizeof(unsigned long long));
     const double *candFb = (const double *) ((const char *) candKx + (long long) WV_L * WV_CAND_PER_DIAG * ringD * sizeof(int2));
     long long nPairs0 = uni64(ld_agent(&state->nPairs)), nTot0 = uni64(ld_agent(&state->nTot));
+
+#if !defined(WV_VANILLA) && !defined(WV_HDP)
+    /* ---------------- phase T0 (after the assembly sweep back, which only parks the operands) ---------------- */
+    /* diagonalCalculationTotalProbability (:736-754): v = cell_dotProduct(forward[t], backward[t]) and w = matches
+     * stepping over t: forward[t-1] --match--> the cells of t+1, dotted with backward[t+1]; the same terms as phase T0 of
+     * backward_window(), a refresh per wave at a time, lanes in the sweep's slots */
+    if (formTerms) {
+        const double *ring = Fring + idx * ringDoubles;
+        const int ringMask = ringD - 1;
+        const double *model = models + (long long) it.model * WV_MODEL_DOUBLES;
+        const double tMM = model[T_MATCH_CONTINUE], tXM = model[T_MATCH_FROM_GAP_X], tYM = model[T_MATCH_FROM_GAP_Y];
+#pragma unroll 1
+        for (int i = wv; i < nTotWin; i += 4) {
+            const WinTotal *w = wtot + i;
+            const int t = uni(w->t), xmn = uni(w->xmin), xmx = uni(w->xmax), nmn = uni(w->nxmin), nmx = uni(w->nxmax);
+            const bool second = uni(w->second) != 0;
+            const int2 pb = bandTab[t - 1 > 0 ? t - 1 : 0];
+            const int pxmin = uni(pb.x), pxmax = uni(pb.y);
+            const double *rowT = ring + (long long) (t & ringMask) * WV_ROW_DOUBLES;
+            const double *rowB = ring + (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
+            const double *src = rf + (long long) i * (5 * WV_P) + lane;
+#pragma unroll
+            for (int j = 0; j < L; j++) {
+                const int sl = lane * L + j, sMin = xmn % WV_P, sMinN = nmn % WV_P;
+                const int xT = xmn + (sl - sMin + (sl < sMin ? WV_P : 0));   /* this slot's k-mer on t ... */
+                const int xN = nmn + (sl - sMinN + (sl < sMinN ? WV_P : 0)); /* ... and on t+1 */
+                const bool tv = xT <= xmx, nv = second && xN <= nmx;
+                const bool below = nv && xN - 1 >= pxmin && xN - 1 <= pxmax;
+                const int sb = sl == 0 ? WV_P - 1 : sl - 1; /* the slot of the k-mer below */
+                if (tv) {
+                    const double *pa = rowT + j * WV_LAYER_DOUBLES;
+                    double v = pa[WV_OFF_FM(lane)] + src[(0 * L + j) * 64];
+                    v = ladd(v, pa[WV_OFF_FX(lane)] + src[(1 * L + j) * 64], cf);
+                    v = ladd(v, pa[WV_OFF_FY(lane)] + src[(2 * L + j) * 64], cf);
+                    vw[((long long) i * 2 + 0) * WV_P + sl] = v;
+                }
+                if (nv) {
+                    const double *pbw = rowB + (below ? sb % L : 0) * WV_LAYER_DOUBLES;
+                    const int lb = below ? sb / L : 0;
+                    const double s0 = below ? pbw[WV_OFF_FM(lb)] : CP_NEG_INF, s1 = below ? pbw[WV_OFF_FX(lb)] : CP_NEG_INF,
+                                 s2 = below ? pbw[WV_OFF_FY(lb)] : CP_NEG_INF;
+                    const double hp = src[(4 * L + j) * 64];
+                    double mm = s0 + (hp + tMM);
+                    mm = ladd(mm, s1 + (hp + tXM), cf);
+                    mm = ladd(mm, s2 + (hp + tYM), cf);
+                    vw[((long long) i * 2 + 1) * WV_P + sl] = mm + src[(3 * L + j) * 64];
+                }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+#else
+    (void) models; (void) Fring; (void) ringDoubles; (void) formTerms;
+#endif
 
     /* ------------------------------ phase T: the totals ------------------------------ */
     /* (plain loads throughout: what this kernel reads was written by an earlier kernel, or by this workgroup
@@ -2384,7 +2438,7 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
 #define WV_LAUNCH_POST                                                                                            \
     hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_post), dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems, P, \
                        (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD,                \
-                       (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, window)
+                       (WvState *) states, pairs, pairLogp, totXay, totVal, scratch, scratchBytes, window, 0)
     if (P.mode != 0) {
 #if defined(WV_VANILLA)
         if (withSwitch) return -1;
@@ -2408,6 +2462,24 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
 #undef WV_LAUNCH_POST
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+#if !defined(WV_VANILLA) && !defined(WV_HDP)
+/* what follows the assembly sweep back of a window (cpecan_asm.h): the refreshes' terms from the operands it parked, the
+ * totals, the decode; then the re-sweep kernel for the windows whose candidates could not be trusted */
+extern "C" int WV_SYM(cpecan_wave_launch_post_asm)(hipStream_t stream, const DevItem *items, long long nItems, DevParams P,
+                                                   const void *bandTab, const double *track, const long long *trackBase,
+                                                   const double *models, double *Fring, long long ringDoubles, int ringD,
+                                                   void *states, long long *pairs, double *pairLogp, long long *totXay,
+                                                   double *totVal, char *scratch, long long scratchBytes, int window) {
+    hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_post), dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems, P,
+                       (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD, (WvState *) states, pairs,
+                       pairLogp, totXay, totVal, scratch, scratchBytes, window, 1);
+    hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_resweep), dim3((unsigned) ((nItems + WV_WPB - 1) / WV_WPB)), dim3(64 * WV_WPB), 0, stream,
+                       items, nItems, P, (const int2 *) bandTab, track, trackBase, models, Fring, ringDoubles, ringD,
+                       (WvState *) states, pairs, pairLogp, scratch, scratchBytes, (double *) nullptr, window);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int WV_SYM(cpecan_wave_launch_expect)(hipStream_t stream, const DevItem *items, long long nItems,
                                                  DevParams P, const void *bandTab, const double *track,
                                                  const long long *trackBase, const unsigned short *kidx,

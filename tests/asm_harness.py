@@ -205,7 +205,9 @@ class Image:
         self.a_ring = mem.alloc(n * self.ring_doubles * 8)
         self.a_states = mem.alloc(n * STATE_BYTES)
         self.a_ctx = mem.alloc(n * 3 * G.CTX_BYTES)
-        self.scratch_bytes = 1 << 20
+        nw = self.ringD // 10 + 8
+        self.scratch_bytes = (2 * self.ringD * 4 + nw * (32 + 7 * P * 8) + 4 * self.ringD * 8
+                              + L * 4 * self.ringD * 16 + 63) // 64 * 64
         self.a_scratch = mem.alloc(n * self.scratch_bytes)
         coef = np.zeros(64)
         t = np.array([-0.009350833524763, 0.130659527668286, 0.498799810682272, 0.693203116424741,
@@ -218,6 +220,17 @@ class Image:
             coef[l] = float(t[piece * 4 + (l & 3)])
         self.a_coef = mem.alloc(512)
         mem.put(self.a_coef, coef)
+        # the mask table: per diagonal the lanes of the band per layer, first and last column (cpecan_k_asm_masks)
+        tabs, diag_base = [], []
+        for (xmin, xmax, _, _) in self.bands:
+            diag_base.append(sum(len(t) for t in tabs))
+            tabs.append(mask_table(xmin, xmax))
+        for i in range(n):
+            dev_items[i, 6] = diag_base[i]
+        mem.put(self.a_items, dev_items)
+        tab = np.concatenate(tabs + [np.zeros((2, 16), np.uint32)])
+        self.a_masktab = mem.alloc(tab.nbytes)
+        mem.put(self.a_masktab, tab)
         self.a_args = mem.alloc(G.ARGS_BYTES)
         self.begin()
 
@@ -235,10 +248,10 @@ class Image:
             mem.put(self.a_ring + i * self.ring_doubles * 8, ring)
 
     def args(self, window, log_thr_slack=0.0):
-        a = struct.pack("<14q4i2qdq", self.a_items, self.a_trackbase, self.a_planwin, self.a_planctl, self.a_planoff,
+        a = struct.pack("<14q4i2qdqq", self.a_items, self.a_trackbase, self.a_planwin, self.a_planctl, self.a_planoff,
                         self.a_events, self.a_models, self.a_track, self.a_ring, self.ring_doubles, self.a_states,
                         self.a_ctx, G.CTX_BYTES, self.a_coef, self.n, window, self.ringD, self.max_windows,
-                        self.a_scratch, self.scratch_bytes, log_thr_slack, MODEL_STRIDE)
+                        self.a_scratch, self.scratch_bytes, log_thr_slack, MODEL_STRIDE, self.a_masktab)
         assert len(a) == G.ARGS_BYTES
         self.mem.put(self.a_args, np.frombuffer(a, np.uint8))
         return self.a_args
@@ -260,9 +273,40 @@ class Image:
         return out
 
 
+def mask_table(xmin, xmax):
+    """cpecan_k_asm_masks: per diagonal the u64 lanes of the band for each layer, the band's first and last column, and
+    the lanes a ring row is stored / loaded under: the band and the slots next to it on either side"""
+    tab = np.zeros((len(xmin), 16), np.uint32)
+    for d in range(len(xmin)):
+        m, g = [0] * L, [0] * L
+        lo, hi = int(xmin[d]), int(xmax[d])
+        for x in range(max(lo - 1, 0), hi + 2):
+            lane, j = (x % P) // L, (x % P) % L
+            g[j] |= 1 << lane
+            if lo <= x <= hi:
+                m[j] |= 1 << lane
+        for j in range(L):
+            tab[d, 2 * j], tab[d, 2 * j + 1] = m[j] & 0xFFFFFFFF, m[j] >> 32
+            tab[d, 8 + 2 * j], tab[d, 9 + 2 * j] = g[j] & 0xFFFFFFFF, g[j] >> 32
+        tab[d, 6], tab[d, 7] = lo, hi
+    return tab
+
+
 def slot_of(x):
     s = x % P
     return s // L, s % L  # lane, layer
+
+
+def run_backward(img, window, item, log_thr_slack, watch=None):
+    text, parsed = generated_text()
+    name = "cpecan_k_asm_backward_l%d" % L
+    a = img.args(window, log_thr_slack)
+    instrs, labels = parsed
+    w = emu.Wave(instrs, labels, img.mem, emu.kernel_lds_bytes(text, name), a, item, name)
+    if watch:
+        w.watch = watch
+    w.run()
+    return w
 
 
 def run_forward(img, window, item=None):

@@ -33,15 +33,14 @@ class Memory:
     def __init__(self, size=1 << 28):
         self.b = np.zeros(size, np.uint8)
         self.top = 1 << 16
-        self.names = {}
+        self.blocks = []
 
     def alloc(self, nbytes, name=None, align=256):
         a = (self.top + align - 1) // align * align
         self.top = a + int(nbytes) + 256
         if self.top > self.b.size:
             raise EmuError("out of emulated memory")
-        if name:
-            self.names[name] = (a, int(nbytes))
+        self.blocks.append((a, a + int(nbytes), name or "block%d" % len(self.blocks)))
         return a
 
     def put(self, addr, arr):
@@ -53,8 +52,10 @@ class Memory:
         return self.b[addr: addr + n].view(dtype).copy()
 
     def check(self, addr, n):
-        if addr < (1 << 16) or addr + n > self.top:
-            raise EmuError("global access outside every allocation: 0x%x (+%d)" % (addr, n))
+        for lo, hi, _ in self.blocks:
+            if lo <= addr and addr + n <= hi:
+                return
+        raise EmuError("global access outside every allocation: 0x%x (+%d)" % (addr, n))
 
 
 _REG = re.compile(r"^(-?)([vs])(\d+)$")
@@ -291,6 +292,9 @@ class Wave:
     # ---------------------------------------------------------------- queues
     def _issue(self, queue, regs, commit):
         for r in regs:
+            if r in self.inflight:
+                # (scalar loads return out of order: two of them in flight to one register leave either value)
+                raise EmuError("%s%d is already the destination of a load in flight" % r)
             self.inflight.add(r)
         queue.append((regs, commit))
 
@@ -423,6 +427,13 @@ class Wave:
     def i_s_cmp_gt_i32(self, ins, o): self._cmp(o, True, lambda a, b: a > b)
     def i_s_cmp_lt_i32(self, ins, o): self._cmp(o, True, lambda a, b: a < b)
     def i_s_cmp_le_i32(self, ins, o): self._cmp(o, True, lambda a, b: a <= b)
+    def i_s_cmp_lg_u64(self, ins, o): self.scc = 1 if self.s_rd(o[0], 64) != self.s_rd(o[1], 64) else 0
+    def i_s_cmp_eq_u64(self, ins, o): self.scc = 1 if self.s_rd(o[0], 64) == self.s_rd(o[1], 64) else 0
+    def i_s_bcnt1_i32_b64(self, ins, o):
+        r = bin(self.s_rd(o[1], 64)).count("1")
+        self.scc = 1 if r else 0
+        self.s_wr(o[0], r)
+
     def i_s_cselect_b32(self, ins, o): self.s_wr(o[0], self.s_rd(o[1]) if self.scc else self.s_rd(o[2]))
 
     def i_s_cselect_b64(self, ins, o):
@@ -579,6 +590,15 @@ class Wave:
     def i_v_max_i32(self, ins, o): self._v32(ins, o, lambda a, b: np.maximum(a.view(np.int32), b.view(np.int32)).view(U32))
     def i_v_min_u32(self, ins, o): self._v32(ins, o, np.minimum)
     def i_v_lshl_add_u32(self, ins, o): self._v32(ins, o, lambda a, s, c: (a << (s & U32(31))) + c, 3)
+    def _mbcnt(self, o, shift):
+        m = (self.s_rd(o[1]) if o[1].kind != "int" else o[1].val) & 0xFFFFFFFF
+        below = np.array([bin(m & ((1 << max(0, min(32, int(l) - shift))) - 1)).count("1") for l in LANES], U32)
+        self._valu_writes(self._dst_regs(o[0], 1))
+        self.wr32(o[0], below + self.rd32(o[2]))
+
+    def i_v_mbcnt_lo_u32_b32(self, ins, o): self._mbcnt(o, 0)
+    def i_v_mbcnt_hi_u32_b32(self, ins, o): self._mbcnt(o, 32)
+
     def i_v_bcnt_u32_b32(self, ins, o):
         self._v32(ins, o, lambda a, b: np.array([bin(int(x)).count("1") for x in a], U32) + b)
 
