@@ -20,6 +20,7 @@ impl/stateMachine.c:333-343.
 
 usage: gen_sweeps.py OUT.s [OUT.h]   (OUT.h: the sizes and offsets the C++ side shares, cpecan_asm_gen.h)
 """
+import os
 import struct
 import sys
 
@@ -75,6 +76,9 @@ LDS_B_BYTES = LDS_PX + PXN * 16
 MAX_WIDTH = 158                          # band widths the staging scheme holds
 BLOCK = 64                               # diagonals per staging block
 
+# timing studies (tools/ablate_asm.sh): wrong results by construction, never part of the product build
+ABLATE = set(os.environ.get("CPECAN_ASM_ABLATE", "").split())
+
 LOG2E_F32 = 0x3FB8AA3B
 LN2_F32 = 0x3F317218
 
@@ -123,7 +127,18 @@ class Kernel(Emitter):
         a = c10.lo
         self.valu("v_cvt_i32_f64_e32", a, t)
         self.valu("v_lshlrev_b32_e32", a, 5, a)
+        if "COEF0" in ABLATE:
+            self.valu("v_mov_b32_e32", a, 0)
+        if "NOLDS" in ABLATE:
+            for q in range(4):
+                self.valu("v_mov_b32_e32", c32.sub(q), d.sub(q % 2))
+                self.valu("v_mov_b32_e32", c10.sub(q), d.sub(q % 2))
+            return (hi, lo, d, c32, c10)
         self.ds_read(128, c32, a)
+        if "HALFLDS" in ABLATE:
+            for q in range(4):
+                self.valu("v_mov_b32_e32", c10.sub(q), d.sub(q % 2))
+            return (hi, lo, d, c32, c10)
         self.ds_read(128, c10, a, 16)
         return (hi, lo, d, c32, c10)
 
@@ -231,11 +246,37 @@ def forward_kernel(name):
     # what a ring row's stores cover (from the mask table): the band and the two slots next to it, which are parked here --
     # the sweep back loads a row under the same lanes and finds -inf emissions where a k-mer has just left or is about
     # to enter, which is what keeps cells outside the band out of its recurrence
-    sMaskS = [S(96 + 2 * j, 2) for j in range(L)]
+    # (two sets, by the parity of the diagonal: a step asks for the next diagonal's while it works under its own)
+    sMaskS = [[S(96 + 2 * j, 2) for j in range(L)], [S(80 + 2 * j, 2) for j in range(L)]]
+    sFullM = S(86, 2)                                   # all ones on a diagonal whose gap states go to the ring too
     sCtxBytes = S(62)                                   # (prologue only: sStagePC is set after it)
     def W(f): return sWin.sub(f)
     sWindow = W(13)                                     # (a spare word of the plan record)
+    sPlanRec = S(90, 2)                                 # (its last two words: the record's address, to read it again at the end)
     lbl = lambda s: ".L_%s_%s" % (name, s)
+
+    def load_store_masks(q):
+        """sMaskS[q] <- the lanes ring row sD is stored under"""
+        k.salu("s_lshl_b32", sT[0], sD, 6)
+        k.salu("s_add_u32", sT[0], sT[0], 32)
+        k.smem("s_load_dwordx4", S(sMaskS[q][0].i, 4), sMaskTab, sT[0])
+        k.salu("s_add_u32", sT[0], sT[0], 16)
+        k.smem("s_load_dwordx2", sMaskS[q][2], sMaskTab, sT[0])
+
+    def masked_store(mask, dwords, voff, data, off, gate=None):
+        if "NOSTORE" in ABLATE or ("NOSTORE4" in ABLATE and dwords == 4) or ("NOSTORE2" in ABLATE and dwords == 2):
+            return
+        if "STOREALL" in ABLATE:
+            if gate is None:
+                k.gstore(dwords, voff, data, sRow0 if off < 4096 else sRow1, off % 4096)
+            return
+        if gate is None:
+            k.salu("s_mov_b64", "exec", mask)
+        else:
+            k.salu("s_and_b64", "exec", mask, gate)
+        if "EXECONLY" not in ABLATE:
+            k.gstore(dwords, voff, data, sRow0 if off < 4096 else sRow1, off % 4096)
+        k.salu("s_mov_b64", "exec", -1)
 
     # ------------------------------------------------------------------ prologue
     k.label(name)
@@ -259,6 +300,7 @@ def forward_kernel(name):
     k.smem("s_load_dwordx2", sP[2], sArg, A_ITEMS)
     k.wait_lgkm()
     k.salu("s_mov_b32", sWindow, S(3))
+    k.salu("s_mov_b64", sPlanRec, sP[1])
     k.salu("s_cmp_ge_i32", sWindow, W(W_NWIN))
     k.branch("s_cbranch_scc1", lbl("exit"))
     # item record
@@ -413,12 +455,8 @@ def forward_kernel(name):
             k.ror64(R[p].sub(2 * q, 2), src)
     # stage from scratch everything the first diagonal's block can ask for
     k.salu("s_add_u32", sD, sD, 1)
-    k.salu("s_lshl_b32", sT[0], sD, 6)
-    k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sT[0]) if False else None
-    k.salu("s_add_u32", sT[0], sT[0], 32)
-    k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sT[0])
-    k.salu("s_add_u32", sT[0], sT[0], 16)
-    k.smem("s_load_dwordx2", S(100, 2), sMaskTab, sT[0])
+    load_store_masks(0)
+    load_store_masks(1)
     k.salu("s_sub_u32", sEvHi, sD, sXmax)
     k.salu("s_sub_u32", sEvHi, sEvHi, 2)
     k.pc_of(sStagePC, lbl("stage"))
@@ -437,14 +475,22 @@ def forward_kernel(name):
     def step(p):
         """Diagonal sD of parity p: X[p] holds the diagonal before last and receives this one, X[1-p] the last one."""
         q = 1 - p
-        k.drain_lgkm()       # this diagonal's store masks (asked for at the end of the step before); the events are in too
+        k.drain_lgkm()       # this diagonal's store masks (asked for a diagonal ago); the events are in too
         pend = []
+        k.salu("s_add_u32", sD, sD, 1)
+        load_store_masks(q)  # the next diagonal's
+        k.salu("s_sub_u32", sD, sD, 1)
+        k.lgkm = []          # (waited for at the top of the next step)
+        k.salu("s_bitcmp1_b64", sFull, sD)
+        k.salu("s_cselect_b64", sFullM, -1, 0)
         # band edges: the k-mer that leaves first (its slot is parked), then the one that enters
         k.salu("s_bitcmp1_b64", sStepMin, sD)
-        k.branch("s_cbranch_scc1", lbl("leave%d" % p))
+        if "NOEVENTS" not in ABLATE:
+            k.branch("s_cbranch_scc1", lbl("leave%d" % p))
         k.label(lbl("left%d" % p))
         k.salu("s_bitcmp1_b64", sStepMax, sD)
-        k.branch("s_cbranch_scc1", lbl("enter%d" % p))
+        if "NOEVENTS" not in ABLATE:
+            k.branch("s_cbranch_scc1", lbl("enter%d" % p))
         k.label(lbl("entered%d" % p))
         k.lgkm = pend
         # this diagonal's ring row
@@ -496,12 +542,15 @@ def forward_kernel(name):
             k.gauss(PY[j], E[j].sub(0, 2), c[8 + CMU], c[8 + CSD], c[8 + CRSD], c[8 + CK1], g0, g1)
             k.gauss(g2, E[j].sub(2, 2), c[8 + CNMU], c[8 + CNSD], c[8 + CRNSD], c[8 + CK2], g0, g1)
             k.add(PY[j], PY[j], g2)
+            if j:            # (a store between stretches of arithmetic: stores issued back to back hold the wave up)
+                masked_store(sMaskS[p][j - 1], 2, vOff8, PY[j - 1], (j - 1) * LAYER_BYTES + OFF_PY)
         pool.give(g0, g1, g2)
         for j in range(L):
             cc = pool.take(2)
             k.add(cc, Xpm(p, j), sTYM)
             k.add(cc, middle(j, 2), cc)
             csum.append(cc)
+        masked_store(sMaskS[p][L - 1], 2, vOff8, PY[L - 1], (L - 1) * LAYER_BYTES + OFF_PY)
         # P6
         for j in range(L):
             k.ladd_back(recs[j], Xm(p, j), s7p5)
@@ -520,40 +569,25 @@ def forward_kernel(name):
         for j in range(L):
             k.valu("v_add_u32_e32", E[j].lo, sDmod, vEvSlot[j])
             k.ds_read(128, E[j], E[j].lo)
-        for j in range(L):
-            k.salu("s_mov_b64", "exec", sMaskS[j])
-            off = j * LAYER_BYTES + OFF_PY
-            k.gstore(2, vOff8, PY[j], sRow0 if off < 4096 else sRow1, off % 4096)
-        k.salu("s_mov_b64", "exec", -1)
-        # P9
+        # P9 (on a diagonal the sweep back reads all three states of, the gap states leave too)
         for j in range(L):
             k.ladd_back(recs[j], Xy(p, j), s7p5)
+            masked_store(sMaskS[p][j], 4, vOff16, V(Xx(p, j).i, 4), j * LAYER_BYTES + OFF_FXY, gate=sFullM)
         # P10: the match cell's third term
         recs = []
         for j in range(L):
             recs.append(k.ladd_front(Xm(p, j), csum[j], free=(csum[j],)))
         # ... meanwhile the gap states leave where the sweep back reads them again, and layer L-1 is rotated up a lane
-        k.salu("s_bitcmp1_b64", sFull, sD)
-        k.branch("s_cbranch_scc1", lbl("full%d" % p))
-        k.label(lbl("fulldone%d" % p))
         k.ror64(R[p].sub(2, 2), Xx(p, L - 1))
         k.ror64(R[p].sub(4, 2), Xy(p, L - 1))
+        # P11: (Fm, pm) leave as they are finished; the match cells of layer L-1 go up a lane
         for j in range(L):
             k.ladd_back(recs[j], Xm(p, j), s7p5)
-        # P11: (Fm, pm) leave; the match cells of layer L-1 go up a lane
-        for j in range(L):
-            k.salu("s_mov_b64", "exec", sMaskS[j])
-            off = j * LAYER_BYTES
-            k.gstore(4, vOff16, V(Xm(p, j).i, 4), sRow0 if off < 4096 else sRow1, off % 4096)
-        k.salu("s_mov_b64", "exec", -1)
+            if j:
+                masked_store(sMaskS[p][j - 1], 4, vOff16, V(Xm(p, j - 1).i, 4), (j - 1) * LAYER_BYTES)
         k.ror64(R[p].sub(0, 2), Xm(p, L - 1))
+        masked_store(sMaskS[p][L - 1], 4, vOff16, V(Xm(p, L - 1).i, 4), (L - 1) * LAYER_BYTES)
         k.salu("s_add_u32", sD, sD, 1)
-        k.salu("s_lshl_b32", sT[0], sD, 6)
-        k.salu("s_add_u32", sT[0], sT[0], 32)
-        k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sT[0])
-        k.salu("s_add_u32", sT[0], sT[0], 16)
-        k.smem("s_load_dwordx2", S(100, 2), sMaskTab, sT[0])
-        k.lgkm = []          # (waited for at the top of the next step, where nothing else is under way)
 
     k.label(lbl("even"))
     step(0)
@@ -633,15 +667,6 @@ def forward_kernel(name):
                 k.salu("s_and_b32", sInL, sInL, 63)
             k.drain_lgkm()
             k.branch("s_branch", lbl("entered%d" % p))
-        # a diagonal the sweep back reads all three states of
-        k.forget()
-        k.label(lbl("full%d" % p))
-        for j in range(L):
-            k.salu("s_mov_b64", "exec", sMaskS[j])
-            off = j * LAYER_BYTES + OFF_FXY
-            k.gstore(4, vOff16, V(Xx(p, j).i, 4), sRow0 if off < 4096 else sRow1, off % 4096)
-        k.salu("s_mov_b64", "exec", -1)
-        k.branch("s_branch", lbl("fulldone%d" % p))
 
     # ------------------------------------------------------------------ staging: control words, events, k-mer rows
     k.forget()
@@ -731,6 +756,12 @@ def forward_tail(k, v):
     Xm, Xx, Xy, C = g["Xm"], g["Xx"], g["Xy"], g["C"]
     vOff16, vOff8 = g["vOff16"], g["vOff8"]
     W = g["W"]
+    # the plan record again (the loop used its registers)
+    k.salu("s_mov_b32", sT[4], sWindow)
+    k.salu("s_mov_b64", sP[3], g["sPlanRec"])
+    k.smem("s_load_dwordx16", sWin, sP[3], 0)
+    k.wait_lgkm()
+    k.salu("s_mov_b32", sWindow, sT[4])
     # the model's record again (its transitions 3..6 for the ragged end vector): models + model * stride * 8
     k.smem("s_load_dwordx2", sP[3], sArg, A_ITEMS)
     k.wait_lgkm()
@@ -1255,7 +1286,8 @@ def backward_loop(k, v):
         pool.give(w, rhB, rhP, rBx)
         # the k-mers that left / entered the band coming down to t: their slots change hands now, for the diagonals below
         k.salu("s_cmp_lg_u64", SM[k1].sub(6, 2), SM[kk].sub(6, 2))
-        k.branch("s_cbranch_scc1", lbl("band%d" % kk))
+        if "NOEVENTS" not in ABLATE:
+            k.branch("s_cbranch_scc1", lbl("band%d" % kk))
         k.label(lbl("banded%d" % kk))
         # the band of t - 2 (into the registers of t + 1's, whose columns the tail still wants), then the ring row of t - 1
         k.salu("s_mov_b64", sNxt, SM[k1].sub(6, 2))
@@ -1263,12 +1295,25 @@ def backward_loop(k, v):
         load_masks(k1, sA[1])
         k.salu("s_sub_u32", sA[1], sTd, 1)
         row_bases(sA[1])
-        fetch_row(k2, sLm)
+        # (t + 1, same slot) upper block, then (t + 1, slot + 1) lower block -- the reference's scatter order per state;
+        # the ring row's loads go out one layer at a time between stretches of arithmetic
+        ra, rb = [], []
+        for j in range(L):
+            ra.append(k.ladd_front(bmin[j], UM[j], free=(bmin[j],)))
+            k.salu("s_mov_b64", "exec", sLm[j])
+            off = j * LAYER_BYTES
+            if "NOLOAD" not in ABLATE:
+                k.gload(4, T[k2][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
+            k.salu("s_mov_b64", "exec", -1)
+        for j in range(L):
+            rb.append(k.ladd_front(byin[j], UY[j], free=(byin[j],)))
+            k.salu("s_mov_b64", "exec", sLm[j])
+            off = j * LAYER_BYTES + OFF_PY
+            if "NOLOAD" not in ABLATE:
+                k.gload(2, PYB[k2][j], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
+            k.salu("s_mov_b64", "exec", -1)
         k.salu("s_sub_u32", sA[1], sTd, 2)
         load_row_masks(sA[1])
-        # (t + 1, same slot) upper block, then (t + 1, slot + 1) lower block -- the reference's scatter order per state
-        ra = [k.ladd_front(bmin[j], UM[j], free=(bmin[j],)) for j in range(L)]
-        rb = [k.ladd_front(byin[j], UY[j], free=(byin[j],)) for j in range(L)]
         for j in range(L):
             k.ladd_back(ra[j], M[kk][j], s7p5)
         rc = [k.ladd_front(bxin[j], y1[j], free=(bxin[j], y1[j])) for j in range(L)]

@@ -1771,6 +1771,9 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
         for (int gi = 0; gi < G && rc == 0; gi++) {
             const long long i0 = gi * per, n = std::min<long long>(per, b->nItems - i0);
             hipStream_t sF = b->gStream[(size_t) gi], sB = b->sy->wave ? b->gStreamB[(size_t) gi] : sF;
+#ifdef CPECAN_TIMING_BUILD
+            if (getenv("CPECAN_TIMING_SERIAL")) sB = sF; /* timing study: every sweep alone on the chip */
+#endif
             hipEvent_t *ev = b->evStage.data() + (size_t) gi * perGroup;
             HIP_TRY(hipStreamWaitEvent(sF, b->evFork, 0));
             if (sB != sF) HIP_TRY(hipStreamWaitEvent(sB, b->evFork, 0));
@@ -1792,11 +1795,20 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                 HIP_TRY(hipEventRecord(e4[1], sF));
                 if (sB != sF) HIP_TRY(hipStreamWaitEvent(sB, e4[1], 0));
                 HIP_TRY(hipEventRecord(e4[2], sB));
+#ifdef CPECAN_TIMING_BUILD
                 static const bool fwdOnly = getenv("CPECAN_TIMING_FORWARD_ONLY") != nullptr; /* timing study: wrong results */
-                if (rc == 0 && n > 0 && asmRun && b->asmBackward) {
+#else
+                const bool fwdOnly = false;
+#endif
+                if (rc == 0 && n > 0 && asmRun && b->asmBackward && !fwdOnly) {
                     asmArgs.window = w;
                     rc = cpecan_asm_launch_backward(c->device, sB, &asmArgs);
-                    if (rc == 0)
+#ifdef CPECAN_TIMING_BUILD
+                    static const bool noPost = getenv("CPECAN_TIMING_NO_POST") != nullptr; /* timing study: sweeps only */
+#else
+                    const bool noPost = false;
+#endif
+                    if (rc == 0 && !noPost)
                         rc = cpecan_wave_launch_post_asm_l3(sB, b->items.p, n, b->P, b->bandTab.p, b->track.p, b->trackBase.p, models,
                                                             b->Fstore.p, b->ringDoubles, b->ringD, b->syStates.p, b->pairs.p,
                                                             b->pairLogp.p, b->totXay.p, b->totVal.p, b->syScratch.p,
