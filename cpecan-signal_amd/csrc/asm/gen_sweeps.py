@@ -932,7 +932,9 @@ def backward_kernel(name):
 
     Everything that lives across diagonals rotates by the diagonal mod 3, so the loop body is written three times:
     M[q] the match cells of the diagonals = q, T[q] the ring's (Fm, pm) pairs of such a diagonal, PYB[q] its gap-Y
-    emissions, SM[q] its band (lanes per layer, first and last column) from the mask table.
+    emissions, PMB[q] its match emissions (copied out of T[q], whose registers take the row three diagonals down: a row is
+    asked for two diagonals before the sweep reaches it), SM[q] its band (lanes per layer, first and last column) from the
+    mask table.
 
     A ring row is loaded under the band of the row and of the row above it: the forward sweep stores -inf emissions for
     the slot of the k-mer that enters next, so a slot whose k-mer has just left the band (going down) reads -inf
@@ -953,7 +955,9 @@ def backward_kernel(name):
     T = [[V(t0 + 4 * L * q + 4 * j, 4) for j in range(L)] for q in range(3)]
     p0 = t0 + 12 * L
     PYB = [[V(p0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]
-    pool0 = p0 + 6 * L
+    q0 = p0 + 6 * L
+    PMB = [[V(q0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]  # match emissions, kept two diagonals longer
+    pool0 = q0 + 6 * L
     pool = Pool(pool0, 255)
     k = Kernel(pool)
     def Tf(q, j): return T[q][j].sub(0, 2)
@@ -1217,15 +1221,16 @@ def backward_kernel(name):
                 k.valu("v_mov_b32_e32", dst.lo, src.lo)
                 k.valu("v_mov_b32_e32", dst.hi, src.hi)
         k.salu("s_mov_b64", "exec", -1)
-        # its ring row, and the row below it
+        # its ring row, and the two rows below it
         row_bases(sTd)
         fetch_row(kk, sLm)
-        k.salu("s_sub_u32", sA[1], sTd, 1)
-        load_row_masks(sA[1])
-        k.drain_lgkm()
-        row_bases(sA[1])
-        fetch_row(k2, sLm)
-        k.salu("s_sub_u32", sA[1], sTd, 2)
+        for back, q in ((1, k2), (2, k1)):
+            k.salu("s_sub_u32", sA[1], sTd, back)
+            load_row_masks(sA[1])
+            k.drain_lgkm()
+            row_bases(sA[1])
+            fetch_row(q, sLm)
+        k.salu("s_sub_u32", sA[1], sTd, 3)
         load_row_masks(sA[1])
         k.label(lbl("entered%d" % kk))
         k.salu("s_mov_b64", S(90, 2), SM[kk].sub(6, 2))
@@ -1241,6 +1246,7 @@ def backward_loop(k, v):
     g = dict(v)
     name, pool, lbl = g["name"], g["pool"], g["lbl"]
     M, BX, BY, UM, UY, T, PYB, PX, RP = g["M"], g["BX"], g["BY"], g["UM"], g["UY"], g["T"], g["PYB"], g["PX"], g["RP"]
+    PMB = g["PMB"]
     Tf, Tpm, PXo, PXe = g["Tf"], g["Tpm"], g["PXo"], g["PXe"]
     vOff16, vOff8, vTmp, vTmp2, vThr, vCthr = g["vOff16"], g["vOff8"], g["vTmp"], g["vTmp2"], g["vThr"], g["vCthr"]
     SM, SMm, SMxmin, SMxmax, sLm, sA, sAp = g["SM"], g["SMm"], g["SMxmin"], g["SMxmax"], g["sLm"], g["sA"], g["sAp"]
@@ -1262,13 +1268,13 @@ def backward_loop(k, v):
         # (lower block); layer L-1 takes them from layer 0 of the lane above
         rhB, rhP, rBx = pool.take(2), pool.take(2), pool.take(2)
         k.rol64(rhB, M[k2][0])
-        k.rol64(rhP, Tpm(k2, 0))
+        k.rol64(rhP, PMB[k2][0])
         k.rol64(rBx, BX[0])
         bmin, bxin, byin, y1, y2 = [], [], [], [], []
         w = pool.take(2)
         for j in range(L):
             sB_ = M[k2][j + 1] if j < L - 1 else rhB
-            sP_ = Tpm(k2, j + 1) if j < L - 1 else rhP
+            sP_ = PMB[k2][j + 1] if j < L - 1 else rhP
             sBx_ = BX[j + 1] if j < L - 1 else rBx
             pe = PXe(j + 1) if j < L - 1 else RP.sub(2, 2)
             po = PXo(j + 1) if j < L - 1 else RP.sub(0, 2)
@@ -1293,26 +1299,27 @@ def backward_loop(k, v):
         k.salu("s_mov_b64", sNxt, SM[k1].sub(6, 2))
         k.salu("s_sub_u32", sA[1], sTd, 2)
         load_masks(k1, sA[1])
-        k.salu("s_sub_u32", sA[1], sTd, 1)
+        k.salu("s_sub_u32", sA[1], sTd, 2)
         row_bases(sA[1])
         # (t + 1, same slot) upper block, then (t + 1, slot + 1) lower block -- the reference's scatter order per state;
-        # the ring row's loads go out one layer at a time between stretches of arithmetic
+        # the loads of ring row t - 2 (into the registers of row t + 1) go out one layer at a time between stretches of
+        # arithmetic
         ra, rb = [], []
         for j in range(L):
             ra.append(k.ladd_front(bmin[j], UM[j], free=(bmin[j],)))
             k.salu("s_mov_b64", "exec", sLm[j])
             off = j * LAYER_BYTES
             if "NOLOAD" not in ABLATE:
-                k.gload(4, T[k2][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
+                k.gload(4, T[k1][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
             k.salu("s_mov_b64", "exec", -1)
         for j in range(L):
             rb.append(k.ladd_front(byin[j], UY[j], free=(byin[j],)))
             k.salu("s_mov_b64", "exec", sLm[j])
             off = j * LAYER_BYTES + OFF_PY
             if "NOLOAD" not in ABLATE:
-                k.gload(2, PYB[k2][j], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
+                k.gload(2, PYB[k1][j], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
             k.salu("s_mov_b64", "exec", -1)
-        k.salu("s_sub_u32", sA[1], sTd, 2)
+        k.salu("s_sub_u32", sA[1], sTd, 3)
         load_row_masks(sA[1])
         for j in range(L):
             k.ladd_back(ra[j], M[kk][j], s7p5)
@@ -1326,7 +1333,10 @@ def backward_loop(k, v):
             k.ladd_back(rd[j], M[kk][j], s7p5)
         # ------------------------------------------------------------ tail: what diagonal t hands down, its candidates
         k.label(lbl("tail%d" % kk))
-        k.raw_wait_vm(2 * L)                   # this diagonal's ring row (the loads of the next one may still be under way)
+        k.raw_wait_vm(4 * L)                   # this diagonal's ring row (the loads of the next two may still be under way)
+        for j in range(L):
+            k.valu("v_mov_b32_e32", PMB[kk][j].lo, Tpm(kk, j).lo)
+            k.valu("v_mov_b32_e32", PMB[kk][j].hi, Tpm(kk, j).hi)
         w = pool.take(2)
         for j in range(L):
             k.add(w, PYB[kk][j], sTMY)
@@ -1427,7 +1437,7 @@ def backward_loop(k, v):
         k.salu("s_mul_i32", sA[0], sNTot, 5 * P * 8)
         k.add64(sAp(4), sRf, sA[0])
         k.add64(sAp(6), sAp(4), 4096)
-        vals = [M[kk], BX, BY, M[k1], [Tpm(k1, j) for j in range(L)]]
+        vals = [M[kk], BX, BY, M[k1], PMB[k1]]
         for q in range(5):
             for j in range(L):
                 off = (q * L + j) * 512

@@ -275,14 +275,15 @@ class Image:
 
 def mask_table(xmin, xmax):
     """cpecan_k_asm_masks: per diagonal the u64 lanes of the band for each layer, the band's first and last column, and
-    the lanes a ring row is stored / loaded under: the band and the slots next to it on either side"""
+    the lanes a ring row is stored / loaded under: the band and the slots next to it on either side, widened to groups of
+    16 lanes (every other slot is parked in the forward sweep: -inf)"""
     tab = np.zeros((len(xmin), 16), np.uint32)
     for d in range(len(xmin)):
         m, g = [0] * L, [0] * L
         lo, hi = int(xmin[d]), int(xmax[d])
         for x in range(max(lo - 1, 0), hi + 2):
             lane, j = (x % P) // L, (x % P) % L
-            g[j] |= 1 << lane
+            g[j] |= 0xFFFF << (lane & ~15)   # whole 128-byte lines of the 8-byte values (16 lanes): no partial writes
             if lo <= x <= hi:
                 m[j] |= 1 << lane
         for j in range(L):
