@@ -215,6 +215,12 @@ class Emitter:
         self._ins("%s %s, %s, %s%s" % (op, dst, voff, sbase, " offset:%d" % offset if offset else ""), "vmem")
         self.vm.append(vregs_of(dst))
 
+    def gload_lds(self, voff, sbase):
+        """global_load_lds_dwordx4: every lane's 16 bytes at sbase + voff go to LDS at M0 + 16 * lane (counted by vmcnt)."""
+        self._touch(vregs_of(voff), set())
+        self._ins("global_load_lds_dwordx4 %s, %s" % (voff, sbase), "vmem")
+        self.vm.append(set())
+
     def gstore(self, dwords, voff, data, sbase, offset=0):
         self._touch(vregs_of(voff) | vregs_of(data), set())
         op = {1: "global_store_dword", 2: "global_store_dwordx2", 4: "global_store_dwordx4"}[dwords]

@@ -71,7 +71,11 @@ LDS_F_BYTES = LDS_ROWS + ROWN * TRACK_ROW_BYTES
 # ... and of the backward kernel
 LDS_PX = 512
 PXN = 64
-LDS_B_BYTES = LDS_PX + PXN * 16
+LDS_RF = LDS_PX + PXN * 16               # the forward cells a refresh of totalProbability wants, fetched ahead by loads to LDS:
+LDS_RF_XY_T = LDS_RF                     # (Fx, Fy) of the refresh's diagonal t, 1024 bytes per layer
+LDS_RF_MP_B = LDS_RF + L * 1024          # (Fm, pm) of t - 1
+LDS_RF_XY_B = LDS_RF + 2 * L * 1024      # (Fx, Fy) of t - 1
+LDS_B_BYTES = LDS_RF + 3 * L * 1024
 
 MAX_WIDTH = 158                          # band widths the staging scheme holds
 BLOCK = 64                               # diagonals per staging block
@@ -923,6 +927,10 @@ CAND_PER_DIAG = 4
 CAND_SLACK = 0.25
 
 
+B_M0 = 8 + 4 * L + 4                      # backward kernel: first register of M[q][j] (2 * L * q + 2 * j on) ...
+B_BX0 = B_M0 + 6 * L                      # ... of BX[j], then BY[j] (the emulator tests read the cells out of these)
+
+
 def backward_kernel(name):
     """The sweep back of one traceback window, one wave per alignment (phase S of backward_window() of
     cpecan_kernel_wave.hip): the backward cells of every diagonal from the traceback point down, the decode candidates
@@ -944,9 +952,9 @@ def backward_kernel(name):
     vThr, vCthr = V(4, 2), V(6, 2)                     # candidate threshold in force / once decoding has begun
     PX = [V(8 + 4 * j, 4) for j in range(L)]           # (gap-X open sum, gap-X extend sum) of the slot's k-mer
     RP = V(8 + 4 * L, 4)                               # ... of layer 0 of the lane above
-    m0 = 8 + 4 * L + 4
+    m0 = B_M0
     M = [[V(m0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]
-    b0 = m0 + 6 * L
+    b0 = B_BX0
     BX = [V(b0 + 2 * j, 2) for j in range(L)]
     BY = [V(b0 + 2 * L + 2 * j, 2) for j in range(L)]
     UM = [V(b0 + 4 * L + 2 * j, 2) for j in range(L)]  # upper-block sums of the diagonal above: By + (py + tP)
@@ -1114,10 +1122,8 @@ def backward_kernel(name):
     k.salu("s_lshr_b32", sA[0], sA[0], 3)
     k.salu("s_add_u32", sA[0], sA[0], 8)                   # nW = ringD / 10 + 8
     k.salu("s_mul_i32", sA[1], sA[0], WINTOTAL_BYTES)
-    k.add64(sRf, sWtot, sA[1])                             # (the terms)
-    k.salu("s_mul_i32", sA[1], sA[0], 2 * P * 8)
-    k.add64(sRf, sRf, sA[1])                               # the parked operands
-    k.salu("s_mul_i32", sA[1], sA[0], 5 * P * 8)
+    k.add64(sRf, sWtot, sA[1])                             # the refreshes' terms
+    k.salu("s_mul_i32", sA[1], sA[0], 7 * P * 8)           # (them, and the operands the compiled sweep parks)
     k.add64(sCandKx, sRf, sA[1])                           # (the hit masks)
     k.salu("s_lshl_b32", sA[1], sB[2], 5)                  # 4 * ringD * 8
     k.add64(sCandKx, sCandKx, sA[1])
@@ -1161,6 +1167,24 @@ def backward_kernel(name):
     k.wait_all()
     for h in range(2):
         k.rol64(RP.sub(2 * h, 2), PX[0].sub(2 * h, 2))
+    def prefetch_terms(dreg):
+        """loads to LDS of what the refresh on diagonal dreg reads of the ring: (Fx, Fy) of its row, (Fm, pm) and
+        (Fx, Fy) of the row below (every lane: a lane outside the band reads whatever the ring holds, nobody uses it)"""
+        k.salu("s_and_b32", sA[0], dreg, sRingMask)
+        k.salu("s_mul_i32", sA[0], sA[0], ROW_BYTES)
+        k.add64(sAp(4), sRing0, sA[0])
+        k.salu("s_sub_u32", sA[1], dreg, 1)
+        k.salu("s_and_b32", sA[1], sA[1], sRingMask)
+        k.salu("s_mul_i32", sA[1], sA[1], ROW_BYTES)
+        k.add64(sAp(6), sRing0, sA[1])
+        for base, off0, dest0 in ((sAp(4), OFF_FXY, LDS_RF_XY_T), (sAp(6), 0, LDS_RF_MP_B), (sAp(6), OFF_FXY, LDS_RF_XY_B)):
+            for j in range(L):
+                k.add64(sAp(2), base, j * LAYER_BYTES + off0)
+                k.salu("s_mov_b32", "m0", dest0 + j * 1024)
+                k.nop(1)
+                k.gload_lds(vOff16, sAp(2))
+
+    prefetch_terms(sTpost0)
     # which third of the loop the traceback point falls in
     k.salu("s_mul_hi_u32", sA[0], sTop, "0x55555556")
     k.salu("s_mul_i32", sA[0], sA[0], 3)
@@ -1256,6 +1280,7 @@ def backward_loop(k, v):
     sRow0, sRow1, sRf, sWtot, sCandKx, sCandFb, sState = g["sRow0"], g["sRow1"], g["sRf"], g["sWtot"], g["sCandKx"], g["sCandFb"], g["sState"]
     sRet, sStagePC, sTrack, sWindow, sMaskTab = g["sRet"], g["sStagePC"], g["sTrack"], g["sWindow"], g["sMaskTab"]
     row_bases, fetch_row, load_masks, load_row_masks, sCmp = g["row_bases"], g["fetch_row"], g["load_masks"], g["load_row_masks"], g["sCmp"]
+    prefetch_terms, sRingMask, sRing0 = g["prefetch_terms"], g["sRingMask"], g["sRing0"]
     sNxt = S(90, 2)                            # band (first, last column) of the diagonal above the current one
 
     for kk in (0, 1, 2):
@@ -1434,14 +1459,67 @@ def backward_loop(k, v):
         k.forget()
         k.label(lbl("refresh%d" % kk))
         k.salu("s_mov_b32", sRefCnt, 9)
-        k.salu("s_mul_i32", sA[0], sNTot, 5 * P * 8)
+        pool.hold(*fb)
+        # its terms (diagonalCalculationTotalProbability, :736-754): per cell of t, v = F(t) . B(t); per cell of t + 1,
+        # w = the match transitions from the cell below-left on t - 1 into it, times B.match(t + 1) -- the ring values
+        # were fetched to LDS a refresh ago; the slot below is the layer before on the same lane, for layer 0 the last
+        # layer of the lane before (whatever a slot outside the band of t - 1 holds is -inf: the forward sweep's guard slots)
+        vPrev = pool.take(2)
+        k.valu("v_add_u32_e32", vPrev.lo, 1008, vOff16)
+        k.valu("v_and_b32_e32", vPrev.lo, 1023, vPrev.lo)
+        k.valu("v_add_u32_e32", vPrev.hi, vOff16, vOff8)       # 24 * lane: a lane's three terms lie together
+        xyT = [pool.take(4) for _ in range(L)]
+        for j in range(L):
+            k.ds_read(128, xyT[j], vOff16, LDS_RF_XY_T + j * 1024)
+        mB, xyB = [pool.take(2) for _ in range(L)], [pool.take(4) for _ in range(L)]
+        for j in range(L):
+            a, lay = (vOff16, j - 1) if j else (vPrev.lo, L - 1)
+            k.ds_read(64, mB[j], a, LDS_RF_MP_B + lay * 1024)
+            k.ds_read(128, xyB[j], a, LDS_RF_XY_B + lay * 1024)
+        out = [pool.take(3 * 2), pool.take(3 * 2)]
+        a1, a2 = [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)]
+        for j in range(L):
+            k.add(a1[j], xyT[j].sub(0, 2), BX[j])
+            k.add(a2[j], xyT[j].sub(2, 2), BY[j])
+        pool.give(*xyT)
+        r = [k.ladd_front(fb[j], a1[j]) for j in range(L)]
+        for j in range(L):
+            k.ladd_back(r[j], a1[j], s7p5)
+        r = [k.ladd_front(a1[j], a2[j]) for j in range(L)]
+        for j in range(L):
+            k.ladd_back(r[j], out[0].sub(2 * j, 2), s7p5)
+        pool.give(*a1)
+        pool.give(*a2)
+        hp = pool.take(2)
+        m0_, m1_, m2_ = [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)]
+        for j in range(L):
+            k.add(hp, PMB[k1][j], sTMM)
+            k.add(m0_[j], mB[j], hp)
+            k.add(hp, PMB[k1][j], sTXM)
+            k.add(m1_[j], xyB[j].sub(0, 2), hp)
+            k.add(hp, PMB[k1][j], sTYM)
+            k.add(m2_[j], xyB[j].sub(2, 2), hp)
+        pool.give(hp, *mB)
+        pool.give(*xyB)
+        r = [k.ladd_front(m0_[j], m1_[j]) for j in range(L)]
+        for j in range(L):
+            k.ladd_back(r[j], m0_[j], s7p5)
+        r = [k.ladd_front(m0_[j], m2_[j]) for j in range(L)]
+        for j in range(L):
+            k.ladd_back(r[j], m1_[j], s7p5)
+        for j in range(L):
+            k.add(out[1].sub(2 * j, 2), m1_[j], M[k1][j])
+        pool.give(*m0_)
+        pool.give(*m1_)
+        pool.give(*m2_)
+        k.salu("s_mul_i32", sA[0], sNTot, 2 * P * 8)
         k.add64(sAp(4), sRf, sA[0])
-        k.add64(sAp(6), sAp(4), 4096)
-        vals = [M[kk], BX, BY, M[k1], PMB[k1]]
-        for q in range(5):
-            for j in range(L):
-                off = (q * L + j) * 512
-                k.gstore(2, vOff8, vals[q][j], sAp(4) if off < 4096 else sAp(6), off % 4096)
+        for f in range(2):
+            if "NOSTORE" not in ABLATE:
+                k.gstore(4, vPrev.hi, out[f].sub(0, 4), sAp(4), f * P * 8)
+                k.gstore(2, vPrev.hi, out[f].sub(4, 2), sAp(4), f * P * 8 + 16)
+        pool.give(vPrev, *out)
+        pool.give(*fb)
         pool.hold(*fb)
         rec = [pool.take(4), pool.take(4)]
         k.salu("s_mov_b64", "exec", 1)
@@ -1459,6 +1537,8 @@ def backward_loop(k, v):
         k.salu("s_add_u32", sNTot, sNTot, 1)
         pool.give(*rec)
         pool.give(*fb)
+        k.salu("s_sub_u32", sA[8], sTd, 10)
+        prefetch_terms(sA[8])
         k.branch("s_branch", lbl("refreshed%d" % kk))
 
     # ------------------------------------------------------------------ the loop pauses: end of the window, the diagonal

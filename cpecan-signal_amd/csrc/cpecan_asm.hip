@@ -124,8 +124,8 @@ extern "C" __global__ void cpecan_k_asm_masks(const DevItem *items, long long nI
     const int lo = bandTab[2 * (it.diagBase + d)], hi = bandTab[2 * (it.diagBase + d) + 1];
     unsigned long long m[ASM_L], g[ASM_L];
     for (int j = 0; j < ASM_L; j++) m[j] = g[j] = 0ull;
-    for (int x = lo > 0 ? lo - 1 : 0; x <= hi + 1; x++) {
-        const int s = x % (64 * ASM_L);
+    for (int x = lo - 1; x <= hi + 1; x++) { /* (column -1: the last slot, parked while the band starts at column 0) */
+        const int s = (x + 64 * ASM_L) % (64 * ASM_L);
         g[s % ASM_L] |= 0xFFFFull << ((s / ASM_L) & ~15); /* whole 128-byte lines of the 8-byte values: no partial writes */
         if (x >= lo && x <= hi) m[s % ASM_L] |= 1ull << (s / ASM_L);
     }

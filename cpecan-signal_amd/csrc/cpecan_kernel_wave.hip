@@ -1726,78 +1726,6 @@ WV_BACKWARD_KERNEL(cpecan_k_wv_backward_em_sw, true, WV_KIND_EXPECT)
  *     whose candidates cannot be trusted (a total strays from the forward kernel's estimate, the list overflowed,
  *     threshold 0) is left to the re-sweep kernel.
  */
-#if !defined(WV_VANILLA) && !defined(WV_HDP)
-/*
- * Phase T0 after the assembly sweep back, which only parks the operands: the per-cell terms of one totalProbability
- * refresh per wave (grid: refreshes x alignments), lanes in the sweep's slots.  diagonalCalculationTotalProbability
- * (:736-754): v = cell_dotProduct(forward[t], backward[t]) and w = matches stepping over t: forward[t-1] --match--> the
- * cells of t+1, dotted with backward[t+1] -- the same terms as phase T0 of backward_window().  Thousands of independent
- * waves: the loads of one hide behind the arithmetic of the others, beside the next window's forward sweep.
- */
-extern "C" __global__ __launch_bounds__(64) void WV_SYM(cpecan_k_wv_terms)(
-    const DevItem *__restrict__ items, long long nItems, const int2 *__restrict__ bandTabAll,
-    const double *__restrict__ models, const double *__restrict__ Fring, long long ringDoubles, int ringD,
-    const WvState *states, char *scratch, long long scratchBytes, int window) {
-    constexpr int L = WV_L;
-    __shared__ double coef[64];
-    const long long idx = blockIdx.y;
-    if (idx >= nItems) return;
-    const WvWindow *wp = &states[idx].win[window & 1];
-    if (uni(wp->valid) != 3) return;
-    const int i = blockIdx.x;
-    if (i >= uni(wp->nRefresh)) return;
-    const int lane = threadIdx.x;
-    init_coef(coef);
-    const unsigned cf = lds_addr(coef);
-    const DevItem it = uniform_item(items[idx]);
-    const int2 *bandTab = bandTabAll + it.diagBase;
-    char *sc = scratch + idx * scratchBytes;
-    const long long nW = (long long) ringD / 10 + 8;
-    const WinTotal *wtot = (const WinTotal *) (sc + 2ll * ringD * sizeof(int));
-    double *vw = (double *) (sc + 2ll * ringD * sizeof(int) + nW * sizeof(WinTotal));
-    const double *rf = vw + nW * 2 * WV_P;
-    const double *ring = Fring + idx * ringDoubles;
-    const int ringMask = ringD - 1;
-    const double *model = models + (long long) it.model * WV_MODEL_DOUBLES;
-    const double tMM = model[T_MATCH_CONTINUE], tXM = model[T_MATCH_FROM_GAP_X], tYM = model[T_MATCH_FROM_GAP_Y];
-    const WinTotal *w = wtot + i;
-    const int t = uni(w->t), xmn = uni(w->xmin), xmx = uni(w->xmax), nmn = uni(w->nxmin), nmx = uni(w->nxmax);
-    const bool second = uni(w->second) != 0;
-    const int2 pb = bandTab[t - 1 > 0 ? t - 1 : 0];
-    const int pxmin = uni(pb.x), pxmax = uni(pb.y);
-    const double *rowT = ring + (long long) (t & ringMask) * WV_ROW_DOUBLES;
-    const double *rowB = ring + (long long) ((t - 1) & ringMask) * WV_ROW_DOUBLES;
-    const double *src = rf + (long long) i * (5 * WV_P) + lane;
-#pragma unroll
-    for (int j = 0; j < L; j++) {
-        const int sl = lane * L + j, sMin = xmn % WV_P, sMinN = nmn % WV_P;
-        const int xT = xmn + (sl - sMin + (sl < sMin ? WV_P : 0));   /* this slot's k-mer on t ... */
-        const int xN = nmn + (sl - sMinN + (sl < sMinN ? WV_P : 0)); /* ... and on t+1 */
-        const bool tv = xT <= xmx, nv = second && xN <= nmx;
-        const bool below = nv && xN - 1 >= pxmin && xN - 1 <= pxmax;
-        const int sb = sl == 0 ? WV_P - 1 : sl - 1; /* the slot of the k-mer below */
-        if (tv) {
-            const double *pa = rowT + j * WV_LAYER_DOUBLES;
-            double v = pa[WV_OFF_FM(lane)] + src[(0 * L + j) * 64];
-            v = ladd(v, pa[WV_OFF_FX(lane)] + src[(1 * L + j) * 64], cf);
-            v = ladd(v, pa[WV_OFF_FY(lane)] + src[(2 * L + j) * 64], cf);
-            vw[((long long) i * 2 + 0) * WV_P + sl] = v;
-        }
-        if (nv) {
-            const double *pbw = rowB + (below ? sb % L : 0) * WV_LAYER_DOUBLES;
-            const int lb = below ? sb / L : 0;
-            const double s0 = below ? pbw[WV_OFF_FM(lb)] : CP_NEG_INF, s1 = below ? pbw[WV_OFF_FX(lb)] : CP_NEG_INF,
-                         s2 = below ? pbw[WV_OFF_FY(lb)] : CP_NEG_INF;
-            const double hp = src[(4 * L + j) * 64];
-            double mm = s0 + (hp + tMM);
-            mm = ladd(mm, s1 + (hp + tXM), cf);
-            mm = ladd(mm, s2 + (hp + tYM), cf);
-            vw[((long long) i * 2 + 1) * WV_P + sl] = mm + src[(3 * L + j) * 64];
-        }
-    }
-}
-#endif
-
 struct PostShared {
     double coef[64];
     double vbuf[256];
@@ -2482,16 +2410,14 @@ extern "C" int WV_SYM(cpecan_wave_launch_backward)(hipStream_t stream, const Dev
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 #if !defined(WV_VANILLA) && !defined(WV_HDP)
-/* what follows the assembly sweep back of a window (cpecan_asm.h): the refreshes' terms from the operands it parked, the
- * totals, the decode; then the re-sweep kernel for the windows whose candidates could not be trusted */
+/* what follows the assembly sweep back of a window (cpecan_asm.h), which leaves the refreshes' terms and the decode
+ * candidates in scratch as the compiled sweep does: the totals, the decode; then the re-sweep kernel for the windows
+ * whose candidates could not be trusted */
 extern "C" int WV_SYM(cpecan_wave_launch_post_asm)(hipStream_t stream, const DevItem *items, long long nItems, DevParams P,
                                                    const void *bandTab, const double *track, const long long *trackBase,
                                                    const double *models, double *Fring, long long ringDoubles, int ringD,
                                                    void *states, long long *pairs, double *pairLogp, long long *totXay,
                                                    double *totVal, char *scratch, long long scratchBytes, int window) {
-    hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_terms), dim3((unsigned) (ringD / 10 + 8), (unsigned) nItems), dim3(64), 0, stream, items,
-                       nItems, (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD,
-                       (const WvState *) states, scratch, scratchBytes, window);
     hipLaunchKernelGGL(WV_SYM(cpecan_k_wv_post), dim3((unsigned) nItems), dim3(256), 0, stream, items, nItems, P,
                        (const int2 *) bandTab, models, (const double *) Fring, ringDoubles, ringD, (WvState *) states, pairs,
                        pairLogp, totXay, totVal, scratch, scratchBytes, window, 0);

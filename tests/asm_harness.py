@@ -260,6 +260,18 @@ class Image:
         base = self.a_ring + item * self.ring_doubles * 8 + (d & (self.ringD - 1)) * G.ROW_BYTES
         return self.mem.get(base, np.float64, G.ROW_DOUBLES)
 
+    def refreshes(self, item, n):
+        """the first n refresh records of the window just swept back and their terms: [(t, xmin, xmax, nxmin, nxmax,
+        second, v[P], w[P])], terms by slot"""
+        base = self.a_scratch + item * self.scratch_bytes + 2 * self.ringD * 4
+        nw = self.ringD // 10 + 8
+        out = []
+        for i in range(n):
+            r = self.mem.get(base + 32 * i, np.int32, 8)
+            vw = self.mem.get(base + 32 * nw + i * 2 * P * 8, np.float64, 2 * P)
+            out.append((int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5]), vw[:P].copy(), vw[P:].copy()))
+        return out
+
     def state(self, item):
         raw = self.mem.get(self.a_states + item * STATE_BYTES, np.uint8, STATE_BYTES)
         i32 = raw.view(np.int32)
@@ -281,7 +293,7 @@ def mask_table(xmin, xmax):
     for d in range(len(xmin)):
         m, g = [0] * L, [0] * L
         lo, hi = int(xmin[d]), int(xmax[d])
-        for x in range(max(lo - 1, 0), hi + 2):
+        for x in range(lo - 1, hi + 2):         # (column -1: the last slot, parked while the band starts at column 0)
             lane, j = (x % P) // L, (x % P) % L
             g[j] |= 0xFFFF << (lane & ~15)   # whole 128-byte lines of the 8-byte values (16 lanes): no partial writes
             if lo <= x <= hi:
