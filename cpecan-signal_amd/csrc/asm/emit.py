@@ -127,6 +127,13 @@ class Emitter:
                 self._ins("s_waitcnt %s(%d)" % (name, left), "wait")
                 del q[: last + 1]
 
+    def need(self, *vs):
+        """One wait for several results that are about to be used one after the other (each wait is an instruction)."""
+        regs = set()
+        for v in vs:
+            regs |= vregs_of(v)
+        self._need(regs)
+
     def wait_lgkm(self, left=0):
         if len(self.lgkm) > left:
             self._ins("s_waitcnt lgkmcnt(%d)" % left, "wait")
@@ -208,23 +215,25 @@ class Emitter:
             for r in vregs_of(data):
                 self.store_r[r] = self.n - 1
 
+    mods = ""                                # cache policy modifiers of the loads and stores that follow (" nt", ...)
+
     def gload(self, dwords, dst, voff, sbase, offset=0):
         """global_load with a scalar base and a 32-bit vector offset (or a 64-bit vector address and 'off')."""
         self._touch(vregs_of(voff), vregs_of(dst))
         op = {1: "global_load_dword", 2: "global_load_dwordx2", 4: "global_load_dwordx4"}[dwords]
-        self._ins("%s %s, %s, %s%s" % (op, dst, voff, sbase, " offset:%d" % offset if offset else ""), "vmem")
+        self._ins("%s %s, %s, %s%s%s" % (op, dst, voff, sbase, " offset:%d" % offset if offset else "", self.mods), "vmem")
         self.vm.append(vregs_of(dst))
 
     def gload_lds(self, voff, sbase):
         """global_load_lds_dwordx4: every lane's 16 bytes at sbase + voff go to LDS at M0 + 16 * lane (counted by vmcnt)."""
         self._touch(vregs_of(voff), set())
-        self._ins("global_load_lds_dwordx4 %s, %s" % (voff, sbase), "vmem")
+        self._ins("global_load_lds_dwordx4 %s, %s%s" % (voff, sbase, self.mods), "vmem")
         self.vm.append(set())
 
     def gstore(self, dwords, voff, data, sbase, offset=0):
         self._touch(vregs_of(voff) | vregs_of(data), set())
         op = {1: "global_store_dword", 2: "global_store_dwordx2", 4: "global_store_dwordx4"}[dwords]
-        self._ins("%s %s, %s, %s%s" % (op, voff, data, sbase, " offset:%d" % offset if offset else ""), "vmem")
+        self._ins("%s %s, %s, %s%s%s" % (op, voff, data, sbase, " offset:%d" % offset if offset else "", self.mods), "vmem")
         self.vm.append(set())
         if dwords > 2:
             for r in vregs_of(data):

@@ -128,9 +128,11 @@ class Kernel(Emitter):
         t = c32.sub(0, 2)
         self.add(t, d, d)
         self.valu("v_ceil_f64_e32", t, t)
+        # n = ceil(2 d) picks the table row: added to 2^47 it lands in the sum's low word times 32, the row's byte
+        # offset (a difference of 2^26 or more, or infinite, gives an offset beyond the table: the row read there is not
+        # used, d >= 7.5; NaN -- both operands -inf -- gives 0)
         a = c10.lo
-        self.valu("v_cvt_i32_f64_e32", a, t)
-        self.valu("v_lshlrev_b32_e32", a, 5, a)
+        self.add(c10.sub(0, 2), t, self.magic)
         if "COEF0" in ABLATE:
             self.valu("v_mov_b32_e32", a, 0)
         if "NOLDS" in ABLATE:
@@ -156,10 +158,14 @@ class Kernel(Emitter):
         self.mul(r, r, d)
         self.add(r, r, c10.sub(2, 2))
         self.add(r, r, lo)
-        self.valu("v_cmp_gt_f64_e32", "vcc", s7p5, d)
+        self.valu("v_cmp_gt_f64_e32", "vcc", "0x401e0000", d)       # 7.5 > d
         self.valu("v_cndmask_b32_e32", dst.lo, hi.lo, r.lo, "vcc")
         self.valu("v_cndmask_b32_e32", dst.hi, hi.hi, r.hi, "vcc")
         self.pool.give(hi, lo, d, c32, c10)
+
+    def need_recs(self, recs):
+        """the table rows of a group of logAdds whose second halves follow: one wait"""
+        self.need(*[r[4] for r in recs], *[r[3] for r in recs])
 
     # ---- log N(x; mu, sd) = K - (a / 2) a, a = (x - mu) / sd as a Markstein-corrected multiply by RN(1 / sd) (lgauss())
     def gauss(self, dst, x, mu, sd, rsd, K, t0, t1):
@@ -401,7 +407,8 @@ def forward_kernel(name):
     k.valu("v_lshlrev_b32_e32", vOff16, 4, V(0))          # (v0 is vOff16 from here on)
     k.ds_write(64, vOff8, tq, LDS_COEF)
     pool.give(tq)
-    k.s_mov64_lit(s7p5, dbits(7.5))
+    k.s_mov64_lit(s7p5, dbits(2.0 ** 47))
+    k.magic = s7p5
     k.s_mov64_lit(sNinf, dbits(float("-inf")))
     # every event of the LDS ring reads as (0, 0) until it is staged: a parked slot scores whatever its stale address
     # points at, and that has to be a number
@@ -479,10 +486,12 @@ def forward_kernel(name):
     def step(p):
         """Diagonal sD of parity p: X[p] holds the diagonal before last and receives this one, X[1-p] the last one."""
         q = 1 - p
+        k.mods = " nt" if "NT" in ABLATE else ""
         k.drain_lgkm()       # this diagonal's store masks (asked for a diagonal ago); the events are in too
         pend = []
         k.salu("s_add_u32", sD, sD, 1)
-        load_store_masks(q)  # the next diagonal's
+        if "NOMASKF" not in ABLATE:
+            load_store_masks(q)  # the next diagonal's
         k.salu("s_sub_u32", sD, sD, 1)
         k.lgkm = []          # (waited for at the top of the next step)
         k.salu("s_bitcmp1_b64", sFull, sD)
@@ -530,6 +539,7 @@ def forward_kernel(name):
             k.add(b, middle(j, 1), b)
             bsum.append(b)
         # P3: gap X done
+        k.need_recs(recs)
         for j in range(L):
             k.ladd_back(recs[j], Xx(p, j), s7p5)
         # P4: match from the middle cell, first two terms
@@ -556,6 +566,7 @@ def forward_kernel(name):
             csum.append(cc)
         masked_store(sMaskS[p][L - 1], 2, vOff8, PY[L - 1], (L - 1) * LAYER_BYTES + OFF_PY)
         # P6
+        k.need_recs(recs)
         for j in range(L):
             k.ladd_back(recs[j], Xm(p, j), s7p5)
         # P7: gap Y from the upper cell
@@ -574,6 +585,7 @@ def forward_kernel(name):
             k.valu("v_add_u32_e32", E[j].lo, sDmod, vEvSlot[j])
             k.ds_read(128, E[j], E[j].lo)
         # P9 (on a diagonal the sweep back reads all three states of, the gap states leave too)
+        k.need_recs(recs)
         for j in range(L):
             k.ladd_back(recs[j], Xy(p, j), s7p5)
             masked_store(sMaskS[p][j], 4, vOff16, V(Xx(p, j).i, 4), j * LAYER_BYTES + OFF_FXY, gate=sFullM)
@@ -585,6 +597,7 @@ def forward_kernel(name):
         k.ror64(R[p].sub(2, 2), Xx(p, L - 1))
         k.ror64(R[p].sub(4, 2), Xy(p, L - 1))
         # P11: (Fm, pm) leave as they are finished; the match cells of layer L-1 go up a lane
+        k.need_recs(recs)
         for j in range(L):
             k.ladd_back(recs[j], Xm(p, j), s7p5)
             if j:
@@ -1138,7 +1151,8 @@ def backward_kernel(name):
     k.valu("v_lshlrev_b32_e32", vOff16, 4, V(0))
     k.ds_write(64, vOff8, tq, LDS_COEF)
     pool.give(tq)
-    k.s_mov64_lit(s7p5, dbits(7.5))
+    k.s_mov64_lit(s7p5, dbits(2.0 ** 47))
+    k.magic = s7p5
     k.s_mov64_lit(sNinf, dbits(float("-inf")))
     # the gap-X sums of the slots at the traceback point are the forward wave's (a parked slot holds -inf)
     k.add64(sAp(8), sAp(8), 8 * 1024)
@@ -1268,6 +1282,7 @@ def backward_kernel(name):
 
 def backward_loop(k, v):
     g = dict(v)
+    k.mods = " nt" if "NT" in ABLATE or "NTB" in ABLATE else ""
     name, pool, lbl = g["name"], g["pool"], g["lbl"]
     M, BX, BY, UM, UY, T, PYB, PX, RP = g["M"], g["BX"], g["BY"], g["UM"], g["UY"], g["T"], g["PYB"], g["PX"], g["RP"]
     PMB = g["PMB"]
@@ -1323,7 +1338,8 @@ def backward_loop(k, v):
         # the band of t - 2 (into the registers of t + 1's, whose columns the tail still wants), then the ring row of t - 1
         k.salu("s_mov_b64", sNxt, SM[k1].sub(6, 2))
         k.salu("s_sub_u32", sA[1], sTd, 2)
-        load_masks(k1, sA[1])
+        if "NOMASKB" not in ABLATE:
+            load_masks(k1, sA[1])
         k.salu("s_sub_u32", sA[1], sTd, 2)
         row_bases(sA[1])
         # (t + 1, same slot) upper block, then (t + 1, slot + 1) lower block -- the reference's scatter order per state;
@@ -1332,28 +1348,29 @@ def backward_loop(k, v):
         ra, rb = [], []
         for j in range(L):
             ra.append(k.ladd_front(bmin[j], UM[j], free=(bmin[j],)))
+            rb.append(k.ladd_front(byin[j], UY[j], free=(byin[j],)))
             k.salu("s_mov_b64", "exec", sLm[j])
             off = j * LAYER_BYTES
             if "NOLOAD" not in ABLATE:
                 k.gload(4, T[k1][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
-            k.salu("s_mov_b64", "exec", -1)
-        for j in range(L):
-            rb.append(k.ladd_front(byin[j], UY[j], free=(byin[j],)))
-            k.salu("s_mov_b64", "exec", sLm[j])
-            off = j * LAYER_BYTES + OFF_PY
-            if "NOLOAD" not in ABLATE:
+                off += OFF_PY
                 k.gload(2, PYB[k1][j], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
             k.salu("s_mov_b64", "exec", -1)
         k.salu("s_sub_u32", sA[1], sTd, 3)
-        load_row_masks(sA[1])
+        if "NOMASKB" not in ABLATE:
+            load_row_masks(sA[1])
+        k.need_recs(ra)
         for j in range(L):
             k.ladd_back(ra[j], M[kk][j], s7p5)
         rc = [k.ladd_front(bxin[j], y1[j], free=(bxin[j], y1[j])) for j in range(L)]
+        k.need_recs(rb)
         for j in range(L):
             k.ladd_back(rb[j], BY[j], s7p5)
         rd = [k.ladd_front(M[kk][j], y2[j], free=(y2[j],)) for j in range(L)]
+        k.need_recs(rc)
         for j in range(L):
             k.ladd_back(rc[j], BX[j], s7p5)
+        k.need_recs(rd)
         for j in range(L):
             k.ladd_back(rd[j], M[kk][j], s7p5)
         # ------------------------------------------------------------ tail: what diagonal t hands down, its candidates
@@ -1483,9 +1500,11 @@ def backward_loop(k, v):
             k.add(a2[j], xyT[j].sub(2, 2), BY[j])
         pool.give(*xyT)
         r = [k.ladd_front(fb[j], a1[j]) for j in range(L)]
+        k.need_recs(r)
         for j in range(L):
             k.ladd_back(r[j], a1[j], s7p5)
         r = [k.ladd_front(a1[j], a2[j]) for j in range(L)]
+        k.need_recs(r)
         for j in range(L):
             k.ladd_back(r[j], out[0].sub(2 * j, 2), s7p5)
         pool.give(*a1)
@@ -1502,9 +1521,11 @@ def backward_loop(k, v):
         pool.give(hp, *mB)
         pool.give(*xyB)
         r = [k.ladd_front(m0_[j], m1_[j]) for j in range(L)]
+        k.need_recs(r)
         for j in range(L):
             k.ladd_back(r[j], m0_[j], s7p5)
         r = [k.ladd_front(m0_[j], m2_[j]) for j in range(L)]
+        k.need_recs(r)
         for j in range(L):
             k.ladd_back(r[j], m1_[j], s7p5)
         for j in range(L):

@@ -133,6 +133,8 @@ def parse(text):
                 elif "(" in w:
                     kk, vv = w.split("(")
                     mods[kk] = int(vv.rstrip(")"), 0)
+                elif w in ("nt", "sc0", "sc1"):
+                    mods[w] = 1                      # (cache policy: nothing to emulate)
                 else:
                     keep.append(w)
             if keep:
@@ -239,6 +241,9 @@ class Wave:
         return u
 
     def rdf64(self, op):
+        if op.kind == "int" and not -16 <= op.val <= 64:
+            # a 32-bit literal as a 64-bit float operand is the value's high half
+            return _f64(np.full(64, (op.val & 0xFFFFFFFF) << 32, U64))
         return _f64(self.rd64(op))
 
     def wr32(self, op, val, masked=True):
