@@ -494,8 +494,6 @@ def forward_kernel(name):
             load_store_masks(q)  # the next diagonal's
         k.salu("s_sub_u32", sD, sD, 1)
         k.lgkm = []          # (waited for at the top of the next step)
-        k.salu("s_bitcmp1_b64", sFull, sD)
-        k.salu("s_cselect_b64", sFullM, -1, 0)
         # band edges: the k-mer that leaves first (its slot is parked), then the one that enters
         k.salu("s_bitcmp1_b64", sStepMin, sD)
         if "NOEVENTS" not in ABLATE:
@@ -584,11 +582,14 @@ def forward_kernel(name):
         for j in range(L):
             k.valu("v_add_u32_e32", E[j].lo, sDmod, vEvSlot[j])
             k.ds_read(128, E[j], E[j].lo)
-        # P9 (on a diagonal the sweep back reads all three states of, the gap states leave too)
+        # P9 (on a diagonal the sweep back reads all three states of, the gap states leave too: out of line, one diagonal
+        # in ten -- a store under an empty EXEC holds the wave up as long as any other)
         k.need_recs(recs)
         for j in range(L):
             k.ladd_back(recs[j], Xy(p, j), s7p5)
-            masked_store(sMaskS[p][j], 4, vOff16, V(Xx(p, j).i, 4), j * LAYER_BYTES + OFF_FXY, gate=sFullM)
+        k.salu("s_bitcmp1_b64", sFull, sD)
+        k.branch("s_cbranch_scc1", lbl("full%d" % p))
+        k.label(lbl("fulled%d" % p))
         # P10: the match cell's third term
         recs = []
         for j in range(L):
@@ -623,6 +624,13 @@ def forward_kernel(name):
     k.branch("s_branch", lbl("even"))
 
     # ------------------------------------------------------------------ out of line: band edges, full rows
+    for p in range(2):
+        # a diagonal whose gap states go to the ring too
+        k.forget()
+        k.label(lbl("full%d" % p))
+        for j in range(L):
+            masked_store(sMaskS[p][j], 4, vOff16, V(X[p][j].i + 4, 4), j * LAYER_BYTES + OFF_FXY)
+        k.branch("s_branch", lbl("fulled%d" % p))
     for p in range(2):
         # the k-mer at the band's low end leaves: its slot scores -inf from now on (K1, K2 of both tables, the gap-X sums)
         k.forget()

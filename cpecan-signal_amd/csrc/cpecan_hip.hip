@@ -1508,7 +1508,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         lap("state, scratch, track allocation");
         /* the hand-scheduled assembly sweeps take the strawMan machine's posterior batches whose bands need three cells
          * per lane and fit their staging scheme (CPECAN_ASM=0: the compiled kernels, for tests and timing) */
-        static const bool asmOff = getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 0;
+        const bool asmOff = getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 0; /* (read per batch) */
         if (wantPlan && !asmOff && b->sy->wave && b->sy->rows == ASM_L && globalMaxWidth <= ASM_MAX_WIDTH && b->nGroups == 1 &&
             b->stateBytes == (int) sizeof(WvState) && cpecan_asm_load(c->device) == 0) {
             b->asmMaxWindows = std::max(maxWindows, 1);

@@ -31,7 +31,9 @@ def batch():
 def result(ctx, batch):
     bp = band_params(0.01, 1000, 40, 100)
     res, b = run_gpu(ctx, batch, bp, ragged=(1, 1))
-    assert b.info()["kernel"] == "systolic"
+    info = b.info()
+    assert info["kernel"] == "systolic" and info["family"] == "wave"
+    assert info["assembly_sweeps"] == 2  # a batch of this shape runs the hand-scheduled forward and backward sweeps
     b.close()
     return bp, res
 
@@ -109,6 +111,33 @@ def test_two_reads_against_the_oracle(batch, result):
         ref = run_oracle_item(batch, i, bp, (1, 1))
         assert_same_pairs(res[i], ref)
         assert np.array_equal(res[i]["totals"], ref["totals"]) and res[i]["cells"] == ref["cells"]
+
+
+def test_two_reads_on_the_workgroup_family_against_the_oracle(ctx, batch):
+    # the kernels pipelined batches and the two-context E-step run on (CPECAN_FLAG_WORKGROUP_KERNELS), at full read size
+    bp = band_params(0.01, 1000, 40, 100)
+    sub = dict(batch, items=[batch["items"][1], batch["items"][N - 2]])
+    res, b = run_gpu(ctx, sub, bp, flags=cp.FLAG_WORKGROUP_KERNELS, ragged=(1, 1))
+    assert b.info()["kernel"] == "systolic" and b.info()["family"] == "workgroup"
+    b.close()
+    for k, i in enumerate((1, N - 2)):
+        ref = run_oracle_item(batch, i, bp, (1, 1))
+        assert_same_pairs(res[k], ref)
+        assert np.array_equal(res[k]["totals"], ref["totals"]) and res[k]["cells"] == ref["cells"]
+
+
+def test_two_reads_on_the_compiled_wave_kernels_against_the_oracle(ctx, batch, monkeypatch):
+    # CPECAN_ASM=0: the compiled wave kernels, which every batch the assembly sweeps do not take runs on
+    monkeypatch.setenv("CPECAN_ASM", "0")
+    bp = band_params(0.01, 1000, 40, 100)
+    sub = dict(batch, items=[batch["items"][2], batch["items"][N - 3]])
+    res, b = run_gpu(ctx, sub, bp, ragged=(1, 1))
+    assert b.info()["family"] == "wave" and b.info()["assembly_sweeps"] == 0
+    b.close()
+    for k, i in enumerate((2, N - 3)):
+        ref = run_oracle_item(batch, i, bp, (1, 1))
+        assert_same_pairs(res[k], ref)
+        assert np.array_equal(res[k]["totals"], ref["totals"]) and res[k]["cells"] == ref["cells"]
 
 
 def test_idempotent_and_kernels_agree(ctx, batch, result):

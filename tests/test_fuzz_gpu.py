@@ -39,15 +39,21 @@ def cases(n, seed):
     return out
 
 
+@pytest.mark.parametrize("family", [0, cp.FLAG_WORKGROUP_KERNELS], ids=["wave", "workgroup"])
 @pytest.mark.parametrize("case", cases(40 * SCALE, 20251004), ids=lambda c: "s%d" % c["seed"])
-def test_random_case(ctx, case):
+def test_random_case(ctx, case, family):
+    """every case on both families of register-resident kernels (one wave / one workgroup per alignment)"""
     batch = synth.make_batch(case["seed"], 2, case["lX"], case["lY"], anchor_every=case["every"])
     bp = band_params(case["thr"], case["md"], case["tb"], case["e"])
-    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_AUTO, ragged=case["ragged"])
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_AUTO, flags=family, ragged=case["ragged"])
     info = b.info()
     if info["kernel"] == "systolic":
         w = info["max_band_width"]
-        assert info["waves_per_workgroup"] == 2 + (w > 120) + (w > 184)
+        assert info["family"] == ("workgroup" if family else "wave")
+        if family:  # the fewest waves that hold the band: 1, 2, 3, 4 for bands up to 56, 120, 184, 248 k-mers
+            assert info["waves_per_workgroup"] == 1 + (w > 56) + (w > 120) + (w > 184)
+        else:       # the fewest cells per lane from 2
+            assert info["waves_per_workgroup"] == 2 + (w > 120) + (w > 184)
     b.close()
     for i in range(2):
         ref = run_oracle_item(batch, i, bp, case["ragged"])

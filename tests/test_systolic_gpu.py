@@ -49,14 +49,33 @@ def rows(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=[0, cp.FLAG_WORKGROUP_KERNELS], ids=["wave", "workgroup"])
+def family(request):
+    """the two families of register-resident kernels, each against the oracle: one wave per alignment (the default;
+    its C3-shaped batches run the assembly sweeps) and one workgroup per alignment (CPECAN_FLAG_WORKGROUP_KERNELS: what
+    pipelined batches and the two-context E-step run on)"""
+    return request.param
+
+
+def expected_build(family, rows, width):
+    """waves_per_workgroup of the build the library picks by itself: the workgroup family takes the fewest waves that
+    hold the band (1, 2, 3, 4 for bands up to 56, 120, 184, 248 k-mers), the wave family the fewest cells per lane
+    from 2 (bands up to 120, 184, 248)"""
+    if rows == 4:
+        return 4
+    if family == cp.FLAG_WORKGROUP_KERNELS:
+        return 1 + (width > 56) + (width > 120) + (width > 184)
+    return 2 + (width > 120) + (width > 184)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_systolic_matches_oracle(ctx, case, rows):
+def test_systolic_matches_oracle(ctx, case, rows, family):
     batch = synth.make_batch(21, case["n"], case["lX"], case["lY"], anchor_every=case["every"])
     bp = band_params(0.01, case["md"], case["tb"], case["e"])
-    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=case["ragged"])
-    width = b.info()["max_band_width"]
-    # the build with the fewest cells per lane that holds the band: 2, 3 or 4 (bands up to 120, 184, 248 k-mers)
-    assert b.info()["waves_per_workgroup"] == (4 if rows == 4 else 2 + (width > 120) + (width > 184))
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, flags=family, ragged=case["ragged"])
+    info = b.info()
+    assert info["family"] == ("workgroup" if family else "wave")
+    assert info["waves_per_workgroup"] == expected_build(family, rows, info["max_band_width"])
     for i in range(case["n"]):
         ref = run_oracle_item(batch, i, bp, case["ragged"])
         assert res[i]["cells"] == ref["cells"]
@@ -66,14 +85,14 @@ def test_systolic_matches_oracle(ctx, case, rows):
 
 
 @pytest.mark.parametrize("threshold", [0.0, 0.01, 1e-4, 1e-7])
-def test_systolic_decode_paths_agree(ctx, threshold, rows):
+def test_systolic_decode_paths_agree(ctx, threshold, rows, family):
     # the candidate-list decode (default) and the full-scan decode (CPECAN_FLAG_SCAN_DECODE, also the
     # path a window falls back to by itself; a tiny threshold makes long candidate lists, threshold 0 emits every
     # cell of the band with x, y > 0 and overflows the first pair allocation: the count-then-allocate re-run)
     batch = synth.make_batch(25, 3, 300, 620, anchor_every=50)
     bp = band_params(threshold, 100, 40, 60)
-    a, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=(1, 1))
-    s, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, flags=cp.FLAG_SCAN_DECODE, ragged=(1, 1))
+    a, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, flags=family, ragged=(1, 1))
+    s, _ = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, flags=family | cp.FLAG_SCAN_DECODE, ragged=(1, 1))
     for i, (x, y) in enumerate(zip(a, s)):
         assert np.array_equal(x["triples"], y["triples"])
         assert np.array_equal(x["logp"], y["logp"])
@@ -81,13 +100,13 @@ def test_systolic_decode_paths_agree(ctx, threshold, rows):
         assert_same_pairs(x, ref)
 
 
-def test_systolic_ragged_batch_and_degenerate_items(ctx):
+def test_systolic_ragged_batch_and_degenerate_items(ctx, family):
     batch = synth.make_batch(22, 12, 200, 400, anchor_every=40, length_sigma=0.6)
     base = batch["items"][0]
     batch["items"] += [dict(base, lX=0, n_anchors=0), dict(base, lY=0, n_anchors=0),
                        dict(base, lX=0, lY=0, n_anchors=0), dict(base, lX=1, lY=1, n_anchors=0)]
     bp = band_params(0.01, 100, 20, 60)
-    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, ragged=(1, 1))
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_SYSTOLIC, flags=family, ragged=(1, 1))
     for i in range(len(batch["items"])):
         ref = run_oracle_item(batch, i, bp, (1, 1))
         assert np.array_equal(res[i]["totals"], ref["totals"]), i
@@ -121,15 +140,16 @@ def test_too_wide_band_is_refused_by_systolic_and_routed_by_auto(ctx):
     dict(n=3, lX=400, lY=800, e=100, md=200, tb=40, every=50, ragged=(0, 0)),
     dict(n=2, lX=200, lY=410, e=30, md=12, tb=10, every=40, ragged=(1, 0)),
 ])
-def test_systolic_expectations_match_oracle(ctx, case, rows):
+def test_systolic_expectations_match_oracle(ctx, case, rows, family):
     # Baum-Welch sufficient statistics from the systolic kernels (forward, backward with the B ring,
     # element-wise expectation kernel) against the oracle and against the general kernel
     import pyoracle as o
     batch = synth.make_batch(27, case["n"], case["lX"], case["lY"], anchor_every=case["every"],
                              distinct_models=False)
     bp = band_params(0.01, case["md"], case["tb"], case["e"])
-    res, b = run_gpu(ctx, batch, bp, mode=cp.MODE_EXPECTATIONS, kernel=cp.KERNEL_SYSTOLIC, ragged=case["ragged"])
-    assert b.info()["kernel"] == "systolic"
+    res, b = run_gpu(ctx, batch, bp, mode=cp.MODE_EXPECTATIONS, kernel=cp.KERNEL_SYSTOLIC, flags=family,
+                     ragged=case["ragged"])
+    assert b.info()["kernel"] == "systolic" and b.info()["family"] == ("workgroup" if family else "wave")
     got = b.expectations(0)
     hmm = o.OrcExpectations()
     for i in range(case["n"]):
