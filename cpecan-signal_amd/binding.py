@@ -44,7 +44,7 @@ EXPORTS = [
     "cpecan_hip_batch_fetch_totals", "cpecan_hip_batch_expectations_device_ptr",
     "cpecan_hip_batch_fetch_expectations", "cpecan_hip_batch_debug_cells",
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
-    "cpecan_hip_batch_systolic_rows", "cpecan_hip_batch_kernel_family", "cpecan_hip_batch_assembly_sweeps", "cpecan_hip_models_set_transitions",
+    "cpecan_hip_batch_systolic_rows", "cpecan_hip_batch_kernel_family", "cpecan_hip_batch_assembly_sweeps", "cpecan_hip_trim_cache", "cpecan_hip_models_set_transitions",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
     "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
     "cpecan_hip_modelsh_create", "cpecan_hip_batch_create_hdp",
@@ -187,6 +187,12 @@ def device_count():
     n = C.c_int(0)
     rc = lib().cpecan_hip_device_count(C.byref(n))
     return n.value if rc == OK else 0
+
+
+def trim_cache():
+    """gives the device and pinned host memory the library keeps for reuse back to the runtime (between phases, when
+    something else in the process or on the card needs it)"""
+    _check(lib().cpecan_hip_trim_cache())
 
 
 def band_construct(anchors, lX, lY, expansion):

@@ -30,11 +30,14 @@ L = 3
 P = 64 * L
 
 # ---------------------------------------------------------------- memory formats shared with the C++ side (cpecan_asm.h)
-ROW_DOUBLES = L * 5 * 64                 # a ring row: per layer (Fm, pm) x 64 | py x 64 | (Fx, Fy) x 64
-ROW_BYTES = ROW_DOUBLES * 8
-LAYER_BYTES = 5 * 64 * 8
-OFF_PY = 128 * 8
-OFF_FXY = 192 * 8
+# a ring row (the layout of cpecan_kernel_wave.hip, WV_ROW_*): per layer (Fm, pm) x 64 | (Fx, Fy) x 64, then the gap-Y
+# emissions of the layers two by two: (py0, py1) x 64 | (py2, unused) x 64 -- every access is 16 bytes per lane
+LAYER_BYTES = 2 * 64 * 16
+OFF_FXY = 64 * 16
+OFF_PY = L * LAYER_BYTES                 # + 1024 per pair of layers
+ROW_BYTES = L * LAYER_BYTES + (L + 1) // 2 * 1024
+ROW_DOUBLES = ROW_BYTES // 8
+assert L == 3                            # (the pairing of the gap-Y emissions below is written for three layers)
 TRACK_ROW_BYTES = 20 * 8                 # a track row: 16 emission constants, gap-X sums (open, extend, switch), gap-X
 NCONST = 18                              # ... of which a slot keeps the first 18 doubles
 
@@ -280,7 +283,9 @@ def forward_kernel(name):
             if gate is None:
                 k.gstore(dwords, voff, data, sRow0 if off < 4096 else sRow1, off % 4096)
             return
-        if gate is None:
+        if isinstance(mask, tuple):
+            k.salu("s_or_b64", "exec", mask[0], mask[1])
+        elif gate is None:
             k.salu("s_mov_b64", "exec", mask)
         else:
             k.salu("s_and_b64", "exec", mask, gate)
@@ -554,15 +559,16 @@ def forward_kernel(name):
             k.gauss(PY[j], E[j].sub(0, 2), c[8 + CMU], c[8 + CSD], c[8 + CRSD], c[8 + CK1], g0, g1)
             k.gauss(g2, E[j].sub(2, 2), c[8 + CNMU], c[8 + CNSD], c[8 + CRNSD], c[8 + CK2], g0, g1)
             k.add(PY[j], PY[j], g2)
-            if j:            # (a store between stretches of arithmetic: stores issued back to back hold the wave up)
-                masked_store(sMaskS[p][j - 1], 2, vOff8, PY[j - 1], (j - 1) * LAYER_BYTES + OFF_PY)
+            if j == 2:       # (a store between stretches of arithmetic: stores issued back to back hold the wave up)
+                masked_store((sMaskS[p][0], sMaskS[p][1]), 4, vOff16, V(PY[0].i, 4), OFF_PY)
         pool.give(g0, g1, g2)
         for j in range(L):
             cc = pool.take(2)
             k.add(cc, Xpm(p, j), sTYM)
             k.add(cc, middle(j, 2), cc)
             csum.append(cc)
-        masked_store(sMaskS[p][L - 1], 2, vOff8, PY[L - 1], (L - 1) * LAYER_BYTES + OFF_PY)
+        # (the last layer's leave with the two registers after them, which hold a constant: 16 bytes per lane again)
+        masked_store(sMaskS[p][L - 1], 4, vOff16, V(PY[L - 1].i, 4), OFF_PY + 1024)
         # P6
         k.need_recs(recs)
         for j in range(L):
@@ -983,8 +989,10 @@ def backward_kernel(name):
     t0 = b0 + 8 * L
     T = [[V(t0 + 4 * L * q + 4 * j, 4) for j in range(L)] for q in range(3)]
     p0 = t0 + 12 * L
-    PYB = [[V(p0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]
-    q0 = p0 + 6 * L
+    # gap-Y emissions as the ring holds them: (py0, py1), (py2, unused)
+    PYB4 = [[V(p0 + 8 * q + 4 * h, 4) for h in range(2)] for q in range(3)]
+    PYB = [[V(p0 + 8 * q + 2 * j, 2) for j in range(L)] for q in range(3)]
+    q0 = p0 + 8 * 3
     PMB = [[V(q0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]  # match emissions, kept two diagonals longer
     pool0 = q0 + 6 * L
     pool = Pool(pool0, 255)
@@ -1229,8 +1237,11 @@ def backward_kernel(name):
             k.salu("s_mov_b64", "exec", masks[j])
             off = j * LAYER_BYTES
             k.gload(4, T[q][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
-            off += OFF_PY
-            k.gload(2, PYB[q][j], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
+            if j:
+                if j == 1:
+                    k.salu("s_or_b64", "exec", masks[0], masks[1])
+                off = OFF_PY + (j - 1) * 1024
+                k.gload(4, PYB4[q][j - 1], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
         k.salu("s_mov_b64", "exec", -1)
 
     def load_masks(q, dreg):
@@ -1293,7 +1304,7 @@ def backward_loop(k, v):
     k.mods = " nt" if "NT" in ABLATE or "NTB" in ABLATE else ""
     name, pool, lbl = g["name"], g["pool"], g["lbl"]
     M, BX, BY, UM, UY, T, PYB, PX, RP = g["M"], g["BX"], g["BY"], g["UM"], g["UY"], g["T"], g["PYB"], g["PX"], g["RP"]
-    PMB = g["PMB"]
+    PMB, PYB4 = g["PMB"], g["PYB4"]
     Tf, Tpm, PXo, PXe = g["Tf"], g["Tpm"], g["PXo"], g["PXe"]
     vOff16, vOff8, vTmp, vTmp2, vThr, vCthr = g["vOff16"], g["vOff8"], g["vTmp"], g["vTmp2"], g["vThr"], g["vCthr"]
     SM, SMm, SMxmin, SMxmax, sLm, sA, sAp = g["SM"], g["SMm"], g["SMxmin"], g["SMxmax"], g["sLm"], g["sA"], g["sAp"]
@@ -1361,8 +1372,11 @@ def backward_loop(k, v):
             off = j * LAYER_BYTES
             if "NOLOAD" not in ABLATE:
                 k.gload(4, T[k1][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
-                off += OFF_PY
-                k.gload(2, PYB[k1][j], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
+                if j:
+                    if j == 1:
+                        k.salu("s_or_b64", "exec", sLm[0], sLm[1])
+                    off = OFF_PY + (j - 1) * 1024
+                    k.gload(4, PYB4[k1][j - 1], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
             k.salu("s_mov_b64", "exec", -1)
         k.salu("s_sub_u32", sA[1], sTd, 3)
         if "NOMASKB" not in ABLATE:
@@ -1383,7 +1397,7 @@ def backward_loop(k, v):
             k.ladd_back(rd[j], M[kk][j], s7p5)
         # ------------------------------------------------------------ tail: what diagonal t hands down, its candidates
         k.label(lbl("tail%d" % kk))
-        k.raw_wait_vm(4 * L)                   # this diagonal's ring row (the loads of the next two may still be under way)
+        k.raw_wait_vm(2 * (L + 2))             # this diagonal's ring row (the L + 2 loads of each of the next two may still be under way)
         for j in range(L):
             k.valu("v_mov_b32_e32", PMB[kk][j].lo, Tpm(kk, j).lo)
             k.valu("v_mov_b32_e32", PMB[kk][j].hi, Tpm(kk, j).hi)
@@ -1734,7 +1748,7 @@ def main():
     text.append("amdhsa.target:   amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\n\t.end_amdgpu_metadata")
     open(out, "w").write("\n".join(text) + "\n")
     if len(sys.argv) > 2:
-        defs = dict(ASM_L=L, ASM_ROW_BYTES=ROW_BYTES, ASM_CTX_X=CTX_X, ASM_CTX_S=CTX_S, ASM_CTX_BYTES=CTX_BYTES,
+        defs = dict(ASM_L=L, ASM_ROW_BYTES=ROW_BYTES, ASM_LAYER_BYTES=LAYER_BYTES, ASM_OFF_FXY=OFF_FXY, ASM_OFF_PY=OFF_PY, ASM_CTX_X=CTX_X, ASM_CTX_S=CTX_S, ASM_CTX_BYTES=CTX_BYTES,
                     ASM_MAX_WIDTH=MAX_WIDTH, ASM_PLANWIN_BYTES=PLANWIN_BYTES, ASM_CTL_BYTES=CTL_BYTES, ASM_BLOCK=BLOCK,
                     ASM_ARGS_BYTES=ARGS_BYTES, ASM_NCONST=NCONST, ASM_MASK_BYTES=MASK_BYTES, ASM_LDS_F_BYTES=LDS_F_BYTES, ASM_LDS_B_BYTES=LDS_B_BYTES)
         with open(sys.argv[2], "w") as h:

@@ -154,10 +154,10 @@ extern "C" __global__ void cpecan_k_asm_begin(const DevItem *items, long long nI
     if (idx >= nItems) return;
     const DevItem it = items[idx];
     double *r = ring + idx * ringDoubles;
-    r[0] = it.raggedL ? CP_NEG_INF : 0.0;            /* Fm */
-    r[1] = 0.0;                                      /* pm */
-    r[128] = 0.0;                                    /* py */
-    r[192] = r[193] = it.raggedL ? 0.0 : CP_NEG_INF; /* Fx, Fy */
+    r[0] = it.raggedL ? CP_NEG_INF : 0.0;                                          /* Fm */
+    r[1] = 0.0;                                                                    /* pm */
+    r[ASM_OFF_PY / 8] = 0.0;                                                       /* py */
+    r[ASM_OFF_FXY / 8] = r[ASM_OFF_FXY / 8 + 1] = it.raggedL ? 0.0 : CP_NEG_INF; /* Fx, Fy */
 }
 
 extern "C" int cpecan_asm_launch_ctx_init(hipStream_t stream, const DevItem *items, long long nItems, char *ctx,

@@ -12,7 +12,9 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -49,7 +51,7 @@ int fail(int code, const char *fmt, ...) {
         if (n_ != ncclSuccess) { rc = fail(CPECAN_EHIP, "%s: %s", #expr, ncclGetErrorString(n_)); goto done; } \
     } while (0)
 
-/* out[i] = pseudocount + sum over the batch's models of their block's entry i (the likelihood, last entry, starts
+/* out[i] = pseudocount (the caller's, times this rank's reads) + sum over the batch's models of their block's entry i (the likelihood, last entry, starts
  * from 0): the per-read expectation blocks of an E-step, added up where they are */
 __global__ void cpecan_k_em_sum_blocks(const double *blocks, int nModels, int len, double pseudocount, double *out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,32 +86,105 @@ void m_step(const double *e, double *transitions, double *gapX) {
     for (int k = 0; k < CPECAN_NUM_KMERS; k++) gapX[k] = log(e[9 + k] / total);
 }
 
-/* rank 0 hands RCCL's unique id to the other ranks through a file */
-int exchange_id(const char *path, int rank, ncclUniqueId *id) {
+/* Rank 0 hands RCCL's unique id to the other ranks through a file.  The file carries a nonce every rank derives the
+ * same way (cpecan_em_set_rendezvous_nonce / CPECAN_EM_NONCE / the launcher's MASTER_ADDR:MASTER_PORT and run id, and
+ * the number of rendezvous this process has made), so that a file left at the path by an earlier run, or by an
+ * earlier rendezvous of this job, is not taken for this one's: rank 0 removes whatever is there before it publishes,
+ * the other ranks accept a file only with their nonce and world size, and rank 0 removes it again once the communicator
+ * exists (cpecan_em_comm_create / cpecan_em_run: ncclCommInitRank returns when every rank has joined). */
+struct IdFile {
+    char magic[8];
+    uint64_t nonce;
+    int32_t world, bytes;
+    unsigned char id[128];
+};
+static_assert(sizeof(ncclUniqueId) <= 128, "id bytes");
+
+std::mutex g_rdvLock;
+uint64_t g_rdvBase = 0;
+bool g_rdvBaseSet = false;
+uint64_t g_rdvCalls = 0;
+
+uint64_t fnv(uint64_t h, const char *s) {
+    for (; s && *s; s++) h = (h ^ (unsigned char) *s) * 1099511628211ull;
+    return h;
+}
+
+/* the nonce of this process's next rendezvous */
+uint64_t next_nonce() {
+    std::lock_guard<std::mutex> g(g_rdvLock);
+    uint64_t base = g_rdvBase;
+    if (!g_rdvBaseSet) {
+        const char *e = getenv("CPECAN_EM_NONCE");
+        if (e && *e) base = strtoull(e, nullptr, 0);
+        else base = fnv(fnv(fnv(14695981039346656037ull, getenv("MASTER_ADDR")), getenv("MASTER_PORT")), getenv("TORCHELASTIC_RUN_ID"));
+    }
+    return base * 1000003ull + g_rdvCalls++;
+}
+
+int exchange_bytes(const char *path, int rank, int world, uint64_t nonce, void *id, size_t n, int timeoutMs) {
+    if (n > sizeof(((IdFile *) nullptr)->id)) return fail(CPECAN_EINVAL, "id too long");
     if (rank == 0) {
-        std::string tmp = std::string(path) + ".tmp";
-        FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f) return fail(CPECAN_EINVAL, "cannot write %s", tmp.c_str());
-        const size_t n = fwrite(id, 1, sizeof *id, f);
-        fclose(f);
-        if (n != sizeof *id || rename(tmp.c_str(), path) != 0) return fail(CPECAN_EINVAL, "cannot publish %s", path);
+        IdFile f;
+        memset(&f, 0, sizeof f);
+        memcpy(f.magic, "CPECANID", 8);
+        f.nonce = nonce;
+        f.world = world;
+        f.bytes = (int32_t) n;
+        memcpy(f.id, id, n);
+        (void) unlink(path); /* whatever an earlier run left */
+        const std::string tmp = std::string(path) + ".tmp." + std::to_string((long long) getpid());
+        FILE *o = fopen(tmp.c_str(), "wb");
+        if (!o) return fail(CPECAN_EINVAL, "cannot write %s", tmp.c_str());
+        const size_t w = fwrite(&f, 1, sizeof f, o);
+        fclose(o);
+        if (w != sizeof f || rename(tmp.c_str(), path) != 0) {
+            (void) unlink(tmp.c_str());
+            return fail(CPECAN_EINVAL, "cannot publish %s", path);
+        }
         return CPECAN_OK;
     }
-    for (int tries = 0; tries < 6000; tries++) { /* up to ten minutes */
-        FILE *f = fopen(path, "rb");
-        if (f) {
-            const size_t n = fread(id, 1, sizeof *id, f);
-            fclose(f);
-            if (n == sizeof *id) return CPECAN_OK;
+    for (int waited = 0; waited <= timeoutMs; waited += 50) {
+        FILE *i = fopen(path, "rb");
+        if (i) {
+            IdFile f;
+            const size_t r = fread(&f, 1, sizeof f, i);
+            fclose(i);
+            if (r == sizeof f && memcmp(f.magic, "CPECANID", 8) == 0 && f.nonce == nonce && f.world == world &&
+                f.bytes == (int32_t) n) {
+                memcpy(id, f.id, n);
+                return CPECAN_OK;
+            }
         }
-        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
-    return fail(CPECAN_EINVAL, "rank %d: no RCCL id appeared at %s", rank, path);
+    return fail(CPECAN_EINVAL, "rank %d: no RCCL id of this rendezvous appeared at %s", rank, path);
+}
+
+int exchange_id(const char *path, int rank, int world, ncclUniqueId *id) {
+    return exchange_bytes(path, rank, world, next_nonce(), id, sizeof *id, 600000 /* ten minutes */);
+}
+
+void rendezvous_done(const char *path, int rank) {
+    if (rank == 0 && path) (void) unlink(path);
 }
 
 } // namespace
 
 extern "C" const char *cpecan_em_last_error(void) { return g_err.c_str(); }
+
+extern "C" void cpecan_em_set_rendezvous_nonce(uint64_t nonce) {
+    std::lock_guard<std::mutex> g(g_rdvLock);
+    g_rdvBase = nonce;
+    g_rdvBaseSet = true;
+}
+
+extern "C" int cpecan_em_rendezvous_exchange(const char *id_file, int rank, int world, void *bytes, int64_t n, int32_t timeout_ms) {
+    if (!id_file || !bytes || n <= 0 || world < 2 || rank < 0 || rank >= world) return fail(CPECAN_EINVAL, "bad argument");
+    return exchange_bytes(id_file, rank, world, next_nonce(), bytes, (size_t) n, timeout_ms);
+}
+
+extern "C" void cpecan_em_rendezvous_done(const char *id_file, int rank) { rendezvous_done(id_file, rank); }
 
 extern "C" int cpecan_em_run(const cpecan_em_input *in, int32_t iterations, double pseudocount, double *transitions,
                              double *gapX, double *runningLikelihood) {
@@ -133,9 +208,10 @@ extern "C" int cpecan_em_run(const cpecan_em_input *in, int32_t iterations, doub
     if (in->world > 1) {
         ncclUniqueId id;
         if (in->rank == 0) EM_NCCL(ncclGetUniqueId(&id));
-        rc = exchange_id(in->id_file, in->rank, &id);
+        rc = exchange_id(in->id_file, in->rank, in->world, &id);
         if (rc != CPECAN_OK) goto done;
         EM_NCCL(ncclCommInitRank(&comm, in->world, id, in->rank));
+        rendezvous_done(in->id_file, in->rank);
     }
     EM_ABI(cpecan_hip_ctx_create(in->device, &ctx));
     EM_ABI(cpecan_hip_ctx_stream(ctx, &stream));
@@ -163,7 +239,7 @@ extern "C" int cpecan_em_run(const cpecan_em_input *in, int32_t iterations, doub
         EM_ABI(cpecan_hip_batch_run(batch));
         EM_ABI(cpecan_hip_batch_sync(batch));
         hipLaunchKernelGGL(cpecan_k_em_sum_blocks, dim3((unsigned) (len + 255) / 256), dim3(256), 0, (hipStream_t) stream,
-                           (const double *) dBlocks, (int) in->n_models, len, pseudocount, dSum);
+                           (const double *) dBlocks, (int) in->n_models, len, pseudocount * (double) in->n_items, dSum);
         EM_HIP(hipGetLastError());
         if (comm) EM_NCCL(ncclAllReduce(dSum, dSum, (size_t) len, ncclDouble, ncclSum, comm, (hipStream_t) stream));
         EM_HIP(hipMemcpyAsync(e.data(), dSum, sizeof(double) * (size_t) len, hipMemcpyDeviceToHost, (hipStream_t) stream));
@@ -202,10 +278,11 @@ extern "C" int cpecan_em_comm_create(int device, int rank, int world, const char
         EM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         if (rank == 0) EM_NCCL(ncclGetUniqueId(&id));
         if (world > 1) {
-            rc = exchange_id(idFile, rank, &id);
+            rc = exchange_id(idFile, rank, world, &id);
             if (rc != CPECAN_OK) goto done;
         }
         EM_NCCL(ncclCommInitRank(&c->comm, world, id, rank));
+        if (world > 1) rendezvous_done(idFile, rank);
     }
 done:
     if (rc != CPECAN_OK) {

@@ -155,8 +155,9 @@ WV_DECLARE(_l4)
 WV_DECLARE(_h2)
 WV_DECLARE(_h3)
 WV_DECLARE(_h4)
-/* ... and for the vanilla signal machine (-DWV_VANILLA, symbols _v2, _v3; its four-cell build does not fit the
- * register file and is not linked: bands above 184 k-mers run on the general kernel) */
+/* ... and for the vanilla signal machine (-DWV_VANILLA, symbols _v2, _v3; its four-cell build is built and linked,
+ * cpecan_kernel_wave_v4.o, but not used: it does not fit the register file without spilling, and bands above 184
+ * k-mers run on the general kernel) */
 WV_DECLARE(_v2)
 WV_DECLARE(_v3)
 extern "C" int cpecan_wave_launch_track_vanilla(hipStream_t stream, const DevItem *items, long long nItems,
@@ -301,8 +302,10 @@ struct PackedPair {
 
 /* Device memory of batches and model tables goes through a small caching allocator: hipMalloc and hipFree wait for
  * the device, so a host thread that prepares the next batch while the GPU works on the current one (one-shot
- * alignment of a stream of batches) would otherwise stall on every buffer.  A released block is kept (per device, up
- * to CPECAN_ALLOC_CACHE_GB, default 96) and handed to the next request it fits within 25 %. */
+ * alignment of a stream of batches) would otherwise stall on every buffer.  A released block is kept (up to
+ * CPECAN_ALLOC_CACHE_GB; by default a quarter of the device's memory, so that co-tenants -- RCCL's buffers, torch in
+ * the same process, other processes on the card -- are not starved; cpecan_hip_trim_cache() gives everything back)
+ * and handed to the next request it fits within 25 %.  A block keeps its real size through every reuse. */
 struct DevCache {
     struct Block { void *p; size_t bytes; int device; };
     std::mutex lock;
@@ -310,16 +313,24 @@ struct DevCache {
     size_t held = 0;
     const bool pinnedHost; /* the same for pinned host memory (the packed pairs of a batch): pinning and unpinning
                               150 MB per batch costs tens of milliseconds; up to CPECAN_PINNED_CACHE_GB, default 8 */
-    const size_t capBytes;
-    explicit DevCache(bool host)
-        : pinnedHost(host), capBytes([host] {
-              const char *e = getenv(host ? "CPECAN_PINNED_CACHE_GB" : "CPECAN_ALLOC_CACHE_GB");
-              return (size_t) ((e ? atof(e) : host ? 8.0 : 96.0) * (double) (1ull << 30));
-          }()) {}
-    size_t cap() const { return capBytes; }
+    size_t capBytes = 0; /* 0: not worked out yet */
+    explicit DevCache(bool host) : pinnedHost(host) {}
+    size_t cap() { /* (under `lock`) */
+        if (capBytes == 0) {
+            const char *e = getenv(pinnedHost ? "CPECAN_PINNED_CACHE_GB" : "CPECAN_ALLOC_CACHE_GB");
+            double gb = e ? atof(e) : 8.0;
+            if (!e && !pinnedHost) {
+                size_t freeB = 0, totalB = 0;
+                gb = hipMemGetInfo(&freeB, &totalB) == hipSuccess ? (double) totalB / 4.0 / (double) (1ull << 30) : 32.0;
+            }
+            capBytes = (size_t) (gb * (double) (1ull << 30)) + 1;
+        }
+        return capBytes;
+    }
     hipError_t raw_alloc(void **out, size_t bytes) { return pinnedHost ? hipHostMalloc(out, bytes, hipHostMallocDefault) : hipMalloc(out, bytes); }
     void raw_free(void *p) { (void) (pinnedHost ? hipHostFree(p) : hipFree(p)); }
-    hipError_t get(void **out, size_t bytes) {
+    hipError_t get(void **out, size_t bytes, size_t *got) {
+        *got = bytes;
         int device = 0;
         (void) hipGetDevice(&device);
         {
@@ -331,6 +342,7 @@ struct DevCache {
                     best = i;
             if (best != blocks.size()) {
                 *out = blocks[best].p;
+                *got = blocks[best].bytes;
                 held -= blocks[best].bytes;
                 blocks.erase(blocks.begin() + (long) best);
                 return hipSuccess;
@@ -377,36 +389,52 @@ DevCache &pinned_cache() {
 /* a block of pinned host memory from the cache (host-built tables on their way to the device) */
 template <typename T> struct PinnedBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0, blockBytes = 0;
     hipError_t alloc(size_t count) {
         release();
         n = count;
         if (count == 0) return hipSuccess;
-        return pinned_cache().get((void **) &p, count * sizeof(T));
+        return pinned_cache().get((void **) &p, count * sizeof(T), &blockBytes);
     }
     void release() {
-        if (p) pinned_cache().put(p, n * sizeof(T));
+        if (p) pinned_cache().put(p, blockBytes);
         p = nullptr;
-        n = 0;
+        n = blockBytes = 0;
     }
     ~PinnedBuf() { release(); }
 };
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0, blockBytes = 0;
     hipError_t alloc(size_t count) {
         release();
         n = count;
         if (count == 0) return hipSuccess;
-        return dev_cache().get((void **) &p, count * sizeof(T));
+        return dev_cache().get((void **) &p, count * sizeof(T), &blockBytes);
     }
     void release() {
-        if (p) dev_cache().put(p, n * sizeof(T));
+        if (p) dev_cache().put(p, blockBytes);
         p = nullptr;
-        n = 0;
+        n = blockBytes = 0;
+    }
+    void swap(DevBuf &o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(blockBytes, o.blockBytes);
     }
     ~DevBuf() { release(); }
+};
+
+/* Declared after a function's own DevBuf / PinnedBuf objects and before its first asynchronous use of them: whichever
+ * way the function returns, the streams it fed are idle before those buffers go back to the cache (a released block
+ * can be handed to another thread at once; hipFree used to wait for the device here). */
+struct StreamFence {
+    hipStream_t a = nullptr, b = nullptr;
+    ~StreamFence() {
+        if (a) (void) hipStreamSynchronize(a);
+        if (b) (void) hipStreamSynchronize(b);
+    }
 };
 
 } // namespace
@@ -459,7 +487,6 @@ struct cpecan_batch {
     DevBuf<int> kid;         /* HDP batches: k-mer id over the model's alphabet per X position */
     DevBuf<unsigned short> kidx;
     DevBuf<double> events;
-    DevBuf<long long> anchors;
     DevBuf<double> Fstore, Bstore, dbgB;
     DevBuf<double> Bring; /* systolic Baum-Welch: backward cells of one window per item */
     DevBuf<long long> pairs;
@@ -508,6 +535,7 @@ struct cpecan_batch {
     PackedPair *hPacked = nullptr; /* hipHostMalloc */
     int *hPost = nullptr;          /* hipHostMalloc: the device's verdict per candidate (cpecan_k_pack_pairs) */
     size_t hPackedCap = 0;
+    size_t hPackedBlock = 0, hPostBlock = 0, hUndecidedBlock = 0; /* the real sizes of those blocks (the allocator's cache) */
     int trackRow = CP_ROW; /* doubles per column of the track */
     bool countsValid = false, ran = false;
     bool packedInRun = false; /* the last run ended with cpecan_k_pack_base + cpecan_k_pack_pairs */
@@ -634,12 +662,23 @@ int cpecan_hip_ctx_create(int device, cpecan_ctx **out) {
 int cpecan_hip_ctx_destroy(cpecan_ctx *c) {
     if (!c) return CPECAN_OK;
     (void) hipSetDevice(c->device);
+    /* the model tables go back to the allocator's cache below: nothing queued through this context may still read them
+     * (a batch of this context that is still running on streams of its own is the caller's to finish first) */
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    if (c->prep) (void) hipStreamSynchronize(c->prep);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     if (c->prep) (void) hipStreamDestroy(c->prep);
     if (c->pinned) (void) hipHostFree(c->pinned);
     for (auto *t : c->hdpTables) delete t;
     c->hdpTables.clear();
     delete c;
+    (void) hipGetLastError();
+    return CPECAN_OK;
+}
+
+int cpecan_hip_trim_cache(void) {
+    dev_cache().trim(0);
+    pinned_cache().trim(0);
     (void) hipGetLastError();
     return CPECAN_OK;
 }
@@ -690,9 +729,12 @@ static int grow_models(cpecan_ctx *c, int32_t n, double **fresh) {
     DevBuf<double> grown;
     hipError_t e = grown.alloc(total);
     if (e != hipSuccess) return fail(CPECAN_EHIP, "model table allocation: %s", hipGetErrorString(e));
-    if (old) HIP_TRY(hipMemcpy(grown.p, c->models.p, old * sizeof(double), hipMemcpyDeviceToDevice));
-    std::swap(grown.p, c->models.p);
-    std::swap(grown.n, c->models.n);
+    {
+        StreamFence fence{ c->prep, nullptr };
+        /* on the stream the uploads that follow use, and over before the old block is released */
+        if (old) HIP_TRY(hipMemcpyAsync(grown.p, c->models.p, old * sizeof(double), hipMemcpyDeviceToDevice, c->prep));
+    }
+    grown.swap(c->models);
     *fresh = c->models.p + old;
     return CPECAN_OK;
 }
@@ -826,6 +868,7 @@ int cpecan_hip_models_create_scaled(cpecan_ctx *c, const cpecan_sm3_model *base,
     int rc = grow_models(c, n, &fresh);
     if (rc != CPECAN_OK) return rc;
     DevBuf<double> dBase, dScal, dPart;
+    StreamFence fence{ c->prep, c->stream };
     HIP_TRY(dBase.alloc(baseRows.size()));
     HIP_TRY(dScal.alloc((size_t) n * 5));
     HIP_TRY(dPart.alloc(part.n));
@@ -880,6 +923,7 @@ int cpecan_hip_models_set_transitions(cpecan_ctx *c, const double *transitions, 
     if (gapX) std::copy(gapX, gapX + CPECAN_NUM_KMERS, v.begin() + 9);
     for (double &t : c->switchToX) t = transitions[T_GAP_SWITCH_TO_X];
     DevBuf<double> dv;
+    StreamFence fence{ c->stream, nullptr };
     HIP_TRY(dv.alloc(v.size()));
     HIP_TRY(hipMemcpyAsync(dv.p, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(cpecan_k_set_transitions, dim3((9 + CPECAN_NUM_KMERS + 255) / 256, (unsigned) std::min(c->nModels, 65535)),
@@ -893,6 +937,7 @@ int cpecan_hip_selftest_division(cpecan_ctx *c, int64_t n, uint64_t seed, int64_
     if (!c || n <= 0 || !mismatches) return fail(CPECAN_EINVAL, "bad argument");
     HIP_TRY(hipSetDevice(c->device));
     DevBuf<unsigned long long> bad;
+    StreamFence fence{ c->stream, nullptr };
     HIP_TRY(bad.alloc(1));
     HIP_TRY(hipMemsetAsync(bad.p, 0, sizeof(unsigned long long), c->stream));
     if (cpecan_systolic_divtest(c->stream, n, seed, bad.p) != 0)
@@ -1093,9 +1138,9 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (b->gStreamOwned)
         for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
-    if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedCap * sizeof(PackedPair));
-    if (b->hPost) pinned_cache().put(b->hPost, b->hPackedCap * sizeof(int));
-    if (b->hUndecided) pinned_cache().put(b->hUndecided, (1 + 2 * CP_UNDECIDED_CAP) * sizeof(long long));
+    if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedBlock);
+    if (b->hPost) pinned_cache().put(b->hPost, b->hPostBlock);
+    if (b->hUndecided) pinned_cache().put(b->hUndecided, b->hUndecidedBlock);
     delete b;
     (void) hipGetLastError(); /* a failed clean-up call must not surface as the "last error" of a later launch */
     return CPECAN_OK;
@@ -1190,6 +1235,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     std::vector<std::vector<AsmPlanWin>> planWins(wantPlan ? (size_t) nItems : 0);
     std::vector<long long> hPlanOff(wantPlan ? (size_t) nItems : 0);
     PinnedBuf<AsmPlanCtl> hCtl;
+    StreamFence prepFence{ c->prep, nullptr }; /* (hTab, hCtl and the plan records below are uploaded through it) */
     long long ctlTotal = 0;
     if (wantPlan) {
         for (int64_t i = 0; i < nItems; i++) {
@@ -1413,10 +1459,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     }
     B_TRY(hipStreamSynchronize(c->prep));
     lap("upload sequences and events");
-    B_TRY(b->anchors.alloc((size_t) 2 * nAnchorPairs + 2));
-    if (nAnchorPairs > 0)
-        B_TRY(hipMemcpyAsync(b->anchors.p, anchors, (size_t) 2 * nAnchorPairs * sizeof(long long),
-                        hipMemcpyHostToDevice));
+    /* (the anchors stay on the host: the bands they describe were built there, above) */
     B_TRY(b->pairs.alloc((size_t) pairTotal * 3));
     B_TRY(b->pairLogp.alloc((size_t) pairTotal));
     B_TRY(b->nPairs.alloc((size_t) nItems));
@@ -1513,6 +1556,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             b->stateBytes == (int) sizeof(WvState) && cpecan_asm_load(c->device) == 0) {
             b->asmMaxWindows = std::max(maxWindows, 1);
             PinnedBuf<AsmPlanWin> hWin;
+            StreamFence winFence{ c->prep, nullptr };
             B_TRY(hWin.alloc((size_t) nItems * (size_t) b->asmMaxWindows));
             memset(hWin.p, 0, (size_t) nItems * (size_t) b->asmMaxWindows * sizeof(AsmPlanWin));
             for (int64_t i = 0; i < nItems; i++)
@@ -2141,17 +2185,17 @@ static int ensure_counts(cpecan_batch *b) {
             HIP_TRY(b->packedPost.alloc((size_t) all + (size_t) all / 8));
         }
         if (b->hPackedCap < (size_t) all) {
-            if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedCap * sizeof(PackedPair));
-            if (b->hPost) pinned_cache().put(b->hPost, b->hPackedCap * sizeof(int));
+            if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedBlock);
+            if (b->hPost) pinned_cache().put(b->hPost, b->hPostBlock);
             b->hPacked = nullptr;
             b->hPost = nullptr;
             b->hPackedCap = (size_t) all + (size_t) all / 8;
-            HIP_TRY(pinned_cache().get((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair)));
-            HIP_TRY(pinned_cache().get((void **) &b->hPost, b->hPackedCap * sizeof(int)));
+            HIP_TRY(pinned_cache().get((void **) &b->hPacked, b->hPackedCap * sizeof(PackedPair), &b->hPackedBlock));
+            HIP_TRY(pinned_cache().get((void **) &b->hPost, b->hPackedCap * sizeof(int), &b->hPostBlock));
         }
         if (b->undecided.n == 0) HIP_TRY(b->undecided.alloc(1 + 2 * CP_UNDECIDED_CAP));
         if (!b->hUndecided)
-            HIP_TRY(pinned_cache().get((void **) &b->hUndecided, (1 + 2 * CP_UNDECIDED_CAP) * sizeof(long long)));
+            HIP_TRY(pinned_cache().get((void **) &b->hUndecided, (1 + 2 * CP_UNDECIDED_CAP) * sizeof(long long), &b->hUndecidedBlock));
         if (!packedAlready) {
         HIP_TRY(hipMemcpyAsync(b->packBase.p, b->hPairBase.data(), ((size_t) b->nItems + 1) * sizeof(long long),
                                hipMemcpyHostToDevice, b->ctx->stream));

@@ -87,17 +87,17 @@
 #define WV_ROWN 32           /* LDS ring of k-mer rows (>= the feed block)                              */
 #define WV_FEED_MAX 32       /* diagonals per feed block of the forward sweep                            */
 #define WV_BITWORDS 256      /* band edge steps kept in LDS: 32 diagonals per word, circular, re-staged in halves */
-#define WV_RING_VALUES 5     /* per cell in the forward ring: Fm, Fx, Fy, match emission, gap-Y emission */
-#define WV_LAYER_BYTES (WV_RING_VALUES * 64 * 8)
-/* a layer of a ring row, in doubles: 64 (Fm, pm) pairs | 64 py | 64 (Fx, Fy) pairs -- what the sweep back reads on
- * every diagonal is one 16-byte and one 8-byte access per lane */
-#define WV_LAYER_DOUBLES (WV_RING_VALUES * 64)
+/* A ring row of the forward sweep, in doubles: per layer 64 (Fm, pm) pairs | 64 (Fx, Fy) pairs; after the layers the
+ * gap-Y emissions, the layers two by two as 64 (py, py) pairs (an odd last layer: (py, unused)) -- every access of the
+ * assembly sweeps is 16 bytes per lane (8-byte streaming stores take 2.5 times as long per instruction:
+ * tools/ubench_vmem.hip); a row of three layers is 8192 bytes */
+#define WV_LAYER_DOUBLES 256
 #define WV_OFF_FM(lane) ((lane) * 2)
 #define WV_OFF_PM(lane) ((lane) * 2 + 1)
-#define WV_OFF_PY(lane) (128 + (lane))
-#define WV_OFF_FX(lane) (192 + (lane) * 2)
-#define WV_OFF_FY(lane) (192 + (lane) * 2 + 1)
-#define WV_ROW_DOUBLES (WV_L * WV_RING_VALUES * 64)
+#define WV_OFF_FX(lane) (128 + (lane) * 2)
+#define WV_OFF_FY(lane) (128 + (lane) * 2 + 1)
+#define WV_ROW_PY(j, lane) (WV_L * WV_LAYER_DOUBLES + ((j) >> 1) * 128 + (lane) * 2 + ((j) & 1)) /* from the row's start */
+#define WV_ROW_DOUBLES (WV_L * WV_LAYER_DOUBLES + ((WV_L + 1) / 2) * 128)
 #define WV_PREFETCH 2        /* diagonals the backward sweep fetches ahead (== its unroll factor) */
 #define WV_CAND_SLACK 0.25   /* candidates: cells within this (log units) below the posterior threshold */
 #define WV_CAND_PER_DIAG 4   /* candidate capacity, in records per ring diagonal and layer */
@@ -533,7 +533,7 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
         mask[0] = 1ull;
         if (lane == 0) {
             fl[0] = 1u;
-            ring[WV_OFF_FM(0)] = Am[0]; ring[WV_OFF_PM(0)] = 0.0; ring[WV_OFF_PY(0)] = 0.0;
+            ring[WV_OFF_FM(0)] = Am[0]; ring[WV_OFF_PM(0)] = 0.0; ring[WV_ROW_PY(0, 0)] = 0.0;
             ring[WV_OFF_FX(0)] = Ax[0]; ring[WV_OFF_FY(0)] = Ay[0];
         }
 #if defined(WV_HDP) || defined(WV_VANILLA)
@@ -791,7 +791,7 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
                 d2 pr;
                 pr.x = nm[j]; pr.y = pm[j];
                 *(d2 *) (q + WV_OFF_FM(lane)) = pr;
-                q[WV_OFF_PY(lane)] = py[j];
+                rowBase[WV_ROW_PY(j, lane)] = py[j];
                 if (full) {
                     d2 gxy;
                     gxy.x = nx[j]; gxy.y = ny[j];
@@ -1101,7 +1101,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
 #pragma unroll
     for (int j = 0; j < L; j++) {
         voffA[j] = (unsigned) ((j * WV_LAYER_DOUBLES + WV_OFF_FM(lane)) * 8);
-        voffB[j] = (unsigned) ((j * WV_LAYER_DOUBLES + WV_OFF_PY(lane)) * 8);
+        voffB[j] = (unsigned) (WV_ROW_PY(j, lane) * 8);
     }
     const unsigned dummyOff = (unsigned) ((long long) ringD * WV_ROW_DOUBLES * 8);
     int nTotWin = 0, nCand = 0;
@@ -2132,7 +2132,7 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
             }
             if (vUpper) {
                 const double u0 = own[r1 + WV_OFF_FM(lane)], u2 = own[r1 + WV_OFF_FY(lane)];
-                const double eP = own[rt + WV_OFF_PY(lane)];
+                const double eP = ring[rt + WV_ROW_PY(j, lane)];
                 acc[6] += exp(u0 + By + (eP + tm[T_GAP_OPEN_Y]) - total);
                 acc[7] += exp(u2 + By + (eP + tm[T_GAP_EXTEND_Y]) - total);
             }

@@ -76,7 +76,8 @@ def gpu_e_step(cp, ctx, batch, bp, read_idx, transitions, gap_x, dist=None, pseu
 
     ctxs = [ctx] if ctx2 is None else [ctx, ctx2]
     dev = torch.device("cuda", ctx.device)
-    total = torch.full((EXP_LEN,), float(pseudocount), dtype=torch.float64, device=dev)
+    # (once per read, as the reference's one process per read does: independent of how the reads are spread over ranks)
+    total = torch.full((EXP_LEN,), float(pseudocount) * len(read_idx), dtype=torch.float64, device=dev)
     total[-1] = 0.0
     parts = [list(read_idx)[k::len(ctxs)] for k in range(len(ctxs))]
     saved = os.environ.get("CPECAN_SYSTOLIC_GROUPS")
@@ -128,6 +129,7 @@ class PersistentEStep:
         import os
         import torch
         self.cp, self.ctxs, self.dist, self.pseudocount = cp, list(contexts), dist, float(pseudocount)
+        self.n_reads = len(list(read_idx))
         self.dev = torch.device("cuda", self.ctxs[0].device)
         saved = os.environ.get("CPECAN_SYSTOLIC_GROUPS")
         if len(self.ctxs) > 1 and saved is None:
@@ -159,7 +161,7 @@ class PersistentEStep:
 
     def __call__(self, transitions, gap_x):
         import torch
-        total = torch.full((EXP_LEN,), self.pseudocount, dtype=torch.float64, device=self.dev)
+        total = torch.full((EXP_LEN,), self.pseudocount * self.n_reads, dtype=torch.float64, device=self.dev)
         total[-1] = 0.0
         for cx, b in self.batches:
             cx.models_set_transitions(transitions, gap_x)

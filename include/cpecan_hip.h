@@ -308,6 +308,12 @@ int cpecan_hip_batch_destroy(cpecan_batch *batch);
  * of operands where the two doubles differ (expected: 0). */
 int cpecan_hip_selftest_division(cpecan_ctx *ctx, int64_t n, uint64_t seed, int64_t *mismatches);
 
+/* Device and pinned host memory released by batches and model tables is kept by the library for the next request
+ * (hipMalloc / hipFree wait for the device; up to a quarter of the card's memory by default, CPECAN_ALLOC_CACHE_GB /
+ * CPECAN_PINNED_CACHE_GB).  This gives all of it back to the runtime: call it between phases when something else in the
+ * process, or on the card, needs the memory. */
+int cpecan_hip_trim_cache(void);
+
 /* Stream of the context as an opaque pointer (a hipStream_t) for callers that need to order
  * their own work (e.g. an RCCL all-reduce of the expectations) after the batch kernels. */
 int cpecan_hip_ctx_stream(cpecan_ctx *ctx, void **stream);

@@ -243,8 +243,8 @@ class Image:
             ring = np.full(self.ring_doubles, np.nan)
             ring[self.ringD * G.ROW_DOUBLES:] = NEG_INF
             ring[0] = NEG_INF if self.ragged[0] else 0.0
-            ring[1] = ring[128] = 0.0
-            ring[192] = ring[193] = 0.0 if self.ragged[0] else NEG_INF
+            ring[1] = ring[G.OFF_PY // 8] = 0.0
+            ring[G.OFF_FXY // 8] = ring[G.OFF_FXY // 8 + 1] = 0.0 if self.ragged[0] else NEG_INF
             mem.put(self.a_ring + i * self.ring_doubles * 8, ring)
 
     def args(self, window, log_thr_slack=0.0):

@@ -32,7 +32,8 @@ def _check_forward_rows(img, item, w, F, off):
         for x in range(xmin[d], xmax[d] + 1):
             lane, j = H.slot_of(x)
             base = j * (G.LAYER_BYTES // 8)
-            got = (row[base + 2 * lane], row[base + 192 + 2 * lane], row[base + 193 + 2 * lane])
+            fxy = base + G.OFF_FXY // 8
+            got = (row[base + 2 * lane], row[fxy + 2 * lane], row[fxy + 2 * lane + 1])
             want = F[off[d] + x - xmin[d]]
             ok = _same(got[0], want[0]) and (not full or (_same(got[1], want[1]) and _same(got[2], want[2])))
             if not ok:

@@ -51,7 +51,8 @@ def test_em_library_exports_declared_symbols():
     header = open(os.path.join(ROOT, "include", "cpecan_em.h")).read()
     names = set(re.findall(r"\b(cpecan_em_[a-z_]+)\s*\(", re.sub(r"/\*.*?\*/", "", header, flags=re.S)))
     assert names == {"cpecan_em_run", "cpecan_em_last_error", "cpecan_em_comm_create", "cpecan_em_comm_reduce",
-                     "cpecan_em_comm_destroy"}
+                     "cpecan_em_comm_destroy", "cpecan_em_set_rendezvous_nonce", "cpecan_em_rendezvous_exchange",
+                     "cpecan_em_rendezvous_done"}
     lib = C.CDLL(os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_em.so"))
     for n in names:
         assert hasattr(lib, n)
