@@ -949,6 +949,7 @@ def forward_tail(k, v):
 # ====================================================================================================== backward
 # more of the formats: the scratch of one alignment (wv_backward_kernel() of cpecan_kernel_wave.hip), the mask table
 MASK_BYTES = 64
+MASK_GROUP = int(os.environ.get("CPECAN_ASM_MASK_GROUP", "8"))  # lanes a ring row's store / load masks are rounded to: 8 lanes x 16 bytes = one 128-byte line
 WINTOTAL_BYTES = 32
 CAND_PER_DIAG = 4
 CAND_SLACK = 0.25
@@ -1750,7 +1751,7 @@ def main():
     if len(sys.argv) > 2:
         defs = dict(ASM_L=L, ASM_ROW_BYTES=ROW_BYTES, ASM_LAYER_BYTES=LAYER_BYTES, ASM_OFF_FXY=OFF_FXY, ASM_OFF_PY=OFF_PY, ASM_CTX_X=CTX_X, ASM_CTX_S=CTX_S, ASM_CTX_BYTES=CTX_BYTES,
                     ASM_MAX_WIDTH=MAX_WIDTH, ASM_PLANWIN_BYTES=PLANWIN_BYTES, ASM_CTL_BYTES=CTL_BYTES, ASM_BLOCK=BLOCK,
-                    ASM_ARGS_BYTES=ARGS_BYTES, ASM_NCONST=NCONST, ASM_MASK_BYTES=MASK_BYTES, ASM_LDS_F_BYTES=LDS_F_BYTES, ASM_LDS_B_BYTES=LDS_B_BYTES)
+                    ASM_ARGS_BYTES=ARGS_BYTES, ASM_NCONST=NCONST, ASM_MASK_BYTES=MASK_BYTES, ASM_MASK_GROUP=MASK_GROUP, ASM_LDS_F_BYTES=LDS_F_BYTES, ASM_LDS_B_BYTES=LDS_B_BYTES)
         with open(sys.argv[2], "w") as h:
             h.write("/* generated by asm/gen_sweeps.py: what the assembly sweeps and the C++ side agree on */\n")
             h.write("#ifndef CPECAN_ASM_GEN_H_\n#define CPECAN_ASM_GEN_H_\n")

@@ -126,7 +126,8 @@ extern "C" __global__ void cpecan_k_asm_masks(const DevItem *items, long long nI
     for (int j = 0; j < ASM_L; j++) m[j] = g[j] = 0ull;
     for (int x = lo - 1; x <= hi + 1; x++) { /* (column -1: the last slot, parked while the band starts at column 0) */
         const int s = (x + 64 * ASM_L) % (64 * ASM_L);
-        g[s % ASM_L] |= 0xFFFFull << ((s / ASM_L) & ~15); /* whole 128-byte lines of the 8-byte values: no partial writes */
+        g[s % ASM_L] |= ((1ull << ASM_MASK_GROUP) - 1) << ((s / ASM_L) & ~(ASM_MASK_GROUP - 1)); /* whole 128-byte lines (every
+                                                                 access of a ring row is 16 bytes per lane): no partial writes */
         if (x >= lo && x <= hi) m[s % ASM_L] |= 1ull << (s / ASM_L);
     }
     unsigned *e = maskTab + (it.diagBase + d) * (ASM_MASK_BYTES / 4);

@@ -295,7 +295,7 @@ def mask_table(xmin, xmax):
         lo, hi = int(xmin[d]), int(xmax[d])
         for x in range(lo - 1, hi + 2):         # (column -1: the last slot, parked while the band starts at column 0)
             lane, j = (x % P) // L, (x % P) % L
-            g[j] |= 0xFFFF << (lane & ~15)   # whole 128-byte lines of the 8-byte values (16 lanes): no partial writes
+            g[j] |= ((1 << G.MASK_GROUP) - 1) << (lane & ~(G.MASK_GROUP - 1))   # whole 128-byte lines: no partial writes
             if lo <= x <= hi:
                 m[j] |= 1 << lane
         for j in range(L):
