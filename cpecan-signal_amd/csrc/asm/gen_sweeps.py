@@ -35,7 +35,9 @@ P = 64 * L
 LAYER_BYTES = 2 * 64 * 16
 OFF_FXY = 64 * 16
 OFF_PY = L * LAYER_BYTES                 # + 1024 per pair of layers
-ROW_BYTES = L * LAYER_BYTES + (L + 1) // 2 * 1024
+PY2_X2 = os.environ.get("CPECAN_ASM_PY2", "x2") == "x2"   # the odd last layer's emissions as 8 bytes per lane (less traffic) or
+                                                           # padded to 16 (fewer, faster instructions)
+ROW_BYTES = L * LAYER_BYTES + 1024 + (512 if PY2_X2 else 1024)
 ROW_DOUBLES = ROW_BYTES // 8
 assert L == 3                            # (the pairing of the gap-Y emissions below is written for three layers)
 TRACK_ROW_BYTES = 20 * 8                 # a track row: 16 emission constants, gap-X sums (open, extend, switch), gap-X
@@ -261,6 +263,7 @@ def forward_kernel(name):
     # to enter, which is what keeps cells outside the band out of its recurrence
     # (two sets, by the parity of the diagonal: a step asks for the next diagonal's while it works under its own)
     sMaskS = [[S(96 + 2 * j, 2) for j in range(L)], [S(80 + 2 * j, 2) for j in range(L)]]
+    sMaskPy2 = [S(56, 2), S(86, 2)]                     # ... and the last layer's 8-byte emissions (16 lanes to a line)
     sFullM = S(86, 2)                                   # all ones on a diagonal whose gap states go to the ring too
     sCtxBytes = S(62)                                   # (prologue only: sStagePC is set after it)
     def W(f): return sWin.sub(f)
@@ -274,7 +277,12 @@ def forward_kernel(name):
         k.salu("s_add_u32", sT[0], sT[0], 32)
         k.smem("s_load_dwordx4", S(sMaskS[q][0].i, 4), sMaskTab, sT[0])
         k.salu("s_add_u32", sT[0], sT[0], 16)
-        k.smem("s_load_dwordx2", sMaskS[q][2], sMaskTab, sT[0])
+        if PY2_X2:
+            k.smem("s_load_dwordx2", sMaskS[q][2], sMaskTab, sT[0])
+            k.salu("s_add_u32", sT[0], sT[0], 8)
+            k.smem("s_load_dwordx2", sMaskPy2[q], sMaskTab, sT[0])
+        else:
+            k.smem("s_load_dwordx2", sMaskS[q][2], sMaskTab, sT[0])
 
     def masked_store(mask, dwords, voff, data, off, gate=None):
         if "NOSTORE" in ABLATE or ("NOSTORE4" in ABLATE and dwords == 4) or ("NOSTORE2" in ABLATE and dwords == 2):
@@ -414,7 +422,6 @@ def forward_kernel(name):
     pool.give(tq)
     k.s_mov64_lit(s7p5, dbits(2.0 ** 47))
     k.magic = s7p5
-    k.s_mov64_lit(sNinf, dbits(float("-inf")))
     # every event of the LDS ring reads as (0, 0) until it is staged: a parked slot scores whatever its stale address
     # points at, and that has to be a number
     tz = pool.take(4)
@@ -568,7 +575,10 @@ def forward_kernel(name):
             k.add(cc, middle(j, 2), cc)
             csum.append(cc)
         # (the last layer's leave with the two registers after them, which hold a constant: 16 bytes per lane again)
-        masked_store(sMaskS[p][L - 1], 4, vOff16, V(PY[L - 1].i, 4), OFF_PY + 1024)
+        if PY2_X2:
+            masked_store(sMaskPy2[p], 2, vOff8, PY[L - 1], OFF_PY + 1024)
+        else:
+            masked_store(sMaskS[p][L - 1], 4, vOff16, V(PY[L - 1].i, 4), OFF_PY + 1024)
         # P6
         k.need_recs(recs)
         for j in range(L):
@@ -653,7 +663,7 @@ def forward_kernel(name):
             k.salu("s_mov_b64", "exec", sBit)
             for q in (CK1, CK2, 8 + CK1, 8 + CK2, CPXO, CPXE):
                 k.valu("v_mov_b32_e32", C[j][q].lo, 0)
-                k.valu("v_mov_b32_e32", C[j][q].hi, sNinf.hi)
+                k.valu("v_mov_b32_e32", C[j][q].hi, "0xfff00000")
             k.salu("s_mov_b64", "exec", -1)
             if j < L - 1:
                 k.salu("s_add_u32", sOutJ, sOutJ, 1)
@@ -851,7 +861,7 @@ def forward_tail(k, v):
     for j in range(L_):
         for q in range(3):
             t = terms[3 * j + q]
-            k.valu("v_mov_b32_e32", vS[0], sNinf.hi)
+            k.valu("v_mov_b32_e32", vS[0], "0xfff00000")
             k.valu("v_cndmask_b32_e64", t.hi, vS[0], t.hi, sMask[j])
             k.valu("v_cndmask_b32_e64", t.lo, 0, t.lo, sMask[j])
     mx = pool.take(2)
@@ -991,9 +1001,11 @@ def backward_kernel(name):
     T = [[V(t0 + 4 * L * q + 4 * j, 4) for j in range(L)] for q in range(3)]
     p0 = t0 + 12 * L
     # gap-Y emissions as the ring holds them: (py0, py1), (py2, unused)
-    PYB4 = [[V(p0 + 8 * q + 4 * h, 4) for h in range(2)] for q in range(3)]
-    PYB = [[V(p0 + 8 * q + 2 * j, 2) for j in range(L)] for q in range(3)]
-    q0 = p0 + 8 * 3
+    pyw = 6 if PY2_X2 else 8
+    PYB4 = [[V(p0 + pyw * q + 4 * h, 4 if h == 0 or not PY2_X2 else 2) for h in range(2)] for q in range(3)]
+    PYB = [[V(p0 + pyw * q + 2 * j, 2) for j in range(L)] for q in range(3)]
+    q0 = p0 + pyw * 3
+    sLmPy2 = S(64, 2)                                   # the lanes the last layer's 8-byte emissions are loaded under
     PMB = [[V(q0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]  # match emissions, kept two diagonals longer
     pool0 = q0 + 6 * L
     pool = Pool(pool0, 255)
@@ -1170,7 +1182,6 @@ def backward_kernel(name):
     pool.give(tq)
     k.s_mov64_lit(s7p5, dbits(2.0 ** 47))
     k.magic = s7p5
-    k.s_mov64_lit(sNinf, dbits(float("-inf")))
     # the gap-X sums of the slots at the traceback point are the forward wave's (a parked slot holds -inf)
     k.add64(sAp(8), sAp(8), 8 * 1024)
     for j in range(L):
@@ -1180,7 +1191,7 @@ def backward_kernel(name):
     # every cell and every ring value starts as -inf
     for r in range(m0, pool0, 2):
         k.valu("v_mov_b32_e32", V(r), 0)
-        k.valu("v_mov_b32_e32", V(r + 1), sNinf.hi)
+        k.valu("v_mov_b32_e32", V(r + 1), "0xfff00000")
     k.salu("s_mov_b32", sNCand, 0)
     k.salu("s_mov_b32", sNTot, 0)
     k.salu("s_mov_b32", sTd, sTop)
@@ -1242,7 +1253,11 @@ def backward_kernel(name):
                 if j == 1:
                     k.salu("s_or_b64", "exec", masks[0], masks[1])
                 off = OFF_PY + (j - 1) * 1024
-                k.gload(4, PYB4[q][j - 1], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
+                if j == 2 and PY2_X2:
+                    k.salu("s_mov_b64", "exec", sLmPy2)
+                    k.gload(2, PYB4[q][1], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
+                else:
+                    k.gload(4, PYB4[q][j - 1], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
         k.salu("s_mov_b64", "exec", -1)
 
     def load_masks(q, dreg):
@@ -1259,6 +1274,9 @@ def backward_kernel(name):
         k.smem("s_load_dwordx4", S(96, 4), sMaskTab, sA[0])
         k.salu("s_add_u32", sA[0], sA[0], 16)
         k.smem("s_load_dwordx2", S(100, 2), sMaskTab, sA[0])
+        if PY2_X2:
+            k.salu("s_add_u32", sA[0], sA[0], 8)
+            k.smem("s_load_dwordx2", sLmPy2, sMaskTab, sA[0])
 
     # ------------------------------------------------------------------ entry: the traceback point = kk mod 3
     for kk in (0, 1, 2):
@@ -1305,7 +1323,7 @@ def backward_loop(k, v):
     k.mods = " nt" if "NT" in ABLATE or "NTB" in ABLATE else ""
     name, pool, lbl = g["name"], g["pool"], g["lbl"]
     M, BX, BY, UM, UY, T, PYB, PX, RP = g["M"], g["BX"], g["BY"], g["UM"], g["UY"], g["T"], g["PYB"], g["PX"], g["RP"]
-    PMB, PYB4 = g["PMB"], g["PYB4"]
+    PMB, PYB4, sLmPy2 = g["PMB"], g["PYB4"], g["sLmPy2"]
     Tf, Tpm, PXo, PXe = g["Tf"], g["Tpm"], g["PXo"], g["PXe"]
     vOff16, vOff8, vTmp, vTmp2, vThr, vCthr = g["vOff16"], g["vOff8"], g["vTmp"], g["vTmp2"], g["vThr"], g["vCthr"]
     SM, SMm, SMxmin, SMxmax, sLm, sA, sAp = g["SM"], g["SMm"], g["SMxmin"], g["SMxmax"], g["sLm"], g["sA"], g["sAp"]
@@ -1377,7 +1395,11 @@ def backward_loop(k, v):
                     if j == 1:
                         k.salu("s_or_b64", "exec", sLm[0], sLm[1])
                     off = OFF_PY + (j - 1) * 1024
-                    k.gload(4, PYB4[k1][j - 1], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
+                    if j == 2 and PY2_X2:
+                        k.salu("s_mov_b64", "exec", sLmPy2)
+                        k.gload(2, PYB4[k1][1], vOff8, sRow0 if off < 4096 else sRow1, off % 4096)
+                    else:
+                        k.gload(4, PYB4[k1][j - 1], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
             k.salu("s_mov_b64", "exec", -1)
         k.salu("s_sub_u32", sA[1], sTd, 3)
         if "NOMASKB" not in ABLATE:
@@ -1448,7 +1470,7 @@ def backward_loop(k, v):
             k.salu("s_andn2_b64", "exec", SMm(k1, j), SMm(kk, j))
             for q in range(2):
                 k.valu("v_mov_b32_e32", PX[j].sub(2 * q), 0)
-                k.valu("v_mov_b32_e32", PX[j].sub(2 * q + 1), sNinf.hi)
+                k.valu("v_mov_b32_e32", PX[j].sub(2 * q + 1), "0xfff00000")
             k.salu("s_andn2_b64", "exec", SMm(kk, j), SMm(k1, j))
             k.ds_read(128, PX[j], vTmp)
         k.salu("s_mov_b64", "exec", -1)
@@ -1570,7 +1592,7 @@ def backward_loop(k, v):
         k.salu("s_add_u32", sA[1], sTd, 1)
         k.salu("s_cmp_le_i32", sA[1], sTop)
         k.salu("s_cselect_b32", sA[1], 1, 0)
-        for i, s in enumerate((sTd, SMxmin(kk), SMxmax(kk), sNxt.lo, sNxt.hi, sA[1], 0, sNinf.hi)):
+        for i, s in enumerate((sTd, SMxmin(kk), SMxmax(kk), sNxt.lo, sNxt.hi, sA[1], 0, "0xfff00000")):
             k.valu("v_mov_b32_e32", rec[i // 4].sub(i % 4), s)
         k.valu("v_mov_b32_e32", vTmp, 0)
         k.salu("s_lshl_b32", sA[0], sNTot, 5)
@@ -1749,7 +1771,7 @@ def main():
     text.append("amdhsa.target:   amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\n\t.end_amdgpu_metadata")
     open(out, "w").write("\n".join(text) + "\n")
     if len(sys.argv) > 2:
-        defs = dict(ASM_L=L, ASM_ROW_BYTES=ROW_BYTES, ASM_LAYER_BYTES=LAYER_BYTES, ASM_OFF_FXY=OFF_FXY, ASM_OFF_PY=OFF_PY, ASM_CTX_X=CTX_X, ASM_CTX_S=CTX_S, ASM_CTX_BYTES=CTX_BYTES,
+        defs = dict(ASM_L=L, ASM_ROW_BYTES=ROW_BYTES, ASM_LAYER_BYTES=LAYER_BYTES, ASM_OFF_FXY=OFF_FXY, ASM_OFF_PY=OFF_PY, ASM_PY2_X2=int(PY2_X2), ASM_CTX_X=CTX_X, ASM_CTX_S=CTX_S, ASM_CTX_BYTES=CTX_BYTES,
                     ASM_MAX_WIDTH=MAX_WIDTH, ASM_PLANWIN_BYTES=PLANWIN_BYTES, ASM_CTL_BYTES=CTL_BYTES, ASM_BLOCK=BLOCK,
                     ASM_ARGS_BYTES=ARGS_BYTES, ASM_NCONST=NCONST, ASM_MASK_BYTES=MASK_BYTES, ASM_MASK_GROUP=MASK_GROUP, ASM_LDS_F_BYTES=LDS_F_BYTES, ASM_LDS_B_BYTES=LDS_B_BYTES)
         with open(sys.argv[2], "w") as h:

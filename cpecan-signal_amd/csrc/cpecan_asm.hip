@@ -139,7 +139,12 @@ extern "C" __global__ void cpecan_k_asm_masks(const DevItem *items, long long nI
     }
     e[6] = (unsigned) lo;
     e[7] = (unsigned) hi;
-    e[14] = e[15] = 0u;
+    /* the last layer's 8-byte emissions: 16 lanes to a line */
+    unsigned long long h = 0ull;
+    for (int q = 0; q < 64; q += 16)
+        if (g[ASM_L - 1] & (0xFFFFull << q)) h |= 0xFFFFull << q;
+    e[14] = (unsigned) h;
+    e[15] = (unsigned) (h >> 32);
 }
 
 extern "C" int cpecan_asm_launch_masks(hipStream_t stream, const DevItem *items, long long nItems, long long maxDiags,

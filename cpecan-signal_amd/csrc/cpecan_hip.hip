@@ -1553,7 +1553,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
          * per lane and fit their staging scheme (CPECAN_ASM=0: the compiled kernels, for tests and timing) */
         const bool asmOff = getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 0; /* (read per batch) */
         if (wantPlan && !asmOff && b->sy->wave && b->sy->rows == ASM_L && globalMaxWidth <= ASM_MAX_WIDTH && b->nGroups == 1 &&
-            b->stateBytes == (int) sizeof(WvState) && cpecan_asm_load(c->device) == 0) {
+            b->stateBytes == (int) sizeof(WvState) && b->sy->ring_row_doubles() * 8 == ASM_ROW_BYTES /* (one ring format) */ &&
+            cpecan_asm_load(c->device) == 0) {
             b->asmMaxWindows = std::max(maxWindows, 1);
             PinnedBuf<AsmPlanWin> hWin;
             StreamFence winFence{ c->prep, nullptr };

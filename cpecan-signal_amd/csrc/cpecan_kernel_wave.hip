@@ -88,16 +88,18 @@
 #define WV_FEED_MAX 32       /* diagonals per feed block of the forward sweep                            */
 #define WV_BITWORDS 256      /* band edge steps kept in LDS: 32 diagonals per word, circular, re-staged in halves */
 /* A ring row of the forward sweep, in doubles: per layer 64 (Fm, pm) pairs | 64 (Fx, Fy) pairs; after the layers the
- * gap-Y emissions, the layers two by two as 64 (py, py) pairs (an odd last layer: (py, unused)) -- every access of the
- * assembly sweeps is 16 bytes per lane (8-byte streaming stores take 2.5 times as long per instruction:
- * tools/ubench_vmem.hip); a row of three layers is 8192 bytes */
+ * gap-Y emissions, the layers two by two as 64 (py, py) pairs, an odd last layer's as 64 doubles -- the sweeps are bound
+ * by HBM traffic (tools/pmc_sweeps.sh), so a row carries nothing but its values; all but the last layer's emissions move
+ * in 16-byte accesses (8-byte streaming stores take 2.5 times as long per instruction: tools/ubench_vmem.hip) */
 #define WV_LAYER_DOUBLES 256
 #define WV_OFF_FM(lane) ((lane) * 2)
 #define WV_OFF_PM(lane) ((lane) * 2 + 1)
 #define WV_OFF_FX(lane) (128 + (lane) * 2)
 #define WV_OFF_FY(lane) (128 + (lane) * 2 + 1)
-#define WV_ROW_PY(j, lane) (WV_L * WV_LAYER_DOUBLES + ((j) >> 1) * 128 + (lane) * 2 + ((j) & 1)) /* from the row's start */
-#define WV_ROW_DOUBLES (WV_L * WV_LAYER_DOUBLES + ((WV_L + 1) / 2) * 128)
+/* from the row's start */
+#define WV_ROW_PY(j, lane) \
+    (WV_L * WV_LAYER_DOUBLES + ((j) >> 1) * 128 + (((WV_L & 1) && (j) == WV_L - 1) ? (lane) : (lane) * 2 + ((j) & 1)))
+#define WV_ROW_DOUBLES (WV_L * WV_LAYER_DOUBLES + (WV_L / 2) * 128 + (WV_L & 1) * 64)
 #define WV_PREFETCH 2        /* diagonals the backward sweep fetches ahead (== its unroll factor) */
 #define WV_CAND_SLACK 0.25   /* candidates: cells within this (log units) below the posterior threshold */
 #define WV_CAND_PER_DIAG 4   /* candidate capacity, in records per ring diagonal and layer */

@@ -302,6 +302,11 @@ def mask_table(xmin, xmax):
             tab[d, 2 * j], tab[d, 2 * j + 1] = m[j] & 0xFFFFFFFF, m[j] >> 32
             tab[d, 8 + 2 * j], tab[d, 9 + 2 * j] = g[j] & 0xFFFFFFFF, g[j] >> 32
         tab[d, 6], tab[d, 7] = lo, hi
+        h = 0   # the last layer's 8-byte emissions: 16 lanes to a line
+        for q in range(0, 64, 16):
+            if g[L - 1] & (0xFFFF << q):
+                h |= 0xFFFF << q
+        tab[d, 14], tab[d, 15] = h & 0xFFFFFFFF, h >> 32
     return tab
 
 
