@@ -58,7 +58,7 @@ W_D0, W_TOP, W_FROM, W_TO, W_ATEND, W_XMINTOP, W_XMAXTOP, W_NWIN, W_CELLS, W_XMI
 PLANWIN_BYTES = 64
 CTL_BYTES = 32                           # per 64 diagonals: u64 stepMin, stepMax, full, spare
 # WvState / WvWindow (cpecan_sweep.h)
-ST_D, ST_TB, ST_FIN, ST_WIN, ST_CELLS, ST_CLKS, ST_CLKR, STATE_BYTES = 0, 4, 8, 16, 112, 120, 128, 136
+ST_D, ST_TB, ST_FIN, ST_WIN, ST_CELLS, ST_CLKS, ST_CLKR, STATE_BYTES = 0, 4, 8, 16, 192, 200, 208, 216   # (WvState: win[4])
 WIN_BYTES = 40
 # the forward sweep's context (registers of a wave between two launches)
 CTX_C = 0                                # L x 36 dwords of constants, 1024 bytes per 4 dwords
@@ -78,9 +78,8 @@ LDS_PX = 512
 PXN = 64
 LDS_RF = LDS_PX + PXN * 16               # the forward cells a refresh of totalProbability wants, fetched ahead by loads to LDS:
 LDS_RF_XY_T = LDS_RF                     # (Fx, Fy) of the refresh's diagonal t, 1024 bytes per layer
-LDS_RF_MP_B = LDS_RF + L * 1024          # (Fm, pm) of t - 1
-LDS_RF_XY_B = LDS_RF + 2 * L * 1024      # (Fx, Fy) of t - 1
-LDS_B_BYTES = LDS_RF + 3 * L * 1024
+LDS_RF_XY_B = LDS_RF + L * 1024          # (Fx, Fy) of t - 1 (its Fm is in the sweep's registers)
+LDS_B_BYTES = LDS_RF + 2 * L * 1024
 
 MAX_WIDTH = 158                          # band widths the staging scheme holds
 BLOCK = 64                               # diagonals per staging block
@@ -911,8 +910,8 @@ def forward_tail(k, v):
     k.valu("v_mov_b32_e32", vZ.lo, 0)
     for i in range(3):
         k.gstore(4, vZ.lo, q4[i], sP[3], 16 * i)
-    # the window for the sweep back: win[window & 1] = { valid 1, top, from, to, atEnd, 0, 0, 0, est }
-    k.salu("s_and_b32", sT[0], sWindow, 1)
+    # the window for the sweep back: win[window & 3] = { valid 1, top, from, to, atEnd, 0, 0, 0, est }
+    k.salu("s_and_b32", sT[0], sWindow, 3)
     k.salu("s_mul_i32", sT[0], sT[0], WIN_BYTES)
     k.salu("s_add_u32", sT[0], sT[0], ST_WIN)
     k.add64(sP[2], sState, sT[0])
@@ -1066,7 +1065,7 @@ def backward_kernel(name):
     # the state record; the window as the forward kernel described it
     k.salu("s_mul_i32", sA[0], sWg, STATE_BYTES)
     k.add64(sState, sBp(6), sA[0])
-    k.salu("s_and_b32", sA[0], sWindow, 1)
+    k.salu("s_and_b32", sA[0], sWindow, 3)
     k.salu("s_mul_i32", sA[0], sA[0], WIN_BYTES)
     k.salu("s_add_u32", sA[0], sA[0], ST_WIN)
     k.add64(sAp(2), sState, sA[0])
@@ -1209,9 +1208,12 @@ def backward_kernel(name):
     k.wait_all()
     for h in range(2):
         k.rol64(RP.sub(2 * h, 2), PX[0].sub(2 * h, 2))
-    def prefetch_terms(dreg):
-        """loads to LDS of what the refresh on diagonal dreg reads of the ring: (Fx, Fy) of its row, (Fm, pm) and
-        (Fx, Fy) of the row below (every lane: a lane outside the band reads whatever the ring holds, nobody uses it)"""
+    def prefetch_terms(dreg, masks=None):
+        """loads to LDS of what the refresh on diagonal dreg reads of the ring beyond the sweep's own loads: (Fx, Fy) of
+        its row and of the row below.  masks: the lanes of a ring row at most eight diagonals above, per layer -- the band
+        moves by at most a column a diagonal, a lane per three columns, so those lanes and the eight below them
+        (cyclically) cover the rows wanted; None: every lane (a lane outside the band reads whatever the ring holds,
+        nobody uses it)"""
         k.salu("s_and_b32", sA[0], dreg, sRingMask)
         k.salu("s_mul_i32", sA[0], sA[0], ROW_BYTES)
         k.add64(sAp(4), sRing0, sA[0])
@@ -1219,12 +1221,19 @@ def backward_kernel(name):
         k.salu("s_and_b32", sA[1], sA[1], sRingMask)
         k.salu("s_mul_i32", sA[1], sA[1], ROW_BYTES)
         k.add64(sAp(6), sRing0, sA[1])
-        for base, off0, dest0 in ((sAp(4), OFF_FXY, LDS_RF_XY_T), (sAp(6), 0, LDS_RF_MP_B), (sAp(6), OFF_FXY, LDS_RF_XY_B)):
-            for j in range(L):
-                k.add64(sAp(2), base, j * LAYER_BYTES + off0)
+        for j in range(L):
+            if masks is not None:
+                k.salu("s_lshr_b64", sAp(8), masks[j], 8)
+                k.salu("s_lshl_b64", sAp(10), masks[j], 56)
+                k.salu("s_or_b64", sAp(8), sAp(8), sAp(10))
+                k.salu("s_or_b64", "exec", sAp(8), masks[j])
+            for base, dest0 in ((sAp(4), LDS_RF_XY_T), (sAp(6), LDS_RF_XY_B)):
+                k.add64(sAp(2), base, j * LAYER_BYTES + OFF_FXY)
                 k.salu("s_mov_b32", "m0", dest0 + j * 1024)
                 k.nop(1)
                 k.gload_lds(vOff16, sAp(2))
+        if masks is not None:
+            k.salu("s_mov_b64", "exec", -1)
 
     prefetch_terms(sTpost0)
     # which third of the loop the traceback point falls in
@@ -1533,10 +1542,13 @@ def backward_loop(k, v):
         xyT = [pool.take(4) for _ in range(L)]
         for j in range(L):
             k.ds_read(128, xyT[j], vOff16, LDS_RF_XY_T + j * 1024)
-        mB, xyB = [pool.take(2) for _ in range(L)], [pool.take(4) for _ in range(L)]
+        # F.match of t - 1 is in the registers of that row (asked for two diagonals ago: its loads are the oldest under way)
+        k.raw_wait_vm(L + 2)
+        mB0, xyB = pool.take(2), [pool.take(4) for _ in range(L)]
+        k.ror64(mB0, Tf(k2, L - 1))
+        mB = [mB0] + [Tf(k2, j - 1) for j in range(1, L)]
         for j in range(L):
             a, lay = (vOff16, j - 1) if j else (vPrev.lo, L - 1)
-            k.ds_read(64, mB[j], a, LDS_RF_MP_B + lay * 1024)
             k.ds_read(128, xyB[j], a, LDS_RF_XY_B + lay * 1024)
         out = [pool.take(3 * 2), pool.take(3 * 2)]
         a1, a2 = [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)]
@@ -1563,7 +1575,7 @@ def backward_loop(k, v):
             k.add(m1_[j], xyB[j].sub(0, 2), hp)
             k.add(hp, PMB[k1][j], sTYM)
             k.add(m2_[j], xyB[j].sub(2, 2), hp)
-        pool.give(hp, *mB)
+        pool.give(hp, mB0)
         pool.give(*xyB)
         r = [k.ladd_front(m0_[j], m1_[j]) for j in range(L)]
         k.need_recs(r)
@@ -1603,8 +1615,8 @@ def backward_loop(k, v):
         k.salu("s_add_u32", sNTot, sNTot, 1)
         pool.give(*rec)
         pool.give(*fb)
-        k.salu("s_sub_u32", sA[8], sTd, 10)
-        prefetch_terms(sA[8])
+        k.salu("s_sub_u32", sA[12], sTd, 10)
+        prefetch_terms(sA[12], sLm)
         k.branch("s_branch", lbl("refreshed%d" % kk))
 
     # ------------------------------------------------------------------ the loop pauses: end of the window, the diagonal
@@ -1652,7 +1664,7 @@ def backward_loop(k, v):
     # ------------------------------------------------------------------ the window is swept: counts for the post kernel
     k.forget()
     k.label(lbl("done"))
-    k.salu("s_and_b32", sA[0], sWindow, 1)
+    k.salu("s_and_b32", sA[0], sWindow, 3)
     k.salu("s_mul_i32", sA[0], sA[0], WIN_BYTES)
     k.salu("s_add_u32", sA[0], sA[0], ST_WIN)
     k.add64(sAp(2), sState, sA[0])

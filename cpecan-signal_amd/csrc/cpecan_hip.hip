@@ -514,6 +514,8 @@ struct cpecan_batch {
      * lasts as long as its slowest workgroup).  evStage: per group, one event after every kernel. */
     int nGroups = 1;
     std::vector<hipStream_t> gStream, gStreamB; /* gStreamB: the wave kernels' backward sweeps (see batch_run) */
+    hipStream_t asmPost = nullptr;     /* assembly sweeps: the totals and the decode of a window, beside the next window's sweeps */
+    std::vector<hipEvent_t> evPost;    /* ... done, per window */
     bool gStreamOwned = true;
     long long modelEpoch = 0; /* the context's when the batch was created */
     int stateBytes = 0;
@@ -1138,6 +1140,8 @@ int cpecan_hip_batch_destroy(cpecan_batch *b) {
     if (b->gStreamOwned)
         for (hipStream_t st : b->gStream) (void) hipStreamDestroy(st);
     for (hipStream_t st : b->gStreamB) (void) hipStreamDestroy(st);
+    if (b->asmPost) (void) hipStreamDestroy(b->asmPost);
+    for (hipEvent_t e : b->evPost) (void) hipEventDestroy(e);
     if (b->hPacked) pinned_cache().put(b->hPacked, b->hPackedBlock);
     if (b->hPost) pinned_cache().put(b->hPost, b->hPostBlock);
     if (b->hUndecided) pinned_cache().put(b->hUndecided, b->hUndecidedBlock);
@@ -1501,8 +1505,13 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         b->nWindows = maxWindows;
         b->ringD = 64;
         /* the kernels mask with ringD-1.  The wave kernels sweep window w back while the forward sweep of window w+1
-         * is writing: the ring holds two windows */
-        while (b->ringD < (b->sy->wave && maxWindows > 1 ? 2 * maxSpan + 8 : maxSpan + 4)) b->ringD *= 2;
+         * is writing: the ring holds two windows -- three where the assembly sweeps may run (decided below; the same
+         * conditions but for what is not known yet): there the forward sweep of window w+2 does not wait for the totals
+         * and the decode of window w, whose re-sweep kernel may still read that window's rows */
+        const bool asmOffEarly = getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 0;
+        const bool asmLikely = wantPlan && !asmOffEarly && b->sy->wave && b->sy->rows == ASM_L && globalMaxWidth <= ASM_MAX_WIDTH;
+        const int ringWindows = !b->sy->wave || maxWindows <= 1 ? 1 : asmLikely && maxWindows > 2 ? 3 : 2;
+        while (b->ringD < (ringWindows > 1 ? ringWindows * maxSpan + 8 : maxSpan + 4)) b->ringD *= 2;
         /* the wave kernels keep one more row behind the ring: the -inf row lanes without a cell read */
         b->ringDoubles = (long long) (b->ringD + (b->sy->wave ? 1 : 0)) * b->sy->ring_row_doubles();
         if (getenv("CPECAN_RING_PAD")) b->ringDoubles += atoll(getenv("CPECAN_RING_PAD"));
@@ -1578,6 +1587,14 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                 return fail(CPECAN_EHIP, "context kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
             }
             B_TRY(hipStreamSynchronize(c->prep)); /* hWin ends here */
+            if (b->ringD >= 3 * maxSpan + 8 || maxWindows <= 2) {
+                /* the post kernel of a window runs beside the next window's sweeps (batch_run): the sweep back of window
+                 * w+1 fills one half of the scratch while the post kernel of window w reads the other */
+                B_TRY(b->syScratch.alloc(2 * (size_t) nItems * (size_t) b->scratchBytes));
+                B_TRY(hipStreamCreateWithFlags(&b->asmPost, hipStreamNonBlocking));
+                b->evPost.assign((size_t) b->asmMaxWindows, nullptr);
+                for (auto &e : b->evPost) B_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            }
             b->useAsm = true;
             /* CPECAN_ASM=1: the forward sweep only (the compiled sweep back reads what it writes: tests, timing) */
             b->asmBackward = !(getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 1);
@@ -1674,7 +1691,17 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                     "its model ids are gone");
     if (after && after->device != b->device) return fail(CPECAN_EINVAL, "the two batches live on different devices");
     HIP_TRY(hipSetDevice(c->device));
-    if (after && after != b && after->ran) HIP_TRY(hipStreamWaitEvent(c->stream, after->ev2, 0));
+    if (after && after != b && after->ran) {
+        /* behind the other batch on the device.  A batch of the wave kernels in one stream group is followed as soon as
+         * its LAST FORWARD sweep is over: this batch's first forward sweep then shares the SIMDs with that batch's last
+         * sweep back, as the forward sweep of that batch's own next window would have, and the totals, decode, counts
+         * and packing of that batch run beside this one's first window. */
+        hipEvent_t done = after->ev2;
+        if (after->kernel == CPECAN_KERNEL_SYSTOLIC && after->sy && after->sy->wave && after->nGroups == 1 && after->nWindows > 0 &&
+            after->evStage.size() == (size_t) (4 * after->nWindows + 1))
+            done = after->evStage[(size_t) (1 + 4 * (after->nWindows - 1) + 1)];
+        HIP_TRY(hipStreamWaitEvent(c->stream, done, 0));
+    }
     b->countsValid = false;
     HIP_TRY(hipEventRecord(b->ev0, c->stream));
     if (b->mode == CPECAN_MODE_EXPECTATIONS)
@@ -1826,7 +1853,16 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
             const long long bringRow = b->sy->bring_row_doubles();
             for (int w = 0; w < b->nWindows && rc == 0; w++) {
                 hipEvent_t *e4 = ev + 1 + 4 * w;
+                /* assembly sweeps: the window's totals and decode (and the re-sweep of what cannot be trusted) run on a
+                 * stream of their own.  The sweep back of the next window does not wait for them (it fills the other
+                 * half of the scratch), nor does the forward sweep of window w+2 (the ring holds three windows, the
+                 * state four window records); what does: the sweep back of w+2 (scratch), the forward sweep of w+3
+                 * (ring rows, window record).  The forward sweep of w+2 still waits for the sweep back of w, which reads
+                 * the context that sweep will overwrite when it ends. */
+                const bool postAside = asmRun && b->asmBackward && sB != sF && b->asmPost != nullptr;
+                char *scratchW = b->syScratch.p + (postAside ? (size_t) (w & 1) * (size_t) b->nItems * (size_t) b->scratchBytes : 0);
                 if (sB != sF && w >= 2) HIP_TRY(hipStreamWaitEvent(sF, ev[1 + 4 * (w - 2) + 3], 0));
+                if (postAside && w >= 3) HIP_TRY(hipStreamWaitEvent(sF, b->evPost[(size_t) w - 3], 0));
                 HIP_TRY(hipEventRecord(e4[0], sF));
                 /* the kernels index everything per alignment by blockIdx: shift the bases */
                 if (n > 0 && asmRun) {
@@ -1847,17 +1883,25 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
 #endif
                 if (rc == 0 && n > 0 && asmRun && b->asmBackward && !fwdOnly) {
                     asmArgs.window = w;
+                    asmArgs.scratch = scratchW;
+                    if (postAside && w >= 2) HIP_TRY(hipStreamWaitEvent(sB, b->evPost[(size_t) w - 2], 0));
                     rc = cpecan_asm_launch_backward(c->device, sB, &asmArgs);
+                    hipStream_t sP = postAside ? b->asmPost : sB;
+                    if (postAside) {
+                        HIP_TRY(hipEventRecord(e4[3], sB));
+                        HIP_TRY(hipStreamWaitEvent(sP, e4[3], 0));
+                    }
 #ifdef CPECAN_TIMING_BUILD
                     static const bool noPost = getenv("CPECAN_TIMING_NO_POST") != nullptr; /* timing study: sweeps only */
 #else
                     const bool noPost = false;
 #endif
                     if (rc == 0 && !noPost)
-                        rc = cpecan_wave_launch_post_asm_l3(sB, b->items.p, n, b->P, b->bandTab.p, b->track.p, b->trackBase.p, models,
+                        rc = cpecan_wave_launch_post_asm_l3(sP, b->items.p, n, b->P, b->bandTab.p, b->track.p, b->trackBase.p, models,
                                                             b->Fstore.p, b->ringDoubles, b->ringD, b->syStates.p, b->pairs.p,
-                                                            b->pairLogp.p, b->totXay.p, b->totVal.p, b->syScratch.p,
+                                                            b->pairLogp.p, b->totXay.p, b->totVal.p, scratchW,
                                                             b->scratchBytes, w);
+                    if (postAside) HIP_TRY(hipEventRecord(b->evPost[(size_t) w], sP));
                 } else if (rc == 0 && n > 0 && !fwdOnly)
                     rc = b->sy->launch_backward(sB, b->items.p + i0, n, b->P, b->bandTab.p, b->track.p,
                                                 b->trackBase.p + i0, models,
@@ -1875,8 +1919,10 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                                               b->syStates.p + i0 * b->stateBytes,
                                               b->syScratch.p + i0 * b->scratchBytes, b->scratchBytes, b->expect.p, w,
                                               b->pairs.p, b->pairLogp.p);
-                HIP_TRY(hipEventRecord(e4[3], sB));
+                if (!postAside) HIP_TRY(hipEventRecord(e4[3], sB));
             }
+            if (asmRun && b->asmBackward && sB != sF && b->asmPost != nullptr && b->nWindows > 0) /* the last post kernel follows all */
+                HIP_TRY(hipStreamWaitEvent(sB, b->evPost[(size_t) b->nWindows - 1], 0));
             HIP_TRY(hipEventRecord(b->evJoin[(size_t) gi], sB)); /* the last sweep back follows every forward sweep */
             HIP_TRY(hipStreamWaitEvent(c->stream, b->evJoin[(size_t) gi], 0));
         }

@@ -841,7 +841,7 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             WvWindow w;
             w.valid = 1; w.top = d; w.from = from; w.to = tracedBackTo; w.atEnd = atEnd ? 1 : 0; w.pad = 0;
             w.est = est;
-            state->win[window & 1] = w;
+            state->win[window & 3] = w;
             state->d = d;
             state->finished = atEnd ? 1 : 0;
             state->tracedBackTo = from;
@@ -1655,7 +1655,7 @@ template <bool SW, int KIND> __device__ __forceinline__ void wv_backward_kernel(
     WvState *state = states + idx;
     WvWindow win;
     {
-        const WvWindow *w = &state->win[window & 1];
+        const WvWindow *w = &state->win[window & 3];
         win.valid = ld_agent(&w->valid); win.top = ld_agent(&w->top); win.from = ld_agent(&w->from);
         win.to = ld_agent(&w->to); win.atEnd = ld_agent(&w->atEnd); win.nCand = win.nRefresh = win.pad = 0;
         win.est = ld_agent(&w->est);
@@ -1686,7 +1686,7 @@ template <bool SW, int KIND> __device__ __forceinline__ void wv_backward_kernel(
                               out, sh, wtot, vw, rf, candKx, candFb,
                               Bring ? Bring + idx * ((long long) ringD * WV_L * 3 * 64) : nullptr, nTot, nCand);
     if ((threadIdx.x & 63) == 0) {
-        WvWindow *w = &state->win[window & 1];
+        WvWindow *w = &state->win[window & 3];
         if (KIND == WV_KIND_REDO) {
             state->nPairs = out.nPairs;
             w->valid = 0;
@@ -1744,7 +1744,7 @@ extern "C" __global__ __launch_bounds__(256) void WV_SYM(cpecan_k_wv_post)(
     const long long idx = blockIdx.x;
     if (idx >= nItems) return;
     WvState *state = states + idx;
-    WvWindow *wp = &state->win[window & 1];
+    WvWindow *wp = &state->win[window & 3];
     if (uni(ld_agent(&wp->valid)) != 3) return;
     const DevItem it = uniform_item(items[idx]);
     const int tid = threadIdx.x, lane = tid & 63, wv = uni(tid >> 6);
@@ -1944,8 +1944,8 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const double *tr = track + trackBase[idx] * WV_ROW;
     const int2 *tab = bandTab + it.diagBase;
     const WinTotal *wtot = (const WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int));
-    const int dTop = uni(state->win[window & 1].top), from = uni(state->win[window & 1].from),
-              to = uni(state->win[window & 1].to);
+    const int dTop = uni(state->win[window & 3].top), from = uni(state->win[window & 3].from),
+              to = uni(state->win[window & 3].to);
     const int tPost0 = dTop < from ? dTop : from;
     double *dst = expect + (long long) it.model * (60 + 1);
     if (threadIdx.x < 64) sBins[threadIdx.x] = 0.0;
@@ -2041,8 +2041,8 @@ extern "C" __global__ __launch_bounds__(WV_P) void WV_SYM(cpecan_k_wv_expect)(
     const unsigned short *kx = kidx + it.xOff;
     const int2 *tab = bandTab + it.diagBase;
     const WinTotal *wtot = (const WinTotal *) (scratch + idx * scratchBytes + 2ll * ringD * sizeof(int));
-    const int dTop = uni(state->win[window & 1].top), from = uni(state->win[window & 1].from),
-              to = uni(state->win[window & 1].to);
+    const int dTop = uni(state->win[window & 3].top), from = uni(state->win[window & 3].from),
+              to = uni(state->win[window & 3].to);
     const int tPost0 = dTop < from ? dTop : from;
 #ifdef WV_HDP
     double *dst = expect + (long long) it.model * (9 + 1);

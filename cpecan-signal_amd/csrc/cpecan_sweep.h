@@ -18,8 +18,9 @@ struct SyState {
                                     ratio is the clock the chip ran at under this load) */
 };
 
-/* The wave kernels' record: the forward kernel of launch w describes its window in win[w & 1] while the backward
- * kernel of launch w - 1 may still be working from the other entry (the two run concurrently). */
+/* The wave kernels' record: the forward kernel of launch w describes its window in win[w & 3] while the backward
+ * kernel of launch w - 1 is working from the entry before and the post kernel of launch w - 2 may still be reading the
+ * one before that (the assembly sweeps' schedule, cpecan_hip.hip: they all run concurrently). */
 struct WvWindow {
     int valid; /* 1: described by the forward kernel; 3: swept back, its totals and pairs are the post kernel's to do;
                   2: its candidates could not be trusted, the re-sweep kernel decodes it; 0: done */
@@ -33,7 +34,7 @@ struct WvState {
     int tracedBackTo; /* as in getPosteriorProbsWithBanding (impl/pairwiseAligner.c:903) */
     int finished;     /* forward reached the last diagonal */
     int expectPending; /* Baum-Welch: the window's backward cells are in the B ring, not yet summed */
-    WvWindow win[2];
+    WvWindow win[4];
     long long nPairs, nTot, cells;
     long long clkShader, clkRef; /* shader-clock and 100 MHz reference ticks the alignment's forward sweeps took (the
                                     ratio is the clock the chip ran at under this load) */

@@ -276,12 +276,12 @@ class Image:
         raw = self.mem.get(self.a_states + item * STATE_BYTES, np.uint8, STATE_BYTES)
         i32 = raw.view(np.int32)
         out = dict(d=int(i32[0]), tracedBackTo=int(i32[1]), finished=int(i32[2]), win=[])
-        for k in range(2):
+        for k in range(4):
             w = raw[16 + 40 * k: 56 + 40 * k]
             wi = w.view(np.int32)
             out["win"].append(dict(valid=int(wi[0]), top=int(wi[1]), frm=int(wi[2]), to=int(wi[3]), atEnd=int(wi[4]),
                                    nCand=int(wi[5]), nRefresh=int(wi[6]), est=float(w[32:40].view(np.float64)[0])))
-        out["cells"] = int(raw[112:120].view(np.int64)[0])
+        out["cells"] = int(raw[G.ST_CELLS: G.ST_CELLS + 8].view(np.int64)[0])
         return out
 
 

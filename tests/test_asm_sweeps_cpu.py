@@ -88,7 +88,7 @@ def test_sweeps_on_the_emulator_equal_the_oracle(lX, lY, ragged, seed):
         cur[0] = w
         H.run_backward(img, wi, 0, thr, watch)
         assert not bad_b, "backward cells, window %d: %r" % (wi, bad_b[:4])
-        rec = img.state(0)["win"][wi & 1]
+        rec = img.state(0)["win"][wi & 3]
         assert rec["valid"] == 3 and rec["top"] == w["top"] and rec["frm"] == w["frm"] and rec["to"] == w["to"]
         n_refresh = len([t for t in range(w["tpost0"], w["to"], -10)])
         assert rec["nRefresh"] == n_refresh
