@@ -78,8 +78,7 @@ LDS_PX = 512
 PXN = 64
 LDS_RF = LDS_PX + PXN * 16               # the forward cells a refresh of totalProbability wants, fetched ahead by loads to LDS:
 LDS_RF_XY_T = LDS_RF                     # (Fx, Fy) of the refresh's diagonal t, 1024 bytes per layer
-LDS_RF_XY_B = LDS_RF + L * 1024          # (Fx, Fy) of t - 1 (its Fm is in the sweep's registers)
-LDS_B_BYTES = LDS_RF + 2 * L * 1024
+LDS_B_BYTES = LDS_RF + L * 1024
 
 MAX_WIDTH = 158                          # band widths the staging scheme holds
 BLOCK = 64                               # diagonals per staging block
@@ -1006,7 +1005,9 @@ def backward_kernel(name):
     q0 = p0 + pyw * 3
     sLmPy2 = S(64, 2)                                   # the lanes the last layer's 8-byte emissions are loaded under
     PMB = [[V(q0 + 2 * L * q + 2 * j, 2) for j in range(L)] for q in range(3)]  # match emissions, kept two diagonals longer
-    pool0 = q0 + 6 * L
+    # F.match + B.match of the diagonal above, kept on the diagonal before a refresh of totalProbability: its second half
+    FBS = V(q0 + 6 * L, 2 * L)
+    pool0 = q0 + 8 * L
     pool = Pool(pool0, 255)
     k = Kernel(pool)
     def Tf(q, j): return T[q][j].sub(0, 2)
@@ -1210,28 +1211,22 @@ def backward_kernel(name):
         k.rol64(RP.sub(2 * h, 2), PX[0].sub(2 * h, 2))
     def prefetch_terms(dreg, masks=None):
         """loads to LDS of what the refresh on diagonal dreg reads of the ring beyond the sweep's own loads: (Fx, Fy) of
-        its row and of the row below.  masks: the lanes of a ring row at most eight diagonals above, per layer -- the band
-        moves by at most a column a diagonal, a lane per three columns, so those lanes and the eight below them
-        (cyclically) cover the rows wanted; None: every lane (a lane outside the band reads whatever the ring holds,
-        nobody uses it)"""
+        its row.  masks: the lanes of a ring row at most eight diagonals above, per layer -- the band moves by at most a
+        column a diagonal, a lane per three columns, so those lanes and the eight below them (cyclically) cover the row
+        wanted; None: every lane (a lane outside the band reads whatever the ring holds, nobody uses it)"""
         k.salu("s_and_b32", sA[0], dreg, sRingMask)
         k.salu("s_mul_i32", sA[0], sA[0], ROW_BYTES)
         k.add64(sAp(4), sRing0, sA[0])
-        k.salu("s_sub_u32", sA[1], dreg, 1)
-        k.salu("s_and_b32", sA[1], sA[1], sRingMask)
-        k.salu("s_mul_i32", sA[1], sA[1], ROW_BYTES)
-        k.add64(sAp(6), sRing0, sA[1])
         for j in range(L):
             if masks is not None:
                 k.salu("s_lshr_b64", sAp(8), masks[j], 8)
                 k.salu("s_lshl_b64", sAp(10), masks[j], 56)
                 k.salu("s_or_b64", sAp(8), sAp(8), sAp(10))
                 k.salu("s_or_b64", "exec", sAp(8), masks[j])
-            for base, dest0 in ((sAp(4), LDS_RF_XY_T), (sAp(6), LDS_RF_XY_B)):
-                k.add64(sAp(2), base, j * LAYER_BYTES + OFF_FXY)
-                k.salu("s_mov_b32", "m0", dest0 + j * 1024)
-                k.nop(1)
-                k.gload_lds(vOff16, sAp(2))
+            k.add64(sAp(2), sAp(4), j * LAYER_BYTES + OFF_FXY)
+            k.salu("s_mov_b32", "m0", LDS_RF_XY_T + j * 1024)
+            k.nop(1)
+            k.gload_lds(vOff16, sAp(2))
         if masks is not None:
             k.salu("s_mov_b64", "exec", -1)
 
@@ -1332,7 +1327,7 @@ def backward_loop(k, v):
     k.mods = " nt" if "NT" in ABLATE or "NTB" in ABLATE else ""
     name, pool, lbl = g["name"], g["pool"], g["lbl"]
     M, BX, BY, UM, UY, T, PYB, PX, RP = g["M"], g["BX"], g["BY"], g["UM"], g["UY"], g["T"], g["PYB"], g["PX"], g["RP"]
-    PMB, PYB4, sLmPy2 = g["PMB"], g["PYB4"], g["sLmPy2"]
+    PMB, PYB4, sLmPy2, FBS = g["PMB"], g["PYB4"], g["sLmPy2"], g["FBS"]
     Tf, Tpm, PXo, PXe = g["Tf"], g["Tpm"], g["PXo"], g["PXe"]
     vOff16, vOff8, vTmp, vTmp2, vThr, vCthr = g["vOff16"], g["vOff8"], g["vTmp"], g["vTmp2"], g["vThr"], g["vCthr"]
     SM, SMm, SMxmin, SMxmax, sLm, sA, sAp = g["SM"], g["SMm"], g["SMxmin"], g["SMxmax"], g["sLm"], g["sA"], g["sAp"]
@@ -1451,7 +1446,7 @@ def backward_loop(k, v):
         k.branch("s_cbranch_scc1", lbl("cand%d" % kk))
         k.label(lbl("canded%d" % kk))
         k.salu("s_sub_u32", sRefCnt, sRefCnt, 1)
-        k.salu("s_cmp_eq_u32", sRefCnt, -1)
+        k.salu("s_cmp_lt_i32", sRefCnt, 1)     # 0: the diagonal below has a refresh of totalProbability; -1: this one
         k.branch("s_cbranch_scc1", lbl("refresh%d" % kk))
         k.label(lbl("refreshed%d" % kk))
         pool.give(*fb)
@@ -1529,28 +1524,26 @@ def backward_loop(k, v):
         # diagonal, B.match and the match emission of the one above -- with the diagonal and the two bands
         k.forget()
         k.label(lbl("refresh%d" % kk))
-        k.salu("s_mov_b32", sRefCnt, 9)
         pool.hold(*fb)
-        # its terms (diagonalCalculationTotalProbability, :736-754): per cell of t, v = F(t) . B(t); per cell of t + 1,
-        # w = the match transitions from the cell below-left on t - 1 into it, times B.match(t + 1) -- the ring values
-        # were fetched to LDS a refresh ago; the slot below is the layer before on the same lane, for layer 0 the last
-        # layer of the lane before (whatever a slot outside the band of t - 1 holds is -inf: the forward sweep's guard slots)
+        # the diagonal before a refresh: F.match + B.match of this one is the refresh's second half.  (Per cell of t + 1,
+        # diagonalCalculationTotalProbability, :736-754, sums the match transitions from the cell below-left on t - 1
+        # into it, times B.match(t + 1): the sum over the three states of t - 1 with the cell's match emission is, term
+        # for term and in the same order, the forward recurrence of the match state, :365-375 -- F.match(t + 1) itself.)
+        k.salu("s_cmp_eq_u32", sRefCnt, 0)
+        k.branch("s_cbranch_scc0", lbl("refresh%d_now" % kk))
+        for j in range(L):
+            k.valu("v_mov_b32_e32", FBS.sub(2 * j), fb[j].lo)
+            k.valu("v_mov_b32_e32", FBS.sub(2 * j + 1), fb[j].hi)
+        k.branch("s_branch", lbl("refreshed%d" % kk))
+        k.label(lbl("refresh%d_now" % kk))
+        k.salu("s_mov_b32", sRefCnt, 9)
+        # the refresh's first half: per cell of t, v = F(t) . B(t) -- (Fx, Fy) of t were fetched to LDS a refresh ago
         vPrev = pool.take(2)
-        k.valu("v_add_u32_e32", vPrev.lo, 1008, vOff16)
-        k.valu("v_and_b32_e32", vPrev.lo, 1023, vPrev.lo)
         k.valu("v_add_u32_e32", vPrev.hi, vOff16, vOff8)       # 24 * lane: a lane's three terms lie together
         xyT = [pool.take(4) for _ in range(L)]
         for j in range(L):
             k.ds_read(128, xyT[j], vOff16, LDS_RF_XY_T + j * 1024)
-        # F.match of t - 1 is in the registers of that row (asked for two diagonals ago: its loads are the oldest under way)
-        k.raw_wait_vm(L + 2)
-        mB0, xyB = pool.take(2), [pool.take(4) for _ in range(L)]
-        k.ror64(mB0, Tf(k2, L - 1))
-        mB = [mB0] + [Tf(k2, j - 1) for j in range(1, L)]
-        for j in range(L):
-            a, lay = (vOff16, j - 1) if j else (vPrev.lo, L - 1)
-            k.ds_read(128, xyB[j], a, LDS_RF_XY_B + lay * 1024)
-        out = [pool.take(3 * 2), pool.take(3 * 2)]
+        out = [pool.take(3 * 2), FBS]
         a1, a2 = [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)]
         for j in range(L):
             k.add(a1[j], xyT[j].sub(0, 2), BX[j])
@@ -1566,37 +1559,13 @@ def backward_loop(k, v):
             k.ladd_back(r[j], out[0].sub(2 * j, 2), s7p5)
         pool.give(*a1)
         pool.give(*a2)
-        hp = pool.take(2)
-        m0_, m1_, m2_ = [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)]
-        for j in range(L):
-            k.add(hp, PMB[k1][j], sTMM)
-            k.add(m0_[j], mB[j], hp)
-            k.add(hp, PMB[k1][j], sTXM)
-            k.add(m1_[j], xyB[j].sub(0, 2), hp)
-            k.add(hp, PMB[k1][j], sTYM)
-            k.add(m2_[j], xyB[j].sub(2, 2), hp)
-        pool.give(hp, mB0)
-        pool.give(*xyB)
-        r = [k.ladd_front(m0_[j], m1_[j]) for j in range(L)]
-        k.need_recs(r)
-        for j in range(L):
-            k.ladd_back(r[j], m0_[j], s7p5)
-        r = [k.ladd_front(m0_[j], m2_[j]) for j in range(L)]
-        k.need_recs(r)
-        for j in range(L):
-            k.ladd_back(r[j], m1_[j], s7p5)
-        for j in range(L):
-            k.add(out[1].sub(2 * j, 2), m1_[j], M[k1][j])
-        pool.give(*m0_)
-        pool.give(*m1_)
-        pool.give(*m2_)
         k.salu("s_mul_i32", sA[0], sNTot, 2 * P * 8)
         k.add64(sAp(4), sRf, sA[0])
         for f in range(2):
             if "NOSTORE" not in ABLATE:
                 k.gstore(4, vPrev.hi, out[f].sub(0, 4), sAp(4), f * P * 8)
                 k.gstore(2, vPrev.hi, out[f].sub(4, 2), sAp(4), f * P * 8 + 16)
-        pool.give(vPrev, *out)
+        pool.give(vPrev, out[0])
         pool.give(*fb)
         pool.hold(*fb)
         rec = [pool.take(4), pool.take(4)]

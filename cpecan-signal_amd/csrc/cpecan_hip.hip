@@ -591,9 +591,12 @@ static void build_asm_plan(const int *tab, long long nDiag, const cpecan_band_pa
     for (size_t wi = 0; wi < wins.size(); wi++) {
         AsmPlanWin &w = wins[wi];
         w.nWindows = (int) wins.size();
-        /* all three states: the two diagonals a launch resumes from, every diagonal a totalProbability refresh of the
-         * window that decodes it reads (every 10th decoded diagonal, counted down from the window's first) and the one
-         * below it; everything where windows are shorter than the traceback margin */
+        /* all three states: the two diagonals a launch resumes from and every diagonal with a totalProbability refresh of
+         * the window that decodes it (every 10th decoded diagonal, counted down from the window's first); the compiled
+         * sweep back (CPECAN_ASM=1: tests, timing) also reads the diagonal below a refresh, the assembly one does not
+         * (gen_sweeps.py: the refresh's second half is F.match + B.match of the diagonal above); everything where windows
+         * are shorter than the traceback margin */
+        const bool belowToo = getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 1;
         const bool endW = w.atEnd != 0;
         const int tpA = w.tpost0;
         int tpB = tpA;
@@ -605,7 +608,7 @@ static void build_asm_plan(const int *tab, long long nDiag, const cpecan_band_pa
         for (int dj = w.d0 + 1; dj <= w.top; dj++) {
             const int rA = ((tpA - dj) % 10 + 10) % 10, rB = endW ? 99 : ((tpB - dj) % 10 + 10) % 10;
             const int rHere = dj <= w.from ? rA : rB, rAbove = dj + 1 <= w.from ? rA : rB;
-            if (allFull || dj >= w.top - 1 || rHere == 0 || rAbove == 1) ctl[dj >> 6].full |= 1ull << (dj & 63);
+            if (allFull || dj >= w.top - 1 || rHere == 0 || (belowToo && rAbove == 1)) ctl[dj >> 6].full |= 1ull << (dj & 63);
         }
     }
 }

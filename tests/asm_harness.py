@@ -109,8 +109,7 @@ def build_plan(xmin, xmax, min_diags, tb_diags, expansion):
             ra = (tpa - dj) % 10
             rb = 99 if endw else (tpb - dj) % 10
             here = ra if dj <= w["frm"] else rb
-            above = ra if dj + 1 <= w["frm"] else rb
-            if allfull or dj >= w["top"] - 1 or here == 0 or above == 1:
+            if allfull or dj >= w["top"] - 1 or here == 0:  # (the assembly sweep back reads no gap states below a refresh)
                 ctl[dj >> 6, 2] |= np.uint64(1 << (dj & 63))
     return wins, ctl
 
