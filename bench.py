@@ -261,10 +261,11 @@ def main(argv=None):
     # batch runs on the wave-per-alignment kernels, whose forward sweep of window w+1 overlaps the backward sweep of
     # window w inside the batch.
     inflight = max(1, min(args.inflight, args.steps))
-    family = args.family if args.family != "auto" else ("workgroup" if inflight > 1 else "wave")
+    # auto: the wave-per-alignment kernels where the batch runs their hand-scheduled assembly sweeps (asked of the first
+    # batch below) -- pipelined batches then follow one another's last forward sweep; otherwise as before: workgroup
+    # kernels for pipelined batches, wave kernels for a batch alone
+    family = args.family if args.family != "auto" else "wave"
     flags = cp.FLAG_WORKGROUP_KERNELS if family == "workgroup" else 0
-    if inflight > 1 and "CPECAN_SYSTOLIC_GROUPS" not in os.environ:
-        os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"
     t_gen = t_models = t_upload = 0.0
     batches, ctxs, bs = [], [], []
     for j in range(inflight):
@@ -280,6 +281,12 @@ def main(argv=None):
         t0 = time.time()
         bs.append(cp.Batch(cx, make_items(cp, bt), bt["x_chars"], bt["events"], bt["anchors"], bp,
                            cp.MODE_POSTERIOR, args.kernel, flags))
+        if j == 0 and args.family == "auto" and inflight > 1 and bs[0].info().get("assembly_sweeps", 0) != 2:
+            family, flags = "workgroup", cp.FLAG_WORKGROUP_KERNELS
+            os.environ.setdefault("CPECAN_SYSTOLIC_GROUPS", "1")
+            bs[0].close()
+            bs[0] = cp.Batch(cx, make_items(cp, bt), bt["x_chars"], bt["events"], bt["anchors"], bp,
+                             cp.MODE_POSTERIOR, args.kernel, flags)
         t_upload += time.time() - t0
         batches.append(bt)
         ctxs.append(cx)
@@ -365,7 +372,8 @@ def main(argv=None):
     if args.single_steps > 0 and world == 1:
         for x in bs[1:]:
             x.close()
-        os.environ.pop("CPECAN_SYSTOLIC_GROUPS", None)
+        if family == "workgroup":
+            os.environ.pop("CPECAN_SYSTOLIC_GROUPS", None)
         single = {}
         for fam, fl in (("wave", 0), ("workgroup", cp.FLAG_WORKGROUP_KERNELS)):
             sb = cp.Batch(ctxs[0], make_items(cp, batch), batch["x_chars"], batch["events"], batch["anchors"], bp,
@@ -401,9 +409,10 @@ def main(argv=None):
     # HBM traffic of one pass from the PMC counters (FETCH_SIZE / WRITE_SIZE collected in separate
     # rocprofv3 --pmc passes of this same command; summary committed under profiles/)
     traffic, traffic_note, valu = None, None, None
-    prof = os.path.join(ROOT, "profiles", "r02_rocprofv3_pmc_summary.json")
+    asm = info.get("assembly_sweeps", 0) == 2
+    prof = os.path.join(ROOT, "profiles", "r03_rocprofv3_pmc_summary.json" if asm else "r02_rocprofv3_pmc_summary.json")
     if os.path.exists(prof) and args.reads == 1024 and args.events == 10000 and args.kmers == 5000:
-        pm = json.load(open(prof))["families"].get(family)
+        pm = json.load(open(prof))["families"].get("assembly" if asm else family)
         if pm and pm.get("FETCH_SIZE_GB_per_pass"):
             # FETCH_SIZE reports half the bytes of coalesced streaming reads on gfx950 (the guide's rule; the
             # calibration kernels in the same profile confirm it for this path's 8-byte-per-lane loads:
@@ -412,8 +421,9 @@ def main(argv=None):
             wr = pm["WRITE_SIZE_GB_per_pass"] * 1e9
             traffic = rd + wr
             traffic_note = ("HBM bytes per pass over the batch, %s kernels, from rocprofv3 --pmc (separate passes, "
-                            "profiles/r02_rocprofv3_pmc_summary.json): 2 x FETCH_SIZE = %.1f GB + WRITE_SIZE = %.1f GB; "
-                            "algorithmic %.1f GB" % (family, rd / 1e9, wr / 1e9, cells * 48.0 / 1e9))
+                            "profiles/%s): 2 x FETCH_SIZE = %.1f GB + WRITE_SIZE = %.1f GB; "
+                            "algorithmic %.1f GB" % ("assembly sweeps, wave" if asm else family, os.path.basename(prof),
+                                                     rd / 1e9, wr / 1e9, cells * 48.0 / 1e9))
             valu = {k: round(v.get("valu_busy_fraction_of_simd_time", 0.0), 3) for k, v in pm.get("SQ", {}).items()}
     roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_note": traffic_note,
@@ -422,9 +432,14 @@ def main(argv=None):
                 "pass_ms": round(1e3 * avg_pass_s, 3), "bytes_per_cell": bytes_per_cell,
                 "frac_of_measured_copy_6290": round(achieved / 6290.0, 5),
                 "fp64_valu_busy": valu,
-                "note": "fp64 log-space recurrence with the reference's approximate logAdd reproduced bit for bit: "
-                        "bound by VALU issue (one fp64 instruction per SIMD per ~4 cycles), not by HBM -- "
-                        "DESIGN.md section 5 gives the instruction count per cell and the time it implies"}
+                "note": ("fp64 log-space recurrence with the reference's approximate logAdd reproduced bit for bit.  The "
+                         "assembly sweeps run at the rate HBM moves their traffic: forward writes and backward reads of "
+                         "the ring overlap at about the rate of a copy (4.6-4.9 TB/s measured on these boxes), same-box "
+                         "A/B runs move with the bytes and not with the instruction count -- DESIGN.md section 5")
+                        if asm else
+                        ("fp64 log-space recurrence with the reference's approximate logAdd reproduced bit for bit: "
+                         "the compiled kernels are bound by VALU issue (one fp64 instruction per SIMD per ~4 cycles) -- "
+                         "DESIGN.md section 5 gives the instruction count per cell and the time it implies")}
     if single:
         best = max(single, key=lambda k: single[k]["frac"])
         roofline["frac_single_batch"] = single[best]["frac"]
@@ -505,7 +520,11 @@ def kernel_stage(info, stage, cells):
     f_ms = float(np.mean([x[0] for x in stage]))
     k_ms = float(np.mean([x[1] for x in stage]))
     n_l = stage[0][2]
-    if info.get("family") == "wave":
+    if info.get("family") == "wave" and info.get("assembly_sweeps", 0) == 2:
+        sfx = "_l%d" % info.get("cells_per_lane", 3)
+        fwd, bwd = "cpecan_k_asm_forward" + sfx, "cpecan_k_asm_backward" + sfx
+        extra = " (the window's cpecan_k_wv_post launch, totals and decode, runs on a stream of its own and is not in it)"
+    elif info.get("family") == "wave":
         sfx = "_l%d" % info.get("cells_per_lane", 4)
         fwd, bwd = "cpecan_k_wv_forward" + sfx, "cpecan_k_wv_backward" + sfx
         extra = " (the backward figure includes the window's cpecan_k_wv_post launch: totals and decode)"
@@ -513,21 +532,17 @@ def kernel_stage(info, stage, cells):
         sfx = {1: "_r1", 2: "_r2", 3: "_r3"}.get(info.get("waves_per_workgroup"), "")
         fwd, bwd = "cpecan_k_sy_forward" + sfx, "cpecan_k_sy_backward" + sfx
         extra = ""
-    # dominant kernel: the backward-window kernel re-reads the 3 forward states of every cell once (24 B per
-    # cell); the forward-window kernel writes them once (24 B per cell)
-    return {"dominant_kernel": {
-                "name": bwd, "launches_per_pass": n_l,
-                "note": "launches of the batches in flight (and a batch's own forward and backward sweeps) overlap, so "
-                        "the sum of launch durations exceeds the pass time" + extra,
-                "avg_launch_ms": round(k_ms / n_l, 4),
+    # the backward-window kernel re-reads the forward sweep's three values of every cell once (24 B per cell); the
+    # forward-window kernel writes them once (24 B per cell).  The one with the longer launches is the dominant kernel.
+    def fig(name, ms):
+        return {"name": name, "launches_per_pass": n_l, "avg_launch_ms": round(ms / n_l, 4),
                 "algorithmic_bytes_per_launch": round(cells * 24.0 / n_l),
-                "achieved": round(cells * 24.0 / (k_ms / 1e3) / 1e9, 2),
-                "frac": round(cells * 24.0 / (k_ms / 1e3) / 1e9 / 8000.0, 5)},
-            "forward_kernel": {
-                "name": fwd, "launches_per_pass": n_l,
-                "avg_launch_ms": round(f_ms / n_l, 4),
-                "achieved": round(cells * 24.0 / (f_ms / 1e3) / 1e9, 2),
-                "frac": round(cells * 24.0 / (f_ms / 1e3) / 1e9 / 8000.0, 5)}}
+                "achieved": round(cells * 24.0 / (ms / 1e3) / 1e9, 2),
+                "frac": round(cells * 24.0 / (ms / 1e3) / 1e9 / 8000.0, 5)}
+    f, k = fig(fwd, f_ms), fig(bwd, k_ms)
+    note = ("launches of the batches in flight (and a batch's own forward and backward sweeps) overlap, so the sum of "
+            "launch durations exceeds the pass time" + extra)
+    return {"dominant_kernel": dict(f if f_ms > k_ms else k, note=note), "forward_kernel": f, "backward_kernel": k}
 
 
 def bench_service(args, cp, bp, rank, local_rank, world, synth):

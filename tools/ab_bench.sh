@@ -16,7 +16,7 @@ import json, sys
 l = [x for x in open(sys.argv[1]) if x.startswith("{")][-1]
 j = json.loads(l)
 print(sys.argv[2], sys.argv[3], "ms_per_step", j["ms_per_step"], "latency", j["config"].get("step_latency_ms"), "clock",
-      j["config"].get("shader_clock_mhz_in_timed_region"), "B", j["roofline"]["dominant_kernel"]["avg_launch_ms"], "F",
+      j["config"].get("shader_clock_mhz_in_timed_region"), "B", j["roofline"]["backward_kernel"]["avg_launch_ms"], "F",
       j["roofline"]["forward_kernel"]["avg_launch_ms"])
 PY
     done

@@ -20,7 +20,7 @@ for v in "$@"; do
   objs="$(ls csrc/*.o | grep -v "cpecan_asm.o\|cpecan_hip.o") $out/cpecan_hip.o"
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libcpecan_hip_abl.so $objs $out/cpecan_asm.o -lpthread
   r=$(cd $root && CPECAN_TIMELINE=1 CPECAN_HIP_LIB=$out/libcpecan_hip_abl.so timeout -k 10 120 python bench.py --steps 8 --warmup 3 --check 0 --cpu-reads 0 --inflight 1 --family wave --single-steps 0 --no-finalise $BENCH_ARGS 2> $out/err.txt | python -c "
-import json,sys;j=json.loads(sys.stdin.read().strip().splitlines()[-1]);r=j['roofline'];print(j['ms_per_step'],r['dominant_kernel']['avg_launch_ms'],r['forward_kernel']['avg_launch_ms'])")
+import json,sys;j=json.loads(sys.stdin.read().strip().splitlines()[-1]);r=j['roofline'];print(j['ms_per_step'],r['backward_kernel']['avg_launch_ms'],r['forward_kernel']['avg_launch_ms'])")
   tl=$(grep "window  7:" $out/err.txt | tail -1)
   echo "$v $r | $tl" | tee -a $out/result.txt
 done

@@ -14,6 +14,6 @@ for v in "$@"; do
       csrc/cpecan_kernel_systolic_r1.o csrc/cpecan_kernel_systolic_r2.o csrc/cpecan_kernel_systolic_r3.o \
       csrc/cpecan_kernel_wave_l2.o $out/wave_l3.o csrc/cpecan_kernel_wave_l4.o csrc/cpecan_kernel_wave_h2.o csrc/cpecan_kernel_wave_h3.o csrc/cpecan_kernel_wave_h4.o csrc/cpecan_kernel_wave_v2.o csrc/cpecan_kernel_wave_v3.o csrc/cpecan_kernel_wave_v4.o csrc/cpecan_geometry.o -lpthread
   r=$(cd $root && CPECAN_HIP_LIB=$out/libcpecan_hip_abl.so timeout -k 10 120 python bench.py --steps 12 --warmup 3 --check 0 --cpu-reads 0 --inflight 1 --family wave --single-steps 0 --no-finalise $BENCH_ARGS 2>/dev/null | python -c "
-import json,sys;j=json.loads(sys.stdin.read().strip().splitlines()[-1]);r=j['roofline'];print(j['ms_per_step'],r['dominant_kernel']['avg_launch_ms'],r['forward_kernel']['avg_launch_ms'])")
+import json,sys;j=json.loads(sys.stdin.read().strip().splitlines()[-1]);r=j['roofline'];print(j['ms_per_step'],r['backward_kernel']['avg_launch_ms'],r['forward_kernel']['avg_launch_ms'])")
   echo "$v $r" | tee -a $out/result.txt
 done

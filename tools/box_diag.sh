@@ -10,7 +10,7 @@ python - <<'PY'
 import json
 j = json.loads(open("gpurun_out/box_diag/bench.json").read().strip().splitlines()[-1])
 r = j["roofline"]
-print("ms_per_step", j["ms_per_step"], "clock", j["config"]["shader_clock_mhz_in_timed_region"], "bwd", r["dominant_kernel"]["avg_launch_ms"], "fwd", r["forward_kernel"]["avg_launch_ms"])
+print("ms_per_step", j["ms_per_step"], "clock", j["config"]["shader_clock_mhz_in_timed_region"], "bwd", r["backward_kernel"]["avg_launch_ms"], "fwd", r["forward_kernel"]["avg_launch_ms"])
 PY
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/ubench_hbm.hip -o /tmp/ubench_hbm 2>/dev/null && /tmp/ubench_hbm
 grep timeline $out/timeline.err | tail -16 | head -6

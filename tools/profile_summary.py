@@ -12,7 +12,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go = os.path.join(root, "gpurun_out")
 PASSES = 3  # bench.py --steps 2 --warmup 1
@@ -29,8 +29,9 @@ def counters(d):
 
 
 def family(fam):
-    out = {"command": "python3 bench.py --steps 2 --warmup 1 --check 0 --cpu-reads 0 --inflight 1 --single-steps 0 "
-                      "--no-finalise --family %s (3 passes over the C3 batch)" % fam, "passes": PASSES}
+    out = {"command": "%spython3 bench.py --steps 2 --warmup 1 --check 0 --cpu-reads 0 --inflight 1 --single-steps 0 "
+                      "--no-finalise --family %s (3 passes over the C3 batch)"
+                      % ("CPECAN_ASM=0 " if fam == "wave" else "", "wave" if fam == "assembly" else fam), "passes": PASSES}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         tot, n = counters("%s_pmc_%s_%s" % (tag, fam, c))
         out[c] = {k[0]: {"sum_KiB": v, "launches": n[k], "GB_per_pass": v * 1024 / PASSES / 1e9}
@@ -39,7 +40,7 @@ def family(fam):
     tot, n = counters("%s_pmc_%s_SQ" % (tag, fam))
     sq = collections.defaultdict(dict)
     for (k, c), v in tot.items():
-        if k.startswith(("cpecan_k_sy", "cpecan_k_wv")):
+        if k.startswith(("cpecan_k_sy", "cpecan_k_wv", "cpecan_k_asm")):
             sq[k][c] = v
             sq[k]["launches"] = n[(k, c)]
     for k, d in sq.items():
@@ -47,7 +48,7 @@ def family(fam):
             # workgroup family: 1024 workgroups on 256 CUs = as many waves per SIMD as a workgroup has waves for the
             # whole launch; wave family: 1024 one-wave workgroups = one wave of this kernel per SIMD (the forward and
             # the backward kernel of neighbouring windows run together: their busy fractions add up per SIMD)
-            per_simd = 1.0 if k.startswith("cpecan_k_wv") else 3.0 if k.endswith("_r3") else 2.0 if k.endswith("_r2") \
+            per_simd = 1.0 if k.startswith(("cpecan_k_wv", "cpecan_k_asm")) else 3.0 if k.endswith("_r3") else 2.0 if k.endswith("_r2") \
                 else 1.0 if k.endswith("_r1") else 4.0
             d["waves_per_simd"] = per_simd
             d["valu_busy_fraction_of_simd_time"] = d["SQ_ACTIVE_INST_VALU"] / (d["SQ_WAVE_CYCLES"] / per_simd)
@@ -56,7 +57,7 @@ def family(fam):
     return out
 
 
-out = {"families": {f: family(f) for f in ("wave", "workgroup")}}
+out = {"families": {f: family(f) for f in ("assembly", "wave", "workgroup")}}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     cal, _ = counters("%s_cal_%s" % (tag, c))
     out[c + "_calibration"] = {k[0]: {"reported_bytes": v * 1024, "true_bytes": 4 * 2 ** 30,
