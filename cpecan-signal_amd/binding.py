@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # runtime's default of four hardware queues per process two of them would share a queue and a batch's forward and
 # backward sweeps would take turns instead of overlapping.  (Read by the HIP runtime when it starts.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-LIB_PATH = os.environ.get("CPECAN_HIP_LIB") or os.path.join(_HERE, "libcpecan_hip.so")  # (the override serves tools/ablate_wave.sh)
+LIB_PATH = os.environ.get("CPECAN_HIP_LIB") or os.path.join(_HERE, "libcpecan_hip.so")  # (the override serves tools/ablate_asm.sh, tools/ab_bench.sh)
 
 OK, ENODEVICE, EINVAL, EHIP, EOVERFLOW, EBAND = 0, -1, -2, -3, -4, -5
 MODE_POSTERIOR, MODE_EXPECTATIONS = 0, 1

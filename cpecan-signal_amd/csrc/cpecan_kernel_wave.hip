@@ -112,8 +112,6 @@
                                 four SIMDs of a CU, which single-wave workgroups are not promised */
 #endif
 
-/* -DWV_ABL_* are timing-study switches (tools/ablate_wave.sh): they compute wrong results by construction and are
- * never built into the product */
 #define WV_FOR_LAYER_1(jv, ...) { constexpr int J = 0; (void) (jv); __VA_ARGS__ }
 #define WV_FOR_LAYER_2(jv, ...) if ((jv) == 0) { constexpr int J = 0; __VA_ARGS__ } else { constexpr int J = 1; __VA_ARGS__ }
 #define WV_FOR_LAYER_3(jv, ...) if ((jv) == 0) { constexpr int J = 0; __VA_ARGS__ } else if ((jv) == 1) { constexpr int J = 1; __VA_ARGS__ } else { constexpr int J = 2; __VA_ARGS__ }
@@ -216,15 +214,9 @@ template <int N> __device__ __forceinline__ void ladd_issue(LaddPending<N> &p, c
         int n;
         asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(__builtin_ceil(p.d[k] + p.d[k])));
         n = n < 15 ? n : 15;
-#ifdef WV_ABL_COEFREG /* timing study: the first piece's coefficients for every d, no table read */
-        (void) coefAddr;
-        p.c32[k].x = -0.009350833524763f; p.c32[k].y = 0.130659527668286f;
-        p.c10[k].x = 0.498799810682272f + 1e-300 * n; p.c10[k].y = 0.693203116424741f;
-#else
         const lds_d2p c = lds_d2p_cast(coefAddr + (unsigned) n * 32u);
         p.c32[k] = c[0];
         p.c10[k] = c[1];
-#endif
     }
 }
 template <int N> __device__ __forceinline__ void ladd_finish(const LaddPending<N> &p, double (&acc)[N]) {
@@ -235,11 +227,6 @@ template <int N> __device__ __forceinline__ void ladd_finish(const LaddPending<N
     }
 }
 template <int N> __device__ __forceinline__ void laddN(double (&acc)[N], const double (&y)[N], unsigned coefAddr) {
-#ifdef WV_ABL_LADD
-#pragma unroll
-    for (int k = 0; k < N; k++) acc[k] = acc[k] > y[k] ? acc[k] : y[k];
-    return;
-#endif
     LaddPending<N> p;
     ladd_issue<N>(p, acc, y, coefAddr);
     ladd_finish<N>(p, acc);
@@ -621,9 +608,6 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
     /* the circular bit strings hold 8192 diagonals: longer launches are staged 4096 diagonals (whole words) at a time */
     int bitsHi = topW - d0 > 4096 ? ((d0 + 1 + 4096) & ~31) - 1 : topW;
     stage_band_steps(sh.bits, bandTab, D, d0 + 1, bitsHi);
-#ifdef WV_ABL_PRIOF
-    __builtin_amdgcn_s_setprio(2);
-#endif
 
     int evHi = d0 - xmax - 1;  /* first event not yet staged: the lowest index diagonal d0 + 1 can ask for */
     int evHiMod = ((evHi % WV_P) + WV_P) % WV_P;
@@ -725,15 +709,10 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
 #pragma unroll
         for (int j = 0; j < L; j++) {
             const Prm &p = prm[j];
-#ifdef WV_ABL_EMIT
-            pm[j] = e[j].x + p.a[1].y;
-            py[j] = e[j].y + p.a[5].y;
-#else
             pm[j] = lgauss(e[j].x, p.a[0].x, p.a[0].y, p.a[1].x, p.a[1].y)
                     + lgauss(e[j].y, p.a[2].x, p.a[2].y, p.a[3].x, p.a[3].y);
             py[j] = lgauss(e[j].x, p.a[4].x, p.a[4].y, p.a[5].x, p.a[5].y)
                     + lgauss(e[j].y, p.a[6].x, p.a[6].y, p.a[7].x, p.a[7].y);
-#endif
         }
 #endif /* WV_HDP */
         double t2[L], t3[L], t4[L];
@@ -787,7 +766,6 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
         for (int j = 0; j < L; j++) {
             /* only cells of the band go to the ring (plain predicated stores: the compiler spreads them over the
              * arithmetic; exec-masking them by hand in asm blocks at the end of the step cost a third of the sweep) */
-#ifndef WV_ABL_FSTORE
             if (fl[j] != 0u) {
                 double *q = rowBase + j * WV_LAYER_DOUBLES;
                 d2 pr;
@@ -800,7 +778,6 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
                     *(d2 *) (q + WV_OFF_FX(lane)) = gxy;
                 }
             }
-#endif
         }
 #pragma unroll
         for (int j = 0; j < L; j++) { qm[j] = nm[j]; qx[j] = nx[j]; qy[j] = ny[j]; }
@@ -857,9 +834,6 @@ template <bool SW> __device__ void forward_window(const DevItem &it, const DevPa
             stage_band_steps(sh.bits, bandTab, D, bitsHi + 1, hi);
             bitsHi = hi;
         }
-#ifdef WV_ABL_FFEED
-        if (db == d0 + 1)
-#endif
         {
             /* stage what this block of diagonals can ask for: the top cell's event index d - xmin - 1 and the
              * entering k-mer xmax + 1 each advance by at most one per diagonal */
@@ -1115,10 +1089,8 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
     /* ------------------------------ phase S: the sweep back ------------------------------ */
     {
         /* the windows' sweeps back are the longer chain of the two that share a SIMD: they go first when both waves
-         * have an instruction ready (-DWV_ABL_NOPRIOB: timing study; 45.7 -> 43.9 ms per pass) */
-#ifndef WV_ABL_NOPRIOB
+         * have an instruction ready (without it: 45.7 instead of 43.9 ms per pass) */
         __builtin_amdgcn_s_setprio(WV_BACKWARD_PRIO);
-#endif
         int bxmin, bxmax; /* band of the diagonal being computed */
         band_load(bandTab, dTop, bxmin, bxmax);
         /* the circular bit strings hold 8192 diagonals: longer windows are staged 4096 diagonals (whole words) at a time */
@@ -1234,11 +1206,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
             const unsigned rowOff = (unsigned) ((long long) (tau & ringMask) * (WV_ROW_DOUBLES * 8));
 #pragma unroll
             for (int j = 0; j < L; j++) {
-#ifdef WV_ABL_BLOAD
-                r.m[j] = live && tau == -5 ? fm[j] : 0ull;
-#else
                 r.m[j] = live ? fm[j] : 0ull;
-#endif
                 unsigned offA, offB;
                 const unsigned realA = rowOff + voffA[j], dummyA = dummyOff + voffA[j];
                 const unsigned realB = rowOff + voffB[j], dummyB = dummyOff + voffB[j];
@@ -1456,11 +1424,7 @@ __device__ void backward_window(const DevItem &it, const DevParams &P, const int
         int t = dTop;
 #pragma unroll 1
         for (;;) {
-#ifdef WV_ABL_BFEED
-            if (t == dTop) {
-#else
             if ((dTop - t) % 30 == 0) {
-#endif
                 /* gap-X rows of the k-mers that can enter during the next 30 diagonals */
                 for (int i = lane; i < 32 * WV_PXW; i += 64) {
                     const int x = bxmin - 1 - i / WV_PXW, k = i % WV_PXW;

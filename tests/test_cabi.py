@@ -35,6 +35,34 @@ def test_no_oracle_in_product():
             assert "liborc" not in text and "pyoracle" not in text and "cpecan_oracle" not in text, f
 
 
+def test_no_wrong_by_construction_switch_in_the_product_library():
+    """timing-study switches that compute wrong results exist only in the side libraries tools/ablate_asm.sh builds
+    (-DCPECAN_TIMING_BUILD, CPECAN_ASM_ABLATE at generation): not in libcpecan_hip.so, not in the sources it is built
+    from by default, not in the assembly it embeds"""
+    so = open(os.path.join(ROOT, "cpecan-signal_amd", "libcpecan_hip.so"), "rb").read()
+    for name in (b"CPECAN_TIMING_FORWARD_ONLY", b"CPECAN_TIMING_SERIAL", b"CPECAN_TIMING_NO_POST", b"CPECAN_ASM_ABLATE", b"WV_ABL_"):
+        assert name not in so, name
+    src = os.path.join(ROOT, "cpecan-signal_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(src, f)).read()
+            assert "WV_ABL_" not in text, f
+            for m in ("CPECAN_TIMING_FORWARD_ONLY", "CPECAN_TIMING_SERIAL", "CPECAN_TIMING_NO_POST"):
+                for line in text.split(m)[:-1]:  # every use sits under #ifdef CPECAN_TIMING_BUILD
+                    assert line.rfind("#ifdef CPECAN_TIMING_BUILD") > line.rfind("#endif"), (f, m)
+    make = open(os.path.join(ROOT, "cpecan-signal_amd", "Makefile")).read()
+    assert "CPECAN_TIMING_BUILD" not in make and "CPECAN_ASM_ABLATE" not in make
+    # the tracked assembly is the unablated one: generating it again without switches gives the same text
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("CPECAN_ASM")}
+        subprocess.check_call([sys.executable, os.path.join(src, "asm", "gen_sweeps.py"), os.path.join(d, "s.s")],
+                              env=env, stderr=subprocess.DEVNULL)
+        assert open(os.path.join(d, "s.s")).read() == open(os.path.join(src, "asm", "cpecan_sweeps_gfx950.s")).read()
+
+
 def test_fails_loudly_without_gpu():
     if cp.device_count() > 0:
         pytest.skip("a GPU is present")

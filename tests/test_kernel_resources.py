@@ -40,9 +40,9 @@ def test_systolic_kernels_fit_four_waves_per_simd(tmp_path, rows, suffix):
 @pytest.mark.parametrize("cells,hdp", [(3, False), (2, False), (3, True), (2, "vanilla")])
 def test_wave_kernels_fit_two_waves_per_simd(tmp_path, cells, hdp):
     """The wave-per-alignment sweeps run as one forward and one backward wave per SIMD (the forward sweep of window
-    w+1 beside the backward sweep of window w): each must stay within 256 VGPRs -- beyond that the compiler moves
-    values to AGPRs / scratch and the pair no longer fits -- and spill nothing to scratch.  The four-cell build is the
-    documented exception (its backward sweep takes 306 registers: one wave per SIMD while it runs)."""
+    w+1 beside the backward sweep of window w): the two allocations (unified register file of 512 per lane, handed
+    out in blocks of 8) must fit together, with nothing in scratch.  The four-cell build is the documented exception
+    (its backward sweep takes 306 registers: one wave per SIMD while it runs)."""
     src = os.path.join(ROOT, "cpecan-signal_amd", "csrc", "cpecan_kernel_wave.hip")
     out = str(tmp_path / "wv.s")
     subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -52,13 +52,17 @@ def test_wave_kernels_fit_two_waves_per_simd(tmp_path, cells, hdp):
                            "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
     text = open(out).read()
     sfx = "_%s%d" % ("v" if hdp == "vanilla" else "h" if hdp else "l", cells)
+    alloc = {}
     for name in ("cpecan_k_wv_forward" + sfx, "cpecan_k_wv_backward" + sfx, "cpecan_k_wv_resweep" + sfx,
                  "cpecan_k_wv_backward_em" + sfx):  # (every machine's E-step sweeps back with this one)
         meta = text[text.index(".name:           " + name + "\n"):]
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
-        assert vgpr <= 256, "%s uses %d VGPRs: a forward and a backward wave no longer share a SIMD" % (name, vgpr)
+        alloc[name] = (vgpr + 7) // 8 * 8
         assert spill == 0, "%s spills %d VGPRs to scratch" % (name, spill)
+    fwd = alloc.pop("cpecan_k_wv_forward" + sfx)
+    for name, a in alloc.items():
+        assert fwd + a <= 512, "%s (%d registers) and the forward sweep (%d) no longer share a SIMD" % (name, a, fwd)
     if hdp is True:  # three register pairs per slot instead of ten: the forward sweep is the light one
         meta = text[text.index(".name:           cpecan_k_wv_forward" + sfx + "\n"):]
         assert int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1)) <= 192
@@ -81,3 +85,25 @@ def test_wave5_pair_kernels_fit_two_waves_per_simd(tmp_path):
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", meta).group(1))
         assert vgpr <= cap, "%s uses %d VGPRs" % (name, vgpr)
         assert spill == 0, "%s spills %d VGPRs to scratch" % (name, spill)
+
+
+def test_assembly_sweeps_share_a_simd_and_a_cu():
+    """The hand-scheduled sweeps (csrc/asm/cpecan_sweeps_gfx950.s): one forward and one backward wave per SIMD, with
+    room left in the register file for the post kernel's waves while the next forward sweep has not begun; four waves of
+    each per CU within the 160 KB of LDS; nothing in scratch (the kernels have no scratch segment at all)."""
+    text = open(os.path.join(ROOT, "cpecan-signal_amd", "csrc", "asm", "cpecan_sweeps_gfx950.s")).read()
+    meta = text[text.index(".amdgpu_metadata"):]
+    res = {}
+    for name in ("cpecan_k_asm_forward_l3", "cpecan_k_asm_backward_l3"):
+        m = meta[meta.index(".name:           " + name + "\n") - 2000: meta.index(".name:           " + name + "\n") + 2000]
+        block = meta[:meta.index(".name:           " + name + "\n")].rsplit("  - .agpr_count", 1)[1] + \
+            meta[meta.index(".name:           " + name + "\n"):].split("  - .agpr_count", 1)[0]
+        res[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, block).group(1))
+                     for k in ("vgpr_count", "group_segment_fixed_size", "private_segment_fixed_size", "vgpr_spill_count")}
+        del m
+    f, b = res["cpecan_k_asm_forward_l3"], res["cpecan_k_asm_backward_l3"]
+    assert f["vgpr_count"] <= 256 and b["vgpr_count"] <= 256 and f["vgpr_count"] + b["vgpr_count"] <= 512
+    assert 512 - b["vgpr_count"] >= 64   # the post kernel (64 registers) beside a backward wave
+    assert 4 * (f["group_segment_fixed_size"] + b["group_segment_fixed_size"]) <= 160 * 1024
+    for r in (f, b):
+        assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0
