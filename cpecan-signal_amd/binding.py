@@ -50,7 +50,7 @@ EXPORTS = [
     "cpecan_hip_batch_destroy", "cpecan_hip_ctx_stream", "cpecan_hip_selftest_division", "cpecan_hip_batch_info", "cpecan_hip_batch_stage_ms",
     "cpecan_hip_batch_systolic_rows", "cpecan_hip_batch_kernel_family", "cpecan_hip_batch_assembly_sweeps", "cpecan_hip_trim_cache", "cpecan_hip_models_set_transitions",
     "cpecan_hip_models5_create", "cpecan_hip_batch_create_dna",
-    "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla",
+    "cpecan_hip_modelsv_create", "cpecan_hip_batch_create_vanilla", "cpecan_hip_models4_create", "cpecan_hip_batch_create_sm4",
     "cpecan_hip_modelsh_create", "cpecan_hip_batch_create_hdp",
 ]
 
@@ -69,6 +69,11 @@ class Sm3ModelDesc(C.Structure):
 class Sm5ModelDesc(C.Structure):
     _fields_ = [("transitions", C.c_double * 17), ("match_probs", C.c_double * 16),
                 ("gap_x_probs", C.c_double * 4), ("gap_y_probs", C.c_double * 4)]
+
+
+class Sm4ModelDesc(C.Structure):
+    _fields_ = [("transitions", C.c_double * 11), ("match_probs", C.c_void_p), ("gap_x_probs", C.c_void_p),
+                ("gap_y_probs", C.c_void_p)]
 
 
 class VanillaModelDesc(C.Structure):
@@ -151,6 +156,10 @@ def lib():
         L.cpecan_hip_modelsv_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.cpecan_hip_modelsh_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.cpecan_hip_batch_create_hdp.argtypes = [
+            C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+            C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
+        L.cpecan_hip_models4_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.cpecan_hip_batch_create_sm4.argtypes = [
             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
             C.c_void_p, C.c_int64, C.POINTER(BandParams), C.c_int32, C.POINTER(C.c_void_p)]
         L.cpecan_hip_batch_create_vanilla.argtypes = [
@@ -332,6 +341,27 @@ class Context:
         _check(lib().cpecan_hip_modelsv_create(self.h, C.cast(descs, C.c_void_p), n, threads, _ptr(ids)))
         return ids
 
+    def models4_create(self, models):
+        """models: list of (transitions[11] in the member order of _StateMachine4, match[20481], gap_x[4096],
+        gap_y[20481]) -> ids (4-state signal machine, getStateMachine4)"""
+        n = len(models)
+        descs = (Sm4ModelDesc * n)()
+        keep = []
+        for i, (t, match, gx, gy) in enumerate(models):
+            match = np.ascontiguousarray(match, dtype=np.float64)
+            gx = np.ascontiguousarray(gx, dtype=np.float64)
+            gy = np.ascontiguousarray(gy, dtype=np.float64)
+            assert match.size == MODEL_TABLE_LEN and gy.size == MODEL_TABLE_LEN and gx.size == NUM_KMERS and len(t) == 11
+            keep += [match, gx, gy]
+            for k in range(11):
+                descs[i].transitions[k] = float(t[k])
+            descs[i].match_probs = match.ctypes.data
+            descs[i].gap_x_probs = gx.ctypes.data
+            descs[i].gap_y_probs = gy.ctypes.data
+        ids = np.zeros(n, np.int32)
+        _check(lib().cpecan_hip_models4_create(self.h, C.cast(descs, C.c_void_p), n, _ptr(ids)))
+        return ids
+
     def modelsh_create(self, models):
         """models: list of (transitions[9], alphabet str, grid[G], y[rows, G], slope[rows, G],
         kmer_row[alphabet_size ** 6] int32) -> ids (HDP signal machine)"""
@@ -373,7 +403,7 @@ class Batch:
     """cpecan_batch: items is a numpy array of ITEM_DTYPE."""
 
     def __init__(self, ctx, items, x_chars, events, anchors, params, mode=MODE_POSTERIOR,
-                 kernel=KERNEL_AUTO, flags=0, y_chars=None, vanilla=False, hdp=False):
+                 kernel=KERNEL_AUTO, flags=0, y_chars=None, vanilla=False, hdp=False, sm4=False):
         """events: double[n][3] for a signal batch (vanilla: with a modelsv_create model); y_chars
         (str/bytes) instead for a DNA batch."""
         self.ctx = ctx
@@ -389,6 +419,11 @@ class Batch:
         elif hdp:
             ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
             _check(lib().cpecan_hip_batch_create_hdp(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
+                                                     _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
+                                                     C.byref(params), flags, C.byref(h)))
+        elif sm4:
+            ev = np.ascontiguousarray(events, dtype=np.float64).reshape(-1)
+            _check(lib().cpecan_hip_batch_create_sm4(ctx.h, _ptr(items), items.shape[0], _ptr(xb), xb.size,
                                                      _ptr(ev), ev.size // 3, _ptr(an), an.shape[0],
                                                      C.byref(params), flags, C.byref(h)))
         elif vanilla:

@@ -43,6 +43,9 @@ extern "C" __global__ void cpecan_k_generalv(const DevItem *, DevParams, const i
                                              const double *, const double *, double *, double *,
                                              long long *, double *, long long *, long long *, double *,
                                              long long *, double *);
+extern "C" __global__ void cpecan_k_general4(const DevItem *, DevParams, const int *, const int *, const long long *,
+                                             const unsigned short *, const double *, const double *, double *, double *,
+                                             long long *, double *, long long *, long long *, double *, long long *);
 extern "C" __global__ void cpecan_k_generalh(const DevItem *, DevParams, const int *, const int *,
                                              const long long *, const int *, const double *,
                                              const DevHdpModel *, double *, double *, long long *, double *,
@@ -467,6 +470,9 @@ struct cpecan_ctx {
     DevBuf<DevHdpModel> modelsH;
     std::string hdpAlphabet;
     DevBuf<double> modelsV; /* vanilla signal models, nModelsV * CP_VMODEL_STRIDE */
+    DevBuf<double> models4; /* 4-state signal models: strawMan tables whose header holds eleven transitions */
+    std::vector<double> hostModels4;
+    int nModels4 = 0;
     std::vector<double> hostModelsV;
     int nModelsV = 0;
 };
@@ -482,7 +488,7 @@ struct cpecan_batch {
     DevBuf<long long> cellPrefix;
     DevBuf<char> chars, charsY; /* charsY: DNA batches (5-state machine) */
     bool dna = false;
-    bool vanilla = false, hdp = false;
+    bool vanilla = false, hdp = false, sm4 = false;
     DevBuf<double> logNoise; /* vanilla batches: log(event noise), host libm */
     DevBuf<int> kid;         /* HDP batches: k-mer id over the model's alphabet per X position */
     DevBuf<unsigned short> kidx;
@@ -1103,6 +1109,34 @@ int cpecan_hip_models5_create(cpecan_ctx *c, const cpecan_sm5_model *models, int
     return CPECAN_OK;
 }
 
+/* 4-state signal models (getStateMachine4): the strawMan rows with the machine's eleven transitions in the header.  A
+ * host mirror is kept and the whole table uploaded again when models are added (a handful of models per call). */
+int cpecan_hip_models4_create(cpecan_ctx *c, const cpecan_sm4_model *models, int32_t n, int32_t *ids) {
+    if (!c || !models || n <= 0 || !ids) return fail(CPECAN_EINVAL, "bad argument");
+    for (int i = 0; i < n; i++)
+        if (!models[i].match_probs || !models[i].gap_x_probs || !models[i].gap_y_probs)
+            return fail(CPECAN_EINVAL, "model %d has a NULL table", i);
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t old = c->hostModels4.size();
+    c->hostModels4.resize(old + (size_t) n * CP_MODEL_STRIDE);
+    for (int i = 0; i < n; i++) {
+        cpecan_sm3_model m3;
+        for (int k = 0; k < 9; k++) m3.transitions[k] = models[i].transitions[k];
+        m3.match_probs = models[i].match_probs;
+        m3.gap_x_probs = models[i].gap_x_probs;
+        m3.gap_y_probs = models[i].gap_y_probs;
+        double *dst = c->hostModels4.data() + old + (size_t) i * CP_MODEL_STRIDE;
+        derive_rows(&m3, dst);
+        for (int k = 0; k < 11; k++) dst[k] = models[i].transitions[k];
+        ids[i] = c->nModels4 + i;
+    }
+    if (c->stream) HIP_TRY(hipStreamSynchronize(c->stream)); /* (the old table goes back to the allocator's cache) */
+    HIP_TRY(c->models4.alloc(c->hostModels4.size()));
+    HIP_TRY(hipMemcpy(c->models4.p, c->hostModels4.data(), c->hostModels4.size() * sizeof(double), hipMemcpyHostToDevice));
+    c->nModels4 += n;
+    return CPECAN_OK;
+}
+
 int cpecan_hip_models_clear(cpecan_ctx *c) {
     if (!c) return fail(CPECAN_EINVAL, "ctx is NULL");
     (void) hipSetDevice(c->device);
@@ -1117,6 +1151,9 @@ int cpecan_hip_models_clear(cpecan_ctx *c) {
     c->modelsV.release();
     c->hostModelsV.clear();
     c->nModelsV = 0;
+    c->models4.release();
+    c->hostModels4.clear();
+    c->nModels4 = 0;
     for (auto *t : c->hdpTables) delete t;
     c->hdpTables.clear();
     c->hostModelsH.clear();
@@ -1170,7 +1207,9 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
                              const char *xChars, int64_t nX, const double *events, const char *yChars,
                              int64_t nEvents, const int64_t *anchors, int64_t nAnchorPairs,
                              const cpecan_band_params *params, int32_t mode, int32_t kernel,
-                             int32_t flags, cpecan_batch **out, bool vanilla = false, bool hdp = false) {
+                             int32_t flags, cpecan_batch **out, bool vanilla = false, bool hdp = false, bool sm4 = false) {
+    if (sm4 && (mode != CPECAN_MODE_POSTERIOR || (flags & CPECAN_FLAG_DEBUG_DUMP)))
+        return fail(CPECAN_EINVAL, "4-state batches: posterior decode only, no cell dumps");
     const bool dna = yChars != nullptr;
     if (hdp && (flags & CPECAN_FLAG_DEBUG_DUMP)) return fail(CPECAN_EINVAL, "HDP batches: no cell dumps");
     if (hdp && mode == CPECAN_MODE_EXPECTATIONS && (flags & CPECAN_FLAG_UNBANDED))
@@ -1178,7 +1217,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     if (vanilla && (flags & CPECAN_FLAG_DEBUG_DUMP)) return fail(CPECAN_EINVAL, "vanilla batches: no cell dumps");
     if (vanilla && mode == CPECAN_MODE_EXPECTATIONS && (flags & CPECAN_FLAG_UNBANDED))
         return fail(CPECAN_EINVAL, "expectations run over the banded matrix only");
-    const int S = dna ? 5 : 3; /* states per cell */
+    const int S = dna ? 5 : sm4 ? 4 : 3; /* states per cell */
     if (!c || !items || nItems <= 0 || !xChars || (!events && !yChars) || !params || !out)
         return fail(CPECAN_EINVAL, "bad argument");
     if (dna && (flags & CPECAN_FLAG_DEBUG_DUMP)) return fail(CPECAN_EINVAL, "DNA batches: no cell dumps");
@@ -1215,7 +1254,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
             s.anchor_offset < 0 || s.x_offset + s.lX + (!dna && s.lX > 0 ? 5 : 0) > nX ||
             s.y_offset + s.lY > nEvents || s.anchor_offset + s.n_anchors > nAnchorPairs)
             return fail(CPECAN_EINVAL, "item %lld points outside the supplied buffers", (long long) i);
-        if (s.model_id < 0 || s.model_id >= (dna ? c->nModels5 : vanilla ? c->nModelsV
+        if (s.model_id < 0 || s.model_id >= (dna ? c->nModels5 : vanilla ? c->nModelsV : sm4 ? c->nModels4
                                                       : hdp ? (int) c->hostModelsH.size() : c->nModels))
             return fail(CPECAN_EINVAL, "item %lld: unknown model id %d", (long long) i, s.model_id);
         if (s.lX + s.lY >= (1ll << 30)) return fail(CPECAN_EINVAL, "item %lld too long", (long long) i);
@@ -1236,7 +1275,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
      * item's intervals stays in its cache. */
     PinnedBuf<int> hTab;
     /* the assembly sweeps' plan (build_asm_plan), for the batches that can run on them */
-    const bool wantPlan = !dna && !vanilla && !hdp && !unbanded && mode == CPECAN_MODE_POSTERIOR &&
+    const bool wantPlan = !dna && !vanilla && !hdp && !sm4 && !unbanded && mode == CPECAN_MODE_POSTERIOR &&
                           kernel != CPECAN_KERNEL_GENERAL && use_wave_kernels() && !(flags & CPECAN_FLAG_WORKGROUP_KERNELS) &&
                           !(flags & CPECAN_FLAG_DEBUG_DUMP);
     std::vector<std::vector<AsmPlanWin>> planWins(wantPlan ? (size_t) nItems : 0);
@@ -1337,7 +1376,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         return CPECAN_OK;
     };
     /* (what the kernel choice below will come to, as far as it is known before the bands are) */
-    const bool surelyGeneral = dna || kernel == CPECAN_KERNEL_GENERAL || unbanded || (flags & CPECAN_FLAG_DEBUG_DUMP) ||
+    const bool surelyGeneral = dna || sm4 || kernel == CPECAN_KERNEL_GENERAL || unbanded || (flags & CPECAN_FLAG_DEBUG_DUMP) ||
                                ((hdp || vanilla) && (flags & CPECAN_FLAG_GENERAL_KERNEL));
     HIP_TRY(hTab.alloc((size_t) diagTotal * 2 + 2));
     {
@@ -1377,7 +1416,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->nItems = nItems;
     b->mode = mode;
     b->flags = flags;
-    b->nModels = dna ? c->nModels5 : vanilla ? c->nModelsV : hdp ? (int) c->hostModelsH.size() : c->nModels;
+    b->nModels = dna ? c->nModels5 : vanilla ? c->nModelsV : sm4 ? c->nModels4 : hdp ? (int) c->hostModelsH.size() : c->nModels;
     b->expectLen = dna ? CPECAN_EXPECTATION5_LEN : vanilla ? CPECAN_EXPECTATIONV_LEN
                    : hdp ? CPECAN_EXPECTATIONH_LEN : CPECAN_EXPECTATION_LEN;
     b->P.threshold = params->threshold;
@@ -1395,7 +1434,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
      * the E-step (the 5-state machine runs on the general kernel); CPECAN_FLAG_GENERAL_KERNEL keeps such a batch on
      * the general kernel */
     const bool machineWave = (hdp || vanilla) && !(flags & CPECAN_FLAG_GENERAL_KERNEL);
-    int useKernel = dna || ((hdp || vanilla) && !machineWave) ? CPECAN_KERNEL_GENERAL
+    int useKernel = dna || sm4 || ((hdp || vanilla) && !machineWave) ? CPECAN_KERNEL_GENERAL
                     : hdp || vanilla ? CPECAN_KERNEL_AUTO : kernel;
     /* the builds of the register-resident kernels this batch would run on, and the widest band they take */
     const SyBuild *fam = hdp ? HV_BUILDS : vanilla ? VV_BUILDS
@@ -1404,6 +1443,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->dna = dna;
     b->vanilla = vanilla;
     b->hdp = hdp;
+    b->sm4 = sm4;
     if (useKernel == CPECAN_KERNEL_AUTO)
         useKernel = (globalMaxWidth <= famMaxWidth && systolicOk && !b->P.debug && !unbanded)
                         ? CPECAN_KERNEL_SYSTOLIC : CPECAN_KERNEL_GENERAL;
@@ -1684,6 +1724,14 @@ int cpecan_hip_batch_create_dna(cpecan_ctx *c, const cpecan_item *items, int64_t
                              CPECAN_KERNEL_GENERAL, flags & ~CPECAN_FLAG_EXPECTATIONS, out);
 }
 
+int cpecan_hip_batch_create_sm4(cpecan_ctx *c, const cpecan_item *items, int64_t nItems, const char *xChars, int64_t nX,
+                                const double *events, int64_t nEvents, const int64_t *anchors, int64_t nAnchorPairs,
+                                const cpecan_band_params *params, int32_t flags, cpecan_batch **out) {
+    if (flags & CPECAN_FLAG_EXPECTATIONS) return fail(CPECAN_EINVAL, "4-state batches: posterior decode only");
+    return batch_create_impl(c, items, nItems, xChars, nX, events, nullptr, nEvents, anchors, nAnchorPairs, params,
+                             CPECAN_MODE_POSTERIOR, CPECAN_KERNEL_GENERAL, flags, out, false, false, true);
+}
+
 int cpecan_hip_batch_run(cpecan_batch *b) { return cpecan_hip_batch_run_after(b, nullptr); }
 
 int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
@@ -1753,6 +1801,13 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
                            (const DevHdpModel *) c->modelsH.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
                            b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p,
                            b->mode == CPECAN_MODE_EXPECTATIONS ? b->expect.p : nullptr);
+        HIP_TRY(hipGetLastError());
+    } else if (b->sm4) {
+        hipLaunchKernelGGL(cpecan_k_general4, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
+                           (const DevItem *) b->items.p, b->P, (const int *) b->bandL.p, (const int *) b->bandR.p,
+                           (const long long *) b->cellPrefix.p, (const unsigned short *) b->kidx.p,
+                           (const double *) b->events.p, (const double *) c->models4.p, b->Fstore.p, b->Bstore.p, b->pairs.p,
+                           b->pairLogp.p, b->nPairs.p, b->totXay.p, b->totVal.p, b->nTot.p);
         HIP_TRY(hipGetLastError());
     } else if (b->vanilla && b->kernel == CPECAN_KERNEL_GENERAL) {
         hipLaunchKernelGGL(cpecan_k_generalv, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,

@@ -99,6 +99,20 @@ typedef struct {
 } cpecan_sm5_model;
 int cpecan_hip_models5_create(cpecan_ctx *ctx, const cpecan_sm5_model *models, int32_t n, int32_t *ids);
 
+/* The 4-state signal machine: getStateMachine4() (impl/stateMachine.c:1750-1759, stateMachine4_cellCalculate :867-897)
+ * after emissions_signal_scaleModel(): match, short gap X, short gap Y, long gap X over the strawMan emissions.
+ * transitions in the member order of struct _StateMachine4 (inc/stateMachine.h:134-152): MATCH_CONTINUE,
+ * MATCH_FROM_SHORT_GAP_X, MATCH_FROM_LONG_GAP_X, MATCH_FROM_SHORT_GAP_Y, GAP_SHORT_OPEN_X, GAP_SHORT_EXTEND_X,
+ * GAP_SHORT_OPEN_Y, GAP_SHORT_EXTEND_Y, GAP_LONG_OPEN_X, GAP_LONG_EXTEND_X, GAP_LONG_SWITCH_TO_X; tables as in the
+ * strawMan model above (the machine's k-mer gap table is all zeros as getStateMachine4 leaves it). */
+typedef struct {
+    double transitions[11];
+    const double *match_probs; /* [CPECAN_MODEL_TABLE_LEN] */
+    const double *gap_x_probs; /* [CPECAN_NUM_KMERS]       */
+    const double *gap_y_probs; /* [CPECAN_MODEL_TABLE_LEN] */
+} cpecan_sm4_model;
+int cpecan_hip_models4_create(cpecan_ctx *ctx, const cpecan_sm4_model *models, int32_t n, int32_t *ids);
+
 /* The 3-state "vanilla" signal machine: getSignalStateMachine3Vanilla() (impl/stateMachine.c:1761) after
  * emissions_signal_scaleModel().  Fields as in struct _StateMachine3Vanilla (inc/stateMachine.h:189-205):
  * the two transition fudge factors (stateMachine3Vanilla_setStrandTransitionsToDefaults :1291), the three
@@ -224,6 +238,14 @@ int cpecan_hip_batch_create_vanilla(cpecan_ctx *ctx, const cpecan_item *items, i
                                     const char *x_chars, int64_t n_x, const double *events, int64_t n_events,
                                     const int64_t *anchors, int64_t n_anchor_pairs,
                                     const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
+
+/* k-mers against events with a 4-state model (getAlignedPairsUsingAnchors / getAlignedPairsWithoutBanding with the
+ * StateMachine of getStateMachine4, sequence_getKmer / sequence_getEvent): same buffers as cpecan_hip_batch_create,
+ * model_id is a cpecan_hip_models4_create id.  General kernel, posterior decode; flags: UNBANDED. */
+int cpecan_hip_batch_create_sm4(cpecan_ctx *ctx, const cpecan_item *items, int64_t n_items,
+                                const char *x_chars, int64_t n_x, const double *events, int64_t n_events,
+                                const int64_t *anchors, int64_t n_anchor_pairs,
+                                const cpecan_band_params *params, int32_t flags, cpecan_batch **out);
 
 /* k-mers against events with an HDP model (getAlignedPairsUsingAnchors with a StateMachine3_HDP,
  * sequence_getKmer3 / sequence_getEvent): same buffers as cpecan_hip_batch_create (x characters over the

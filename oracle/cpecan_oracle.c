@@ -197,6 +197,11 @@ void orc_defaults_sm3_nanopore(orc_model *m) {
 }
 
 /* sm5 transition slots follow struct _StateMachine5 (inc/stateMachine.h:108-124) */
+enum { /* _StateMachine4's members in order (inc/stateMachine.h:134-152) */
+    T4_MATCH_CONTINUE = 0, T4_MATCH_FROM_SHORT_GAP_X, T4_MATCH_FROM_LONG_GAP_X, T4_MATCH_FROM_SHORT_GAP_Y,
+    T4_GAP_SHORT_OPEN_X, T4_GAP_SHORT_EXTEND_X, T4_GAP_SHORT_OPEN_Y, T4_GAP_SHORT_EXTEND_Y,
+    T4_GAP_LONG_OPEN_X, T4_GAP_LONG_EXTEND_X, T4_GAP_LONG_SWITCH_TO_X
+};
 enum {
     T5_MATCH_CONTINUE = 0, T5_MATCH_FROM_SHORT_GAP_X, T5_MATCH_FROM_LONG_GAP_X, T5_GAP_SHORT_OPEN_X,
     T5_GAP_SHORT_EXTEND_X, T5_GAP_SHORT_SWITCH_TO_X, T5_GAP_LONG_OPEN_X, T5_GAP_LONG_EXTEND_X,
@@ -219,6 +224,23 @@ void orc_defaults_vanilla(orc_model *m) {
     m->t[2] = -0.23552123624314988; /* DEFAULT_END_MATCH_PROB  */
     m->t[3] = -1.6269694202638481;  /* DEFAULT_END_FROM_X_PROB */
     m->t[4] = -4.3187242127300092;  /* DEFAULT_END_FROM_Y_PROB */
+}
+
+void orc_defaults_sm4(orc_model *m) {
+    /* impl/stateMachine.c:992-1011: "set transitions to defaults (these are from a template read)" */
+    m->kind = ORC_SM4_SIGNAL;
+    m->stateNumber = 4;
+    m->t[T4_MATCH_CONTINUE] = -0.23552123624314988;
+    m->t[T4_GAP_SHORT_OPEN_X] = -1.6269694202638481;
+    m->t[T4_GAP_SHORT_OPEN_Y] = -4.7241893208381773;
+    m->t[T4_GAP_LONG_OPEN_X] = -5.4173365013981227;
+    m->t[T4_GAP_SHORT_EXTEND_X] = -1.6269694202638481;
+    m->t[T4_MATCH_FROM_SHORT_GAP_X] = -0.21880828092192281;
+    m->t[T4_GAP_LONG_EXTEND_X] = -0.003442492794189331;
+    m->t[T4_MATCH_FROM_LONG_GAP_X] = -5.6732801731704612;
+    m->t[T4_MATCH_FROM_SHORT_GAP_Y] = -0.013406326748077823;
+    m->t[T4_GAP_SHORT_EXTEND_Y] = -4.724189320832104;
+    m->t[T4_GAP_LONG_SWITCH_TO_X] = -5.4173365013920494;
 }
 
 void orc_defaults_sm5(orc_model *m, double *match16, double *gap4x, double *gap4y) {
@@ -298,7 +320,7 @@ static inline void get_symbols(const seqs_t *s, int64_t ix, int64_t iy, symbols_
         o->kx = orc_kmer_index(p + 1);
         o->ev = iy >= 0 ? ((const double *) s->y) + 3 * iy : NULLEVENT;
         o->ky = 0;
-    } else if (s->m->kind == ORC_SM3_STRAWMAN) {
+    } else if (s->m->kind == ORC_SM3_STRAWMAN || s->m->kind == ORC_SM4_SIGNAL) {
         /* index < 0 yields the literal "n" (:315-317): first char non-ACGT => index > 4096 */
         o->kx = ix >= 0 ? orc_kmer_index(s->x + ix) : (int64_t) ORC_NUM_KMERS * 4097;
         o->ev = iy >= 0 ? ((const double *) s->y) + 3 * iy : NULLEVENT;
@@ -413,6 +435,32 @@ static void cell_sm3(const orc_model *m, double *cur, double *lower, double *mid
     }
 }
 
+/* stateMachine4_cellCalculate impl/stateMachine.c:867-897 */
+static void cell_sm4(const orc_model *m, double *cur, double *lower, double *middle, double *upper,
+                     const symbols_t *s, trans_fn fn, void *extra) {
+    const double *t = m->t;
+    if (lower != NULL) {
+        double eP = orc_kmer_gap(m->gapX, s->kx);
+        fn(lower, cur, ST_MATCH, ST_SHORT_GAP_X, eP, t[T4_GAP_SHORT_OPEN_X], extra);
+        fn(lower, cur, ST_SHORT_GAP_X, ST_SHORT_GAP_X, eP, t[T4_GAP_SHORT_EXTEND_X], extra);
+        fn(lower, cur, ST_MATCH, ST_LONG_GAP_X, eP, t[T4_GAP_LONG_OPEN_X], extra);
+        fn(lower, cur, ST_LONG_GAP_X, ST_LONG_GAP_X, eP, t[T4_GAP_LONG_EXTEND_X], extra);
+        fn(lower, cur, ST_SHORT_GAP_Y, ST_LONG_GAP_X, eP, t[T4_GAP_LONG_SWITCH_TO_X], extra);
+    }
+    if (middle != NULL) {
+        double eP = orc_strawman_match(m->match, s->kx, s->ev);
+        fn(middle, cur, ST_MATCH, ST_MATCH, eP, t[T4_MATCH_CONTINUE], extra);
+        fn(middle, cur, ST_SHORT_GAP_X, ST_MATCH, eP, t[T4_MATCH_FROM_SHORT_GAP_X], extra);
+        fn(middle, cur, ST_SHORT_GAP_Y, ST_MATCH, eP, t[T4_MATCH_FROM_SHORT_GAP_Y], extra);
+        fn(middle, cur, ST_LONG_GAP_X, ST_MATCH, eP, t[T4_MATCH_FROM_LONG_GAP_X], extra);
+    }
+    if (upper != NULL) {
+        double eP = orc_strawman_match(m->gapY, s->kx, s->ev);
+        fn(upper, cur, ST_MATCH, ST_SHORT_GAP_Y, eP, t[T4_GAP_SHORT_OPEN_Y], extra);
+        fn(upper, cur, ST_SHORT_GAP_Y, ST_SHORT_GAP_Y, eP, t[T4_GAP_SHORT_EXTEND_Y], extra);
+    }
+}
+
 /* stateMachine3HDP_cellCalculate impl/stateMachine.c:1336-1366 */
 static void cell_hdp(const orc_model *m, double *cur, double *lower, double *middle, double *upper,
                      const symbols_t *s, trans_fn fn, void *extra) {
@@ -504,6 +552,7 @@ static inline void cell_calc(const orc_model *m, double *cur, double *lower, dou
     if (m->kind == ORC_SM3_HDP) cell_hdp(m, cur, lower, middle, upper, s, fn, extra);
     else if (m->kind == ORC_SM3_VANILLA) cell_vanilla(m, cur, lower, middle, upper, s, fn, extra);
     else if (m->kind == ORC_SM3_STRAWMAN) cell_sm3(m, cur, lower, middle, upper, s, fn, extra);
+    else if (m->kind == ORC_SM4_SIGNAL) cell_sm4(m, cur, lower, middle, upper, s, fn, extra);
     else cell_sm5(m, cur, lower, middle, upper, s, fn, extra);
 }
 
@@ -517,6 +566,16 @@ static double state_value(const orc_model *m, int which, int s) {
         case 1: return (s == ST_SHORT_GAP_X || s == ST_SHORT_GAP_Y) ? 0 : LOG_ZERO;
         case 2: return s == ST_MATCH ? t[2] : s == ST_SHORT_GAP_X ? t[3] : t[4];
         default: return s == ST_MATCH ? (t[3] + t[4]) / 2.0 : s == ST_SHORT_GAP_X ? t[3] : t[4];
+        }
+    }
+    if (m->kind == ORC_SM4_SIGNAL) { /* start: stateMachine5's (:743); the rest impl/stateMachine.c:791-829 */
+        switch (which) {
+        case 0: return s == ST_MATCH ? 0 : LOG_ZERO;
+        case 1: return (s == ST_LONG_GAP_X || s == ST_SHORT_GAP_Y) ? 0 : LOG_ZERO;
+        case 2:
+            return s == ST_MATCH ? t[T4_MATCH_CONTINUE] : s == ST_SHORT_GAP_X ? t[T4_MATCH_FROM_SHORT_GAP_X]
+                   : s == ST_SHORT_GAP_Y ? t[T4_MATCH_FROM_SHORT_GAP_Y] : t[T4_MATCH_FROM_LONG_GAP_X];
+        default: return s == ST_LONG_GAP_X ? t[T4_GAP_LONG_EXTEND_X] : t[T4_GAP_LONG_OPEN_X];
         }
     }
     if (m->kind == ORC_SM3_STRAWMAN || m->kind == ORC_SM3_HDP) {

@@ -44,9 +44,14 @@ enum {
                               X-gap emission log(0.1), match and Y-gap emission = the HDP's posterior-predictive
                               DENSITY at the event mean for the k-mer's Dirichlet process (a linear density used
                               where a log is expected: quirk Q6); X elements read with sequence_getKmer3 */
+#define ORC_SM4_SIGNAL 4   /* stateMachine4_cellCalculate (impl/stateMachine.c:867-918): match, short gap X, short gap Y,
+                            * long gap X over the strawMan emissions; t[] in the member order of _StateMachine4
+                            * (inc/stateMachine.h:134-152): MATCH_CONTINUE, MATCH_FROM_SHORT_GAP_X, MATCH_FROM_LONG_GAP_X,
+                            * MATCH_FROM_SHORT_GAP_Y, GAP_SHORT_OPEN_X, GAP_SHORT_EXTEND_X, GAP_SHORT_OPEN_Y,
+                            * GAP_SHORT_EXTEND_Y, GAP_LONG_OPEN_X, GAP_LONG_EXTEND_X, GAP_LONG_SWITCH_TO_X */
 typedef struct {
-    int32_t kind;          /* ORC_SM3_STRAWMAN | ORC_SM5_SYMBOL | ORC_SM3_VANILLA | ORC_SM3_HDP */
-    int32_t stateNumber;   /* 3 | 5 */
+    int32_t kind;          /* ORC_SM3_STRAWMAN | ORC_SM5_SYMBOL | ORC_SM3_VANILLA | ORC_SM3_HDP | ORC_SM4_SIGNAL */
+    int32_t stateNumber;   /* 3 | 4 | 5 */
     double t[17];          /* transitions: sm3 uses ORC_T3_*, sm5 uses struct order of _StateMachine5 */
     const double *match;   /* sm3: [1+4096*5] EMISSION_MATCH_PROBS; sm5: [16] */
     const double *gapX;    /* sm3: [4096] EMISSION_GAP_X_PROBS;    sm5: [4]  */
@@ -98,6 +103,7 @@ typedef struct {
 void orc_defaults_sm3_nanopore(orc_model *m);   /* impl/stateMachine.c:1278-1289 */
 void orc_defaults_sm5(orc_model *m, double *match16, double *gap4x, double *gap4y); /* :60-82,:920-937 */
 void orc_defaults_vanilla(orc_model *m);       /* stateMachine3Vanilla_construct :1560-1600 */
+void orc_defaults_sm4(orc_model *m);           /* stateMachine4_construct :960-1037 (template-read transitions) */
 void orc_defaults_hdp(orc_model *m);           /* stateMachine3Hdp_construct + nanopore defaults */
 double orc_grid_spline_interp(double query_x, const double *x, const double *y, const double *slope,
                               int64_t length); /* impl/hdp_math_utils.c:471-495 */

@@ -100,6 +100,7 @@ def lib():
         L.orc_defaults_sm5.argtypes = [C.POINTER(OrcModel), C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_defaults_vanilla.argtypes = [C.POINTER(OrcModel)]
         L.orc_defaults_hdp.argtypes = [C.POINTER(OrcModel)]
+        L.orc_defaults_sm4.argtypes = [C.POINTER(OrcModel)]
         L.orc_hdp_density.restype = C.c_double
         L.orc_hdp_density.argtypes = [C.POINTER(OrcModel), C.c_char_p, C.c_double]
         L.orc_hdp_kmer_id.restype = C.c_int64
@@ -178,6 +179,35 @@ class Sm3Model:
         m = self.match.copy()
         lib().orc_scale_model(_ptr(m), scale, shift, var, scale_sd, var_sd)
         return Sm3Model(m, self.gap_y, self.gap_x, self.transitions)
+
+
+class Sm4Model:
+    """4-state signal model (getStateMachine4, impl/stateMachine.c:1750-1759): the strawMan emissions, the k-mer gap
+    table left at zero by emissions_signal_initEmissionsToZero (:374-386), the template-read transitions of
+    stateMachine4_construct (:992-1011)."""
+
+    def __init__(self, match, gap_y, gap_x=None, transitions=None):
+        self.match = np.ascontiguousarray(match, dtype=np.float64)
+        self.gap_y = np.ascontiguousarray(gap_y, dtype=np.float64)
+        self.gap_x = np.ascontiguousarray(np.zeros(NUM_KMERS) if gap_x is None else gap_x, dtype=np.float64)
+        assert self.match.size == MODEL_LEN and self.gap_y.size == MODEL_LEN and self.gap_x.size == NUM_KMERS
+        self.c = OrcModel()
+        lib().orc_defaults_sm4(C.byref(self.c))
+        if transitions is not None:
+            for i, v in enumerate(transitions):
+                self.c.t[i] = v
+        self.c.match = self.match.ctypes.data
+        self.c.gapX = self.gap_x.ctypes.data
+        self.c.gapY = self.gap_y.ctypes.data
+
+    @property
+    def transitions(self):
+        return np.array([self.c.t[i] for i in range(11)])
+
+    def scaled(self, scale, shift, var, scale_sd, var_sd):
+        m = self.match.copy()
+        lib().orc_scale_model(_ptr(m), scale, shift, var, scale_sd, var_sd)
+        return Sm4Model(m, self.gap_y, self.gap_x, self.transitions)
 
 
 class VanillaModel:

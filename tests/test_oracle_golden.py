@@ -124,6 +124,34 @@ def test_vanilla_toy_pairs(template_model):
     assert pairs == [(2, 0), (3, 3), (5, 4), (6, 5), (7, 6)]
 
 
+TOY_EVENTS = [58.743435, 0.887833, 0.0571, 53.604965, 0.816836, 0.0571, 58.432015, 0.735143, 0.0571,
+              63.684352, 0.795437, 0.0571, 58.921430, 0.812959, 0.0571, 59.895882, 0.740952, 0.0571,
+              61.684303, 0.722332, 0.0571]
+TOY4_X = "CCAAATATATTACAACACACGATACGGACATCCAAATATATTACAACACCCAAATATAGCGTAACAC"
+TOY4_PAIRS = [(18, 0), (19, 1), (20, 2), (21, 3), (22, 3), (23, 4), (24, 5), (25, 6)]
+
+
+def test_four_state_toy_pairs(template_model):
+    # tests/signalPairwiseTest.c:687-787 (test_stateMachine4_diagonalDPCalculations): the seven toy events inside a
+    # 67-nucleotide sequence under getStateMachine4, exactly these 8 pairs >= 0.2
+    match, _, gapy = template_model
+    r = o.aligned_pairs_without_banding(o.Sm4Model(match, gapy), TOY4_X, len(TOY4_X) - 5, TOY_EVENTS,
+                                        o.default_params(threshold=0.2))
+    assert sorted((int(x), int(y)) for _, x, y in r["triples"]) == TOY4_PAIRS
+
+
+def test_real_read_unbanded_four_state_988(template_model, zymo_read):
+    # tests/signalPairwiseTest.c:1230-1237 (test_stateMachine4_getAlignedPairsWithBanding): the 4-state machine,
+    # scaled for the read, un-banded at the default threshold -> exactly 988 aligned pairs
+    match, _, gapy = template_model
+    m = o.Sm4Model(match, gapy).scaled(*zymo_read["template_params"])
+    ref = zymo_read["reference"]
+    r = o.aligned_pairs_without_banding(m, ref, len(ref) - 5, zymo_read["template_events"], o.default_params())
+    tri = r["triples"]
+    assert len(tri) == 988
+    assert len({(int(x), int(y)) for _, x, y in tri}) == 988
+
+
 def test_five_state_toy_pairs():
     # tests/pairwiseAlignerTest.c:278-373: "AGCG" vs "AGTTCG", exactly 4 pairs >= 0.2
     r = o.aligned_pairs_without_banding(o.Sm5Model(), "AGCG", 4, "AGTTCG",
