@@ -300,6 +300,24 @@ StateMachine *getStrawManStateMachine3(const char *modelFile) {
     return (StateMachine *) s;
 }
 
+StateMachine *getStateMachine4(const char *modelFile) { /* impl/stateMachine.c:1750-1759 */
+    StateMachine *sM = stateMachine4_construct(fourState, NUM_OF_KMERS, emissions_signal_initEmissionsToZero,
+                                               emissions_kmer_getGapProb, emissions_signal_strawManGetKmerEventMatchProb,
+                                               emissions_signal_strawManGetKmerEventMatchProb,
+                                               cell_signal_updateTransAndKmerSkipExpectations);
+    if (modelFile) { /* emissions_signal_loadPoreModel :242-320: match table, 30 skip bins (not this machine's), Y-gap table */
+        const int64_t tableLen = 1 + NUM_OF_KMERS * MODEL_PARAMS;
+        FILE *f = fopen(modelFile, "r");
+        double skip[30];
+        if (!f) die("cpecan: cannot open pore model %s", modelFile);
+        if (!read_doubles(f, sM->EMISSION_MATCH_PROBS, tableLen) || !read_doubles(f, skip, 30) ||
+            !read_doubles(f, sM->EMISSION_GAP_Y_PROBS, tableLen))
+            die("This stateMachine is not correct for signal model (%s)", modelFile);
+        fclose(f);
+    }
+    return sM;
+}
+
 /* ---- NanoporeHDP: the reader of serialized HDPs (impl/nanopore_hdp.c:845-870, impl/hdp.c:3009-3273) ---- */
 static char *read_line(FILE *f) { /* one line of any length, without the newline; NULL at EOF */
     size_t cap = 1 << 16, n = 0;
@@ -744,8 +762,8 @@ static cpecan_ctx *context(void) {
 
 /* returns 1 for the DNA-against-DNA combination (5-state machine, sequence_getBase on both sides),
  * 2 for k-mers against events under the vanilla machine (sequence_getKmer2), 3 under the HDP machine
- * (sequence_getKmer3), 0 under the 3-state strawMan machine (sequence_getKmer); anything else is not on
- * the GPU path */
+ * (sequence_getKmer3), 4 under the 4-state signal machine and 0 under the 3-state strawMan machine (both
+ * sequence_getKmer); anything else is not on the GPU path */
 static int check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY) {
     if (!cpecan_sm_functions_known(sM))
         die("cpecan: this StateMachine carries a cellCalculate or emission function of the caller's own; the GPU path "
@@ -767,8 +785,13 @@ static int check_known_combination(StateMachine *sM, Sequence *sX, Sequence *sY)
             die("cpecan: the vanilla machine needs sequence_getKmer2 / sequence_getEvent element getters");
         return 2;
     }
+    if (sM->type == fourState && sM->stateNumber == 4) {
+        if (sX->get != sequence_getKmer || sY->get != sequence_getEvent)
+            die("cpecan: the 4-state machine needs sequence_getKmer / sequence_getEvent element getters");
+        return 4;
+    }
     if (sM->type != threeState || sM->stateNumber != 3)
-        die("cpecan: only the threeState (strawMan) and vanilla signal StateMachines and the fiveState "
+        die("cpecan: only the threeState (strawMan), fourState, vanilla and HDP signal StateMachines and the fiveState "
             "symbol StateMachine run on the GPU path (type %d)", sM->type);
     if (sX->get != sequence_getKmer || sY->get != sequence_getEvent)
         die("cpecan: the GPU path needs sequence_getKmer / sequence_getEvent element getters");
@@ -787,7 +810,8 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
     cpecan_ctx *ctx = context();
     int64_t nX = 0, nY = 0, nA = 0, nItems = 0, capItems = 0;
     const int kind = n > 0 ? check_known_combination(sMs[0], sXs[0], sYs[0]) : 0;
-    const int dna = kind == 1, van = kind == 2, hdp = kind == 3;
+    const int dna = kind == 1, van = kind == 2, hdp = kind == 3, sm4 = kind == 4;
+    if (sm4 && mode != 0) die("cpecan: the 4-state machine has no expectations (the reference has no Hmm for it)");
     const int64_t xPad = dna ? 0 : KMER_LENGTH - 1; /* a k-mer sequence of lX elements spans lX + 5 chars */
     for (int64_t i = 0; i < n; i++) {
         if (check_known_combination(sMs[i], sXs[i], sYs[i]) != kind)
@@ -883,11 +907,29 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         }
         modelOf[i] = found;
     }
+    cpecan_sm4_model *models4 = malloc(sizeof(cpecan_sm4_model) * (size_t) (sm4 ? n : 1));
+    for (int64_t i = 0; sm4 && i < n; i++) { /* one model per distinct StateMachine4 */
+        int32_t found = -1;
+        for (int32_t k = 0; k < nModels && found < 0; k++)
+            if (owner5[k] == sMs[i]) found = k;
+        if (found < 0) {
+            const StateMachine4 *s4 = (const StateMachine4 *) sMs[i];
+            cpecan_sm4_model *m = &models4[nModels];
+            memcpy(m->transitions, &s4->TRANSITION_MATCH_CONTINUE, sizeof m->transitions);
+            m->match_probs = sMs[i]->EMISSION_MATCH_PROBS;
+            m->gap_x_probs = sMs[i]->EMISSION_GAP_X_PROBS;
+            m->gap_y_probs = sMs[i]->EMISSION_GAP_Y_PROBS;
+            owner5[nModels] = sMs[i];
+            found = nModels++;
+        }
+        modelOf[i] = found;
+    }
     int32_t *ids = malloc(sizeof(int32_t) * (size_t) nModels);
     CHECK(cpecan_hip_models_clear(ctx));
     if (dna) CHECK(cpecan_hip_models5_create(ctx, models5, nModels, ids));
     else if (van) CHECK(cpecan_hip_modelsv_create(ctx, modelsV, nModels, 0, ids));
     else if (hdp) CHECK(cpecan_hip_modelsh_create(ctx, modelsH, nModels, ids));
+    else if (sm4) CHECK(cpecan_hip_models4_create(ctx, models4, nModels, ids));
     else CHECK(cpecan_hip_models_create(ctx, models, nModels, 0, ids));
 
     int64_t xo = 0, yo = 0, ao = 0;
@@ -956,6 +998,9 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
             CHECK(cpecan_hip_batch_create_hdp(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                               (unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0) |
                                                   (mode ? CPECAN_FLAG_EXPECTATIONS : 0), &batch));
+        else if (sm4)
+            CHECK(cpecan_hip_batch_create_sm4(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
+                                              unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
         else if (van)
             CHECK(cpecan_hip_batch_create_vanilla(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                                   (unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0) |
@@ -1074,7 +1119,7 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         for (int64_t i = 0; i < n; i++) lists[i] = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
     }
     free(chars); free(events); free(anchors); free(items); free(origin); free(firstItem);
-    free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars); free(modelsV); free(modelsH);
+    free(models); free(modelOf); free(ids); free(models5); free(owner5); free(ychars); free(modelsV); free(modelsH); free(models4);
 }
 
 stList *getAlignedPairsUsingAnchors(StateMachine *sM, Sequence *SsX, Sequence *SsY, stList *anchorPairs,

@@ -296,6 +296,88 @@ static void sm3_cell(StateMachine *sM, double *current, double *lower, double *m
         walk(a, 2, upper, current, s->getYGapProbFcn(sM->EMISSION_GAP_Y_PROBS, cX, cY), doTransition, extraArgs);
     }
 }
+/* stateMachine4_cellCalculate :867-897 and its state vectors :791-829 (start: stateMachine5_startStateProb :743) */
+static void sm4_cell(StateMachine *sM, double *current, double *lower, double *middle, double *upper, void *cX,
+                     void *cY, DoTransitionFn doTransition, void *extraArgs) {
+    const StateMachine4 *s = (StateMachine4 *) sM;
+    if (lower) {
+        const Arc a[5] = { { match, shortGapX, s->TRANSITION_GAP_SHORT_OPEN_X },
+                           { shortGapX, shortGapX, s->TRANSITION_GAP_SHORT_EXTEND_X },
+                           { match, longGapX, s->TRANSITION_GAP_LONG_OPEN_X },
+                           { longGapX, longGapX, s->TRANSITION_GAP_LONG_EXTEND_X },
+                           { shortGapY, longGapX, s->TRANSITION_GAP_LONG_SWITCH_TO_X } };
+        walk(a, 5, lower, current, s->getXGapProbFcn(sM->EMISSION_GAP_X_PROBS, cX), doTransition, extraArgs);
+    }
+    if (middle) {
+        const Arc a[4] = { { match, match, s->TRANSITION_MATCH_CONTINUE },
+                           { shortGapX, match, s->TRANSITION_MATCH_FROM_SHORT_GAP_X },
+                           { shortGapY, match, s->TRANSITION_MATCH_FROM_SHORT_GAP_Y },
+                           { longGapX, match, s->TRANSITION_MATCH_FROM_LONG_GAP_X } };
+        walk(a, 4, middle, current, s->getMatchProbFcn(sM->EMISSION_MATCH_PROBS, cX, cY), doTransition, extraArgs);
+    }
+    if (upper) {
+        const Arc a[2] = { { match, shortGapY, s->TRANSITION_GAP_SHORT_OPEN_Y },
+                           { shortGapY, shortGapY, s->TRANSITION_GAP_SHORT_EXTEND_Y } };
+        walk(a, 2, upper, current, s->getYGapProbFcn(sM->EMISSION_GAP_Y_PROBS, cX, cY), doTransition, extraArgs);
+    }
+}
+static double sm4_ragged_start(StateMachine *sM, int64_t state) {
+    state_check(sM, state);
+    return (state == longGapX || state == shortGapY) ? 0 : LOG_ZERO;
+}
+static double sm4_end(StateMachine *sM, int64_t state) {
+    const StateMachine4 *s = (StateMachine4 *) sM;
+    state_check(sM, state);
+    const double v[4] = { s->TRANSITION_MATCH_CONTINUE, s->TRANSITION_MATCH_FROM_SHORT_GAP_X,
+                          s->TRANSITION_MATCH_FROM_SHORT_GAP_Y, s->TRANSITION_MATCH_FROM_LONG_GAP_X };
+    return v[state];
+}
+static double sm4_ragged_end(StateMachine *sM, int64_t state) {
+    const StateMachine4 *s = (StateMachine4 *) sM;
+    state_check(sM, state);
+    return state == longGapX ? s->TRANSITION_GAP_LONG_EXTEND_X : s->TRANSITION_GAP_LONG_OPEN_X;
+}
+void cpecan_sm4_set_functions(StateMachine4 *s) {
+    s->model.startStateProb = only_match_starts;
+    s->model.raggedStartStateProb = sm4_ragged_start;
+    s->model.endStateProb = sm4_end;
+    s->model.raggedEndStateProb = sm4_ragged_end;
+    s->model.cellCalculate = sm4_cell;
+}
+/* stateMachine4_construct :960-1037: the transitions are "from a template read" */
+StateMachine *stateMachine4_construct(StateMachineType type, int64_t parameterSetSize,
+                                      void (*setEmissionsToDefaults)(StateMachine *sM, int64_t nbSkipParams),
+                                      double (*gapXProbFcn)(const double *, void *),
+                                      double (*gapYProbFcn)(const double *, void *, void *),
+                                      double (*matchProbFcn)(const double *, void *, void *),
+                                      void (*cellCalcUpdateFcn)(double *, double *, int64_t, int64_t, double, double,
+                                                                void *)) {
+    if (type != fourState) die("Tried to make four-state stateMachine, with wrong type");
+    StateMachine4 *s = calloc(1, sizeof *s);
+    s->model.type = type;
+    s->model.parameterSetSize = parameterSetSize;
+    s->model.stateNumber = 4;
+    s->model.matchState = match;
+    cpecan_sm4_set_functions(s);
+    s->model.cellCalculateUpdateExpectations = cellCalcUpdateFcn;
+    s->getXGapProbFcn = gapXProbFcn;
+    s->getYGapProbFcn = gapYProbFcn;
+    s->getMatchProbFcn = matchProbFcn;
+    s->TRANSITION_MATCH_CONTINUE = -0.23552123624314988;
+    s->TRANSITION_GAP_SHORT_OPEN_X = -1.6269694202638481;
+    s->TRANSITION_GAP_SHORT_OPEN_Y = -4.7241893208381773;
+    s->TRANSITION_GAP_LONG_OPEN_X = -5.4173365013981227;
+    s->TRANSITION_GAP_SHORT_EXTEND_X = -1.6269694202638481;
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_X = -0.21880828092192281;
+    s->TRANSITION_GAP_LONG_EXTEND_X = -0.003442492794189331;
+    s->TRANSITION_MATCH_FROM_LONG_GAP_X = -5.6732801731704612;
+    s->TRANSITION_MATCH_FROM_SHORT_GAP_Y = -0.013406326748077823;
+    s->TRANSITION_GAP_SHORT_EXTEND_Y = -4.724189320832104;
+    s->TRANSITION_GAP_LONG_SWITCH_TO_X = -5.4173365013920494;
+    setEmissionsToDefaults((StateMachine *) s, parameterSetSize);
+    return (StateMachine *) s;
+}
+
 /* stateMachine3HDP_cellCalculate :1338-1370: as above with the densities of the HDP and a flat log(0.1) k-mer gap */
 static void sm3hdp_cell(StateMachine *sM, double *current, double *lower, double *middle, double *upper, void *cX,
                         void *cY, DoTransitionFn doTransition, void *extraArgs) {
@@ -409,6 +491,12 @@ int cpecan_sm_functions_known(StateMachine *sM) {
     }
     if (cell == (const void *) sm3_cell) {
         const StateMachine3 *s = (StateMachine3 *) sM;
+        return s->getXGapProbFcn == emissions_kmer_getGapProb &&
+               s->getYGapProbFcn == emissions_signal_strawManGetKmerEventMatchProb &&
+               s->getMatchProbFcn == emissions_signal_strawManGetKmerEventMatchProb;
+    }
+    if (cell == (const void *) sm4_cell) {
+        const StateMachine4 *s = (StateMachine4 *) sM;
         return s->getXGapProbFcn == emissions_kmer_getGapProb &&
                s->getYGapProbFcn == emissions_signal_strawManGetKmerEventMatchProb &&
                s->getMatchProbFcn == emissions_signal_strawManGetKmerEventMatchProb;

@@ -7,7 +7,8 @@
  * alignments run on the GPU side by side.
  *
  * Not carried over: --buildHDP / --alignments (training and re-sampling HDPs is outside this path; the option is
- * refused with a message), the fourState and echelon machines (not on the GPU path).
+ * refused with a message), the echelon machine (the reference marks it as not working, impl/stateMachine.c:1617), and
+ * expectations under the fourState machine (hmmContinuous_getEmptyHmm has no container for it in the reference either).
  *
  * The guide alignment comes through sonLib's cigarRead in the reference.  sonLib is not part of this build, so
  * the line format is read here directly: "cigar: <query> <qStart> <qEnd> <+|-> <target> <tStart> <tEnd> <+|-> <score>
@@ -179,8 +180,8 @@ static StateMachine *build_state_machine(const char *modelFile, NanoporeReadAdju
         stateMachine3Vanilla_setStrandTransitionsToDefaults(sM, strand);
         return sM;
     }
-    if (type == threeState) {
-        StateMachine *sM = getStrawManStateMachine3(modelFile);
+    if (type == threeState || type == fourState) { /* vanillaAlign.c:104-140 */
+        StateMachine *sM = type == fourState ? getStateMachine4(modelFile) : getStrawManStateMachine3(modelFile);
         emissions_signal_scaleModel(sM, npp.scale, npp.shift, npp.var, npp.scale_sd, npp.var_sd);
         return sM;
     }
@@ -432,7 +433,8 @@ int main(int argc, char *argv[]) {
         switch (key) {
         case 's': sMtype = threeState; break;
         case 'd': sMtype = threeStateHdp; break;
-        case 'f': case 'e': die("vanillaAlign - the fourState and echelon machines are not on the GPU path");
+        case 'f': sMtype = fourState; break;
+        case 'e': die("vanillaAlign - the echelon machine is not on the GPU path");
         case 'U': case 'a': case 'p':
             die("vanillaAlign - building and re-sampling HDPs is outside this path (run the reference's --buildHDP)");
         case 'M': substitute = optarg; break;
@@ -480,7 +482,7 @@ int main(int argc, char *argv[]) {
     if (!npReadFile || !targetFile) die("vanillaAlign - ERROR: --npRead and --reference are required");
     if (!readLabel) readLabel = npReadFile;
     fprintf(stderr, "vanillaAlign - using %s model\n",
-            sMtype == threeState ? "strawMan" : sMtype == vanilla ? "vanilla" : "strawMan-HDP");
+            sMtype == threeState ? "strawMan" : sMtype == vanilla ? "vanilla" : sMtype == fourState ? "fourState" : "strawMan-HDP");
     if ((templateHdp != NULL) != (complementHdp != NULL)) die("Need to have template and complement HDPs");
     NanoporeHDP *nHdpT = templateHdp ? deserialize_nhdp(templateHdp) : NULL;
     NanoporeHDP *nHdpC = complementHdp ? deserialize_nhdp(complementHdp) : NULL;
@@ -514,6 +516,8 @@ int main(int argc, char *argv[]) {
     stList *anchorPairs = guide_to_anchor_pairs(pA, p);
 
     const bool expectations = templateExpectationsFile && complementExpectationsFile;
+    if (expectations && sMtype == fourState)
+        die("vanillaAlign - the fourState machine has no expectations (the reference has no Hmm container for it)");
     StrandJob jobs[2] = {
         { template, sMtype, templateModelFile, templateHmmFile, templateExpectationsFile, posteriorProbsFile, readLabel, nHdpT,
           npRead->templateParams, tEventSequence, npRead->templateEvents, npRead->templateEventMap, pA->start2,

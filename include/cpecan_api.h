@@ -136,6 +136,26 @@ typedef struct _StateMachine3 {
     double (*getMatchProbFcn)(const double *emissionMatchProbs, void *x, void *y);
 } StateMachine3;
 
+/* 4-state signal machine (inc/stateMachine.h:132-165): match, short gap X, short gap Y and a long gap X over the strawMan
+ * emissions; stateMachine4_cellCalculate impl/stateMachine.c:867-897 */
+typedef struct _StateMachine4 {
+    StateMachine model;
+    double TRANSITION_MATCH_CONTINUE;
+    double TRANSITION_MATCH_FROM_SHORT_GAP_X;
+    double TRANSITION_MATCH_FROM_LONG_GAP_X;
+    double TRANSITION_MATCH_FROM_SHORT_GAP_Y;
+    double TRANSITION_GAP_SHORT_OPEN_X;
+    double TRANSITION_GAP_SHORT_EXTEND_X;
+    double TRANSITION_GAP_SHORT_OPEN_Y;
+    double TRANSITION_GAP_SHORT_EXTEND_Y;
+    double TRANSITION_GAP_LONG_OPEN_X;
+    double TRANSITION_GAP_LONG_EXTEND_X;
+    double TRANSITION_GAP_LONG_SWITCH_TO_X;
+    double (*getXGapProbFcn)(const double *emissionXGapProbs, void *kmer);
+    double (*getYGapProbFcn)(const double *scaledMatchModel, void *kmer, void *event);
+    double (*getMatchProbFcn)(const double *matchModel, void *kmer, void *event);
+} StateMachine4;
+
 /* 5-state symbol machine of DNA-against-DNA alignment (inc/stateMachine.h:104-124; data members) */
 typedef struct _StateMachine5 {
     StateMachine model;
@@ -257,6 +277,11 @@ void cpecan_hdp_machine_as_model(StateMachine *sM, void *cpecan_hdp_model_out);
 /* getStrawManStateMachine3 (impl/stateMachine.c:1725): 3-state machine with nanopore default
  * transitions (:1278), log(0.1) k-mer gap table (:1506), emission tables from a 3-line .model file */
 StateMachine *getStrawManStateMachine3(const char *modelFile);
+/* getStateMachine4 (impl/stateMachine.c:1750-1759): the 4-state machine with its template-read transitions
+ * (stateMachine4_construct :992-1011), the pore model's match and extra-event tables, the k-mer gap table left at zero
+ * (emissions_signal_initEmissionsToZero).  Posterior decode on the GPU (cpecan_k_general4); the reference has no Hmm
+ * container for it. */
+StateMachine *getStateMachine4(const char *modelFile);
 void stateMachine3_setTransitionsToNanoporeDefaults(StateMachine *sM);
 void emissions_signal_scaleModel(StateMachine *sM, double scale, double shift, double var,
                                  double scale_sd, double var_sd); /* :631-651 */
@@ -646,6 +671,13 @@ StateMachine *stateMachine3_construct(StateMachineType type, int64_t parameterSe
                                       double (*matchProbFcn)(const double *, void *, void *),
                                       void (*cellCalcUpdateExpFcn)(double *fromCells, double *toCells, int64_t from,
                                                                    int64_t to, double eP, double tP, void *extraArgs));
+StateMachine *stateMachine4_construct(StateMachineType type, int64_t parameterSetSize,
+                                      void (*setEmissionsToDefaults)(StateMachine *sM, int64_t nbSkipParams),
+                                      double (*gapXProbFcn)(const double *, void *),
+                                      double (*gapYProbFcn)(const double *, void *, void *),
+                                      double (*matchProbFcn)(const double *, void *, void *),
+                                      void (*cellCalcUpdateFcn)(double *fromCells, double *toCells, int64_t from,
+                                                                int64_t to, double eP, double tP, void *extraArgs));
 StateMachine *stateMachine3Hdp_construct(StateMachineType type, int64_t parameterSetSize,
                                          void (*setTransitionsToDefaults)(StateMachine *sM),
                                          void (*setEmissionsDefaults)(StateMachine *sM, int64_t nbSkipParams),
@@ -714,6 +746,8 @@ _Static_assert(offsetof(struct _stateMachine, cellCalculate) == 88, "StateMachin
 _Static_assert(sizeof(struct _stateMachine) == 104, "StateMachine layout");
 _Static_assert(offsetof(StateMachine3, TRANSITION_MATCH_CONTINUE) == 104, "StateMachine3 layout");
 _Static_assert(offsetof(StateMachine3, getXGapProbFcn) == 176 && sizeof(StateMachine3) == 200, "StateMachine3 layout");
+_Static_assert(offsetof(StateMachine4, TRANSITION_GAP_LONG_SWITCH_TO_X) == 184 && offsetof(StateMachine4, getXGapProbFcn) == 192 &&
+               sizeof(StateMachine4) == 216, "StateMachine4 layout");
 _Static_assert(offsetof(StateMachine5, getXGapProbFcn) == 240 && sizeof(StateMachine5) == 264, "StateMachine5 layout");
 _Static_assert(offsetof(StateMachine3_HDP, hdpModel) == 184 && sizeof(StateMachine3_HDP) == 208, "StateMachine3_HDP layout");
 _Static_assert(offsetof(StateMachine3Vanilla, getKmerSkipProb) == 144 && sizeof(StateMachine3Vanilla) == 168,

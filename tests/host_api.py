@@ -60,7 +60,7 @@ EXPORTS = [
     "getAlignedPairsUsingAnchorsBatch", "sequence_getBase", "sequence_sliceNucleotideSequence",
     "stateMachine5_construct", "emissions_symbol_setEmissionsToDefaults", "emissions_symbol_getGapProb",
     "emissions_symbol_getMatchProb", "cell_updateExpectations", "sequence_getKmer2",
-    "getSignalStateMachine3Vanilla", "stateMachine3Vanilla_setStrandTransitionsToDefaults",
+    "getSignalStateMachine3Vanilla", "stateMachine3Vanilla_setStrandTransitionsToDefaults", "getStateMachine4", "stateMachine4_construct",
     "sequence_getKmer3", "deserialize_nhdp", "destroy_nanopore_hdp", "get_nanopore_hdp_alphabet_size",
     "get_nanopore_hdp_alphabet", "get_nanopore_kmer_density", "getHdpStateMachine3",
     "getPosteriorProbsWithBanding", "filterToRemoveOverlap", "diagonal_construct", "diagonal_getXay",
@@ -180,6 +180,8 @@ def lib():
         L.stateMachine_destruct.argtypes = [vp]
         L.getSignalStateMachine3Vanilla.restype = vp
         L.getSignalStateMachine3Vanilla.argtypes = [C.c_char_p]
+        L.getStateMachine4.restype = vp
+        L.getStateMachine4.argtypes = [C.c_char_p]
         L.stateMachine3Vanilla_setStrandTransitionsToDefaults.argtypes = [vp, C.c_int]
         L.diagonal_construct.restype = Diagonal
         L.diagonal_construct.argtypes = [C.c_int64] * 3

@@ -265,6 +265,52 @@ def test_five_state_dna_through_host_api():
 
 
 @pytest.mark.gpu
+def test_four_state_machine_through_host_api(golden_dir, zymo_read, template_model):
+    """test_stateMachine4_getAlignedPairsWithBanding (tests/signalPairwiseTest.c:1180-1245) through the host API:
+    getStateMachine4 + scaleModel, un-banded at the default threshold: exactly 988 pairs, identical to the oracle;
+    then banded with the oracle's anchors-free band of the shipped read replaced by anchors every 50 k-mers on the
+    un-banded result (lastz is not here): identical to the oracle as well."""
+    L = h.lib()
+    sm = L.getStateMachine4(os.path.join(golden_dir, "template_median68pA.model").encode())
+    L.emissions_signal_scaleModel(sm, *zymo_read["template_params"])
+    ref_seq = zymo_read["reference"]
+    xbuf = C.create_string_buffer(ref_seq.encode())
+    ev = np.ascontiguousarray(zymo_read["template_events"], dtype=np.float64).reshape(-1)
+    lX, lY = len(ref_seq) - 5, ev.size // 3
+    p = L.pairwiseAlignmentBandingParameters_construct()
+    pairs = L.getAlignedPairsWithoutBanding(sm, C.cast(xbuf, C.c_void_p), ev.ctypes.data_as(C.c_void_p), lX, lY, p,
+                                            h.fn_ptr("sequence_getKmer"), h.fn_ptr("sequence_getEvent"),
+                                            h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), True, True)
+    got = h.list_to_array(pairs)
+    L.stList_destruct(pairs)
+    assert len(got) == 988
+    match, _, gapy = template_model
+    om = o.Sm4Model(match, gapy).scaled(*zymo_read["template_params"])
+    ref = o.aligned_pairs_without_banding(om, ref_seq, lX, zymo_read["template_events"], o.default_params(), 1, 1)
+    assert np.array_equal(got, ref["triples"])
+    # banded, anchored on every 50th pair of the un-banded alignment with posterior >= 0.9
+    strong = got[got[:, 0] >= 9000000]
+    anchors = np.ascontiguousarray(strong[np.argsort(strong[:, 1])][::50, 1:3])
+    anchors = anchors[np.concatenate([[True], (np.diff(anchors[:, 0]) > 0) & (np.diff(anchors[:, 1]) > 0)])]
+    lst = h.make_anchor_list(anchors)
+    sX = L.sequence_construct2(lX, C.cast(xbuf, C.c_void_p), h.fn_ptr("sequence_getKmer"),
+                               h.fn_ptr("sequence_sliceNucleotideSequence2"))
+    sY = L.sequence_construct2(lY, ev.ctypes.data_as(C.c_void_p), h.fn_ptr("sequence_getEvent"),
+                               h.fn_ptr("sequence_sliceEventSequence2"))
+    banded = L.getAlignedPairsUsingAnchors(sm, sX, sY, lst, p, h.fn_ptr("diagonalCalculationPosteriorMatchProbs"), True, True)
+    gotb = h.list_to_array(banded)
+    refb = o.aligned_pairs_using_anchors(om, ref_seq, lX, zymo_read["template_events"], anchors, o.default_params(), 1, 1)
+    assert np.array_equal(gotb, refb["triples"])
+    assert 900 < len(gotb) < 1100
+    L.stList_destruct(banded)
+    L.stList_destruct(lst)
+    L.sequence_sequenceDestroy(sX)
+    L.sequence_sequenceDestroy(sY)
+    L.pairwiseAlignmentBandingParameters_destruct(p)
+    L.stateMachine_destruct(sm)
+
+
+@pytest.mark.gpu
 def test_vanilla_zymo_read_through_host_api(golden_dir, zymo_read, template_model):
     """test_vanilla_strandAlignmentNoBanding (tests/signalPairwiseTest.c:1042-1075) through the host API:
     getSignalStateMachine3Vanilla + scaleModel + sequence_getKmer2, un-banded, then banded with anchors and

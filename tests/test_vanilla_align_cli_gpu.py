@@ -85,10 +85,10 @@ def test_driver_refuses_an_event_map_that_runs_backwards(golden_dir, zymo_read, 
     assert r.returncode == 1 and "runs against the read" in r.stderr
 
 
-@pytest.mark.parametrize("machine", ["strawMan", "vanilla", "sm3Hdp"])
+@pytest.mark.parametrize("machine", ["strawMan", "vanilla", "sm3Hdp", "fourState"])
 def test_cli_alignment_matches_the_host_api(machine, golden_dir, zymo_read, template_model, tmp_path):
-    """the three machines the driver runs: --strawMan, the default (vanilla: sequence_getKmer2, the strand's transition
-    defaults) and --sm3Hdp (de-scaled events, sequence_getKmer3, the .nhdp files of -v / -w)"""
+    """the machines the driver runs: --strawMan, the default (vanilla: sequence_getKmer2, the strand's transition
+    defaults), --sm3Hdp (de-scaled events, sequence_getKmer3, the .nhdp files of -v / -w) and --fourState"""
     L = h.lib()
     pts, ops, cigar = _guide(zymo_read, template_model)
     assert len(pts) > 8
@@ -97,7 +97,8 @@ def test_cli_alignment_matches_the_host_api(machine, golden_dir, zymo_read, temp
     models = [os.path.join(golden_dir, "template_median68pA.model"),
               os.path.join(golden_dir, "complement_median68pA_pop2.model")]
     nhdp = os.path.join(golden_dir, "testTemplate.nhdp")
-    cmd = [EXE] + {"strawMan": ["--strawMan"], "vanilla": [], "sm3Hdp": ["--sm3Hdp", "-v", nhdp, "-w", nhdp]}[machine] + [
+    cmd = [EXE] + {"strawMan": ["--strawMan"], "vanilla": [], "sm3Hdp": ["--sm3Hdp", "-v", nhdp, "-w", nhdp],
+                   "fourState": ["--fourState"]}[machine] + [
         "-T", models[0], "-C", models[1], "-q", npread, "-r", os.path.join(golden_dir, "ZymoRef.txt"), "-u", tsv, "-L",
         "zymo_read", "-x", "50"]
     r = subprocess.run(cmd, input=cigar, capture_output=True, text=True, timeout=600)
@@ -128,6 +129,9 @@ def test_cli_alignment_matches_the_host_api(machine, golden_dir, zymo_read, temp
         if machine == "strawMan":
             sm = L.getStrawManStateMachine3(model.encode())
             L.emissions_signal_scaleModel(sm, *params)
+        elif machine == "fourState":
+            sm = L.getStateMachine4(model.encode())
+            L.emissions_signal_scaleModel(sm, *params)
         elif machine == "vanilla":
             sm = L.getSignalStateMachine3Vanilla(model.encode())
             L.emissions_signal_scaleModel(sm, *params)
@@ -139,7 +143,8 @@ def test_cli_alignment_matches_the_host_api(machine, golden_dir, zymo_read, temp
             # the means of the first third of the events are taken back to the model's scale, nothing else (kept as is)
             idx = np.arange(0, ev.size // 3, 3)
             ev[idx] = (ev[idx] - params[1]) / params[0]
-        getter = {"strawMan": "sequence_getKmer", "vanilla": "sequence_getKmer2", "sm3Hdp": "sequence_getKmer3"}[machine]
+        getter = {"strawMan": "sequence_getKmer", "vanilla": "sequence_getKmer2", "sm3Hdp": "sequence_getKmer3",
+                  "fourState": "sequence_getKmer"}[machine]
         remapped = L.nanopore_remapAnchorPairsWithOffset(filtered, emap.ctypes.data_as(C.POINTER(C.c_int64)), r0)
         anchors = L.filterToRemoveOverlap(remapped)
         xbuf = C.create_string_buffer(target.encode())
