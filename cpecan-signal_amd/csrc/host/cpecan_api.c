@@ -300,6 +300,23 @@ StateMachine *getStrawManStateMachine3(const char *modelFile) {
     return (StateMachine *) s;
 }
 
+/* impl/pairwiseAligner.c:1039-1063: the match runs of a forward-strand alignment as (x, y) pairs, `trim` positions cut
+ * from either end of a run */
+stList *convertPairwiseForwardStrandAlignmentToAnchorPairs(struct PairwiseAlignment *pA, int64_t trim) {
+    stList *pairs = stList_construct3(0, (void (*)(void *)) stIntTuple_destruct);
+    if (!pA->strand1 || !pA->strand2) die("cpecan: convertPairwiseForwardStrandAlignmentToAnchorPairs takes forward strands");
+    int64_t j = pA->start1, k = pA->start2;
+    for (int64_t i = 0; i < pA->operationList->length; i++) {
+        const struct AlignmentOperation *op = pA->operationList->list[i];
+        if (op->opType == PAIRWISE_MATCH)
+            for (int64_t l = trim; l < op->length - trim; l++) stList_append(pairs, stIntTuple_construct2(j + l, k + l));
+        if (op->opType != PAIRWISE_INDEL_Y) j += op->length;
+        if (op->opType != PAIRWISE_INDEL_X) k += op->length;
+    }
+    if (j != pA->end1 || k != pA->end2) die("cpecan: the operations of the alignment do not span its intervals");
+    return pairs;
+}
+
 StateMachine *getStateMachine4(const char *modelFile) { /* impl/stateMachine.c:1750-1759 */
     StateMachine *sM = stateMachine4_construct(fourState, NUM_OF_KMERS, emissions_signal_initEmissionsToZero,
                                                emissions_kmer_getGapProb, emissions_signal_strawManGetKmerEventMatchProb,
@@ -1307,6 +1324,7 @@ void hmmDiscrete_randomize(Hmm *hmm) {
     hmmDiscrete_randomizeEmissions(hmm);
     hmmDiscrete_normalize2(hmm, true);
 }
+void hmmDiscrete_normalize(Hmm *hmm) { hmmDiscrete_normalize2(hmm, true); }
 void hmmDiscrete_normalize2(Hmm *hmm, bool normalizeEmissions) {
     for (int64_t from = 0; from < hmm->stateNumber; from++) {
         double total = 0.0;

@@ -1106,6 +1106,7 @@ void hdpHmm_writeToFile(Hmm *hmm, FILE *fileHandle) {
     cpecan_hdpExpectations_write(e, fileHandle);
     cpecan_hdpExpectations_destruct(e);
 }
+Hmm *hdpHmm_loadFromFile2(const char *fileName, NanoporeHDP *nHdp) { return hdpHmm_loadFromFile(fileName, nHdp); }
 Hmm *hdpHmm_loadFromFile(const char *fileName, NanoporeHDP *nHdp) {
     HdpHmmExpectations *e = cpecan_hdpExpectations_read(fileName);
     Hmm *hmm = hmmContinuous_getEmptyHmm(threeStateHdp, 0.0, e->threshold);

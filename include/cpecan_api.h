@@ -469,6 +469,9 @@ void hmmDiscrete_randomizeTransitions(Hmm *hmm);
 void hmmDiscrete_randomizeEmissions(Hmm *hmm);
 void hmmDiscrete_randomize(Hmm *hmm);                          /* uniform draws, then normalize2(TRUE) */
 void hmmDiscrete_normalize2(Hmm *hmm, bool normalizeEmissions); /* :125-153 */
+/* declared by the reference (inc/discreteHmm.h:38) and defined nowhere in it; here: transitions and emissions, what
+ * hmmDiscrete_randomize (:113-123) calls normalize2 with */
+void hmmDiscrete_normalize(Hmm *hmm);
 void hmmDiscrete_write(Hmm *hmm, FILE *fileHandle);            /* :156-180: 3 lines, "%f" fields */
 Hmm *hmmDiscrete_loadFromFile(const char *fileName);           /* :183-273 */
 void hmmDiscrete_destruct(Hmm *hmm);
@@ -652,6 +655,8 @@ Hmm *hdpHmm_constructEmpty(double pseudocount, int64_t stateNumber, StateMachine
                            double (*getTransitionsExpFcn)(Hmm *hmm, int64_t from, int64_t to));
 void hdpHmm_loadTransitions(StateMachine *sM, Hmm *hmm);                           /* :681-699 */
 void hdpHmm_writeToFile(Hmm *hmm, FILE *fileHandle);                               /* :701-753 */
+/* declared by the reference (inc/continuousHmm.h:109) and defined nowhere in it; here: hdpHmm_loadFromFile */
+Hmm *hdpHmm_loadFromFile2(const char *fileName, NanoporeHDP *nHdp);
 Hmm *hdpHmm_loadFromFile(const char *fileName, NanoporeHDP *nHdp); /* :755-900: transitions and assignments; the
                                                                        Gibbs update of nHdp is not part of this path */
 void hdpHmm_destruct(Hmm *hmm);
@@ -661,6 +666,33 @@ Hmm *hmmContinuous_getEmptyHmm(StateMachineType type, double pseudocount, double
 void hmmContinuous_normalize(Hmm *hmm, StateMachineType type);
 void hmmContinuous_writeToFile(const char *outFile, Hmm *hmm, StateMachineType type);
 int64_t hmmContinuous_howManyAssignments(Hmm *hmm);
+
+/* ---- sonLib's pairwise alignment record (sonLib C/inc/pairwiseAlignment.h, commonC.h: the library the reference links and
+ * does not vendor -- include.mk points at a checkout beside it, no version is pinned; the layouts below are sonLib's
+ * published ones).  getBlastPairs reads lastz's cigars into these through sonLib's cigarRead; here the cigar lines are
+ * parsed directly (cpecan_api.c) and this converter is offered for callers that hold such a record.
+ * convertPairwiseForwardStrandAlignmentToAnchorPairs impl/pairwiseAligner.c:1039-1063 ------------------------------ */
+#define PAIRWISE_INDEL_X 0
+#define PAIRWISE_INDEL_Y 1
+#define PAIRWISE_MATCH 2
+struct List {
+    int64_t length, maxLength;
+    void **list;
+    void (*destroyElement)(void *);
+};
+struct AlignmentOperation {
+    int64_t opType, length;
+    float score;
+};
+struct PairwiseAlignment {
+    char *contig1;
+    int64_t start1, end1, strand1;
+    char *contig2;
+    int64_t start2, end2, strand2;
+    float score;
+    struct List *operationList;
+};
+stList *convertPairwiseForwardStrandAlignmentToAnchorPairs(struct PairwiseAlignment *pA, int64_t trim);
 
 /* ---- the constructors that take plug-ins (inc/stateMachine.h:259-312) and the plug-ins themselves ------------ */
 StateMachine *stateMachine3_construct(StateMachineType type, int64_t parameterSetSize,

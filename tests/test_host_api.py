@@ -900,3 +900,41 @@ def test_single_banded_call_appends_in_emission_order(golden_dir):
     L.sequence_sequenceDestroy(sY)
     L.pairwiseAlignmentBandingParameters_destruct(p)
     L.stateMachine_destruct(sm)
+
+
+def test_names_the_reference_declares_and_this_library_now_exports():
+    """hmmDiscrete_normalize (inc/discreteHmm.h:38), hdpHmm_loadFromFile2 (inc/continuousHmm.h:109),
+    convertPairwiseForwardStrandAlignmentToAnchorPairs (inc/pairwiseAligner.h:109), the 4-state machine's
+    constructors (inc/stateMachine.h:289, :378)"""
+    L = h.lib()
+    for name in ("hmmDiscrete_normalize", "hdpHmm_loadFromFile2", "convertPairwiseForwardStrandAlignmentToAnchorPairs",
+                 "stateMachine4_construct", "getStateMachine4"):
+        assert hasattr(L, name), name
+
+
+def test_convert_pairwise_alignment_to_anchor_pairs():
+    """impl/pairwiseAligner.c:1039-1063 over sonLib's record: match runs as (x, y) pairs, trimmed at both ends"""
+    L = h.lib()
+
+    class Op(C.Structure):
+        _fields_ = [("opType", C.c_int64), ("length", C.c_int64), ("score", C.c_float)]
+
+    class List(C.Structure):
+        _fields_ = [("length", C.c_int64), ("maxLength", C.c_int64), ("list", C.POINTER(C.c_void_p)), ("destroy", C.c_void_p)]
+
+    class PA(C.Structure):
+        _fields_ = [("contig1", C.c_char_p), ("start1", C.c_int64), ("end1", C.c_int64), ("strand1", C.c_int64),
+                    ("contig2", C.c_char_p), ("start2", C.c_int64), ("end2", C.c_int64), ("strand2", C.c_int64),
+                    ("score", C.c_float), ("operationList", C.POINTER(List))]
+
+    ops = [Op(2, 5, 0.0), Op(0, 2, 0.0), Op(2, 3, 0.0), Op(1, 1, 0.0), Op(2, 4, 0.0)]  # M5 X2 M3 Y1 M4
+    arr = (C.c_void_p * len(ops))(*[C.cast(C.pointer(o_), C.c_void_p) for o_ in ops])
+    lst = List(len(ops), len(ops), arr, None)
+    # INDEL_X: X advances alone (j += length); INDEL_Y: Y advances alone
+    pa = PA(b"a", 10, 10 + 5 + 2 + 3 + 4, 1, b"b", 20, 20 + 5 + 3 + 1 + 4, 1, 0.0, C.pointer(lst))
+    L.convertPairwiseForwardStrandAlignmentToAnchorPairs.restype = C.c_void_p
+    L.convertPairwiseForwardStrandAlignmentToAnchorPairs.argtypes = [C.c_void_p, C.c_int64]
+    got = h.list_to_array(L.convertPairwiseForwardStrandAlignmentToAnchorPairs(C.byref(pa), 1), 2)
+    want = [(10 + l, 20 + l) for l in range(1, 4)] + [(17 + l, 25 + l) for l in range(1, 2)] + \
+           [(20 + l, 29 + l) for l in range(1, 3)]
+    assert [tuple(r) for r in got.tolist()] == want
