@@ -555,8 +555,9 @@ def bench_service(args, cp, bp, rank, local_rank, world, synth):
         sys.exit("--mode service is a one-GPU measurement")
     n = args.warmup + args.steps
     data = [synth.make_batch(3 + 10 * k, args.reads, args.kmers, args.events, anchor_every=50) for k in range(min(n, 4))]
-    family = "workgroup" if args.family == "auto" else args.family
-    flags = cp.FLAG_WORKGROUP_KERNELS if family == "workgroup" else 0
+    family = "wave" if args.family == "auto" else args.family
+    # (several one-shot batches alive at once: the wave family's assembly sweeps with their smaller footprint)
+    flags = cp.FLAG_WORKGROUP_KERNELS if family == "workgroup" else cp.FLAG_SMALL_FOOTPRINT
     if family == "workgroup" and "CPECAN_SYSTOLIC_GROUPS" not in os.environ:
         os.environ["CPECAN_SYSTOLIC_GROUPS"] = "1"  # one stream group per batch: two batches' kernels overlap
     NSLOT = max(3, args.service_slots)  # one batch running, one queued behind it on the device, the others being prepared

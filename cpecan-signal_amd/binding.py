@@ -28,6 +28,7 @@ KERNEL_AUTO, KERNEL_GENERAL, KERNEL_SYSTOLIC = 0, 1, 2
 FLAG_DEBUG_DUMP = 1
 FLAG_UNBANDED = 2
 FLAG_SCAN_DECODE = 4
+FLAG_SMALL_FOOTPRINT = 64
 FLAG_EXPECTATIONS = 8
 FLAG_WORKGROUP_KERNELS = 16
 FLAG_GENERAL_KERNEL = 32

@@ -306,8 +306,9 @@ struct PackedPair {
 /* Device memory of batches and model tables goes through a small caching allocator: hipMalloc and hipFree wait for
  * the device, so a host thread that prepares the next batch while the GPU works on the current one (one-shot
  * alignment of a stream of batches) would otherwise stall on every buffer.  A released block is kept (up to
- * CPECAN_ALLOC_CACHE_GB; by default a quarter of the device's memory, so that co-tenants -- RCCL's buffers, torch in
- * the same process, other processes on the card -- are not starved; cpecan_hip_trim_cache() gives everything back)
+ * CPECAN_ALLOC_CACHE_GB; by default half of the device's memory -- one process per GPU is the deployment, and RCCL's
+ * buffers, torch in the same process or other processes on the card keep the other half; cpecan_hip_trim_cache()
+ * gives everything back)
  * and handed to the next request it fits within 25 %.  A block keeps its real size through every reuse. */
 struct DevCache {
     struct Block { void *p; size_t bytes; int device; };
@@ -324,7 +325,9 @@ struct DevCache {
             double gb = e ? atof(e) : 8.0;
             if (!e && !pinnedHost) {
                 size_t freeB = 0, totalB = 0;
-                gb = hipMemGetInfo(&freeB, &totalB) == hipSuccess ? (double) totalB / 4.0 / (double) (1ull << 30) : 32.0;
+                /* half the card: three C3 batches on the assembly sweeps (ring of three windows: 45 GB each) alive at once,
+                 * as a one-shot service keeps them, still turn over inside the cache */
+                gb = hipMemGetInfo(&freeB, &totalB) == hipSuccess ? (double) totalB / 2.0 / (double) (1ull << 30) : 32.0;
             }
             capBytes = (size_t) (gb * (double) (1ull << 30)) + 1;
         }
@@ -1553,7 +1556,8 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
          * and the decode of window w, whose re-sweep kernel may still read that window's rows */
         const bool asmOffEarly = getenv("CPECAN_ASM") != nullptr && atoi(getenv("CPECAN_ASM")) == 0;
         const bool asmLikely = wantPlan && !asmOffEarly && b->sy->wave && b->sy->rows == ASM_L && globalMaxWidth <= ASM_MAX_WIDTH;
-        const int ringWindows = !b->sy->wave || maxWindows <= 1 ? 1 : asmLikely && maxWindows > 2 ? 3 : 2;
+        const int ringWindows = !b->sy->wave || maxWindows <= 1 ? 1
+                                : asmLikely && maxWindows > 2 && !(flags & CPECAN_FLAG_SMALL_FOOTPRINT) ? 3 : 2;
         while (b->ringD < (ringWindows > 1 ? ringWindows * maxSpan + 8 : maxSpan + 4)) b->ringD *= 2;
         /* the wave kernels keep one more row behind the ring: the -inf row lanes without a cell read */
         b->ringDoubles = (long long) (b->ringD + (b->sy->wave ? 1 : 0)) * b->sy->ring_row_doubles();

@@ -1025,7 +1025,9 @@ static void run_reads(int64_t n, StateMachine **sMs, Sequence **sXs, Sequence **
         else
             CHECK(cpecan_hip_batch_create(ctx, items, nItems, chars, xo, events, yo, anchors, ao, &bp,
                                           mode ? CPECAN_MODE_EXPECTATIONS : CPECAN_MODE_POSTERIOR,
-                                          CPECAN_KERNEL_AUTO, unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0, &batch));
+                                          CPECAN_KERNEL_AUTO,
+                                          /* (one batch per call, nothing chained behind it: the smaller footprint) */
+                                          (unbanded == 1 ? CPECAN_FLAG_UNBANDED : 0) | CPECAN_FLAG_SMALL_FOOTPRINT, &batch));
         CHECK(cpecan_hip_batch_run(batch));
         CHECK(cpecan_hip_batch_sync(batch));
         if (mode == 0) {

@@ -208,6 +208,11 @@ typedef struct {
                                            once well (more, smaller-footprint workgroups per CU).  The environment
                                            variable CPECAN_KERNELS=systolic asks the same for every batch. */
 
+#define CPECAN_FLAG_SMALL_FOOTPRINT 64 /* a batch that may run the assembly sweeps keeps the two-window ring and the single
+                                        * scratch of the compiled wave kernels (24 instead of 45 GB for 1024 reads of
+                                        * 10k events x 5k k-mers): its post kernel then runs between its backward sweeps
+                                        * (-10 % when batches are chained, nothing for a batch alone).  For callers that
+                                        * keep several one-shot batches alive at once. */
 #define CPECAN_FLAG_GENERAL_KERNEL 32 /* cpecan_hip_batch_create_hdp / _vanilla: keep the batch on the general kernel
                                          (any band width) instead of the wave-per-alignment kernels of that machine
                                          (posterior decode; bands <= 248 k-mers for the HDP machine, <= 184 for the
@@ -331,7 +336,7 @@ int cpecan_hip_batch_destroy(cpecan_batch *batch);
 int cpecan_hip_selftest_division(cpecan_ctx *ctx, int64_t n, uint64_t seed, int64_t *mismatches);
 
 /* Device and pinned host memory released by batches and model tables is kept by the library for the next request
- * (hipMalloc / hipFree wait for the device; up to a quarter of the card's memory by default, CPECAN_ALLOC_CACHE_GB /
+ * (hipMalloc / hipFree wait for the device; up to half of the card's memory by default, CPECAN_ALLOC_CACHE_GB /
  * CPECAN_PINNED_CACHE_GB).  This gives all of it back to the runtime: call it between phases when something else in the
  * process, or on the card, needs the memory. */
 int cpecan_hip_trim_cache(void);
