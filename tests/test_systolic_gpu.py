@@ -84,6 +84,30 @@ def test_systolic_matches_oracle(ctx, case, rows, family):
         assert_same_pairs(res[i], ref)
 
 
+@pytest.mark.parametrize("flags", [0, cp.FLAG_SMALL_FOOTPRINT], ids=["three-window-ring", "small-footprint"])
+def test_assembly_sweeps_in_both_layouts_match_oracle(ctx, flags):
+    # a band of 121-158 k-mers over seven traceback windows: the hand-scheduled sweeps, with the ring of three windows
+    # and the post kernel on a stream of its own, and with the two-window ring of CPECAN_FLAG_SMALL_FOOTPRINT
+    batch = synth.make_batch(33, 3, 700, 1400, anchor_every=50)
+    bp = band_params(0.01, 300, 40, 100)
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_AUTO, flags=flags, ragged=(1, 1))
+    assert b.info()["assembly_sweeps"] == 2
+    for i in range(3):
+        ref = run_oracle_item(batch, i, bp, (1, 1))
+        assert res[i]["cells"] == ref["cells"]
+        assert np.array_equal(res[i]["totals_xay"], ref["totals_xay"])
+        assert np.array_equal(res[i]["totals"], ref["totals"])
+        assert_same_pairs(res[i], ref)
+    # run again on the same batch (the windows' records, ring and scratch halves are reused)
+    b.run()
+    b.sync()
+    npairs, _, _ = b.counts()
+    for i in range(3):
+        tri, lp = b.pairs(i, npairs[i])
+        assert np.array_equal(tri, res[i]["triples"]) and np.array_equal(lp, res[i]["logp"])
+    b.close()
+
+
 @pytest.mark.parametrize("threshold", [0.0, 0.01, 1e-4, 1e-7])
 def test_systolic_decode_paths_agree(ctx, threshold, rows, family):
     # the candidate-list decode (default) and the full-scan decode (CPECAN_FLAG_SCAN_DECODE, also the
