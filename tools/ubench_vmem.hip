@@ -34,6 +34,12 @@
 #define ST16 asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0xffff\n global_store_dwordx4 %0, v[104:107], off\n s_mov_b64 exec, s[20:21]" ::"v"(p) : "memory", "s20", "s21")
 #define LD4 asm volatile("global_load_dwordx4 v[100:103], %0, off" ::"v"(p) : "memory", "v100", "v101", "v102", "v103")
 #define NONE
+// three 16-byte stores / loads that together cover 3 KB: each instruction a contiguous KB (lane * 16 in its own KB), or the
+// three interleaved per lane (lane * 48 + 16 j: every instruction touches all 24 lines, a third of each)
+#define ST4x3 asm volatile("global_store_dwordx4 %0, v[104:107], off\n global_store_dwordx4 %0, v[104:107], off offset:1024\n global_store_dwordx4 %0, v[104:107], off offset:2048" ::"v"(p) : "memory")
+#define ST4x3S asm volatile("global_store_dwordx4 %0, v[104:107], off\n global_store_dwordx4 %0, v[104:107], off offset:16\n global_store_dwordx4 %0, v[104:107], off offset:32" ::"v"(p + (threadIdx.x & 63) * 32) : "memory")
+#define LD4x3 asm volatile("global_load_dwordx4 v[100:103], %0, off\n global_load_dwordx4 v[108:111], %0, off offset:1024\n global_load_dwordx4 v[112:115], %0, off offset:2048" ::"v"(p) : "memory", "v100", "v101", "v102", "v103", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115")
+#define LD4x3S asm volatile("global_load_dwordx4 v[100:103], %0, off\n global_load_dwordx4 v[108:111], %0, off offset:16\n global_load_dwordx4 v[112:115], %0, off offset:32" ::"v"(p + (threadIdx.x & 63) * 32) : "memory", "v100", "v101", "v102", "v103", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115")
 
 KERNEL(k_none16, FMA16, NONE)
 KERNEL(k_st4_16, FMA16, ST4)
@@ -45,6 +51,10 @@ KERNEL(k_none64, FMA16 FMA16 FMA16 FMA16, NONE)
 KERNEL(k_st4_64, FMA16 FMA16 FMA16 FMA16, ST4)
 KERNEL(k_st0_64, FMA16 FMA16 FMA16 FMA16, ST0)
 KERNEL(k_ld4_64, FMA16 FMA16 FMA16 FMA16, LD4)
+KERNEL(k_st3_64, FMA16 FMA16 FMA16 FMA16, ST4x3)
+KERNEL(k_st3s_64, FMA16 FMA16 FMA16 FMA16, ST4x3S)
+KERNEL(k_ld3_64, FMA16 FMA16 FMA16 FMA16, LD4x3)
+KERNEL(k_ld3s_64, FMA16 FMA16 FMA16 FMA16, LD4x3S)
 
 struct K { const char *name; void (*fn)(unsigned long long *, char *, long long, int); };
 
@@ -56,7 +66,9 @@ int main() {
     if (hipMalloc(&buf, (size_t) maxWaves * (8 << 20)) != hipSuccess) { printf("no memory\n"); return 1; }
     K ks[] = { {"16 fma", k_none16}, {"16 fma + store x4", k_st4_16}, {"16 fma + store x2", k_st2_16}, {"16 fma + store x4 exec=0", k_st0_16},
                {"16 fma + store x4 16 lanes", k_st16_16}, {"16 fma + load x4", k_ld4_16}, {"64 fma", k_none64},
-               {"64 fma + store x4", k_st4_64}, {"64 fma + store x4 exec=0", k_st0_64}, {"64 fma + load x4", k_ld4_64} };
+               {"64 fma + store x4", k_st4_64}, {"64 fma + store x4 exec=0", k_st0_64}, {"64 fma + load x4", k_ld4_64},
+               {"64 fma + 3 stores, a KB each", k_st3_64}, {"64 fma + 3 stores, 48-byte lanes", k_st3s_64},
+               {"64 fma + 3 loads, a KB each", k_ld3_64}, {"64 fma + 3 loads, 48-byte lanes", k_ld3s_64} };
     for (long long stride : {0ll, 7680ll}) {
         printf("stride %lld: cycles per iteration per wave, avg (max), at 1 / 4 / 8 waves per CU\n", stride);
         for (auto &k : ks) {
