@@ -764,11 +764,20 @@ def forward_kernel(name):
     k.valu("v_mul_u32_u24_e32", tB.lo, TRACK_ROW_BYTES, tB.lo)
     k.valu("v_add_u32_e32", tB.lo, LDS_ROWS, tB.lo)
     rows = [pool.take(4) for _ in range(3)]
+    # ... as many as k-mers enter during the block (the control word's bits, which the load above has brought by now) and
+    # one to spare, not all 64: 144 bytes a lane
+    k.drain_lgkm()
+    k.salu("s_bcnt1_i32_b64", sT[2], sStepMax)
+    k.salu("s_add_u32", sT[2], sT[2], 1)
+    k.salu("s_bfm_b64", sP[2], sT[2], 0)                   # (a width of 6 bits: 63 lanes at most ...
+    k.salu("s_cmp_gt_u32", sT[2], 63)                      # ... a k-mer entering on every diagonal of the block takes all 64)
+    k.salu("s_cselect_b64", "exec", -1, sP[2])
     for base in range(0, 9, 3):
         for q in range(3):
             k.gload(4, rows[q], tA.lo, sTrack, 16 * (base + q))
         for q in range(3):
             k.ds_write(128, tB.lo, rows[q], 16 * (base + q))
+    k.salu("s_mov_b64", "exec", -1)
     pool.give(tE, tI, tA, tB, *rows)
     k.wait_all()
     k.salu("s_setpc_b64", sRet)

@@ -451,6 +451,15 @@ class Wave:
     def i_s_cmp_le_i32(self, ins, o): self._cmp(o, True, lambda a, b: a <= b)
     def i_s_cmp_lg_u64(self, ins, o): self.scc = 1 if self.s_rd(o[0], 64) != self.s_rd(o[1], 64) else 0
     def i_s_cmp_eq_u64(self, ins, o): self.scc = 1 if self.s_rd(o[0], 64) == self.s_rd(o[1], 64) else 0
+    def i_s_min_u32(self, ins, o):
+        a, b = self.s_rd(o[1]), self.s_rd(o[2])
+        self.scc = int(a <= b)
+        self.s_wr(o[0], min(a, b))
+
+    def i_s_bfm_b64(self, ins, o):
+        width, offset = self.s_rd(o[1]) & 63, self.s_rd(o[2]) & 63
+        self.s_wr(o[0], (((1 << width) - 1) << offset) & ((1 << 64) - 1), 64)
+
     def i_s_bcnt1_i32_b64(self, ins, o):
         r = bin(self.s_rd(o[1], 64)).count("1")
         self.scc = 1 if r else 0

@@ -65,9 +65,11 @@ def _backward_hooks(img, item, cur, B, off, bad):
     return {".L_%s_tail%d" % (BACKWARD, kk): make(kk) for kk in range(3)}
 
 
-@pytest.mark.parametrize("lX,lY,ragged,seed", [(257, 330, (1, 0), 21), (90, 420, (0, 1), 5)])
-def test_sweeps_on_the_emulator_equal_the_oracle(lX, lY, ragged, seed):
-    batch = synth.make_batch(seed, 1, lX, lY, anchor_every=50)
+@pytest.mark.parametrize("lX,lY,ragged,seed,every", [(257, 330, (1, 0), 21, 50), (90, 420, (0, 1), 5, 50),
+                                                     # no anchors: the whole matrix, a k-mer enters on every diagonal
+                                                     (100, 230, (1, 1), 9, 10 ** 6)])
+def test_sweeps_on_the_emulator_equal_the_oracle(lX, lY, ragged, seed, every):
+    batch = synth.make_batch(seed, 1, lX, lY, anchor_every=every)
     bp = band_params(0.01, 150, 40, 100)
     img = H.Image(batch, bp, ragged, cp.NANOPORE_TRANSITIONS)
     ref = run_oracle_item(batch, 0, bp, ragged, dump=True)
