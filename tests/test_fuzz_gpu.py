@@ -63,6 +63,40 @@ def test_random_case(ctx, case, family):
         assert_same_pairs(res[i], ref)
 
 
+def asm_cases(n, seed):
+    """bands of 121-158 k-mers (diagonalExpansion 100-128 around anchors on the path): what the assembly sweeps take"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for k in range(n):
+        lX = int(rng.integers(250, 1100))
+        c = dict(seed=5000 + k, lX=lX, lY=int(lX * rng.uniform(1.6, 2.4)), every=int(rng.choice([25, 50, 80])),
+                 e=int(rng.choice([100, 104, 110, 120, 128])), tb=int(rng.integers(1, 60)),
+                 thr=float(rng.choice([0.5, 0.01, 1e-4, 0.0])), ragged=(int(rng.integers(0, 2)), int(rng.integers(0, 2))),
+                 flags=int(rng.choice([0, cp.FLAG_SMALL_FOOTPRINT])), n=int(rng.integers(1, 4)))
+        c["md"] = c["tb"] + 2 + int(rng.integers(0, 500))
+        out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("case", asm_cases(24 * SCALE, 31337), ids=lambda c: "a%d" % c["seed"])
+def test_random_case_assembly_sweeps(ctx, case):
+    """the hand-scheduled sweeps (both layouts of their ring) wherever the batch is shaped for them; the compiled kernels
+    take what is left (a band that turns out narrower or wider), to the same bar"""
+    batch = synth.make_batch(case["seed"], case["n"], case["lX"], case["lY"], anchor_every=case["every"], length_sigma=0.2)
+    bp = band_params(case["thr"], case["md"], case["tb"], case["e"])
+    res, b = run_gpu(ctx, batch, bp, kernel=cp.KERNEL_AUTO, flags=case["flags"], ragged=case["ragged"])
+    info = b.info()
+    if info["kernel"] == "systolic" and info["waves_per_workgroup"] == 3 and info["max_band_width"] <= 158:
+        assert info["assembly_sweeps"] == 2
+    b.close()
+    for i in range(case["n"]):
+        ref = run_oracle_item(batch, i, bp, case["ragged"])
+        assert res[i]["cells"] == ref["cells"]
+        assert np.array_equal(res[i]["totals_xay"], ref["totals_xay"])
+        assert np.array_equal(res[i]["totals"], ref["totals"])
+        assert_same_pairs(res[i], ref)
+
+
 @pytest.mark.parametrize("case", cases(10 * SCALE, 77), ids=lambda c: "v%d" % c["seed"])
 def test_random_case_vanilla(ctx, case):
     import pyoracle as o
