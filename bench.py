@@ -796,7 +796,7 @@ def bench_em(args, cp, em, bp, rank, local_rank, world, dist, torch, synth, sync
     bt = first_batch if first_batch is not None else \
         synth.make_batch(3 + 100 * rank, args.reads, args.kmers, args.events, anchor_every=50)
     t0 = time.time()
-    ctxs = [cp.Context(local_rank) for _ in range(max(1, min(4, args.em_contexts)))]
+    ctxs = [cp.Context(local_rank) for _ in range(max(1, min(8, args.em_contexts)))]
     gap_x = np.full(4096, -2.3025850929940455)
     trans = np.array(cp.NANOPORE_TRANSITIONS, dtype=np.float64)
     e_step = em.PersistentEStep(cp, ctxs, bt, bp, range(len(bt["items"])), trans, gap_x,
