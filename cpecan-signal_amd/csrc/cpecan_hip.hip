@@ -550,6 +550,8 @@ struct cpecan_batch {
     int trackRow = CP_ROW; /* doubles per column of the track */
     bool countsValid = false, ran = false;
     bool packedInRun = false; /* the last run ended with cpecan_k_pack_base + cpecan_k_pack_pairs */
+    bool compactPairs = false; /* every sequence of the batch is shorter than 65536 elements: a packed candidate crosses
+                                  PCIe as (x | y << 16) and its verdict, 8 bytes instead of 12 */
     /* the hand-scheduled assembly sweeps (cpecan_asm.h): the host's plan of windows and band steps, the forward waves'
      * contexts */
     bool useAsm = false, asmBackward = false;
@@ -624,7 +626,7 @@ static void build_asm_plan(const int *tab, long long nDiag, const cpecan_band_pa
 
 extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
                                                const double *logp, double threshold, long long capacity,
-                                               PackedPair *out, int *post, long long *undecided);
+                                               PackedPair *out, int *post, long long *undecided, int compact);
 extern "C" __global__ void cpecan_k_pack_base(const DevItem *items, const long long *nPairs, long long nItems,
                                               long long *packBase);
 
@@ -1247,6 +1249,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     std::vector<long long, NoInit<long long>> hPre;
     long long cellTotal = 0, pairTotal = 0, totTotal = 0, bwsTotal = 0, trackTotal = 0;
     int globalMaxWidth = 0, maxSpan = 1, maxLX = 0, maxWindows = 0;
+    long long maxLXY = 0; /* the longest sequence of the batch, either side */
     bool systolicOk = true; /* band edges move by at most one k-mer per diagonal */
     std::vector<long long> hTrackBase((size_t) nItems);
     Lap lap("batch_create");
@@ -1393,6 +1396,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
         hTrackBase[(size_t) i] = trackTotal;
         trackTotal += s.lX + 1;
         maxLX = std::max<int>(maxLX, (int) s.lX);
+        maxLXY = std::max<long long>(maxLXY, std::max<long long>(s.lX, s.lY));
         globalMaxWidth = std::max(globalMaxWidth, d.maxWidth);
         d.cellBase = cellTotal;
         cellTotal += d.nCells;
@@ -1419,6 +1423,7 @@ static int batch_create_impl(cpecan_ctx *c, const cpecan_item *items, int64_t nI
     b->nItems = nItems;
     b->mode = mode;
     b->flags = flags;
+    b->compactPairs = maxLXY < 65536;
     b->nModels = dna ? c->nModels5 : vanilla ? c->nModelsV : sm4 ? c->nModels4 : hdp ? (int) c->hostModelsH.size() : c->nModels;
     b->expectLen = dna ? CPECAN_EXPECTATION5_LEN : vanilla ? CPECAN_EXPECTATIONV_LEN
                    : hdp ? CPECAN_EXPECTATIONH_LEN : CPECAN_EXPECTATION_LEN;
@@ -2015,7 +2020,7 @@ int cpecan_hip_batch_run_after(cpecan_batch *b, cpecan_batch *after) {
         hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, c->stream,
                            (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
                            (const double *) b->pairLogp.p, b->P.threshold, (long long) b->packed.n, b->packed.p,
-                           b->packedPost.p, b->undecided.p);
+                           b->packedPost.p, b->undecided.p, b->compactPairs ? 1 : 0);
         HIP_TRY(hipGetLastError());
         b->packedInRun = true;
     }
@@ -2132,7 +2137,8 @@ int cpecan_hip_batch_elapsed_ms(cpecan_batch *b, float *msTotal, float *msKernel
 extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long long *packBase, const long long *pairs,
                                                const double *logp, double threshold, long long capacity,
                                                PackedPair *out, int *post, long long *undecided /* [0] count, then
-                                               CP_UNDECIDED_CAP x (packed index, exponent bits) */) {
+                                               CP_UNDECIDED_CAP x (packed index, exponent bits) */,
+                                               int compact /* both coordinates below 65536: four bytes a pair */) {
     const DevItem &d = items[blockIdx.x];
     if (packBase[gridDim.x] > capacity) return; /* (packed at the end of a run into a buffer sized by a guess: the host
                                                    sees the same total and packs again into one that fits) */
@@ -2141,7 +2147,8 @@ extern "C" __global__ void cpecan_k_pack_pairs(const DevItem *items, const long 
         PackedPair r;
         r.x = (int) pairs[(d.pairBase + k) * 3 + 1];
         r.y = (int) pairs[(d.pairBase + k) * 3 + 2];
-        out[o + k] = r;
+        if (compact) ((unsigned *) out)[o + k] = (unsigned) r.x | ((unsigned) r.y << 16);
+        else out[o + k] = r;
         const double e = logp[d.pairBase + k];
         const double p = exp(e);
         int v = -1;
@@ -2312,13 +2319,13 @@ static int ensure_counts(cpecan_batch *b) {
         hipLaunchKernelGGL(cpecan_k_pack_pairs, dim3((unsigned) b->nItems), dim3(256), 0, b->ctx->stream,
                            (const DevItem *) b->items.p, (const long long *) b->packBase.p, (const long long *) b->pairs.p,
                            (const double *) b->pairLogp.p, b->P.threshold, (long long) b->packed.n, b->packed.p,
-                           b->packedPost.p, b->undecided.p);
+                           b->packedPost.p, b->undecided.p, b->compactPairs ? 1 : 0);
         HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipMemcpyAsync(b->hUndecided, b->undecided.p, (1 + 2 * CP_UNDECIDED_CAP) * sizeof(long long),
                                hipMemcpyDeviceToHost, b->ctx->stream));
-        HIP_TRY(hipMemcpyAsync(b->hPacked, b->packed.p, (size_t) all * sizeof(PackedPair), hipMemcpyDeviceToHost,
-                               b->ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->hPacked, b->packed.p, (size_t) all * (b->compactPairs ? sizeof(unsigned) : sizeof(PackedPair)),
+                               hipMemcpyDeviceToHost, b->ctx->stream));
         HIP_TRY(hipMemcpyAsync(b->hPost, b->packedPost.p, (size_t) all * sizeof(int), hipMemcpyDeviceToHost,
                                b->ctx->stream));
         HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -2430,8 +2437,14 @@ int cpecan_hip_batch_fetch_pairs(cpecan_batch *b, int64_t item, int64_t *triples
         const int v = b->hPost[o + k];
         if (v < 0) continue;
         triples[kept * 3] = v;
-        triples[kept * 3 + 1] = b->hPacked[o + k].x;
-        triples[kept * 3 + 2] = b->hPacked[o + k].y;
+        if (b->compactPairs) {
+            const unsigned xy = ((const unsigned *) b->hPacked)[o + k];
+            triples[kept * 3 + 1] = xy & 0xFFFFu;
+            triples[kept * 3 + 2] = xy >> 16;
+        } else {
+            triples[kept * 3 + 1] = b->hPacked[o + k].x;
+            triples[kept * 3 + 2] = b->hPacked[o + k].y;
+        }
         if (logp) logp[kept] = e[(size_t) k];
         kept++;
     }

@@ -232,3 +232,15 @@ def test_config4_ragged_batch_expectations_against_the_oracle(ctx):
         run_oracle_item(rb, i, bp, (1, 1), expectations=hmm)
     ref = np.concatenate([np.array(hmm.transitions), np.array(hmm.kmerGap), [hmm.likelihood]])
     assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
+
+
+def test_coordinates_beyond_sixteen_bits(ctx):
+    """a read of 70 000 events: its pairs cross PCIe as 32-bit coordinates (shorter sequences travel as x | y << 16)"""
+    batch = synth.make_batch(11, 1, 33000, 70000, anchor_every=50)
+    bp = band_params(0.01, 1000, 40, 20)
+    res, b = run_gpu(ctx, batch, bp, ragged=(1, 1))
+    b.close()
+    ref = run_oracle_item(batch, 0, bp, (1, 1))
+    assert_same_pairs(res[0], ref)
+    assert np.array_equal(res[0]["totals"], ref["totals"]) and res[0]["cells"] == ref["cells"]
+    assert res[0]["triples"][:, 2].max() > 65535
