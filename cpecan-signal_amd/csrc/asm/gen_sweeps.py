@@ -571,7 +571,7 @@ def forward_kernel(name):
             k.gauss(PY[j], E[j].sub(0, 2), c[8 + CMU], c[8 + CSD], c[8 + CRSD], c[8 + CK1], g0, g1)
             k.gauss(g2, E[j].sub(2, 2), c[8 + CNMU], c[8 + CNSD], c[8 + CRNSD], c[8 + CK2], g0, g1)
             k.add(PY[j], PY[j], g2)
-            if j == 2:       # (a store between stretches of arithmetic: stores issued back to back hold the wave up)
+            if j == 2 and "NOPY" not in ABLATE:       # (a store between stretches of arithmetic: stores issued back to back hold the wave up)
                 masked_store((sMaskS[p][0], sMaskS[p][1]), 4, vOff16, V(PY[0].i, 4), OFF_PY)
         pool.give(g0, g1, g2)
         for j in range(L):
@@ -580,7 +580,9 @@ def forward_kernel(name):
             k.add(cc, middle(j, 2), cc)
             csum.append(cc)
         # (the last layer's leave with the two registers after them, which hold a constant: 16 bytes per lane again)
-        if PY2_X2:
+        if "NOPY" in ABLATE:
+            pass
+        elif PY2_X2:
             masked_store(sMaskPy2[p], 2, vOff8, PY[L - 1], OFF_PY + 1024)
         else:
             masked_store(sMaskS[p][L - 1], 4, vOff16, V(PY[L - 1].i, 4), OFF_PY + 1024)
@@ -1415,7 +1417,7 @@ def backward_loop(k, v):
             off = j * LAYER_BYTES
             if "NOLOAD" not in ABLATE:
                 k.gload(4, T[k1][j], vOff16, sRow0 if off < 4096 else sRow1, off % 4096)
-                if j:
+                if j and "NOPY" not in ABLATE:
                     if j == 1:
                         k.salu("s_or_b64", "exec", sLm[0], sLm[1])
                     off = OFF_PY + (j - 1) * 1024
@@ -1444,10 +1446,29 @@ def backward_loop(k, v):
             k.ladd_back(rd[j], M[kk][j], s7p5)
         # ------------------------------------------------------------ tail: what diagonal t hands down, its candidates
         k.label(lbl("tail%d" % kk))
-        k.raw_wait_vm(2 * (L + 2))             # this diagonal's ring row (the L + 2 loads of each of the next two may still be under way)
+        k.raw_wait_vm(2 * L if "NOPY" in ABLATE else 2 * (L + 2))   # this diagonal's ring row (the L + 2 loads of each of the next two may still be under way)
         for j in range(L):
             k.valu("v_mov_b32_e32", PMB[kk][j].lo, Tpm(kk, j).lo)
             k.valu("v_mov_b32_e32", PMB[kk][j].hi, Tpm(kk, j).hi)
+        if "NOPY0" in ABLATE:
+            for j in range(L):
+                k.valu("v_mov_b32_e32", PYB[kk][j].lo, Tpm(kk, j).lo)
+                k.valu("v_mov_b32_e32", PYB[kk][j].hi, Tpm(kk, j).hi)
+        elif "NOPY" in ABLATE:                   # timing only: the work of computing the gap-Y emissions here
+            for j in range(L):
+                cs = [pool.take(4) for _ in range(4)]
+                ev = pool.take(4)
+                g0, g1, g2 = pool.take(2), pool.take(2), pool.take(2)
+                k.valu("v_add_u32_e32", vTmp, 64 * j, vOff16)
+                for i in range(4):
+                    k.ds_read(128, cs[i], vOff16, offset=1024 * i)
+                k.ds_read(128, ev, vTmp)
+                k.gauss(PYB[kk][j], ev.sub(0, 2), cs[0].sub(0, 2), cs[0].sub(2, 2), cs[1].sub(0, 2), cs[1].sub(2, 2), g0, g1)
+                k.gauss(g2, ev.sub(2, 2), cs[2].sub(0, 2), cs[2].sub(2, 2), cs[3].sub(0, 2), cs[3].sub(2, 2), g0, g1)
+                k.add(PYB[kk][j], PYB[kk][j], g2)
+                k.mul(PYB[kk][j], Tpm(kk, j), "4.0")                   # (benign: 16 x the match emissions instead)
+                k.mul(PYB[kk][j], PYB[kk][j], "4.0")
+                pool.give(*cs, ev, g0, g1, g2)
         w = pool.take(2)
         for j in range(L):
             k.add(w, PYB[kk][j], sTMY)
@@ -1463,7 +1484,8 @@ def backward_loop(k, v):
         k.salu("s_or_b64", sAp(2), sCmp[0], sCmp[1])
         for j in range(2, L):
             k.salu("s_or_b64", sAp(2), sAp(2), sCmp[j])
-        k.branch("s_cbranch_scc1", lbl("cand%d" % kk))
+        if "NOCAND" not in ABLATE:
+            k.branch("s_cbranch_scc1", lbl("cand%d" % kk))
         k.label(lbl("canded%d" % kk))
         k.salu("s_sub_u32", sRefCnt, sRefCnt, 1)
         k.salu("s_cmp_lt_i32", sRefCnt, 1)     # 0: the diagonal below has a refresh of totalProbability; -1: this one
