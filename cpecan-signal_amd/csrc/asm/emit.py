@@ -86,6 +86,7 @@ class Emitter:
         self.vm = []               # pending vector-memory operations, oldest first
         self.valu_w = {}           # VGPR -> index of the last VALU instruction that wrote it
         self.store_r = {}          # VGPR -> index of the last wide store that reads it as data
+        self.sgpr_w = {}           # SGPR pair (its first register) -> index of the last VALU instruction that wrote it
         self.label_n = 0
         self.stats = {}
 
@@ -161,7 +162,7 @@ class Emitter:
     def forget(self):
         """Control flow joins here: nothing is known about pending operations (the caller drains or knows better)."""
         self.lgkm, self.vm = [], []
-        self.valu_w, self.store_r = {}, {}
+        self.valu_w, self.store_r, self.sgpr_w = {}, {}, {}
 
     # ------------------------------------------------------------------ instruction classes
     def _touch(self, reads, writes):
@@ -185,6 +186,12 @@ class Emitter:
         gap = self.n - worst - 1
         if gap < 2:
             self.nop(1 - gap)
+        # a VALU instruction that reads an SGPR as an explicit operand needs two wait states after the VALU instruction
+        # that wrote it (gfx940 and later; vcc read implicitly by the 32-bit encodings is interlocked by the hardware)
+        worst = max([self.sgpr_w.get(q, -10) for x in srcs if isinstance(x, S) for q in range(x.i, x.i + x.n)] or [-10])
+        gap = self.n - worst - 1
+        if gap < 2:
+            self.nop(1 - gap)
         text = "%s %s" % (op, ", ".join(str(x) for x in dsts + srcs))
         if dpp:
             text += " " + dpp
@@ -193,6 +200,10 @@ class Emitter:
         self._ins(text, "valu")
         for r in writes:
             self.valu_w[r] = self.n - 1
+        for d in dsts:
+            if isinstance(d, S):
+                for q in range(d.i, d.i + d.n):
+                    self.sgpr_w[q] = self.n - 1
 
     def salu(self, op, *ops):
         self._ins("%s %s" % (op, ", ".join(str(x) for x in ops)) if ops else op, "salu")

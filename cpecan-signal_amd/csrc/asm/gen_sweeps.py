@@ -115,70 +115,127 @@ class Kernel(Emitter):
     def mul(self, dst, a, b):
         self.valu("v_mul_f64", dst, a, b)
 
-    # ---- logAdd in two halves (impl/pairwiseAligner.c:235-255; ladd() in cpecan_kernel_wave.hip): hi / lo are the
+    # ---- logAdd in three parts (impl/pairwiseAligner.c:235-255; ladd() in cpecan_kernel_wave.hip): hi / lo are the
     # operands as the reference's two branches order them, d = hi - lo, the cubic's four float-literal coefficients
     # come from the LDS table at offset 0 indexed by ceil(2 d) (the pieces' limits are multiples of 1/2).  d >= 7.5,
     # an infinite or a NaN d discard the cubic: the index is then anything at all -- an LDS read beyond the allocation
     # returns zero (measured: profiles/r03_ubench2_exec_lds_branch.txt) -- so it is not clamped.
-    def ladd_front(self, x, y, free=()):
+    def ladd_rows(self, recs):
+        """The table rows of a group of logAdds.  n = ceil(2 d) picks the row: 2 d + 2^52 rounded towards +inf IS
+        2^52 + n (doubles are a unit apart there; the product is exact, the fma rounds once, upwards), so the sum's low
+        word holds n.  Only these fmas run under that rounding mode: everything else is the reference's round-to-nearest.
+        (A difference of 2^31 or more, or infinite, gives an offset beyond the table: the row read there is not used,
+        d >= 7.5; NaN -- both operands -inf -- gives whatever, unused as well.)  Written add / ceil / add this was three
+        instructions, and v_ceil_f64 is not a fast one: the pass went from 32.7 to 30.8 ms when a timing build merely
+        left it out (profiles/r03_ablate_valu.txt)."""
         p = self.pool
-        hi, lo, d = p.take(2), p.take(2), p.take(2)
-        self.valu("v_max_f64", hi, x, y)
-        self.valu("v_min_f64", lo, x, y)
-        p.give(*free)
-        self.add(d, hi, Neg(lo))
-        c32, c10 = p.take(4), p.take(4)
-        t = c32.sub(0, 2)
-        self.add(t, d, d)
-        self.valu("v_ceil_f64_e32", t, t)
-        # n = ceil(2 d) picks the table row: added to 2^47 it lands in the sum's low word times 32, the row's byte
-        # offset (a difference of 2^26 or more, or infinite, gives an offset beyond the table: the row read there is not
-        # used, d >= 7.5; NaN -- both operands -inf -- gives 0)
-        a = c10.lo
-        self.add(c10.sub(0, 2), t, self.magic)
-        if "COEF0" in ABLATE:
-            self.valu("v_mov_b32_e32", a, 0)
-        if "NOLDS" in ABLATE:
-            for q in range(4):
-                self.valu("v_mov_b32_e32", c32.sub(q), d.sub(q % 2))
-                self.valu("v_mov_b32_e32", c10.sub(q), d.sub(q % 2))
-            return (hi, lo, d, c32, c10)
-        self.ds_read(128, c32, a)
-        if "HALFLDS" in ABLATE:
-            for q in range(4):
-                self.valu("v_mov_b32_e32", c10.sub(q), d.sub(q % 2))
-            return (hi, lo, d, c32, c10)
-        self.ds_read(128, c10, a, 16)
-        return (hi, lo, d, c32, c10)
+        for r in recs:
+            r[3], r[4] = p.take(4), p.take(4)
+        if "OLDIDX" in ABLATE:                 # (timing: the three-instruction form, with or without its v_ceil_f64)
+            for r in recs:
+                t = r[3].sub(0, 2)
+                self.add(t, r[2], r[2])
+                if "NOCEIL" not in ABLATE:
+                    self.valu("v_ceil_f64_e32", t, t)
+                self.add(r[4].sub(0, 2), t, self.magic)
+                self.ds_read(128, r[3], r[4].lo)
+                self.ds_read(128, r[4], r[4].lo, 16)
+            return
+        if "NOSETREG" not in ABLATE:           # (timing: what the two mode switches cost)
+            self.salu("s_setreg_imm32_b32", "hwreg(HW_REG_MODE, 2, 2)", 1) # fp64 rounding: towards +inf
+        for r in recs:
+            self.valu("v_fma_f64", r[4].sub(0, 2), r[2], "2.0", self.magic)
+        if "NOSETREG" not in ABLATE:
+            self.salu("s_setreg_imm32_b32", "hwreg(HW_REG_MODE, 2, 2)", 0) # ... to nearest even again
+        for r in recs:
+            a = r[4].lo
+            self.valu("v_lshlrev_b32_e32", a, 5, a)                        # 32 bytes a row
+            if "COEF0" in ABLATE:
+                self.valu("v_mov_b32_e32", a, 0)
+            if "NOLDS" in ABLATE:
+                for q in range(4):
+                    self.valu("v_mov_b32_e32", r[3].sub(q), r[2].sub(q % 2))
+                    self.valu("v_mov_b32_e32", r[4].sub(q), r[2].sub(q % 2))
+                continue
+            self.ds_read(128, r[3], a)
+            if "HALFLDS" in ABLATE:
+                for q in range(4):
+                    self.valu("v_mov_b32_e32", r[4].sub(q), r[2].sub(q % 2))
+                continue
+            self.ds_read(128, r[4], a, 16)
 
-    def ladd_back(self, rec, dst, s7p5):
-        hi, lo, d, c32, c10 = rec
-        r = c32.sub(0, 2)
-        self.mul(r, c32.sub(0, 2), d)
-        self.add(r, r, c32.sub(2, 2))
-        self.mul(r, r, d)
-        self.add(r, r, c10.sub(0, 2))
-        self.mul(r, r, d)
-        self.add(r, r, c10.sub(2, 2))
-        self.add(r, r, lo)
-        self.valu("v_cmp_gt_f64_e32", "vcc", "0x401e0000", d)       # 7.5 > d
-        self.valu("v_cndmask_b32_e32", dst.lo, hi.lo, r.lo, "vcc")
-        self.valu("v_cndmask_b32_e32", dst.hi, hi.hi, r.hi, "vcc")
-        self.pool.give(hi, lo, d, c32, c10)
+    def ladd_back_group(self, recs, dsts):
+        """The second halves of a group of independent logAdds, stage by stage: a wave issues a vector instruction
+        that depends on the one before it 8.8 cycles after it, one that does not 5.8 (profiles/r03_ubench_dep.txt), and
+        a logAdd's second half is a chain of ten."""
+        rs = [rec[3].sub(0, 2) for rec in recs]
+        for rec, r in zip(recs, rs):
+            self.mul(r, rec[3].sub(0, 2), rec[2])
+        for rec, r in zip(recs, rs):
+            self.add(r, r, rec[3].sub(2, 2))
+        for rec, r in zip(recs, rs):
+            self.mul(r, r, rec[2])
+        for rec, r in zip(recs, rs):
+            self.add(r, r, rec[4].sub(0, 2))
+        for rec, r in zip(recs, rs):
+            self.mul(r, r, rec[2])
+        for rec, r in zip(recs, rs):
+            self.add(r, r, rec[4].sub(2, 2))
+        for rec, r in zip(recs, rs):
+            self.add(r, r, rec[1])
+        # (the compares' outcomes in vcc, one logAdd after the other; kept in vcc and two SGPR pairs so that the selects
+        # could be interleaved too it measured the same, profiles/r03_same_box_ab_runs.txt)
+        for rec, r, dst in zip(recs, rs, dsts):
+            self.valu("v_cmp_gt_f64_e32", "vcc", "0x401e0000", rec[2])      # 7.5 > d
+            self.valu("v_cndmask_b32_e32", dst.lo, rec[0].lo, r.lo, "vcc")
+            self.valu("v_cndmask_b32_e32", dst.hi, rec[0].hi, r.hi, "vcc")
+        for rec in recs:
+            self.pool.give(*rec)
 
     def need_recs(self, recs):
         """the table rows of a group of logAdds whose second halves follow: one wait"""
         self.need(*[r[4] for r in recs], *[r[3] for r in recs])
 
-    # ---- log N(x; mu, sd) = K - (a / 2) a, a = (x - mu) / sd as a Markstein-corrected multiply by RN(1 / sd) (lgauss())
+    # ---- log N(x; mu, sd) = K - (a / 2) a, a = (x - mu) / sd as a Markstein-corrected multiply by RN(1 / sd) (lgauss());
+    # (a / 2) a = RN(a a) / 2 exactly (but where a a is subnormal, which K absorbs whole), so the last two steps are one fma
     def gauss(self, dst, x, mu, sd, rsd, K, t0, t1):
         self.add(t0, x, Neg(mu))
         self.mul(t1, t0, rsd)
         self.valu("v_fma_f64", t0, Neg(t1), sd, t0)
         self.valu("v_fma_f64", t1, t0, rsd, t1)
-        self.mul(t0, t1, "0.5")
-        self.mul(t0, t1, t0)
-        self.add(dst, K, Neg(t0))
+        self.mul(t0, t1, t1)
+        self.valu("v_fma_f64", dst, t0, "-0.5", K)   # K - (a / 2) a: halving is exact, so this is the same sum rounded once
+
+    def gauss_group(self, items):
+        """gauss() of independent arguments, stage by stage: items = (dst, x, mu, sd, rsd, K); dst serves as the first
+        temporary, the second comes from the pool"""
+        t1s = [self.pool.take(2) for _ in items]
+        for (dst, x, mu, sd, rsd, K), t1 in zip(items, t1s):
+            self.add(dst, x, Neg(mu))
+        for (dst, x, mu, sd, rsd, K), t1 in zip(items, t1s):
+            self.mul(t1, dst, rsd)
+        for (dst, x, mu, sd, rsd, K), t1 in zip(items, t1s):
+            self.valu("v_fma_f64", dst, Neg(t1), sd, dst)
+        for (dst, x, mu, sd, rsd, K), t1 in zip(items, t1s):
+            self.valu("v_fma_f64", t1, dst, rsd, t1)
+        for (dst, x, mu, sd, rsd, K), t1 in zip(items, t1s):
+            self.mul(dst, t1, t1)
+        for (dst, x, mu, sd, rsd, K), t1 in zip(items, t1s):
+            self.valu("v_fma_f64", dst, dst, "-0.5", K)
+        self.pool.give(*t1s)
+
+    def ladd_front_group(self, pairs, free=()):
+        """the first halves of independent logAdds, stage by stage"""
+        p = self.pool
+        recs = [[p.take(2), p.take(2), p.take(2), None, None] for _ in pairs]
+        for (x, y), r in zip(pairs, recs):
+            self.valu("v_max_f64", r[0], x, y)
+        for (x, y), r in zip(pairs, recs):
+            self.valu("v_min_f64", r[1], x, y)
+        p.give(*free)
+        for r in recs:
+            self.add(r[2], r[0], Neg(r[1]))
+        return recs
 
     def s_mov64_lit(self, dst, value):
         self.salu("s_mov_b32", dst.lo, "0x%x" % (value & 0xFFFFFFFF))
@@ -301,7 +358,11 @@ def forward_kernel(name):
 
     # ------------------------------------------------------------------ prologue
     k.label(name)
-    if "PRIOF" in ABLATE:
+    # the forward wave goes first on its SIMD (CPECAN_ASM_ABLATE=NOPRIO: never; HALFPRIO: for the first half of every
+    # step, which balanced the two sweeps of a window while their arithmetic was emitted chain after chain): now that the
+    # sweep back is the shorter one by a fifth, this is what makes both last equally long -- the pass 4 % shorter than
+    # with HALFPRIO, 7 % than with none (profiles/r03_same_box_ab_runs.txt)
+    if "NOPRIO" not in ABLATE and "HALFPRIO" not in ABLATE:
         k.salu("s_setprio", 2)
     k.salu("s_memtime", sP[0])
     k.salu("s_memrealtime", sP[3])
@@ -420,7 +481,7 @@ def forward_kernel(name):
     k.valu("v_lshlrev_b32_e32", vOff16, 4, V(0))          # (v0 is vOff16 from here on)
     k.ds_write(64, vOff8, tq, LDS_COEF)
     pool.give(tq)
-    k.s_mov64_lit(s7p5, dbits(2.0 ** 47))
+    k.s_mov64_lit(s7p5, dbits(2.0 ** (47 if "OLDIDX" in ABLATE else 52)))
     k.magic = s7p5
     # every event of the LDS ring reads as (0, 0) until it is staged: a parked slot scores whatever its stale address
     # points at, and that has to be a number
@@ -528,57 +589,54 @@ def forward_kernel(name):
         def middle(j, w):  # (x-1, y-1) on the diagonal before: m, x, y
             return (Xm(p, j - 1), Xx(p, j - 1), Xy(p, j - 1))[w] if j else R[p].sub(2 * w, 2)
 
-        # the forward wave goes first on its SIMD for the first half of a step (CPECAN_ASM_ABLATE=NOPRIO: never): alone
-        # it is the longer of the two sweeps, with the priority for a whole step (PRIOF) the sweep back becomes it; two
-        # batches chained run 3 % faster this way, a batch alone 0.5 % (profiles/r03_same_box_ab_runs.txt)
-        if "NOPRIO" not in ABLATE and "PRIOF" not in ABLATE:
+        if "HALFPRIO" in ABLATE:
             k.salu("s_setprio", 2)
         # P1: gap X from the lower cell -- needs no emission
-        recs = []
+        aa, bb = [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)]
         for j in range(L):
-            a, b = pool.take(2), pool.take(2)
-            k.add(a, lower(j, 0), C[j][CPXO])
-            k.add(b, lower(j, 1), C[j][CPXE])
-            recs.append(k.ladd_front(a, b, free=(a, b)))
+            k.add(aa[j], lower(j, 0), C[j][CPXO])
+        for j in range(L):
+            k.add(bb[j], lower(j, 1), C[j][CPXE])
+        recs = k.ladd_front_group(list(zip(aa, bb)), free=aa + bb)
+        k.ladd_rows(recs)
         # P2: match emissions; the sums of the middle cell's gap-X state, which the gap-X results are about to overwrite
-        g0, g1, g2 = pool.take(2), pool.take(2), pool.take(2)
-        bsum = []
+        k.gauss_group([(Xpm(p, j), E[j].sub(0, 2), C[j][CMU], C[j][CSD], C[j][CRSD], C[j][CK1]) for j in range(L)])
+        gn = [pool.take(2) for _ in range(L)]
+        k.gauss_group([(gn[j], E[j].sub(2, 2), C[j][CNMU], C[j][CNSD], C[j][CRNSD], C[j][CK2]) for j in range(L)])
         for j in range(L):
-            c = C[j]
-            k.gauss(Xpm(p, j), E[j].sub(0, 2), c[CMU], c[CSD], c[CRSD], c[CK1], g0, g1)
-            k.gauss(g2, E[j].sub(2, 2), c[CNMU], c[CNSD], c[CRNSD], c[CK2], g0, g1)
-            k.add(Xpm(p, j), Xpm(p, j), g2)
+            k.add(Xpm(p, j), Xpm(p, j), gn[j])
+        pool.give(*gn)
+        bsum = [pool.take(2) for _ in range(L)]
         for j in range(L):
-            b = pool.take(2)
-            k.add(b, Xpm(p, j), sTXM)
-            k.add(b, middle(j, 1), b)
-            bsum.append(b)
+            k.add(bsum[j], Xpm(p, j), sTXM)
+        for j in range(L):
+            k.add(bsum[j], middle(j, 1), bsum[j])
         # P3: gap X done
         k.need_recs(recs)
-        for j in range(L):
-            k.ladd_back(recs[j], Xx(p, j), s7p5)
+        k.ladd_back_group(recs, [Xx(p, j) for j in range(L)])
         # P4: match from the middle cell, first two terms
-        recs = []
+        aa = [pool.take(2) for _ in range(L)]
         for j in range(L):
-            a = pool.take(2)
-            k.add(a, Xpm(p, j), sTMM)
-            k.add(a, middle(j, 0), a)
-            recs.append(k.ladd_front(a, bsum[j], free=(a, bsum[j])))
+            k.add(aa[j], Xpm(p, j), sTMM)
+        for j in range(L):
+            k.add(aa[j], middle(j, 0), aa[j])
+        recs = k.ladd_front_group(list(zip(aa, bsum)), free=aa + bsum)
+        k.ladd_rows(recs)
         # P5: gap-Y emissions; the third match term (the middle cell's gap-Y state dies with this diagonal's gap-Y results)
-        csum = []
+        k.gauss_group([(PY[j], E[j].sub(0, 2), C[j][8 + CMU], C[j][8 + CSD], C[j][8 + CRSD], C[j][8 + CK1]) for j in range(L)])
+        gn = [pool.take(2) for _ in range(L)]
+        k.gauss_group([(gn[j], E[j].sub(2, 2), C[j][8 + CNMU], C[j][8 + CNSD], C[j][8 + CRNSD], C[j][8 + CK2])
+                       for j in range(L)])
         for j in range(L):
-            c = C[j]
-            k.gauss(PY[j], E[j].sub(0, 2), c[8 + CMU], c[8 + CSD], c[8 + CRSD], c[8 + CK1], g0, g1)
-            k.gauss(g2, E[j].sub(2, 2), c[8 + CNMU], c[8 + CNSD], c[8 + CRNSD], c[8 + CK2], g0, g1)
-            k.add(PY[j], PY[j], g2)
-            if j == 2 and "NOPY" not in ABLATE:       # (a store between stretches of arithmetic: stores issued back to back hold the wave up)
-                masked_store((sMaskS[p][0], sMaskS[p][1]), 4, vOff16, V(PY[0].i, 4), OFF_PY)
-        pool.give(g0, g1, g2)
+            k.add(PY[j], PY[j], gn[j])
+        pool.give(*gn)
+        if "NOPY" not in ABLATE:                      # (a store between stretches of arithmetic: stores issued back to back hold the wave up)
+            masked_store((sMaskS[p][0], sMaskS[p][1]), 4, vOff16, V(PY[0].i, 4), OFF_PY)
+        csum = [pool.take(2) for _ in range(L)]
         for j in range(L):
-            cc = pool.take(2)
-            k.add(cc, Xpm(p, j), sTYM)
-            k.add(cc, middle(j, 2), cc)
-            csum.append(cc)
+            k.add(csum[j], Xpm(p, j), sTYM)
+        for j in range(L):
+            k.add(csum[j], middle(j, 2), csum[j])
         # (the last layer's leave with the two registers after them, which hold a constant: 16 bytes per lane again)
         if "NOPY" in ABLATE:
             pass
@@ -588,19 +646,21 @@ def forward_kernel(name):
             masked_store(sMaskS[p][L - 1], 4, vOff16, V(PY[L - 1].i, 4), OFF_PY + 1024)
         # P6
         k.need_recs(recs)
-        for j in range(L):
-            k.ladd_back(recs[j], Xm(p, j), s7p5)
-        if "NOPRIO" not in ABLATE and "PRIOF" not in ABLATE:
+        k.ladd_back_group(recs, [Xm(p, j) for j in range(L)])
+        if "HALFPRIO" in ABLATE:
             k.salu("s_setprio", 0)
         # P7: gap Y from the upper cell
-        recs = []
+        aa, bb = [pool.take(2) for _ in range(L)], [pool.take(2) for _ in range(L)]
         for j in range(L):
-            a, b = pool.take(2), pool.take(2)
-            k.add(a, PY[j], sTMY)
-            k.add(a, Xm(q, j), a)
-            k.add(b, PY[j], sTYY)
-            k.add(b, Xy(q, j), b)
-            recs.append(k.ladd_front(a, b, free=(a, b)))
+            k.add(aa[j], PY[j], sTMY)
+        for j in range(L):
+            k.add(bb[j], PY[j], sTYY)
+        for j in range(L):
+            k.add(aa[j], Xm(q, j), aa[j])
+        for j in range(L):
+            k.add(bb[j], Xy(q, j), bb[j])
+        recs = k.ladd_front_group(list(zip(aa, bb)), free=aa + bb)
+        k.ladd_rows(recs)
         # ... while its table reads are under way: the next diagonal's events, the gap-Y emissions' stores
         k.salu("s_add_u32", sDmod, sDmod, 16)
         k.salu("s_and_b32", sDmod, sDmod, 16 * (EVN - 1))
@@ -610,26 +670,23 @@ def forward_kernel(name):
         # P9 (on a diagonal the sweep back reads all three states of, the gap states leave too: out of line, one diagonal
         # in ten -- a store under an empty EXEC holds the wave up as long as any other)
         k.need_recs(recs)
-        for j in range(L):
-            k.ladd_back(recs[j], Xy(p, j), s7p5)
+        k.ladd_back_group(recs, [Xy(p, j) for j in range(L)])
         k.salu("s_bitcmp1_b64", sFull, sD)
         k.branch("s_cbranch_scc1", lbl("full%d" % p))
         k.label(lbl("fulled%d" % p))
         # P10: the match cell's third term
-        recs = []
-        for j in range(L):
-            recs.append(k.ladd_front(Xm(p, j), csum[j], free=(csum[j],)))
+        recs = k.ladd_front_group([(Xm(p, j), csum[j]) for j in range(L)], free=csum)
+        k.ladd_rows(recs)
         # ... meanwhile the gap states leave where the sweep back reads them again, and layer L-1 is rotated up a lane
         k.ror64(R[p].sub(2, 2), Xx(p, L - 1))
         k.ror64(R[p].sub(4, 2), Xy(p, L - 1))
         # P11: (Fm, pm) leave as they are finished; the match cells of layer L-1 go up a lane
         k.need_recs(recs)
-        for j in range(L):
-            k.ladd_back(recs[j], Xm(p, j), s7p5)
-            if j:
-                masked_store(sMaskS[p][j - 1], 4, vOff16, V(Xm(p, j - 1).i, 4), (j - 1) * LAYER_BYTES)
+        k.ladd_back_group(recs, [Xm(p, j) for j in range(L)])
+        masked_store(sMaskS[p][0], 4, vOff16, V(Xm(p, 0).i, 4), 0)
         k.ror64(R[p].sub(0, 2), Xm(p, L - 1))
-        masked_store(sMaskS[p][L - 1], 4, vOff16, V(Xm(p, L - 1).i, 4), (L - 1) * LAYER_BYTES)
+        for j in range(1, L):
+            masked_store(sMaskS[p][j], 4, vOff16, V(Xm(p, j).i, 4), j * LAYER_BYTES)
         k.salu("s_add_u32", sD, sD, 1)
 
     k.label(lbl("even"))
@@ -1202,7 +1259,7 @@ def backward_kernel(name):
     k.valu("v_lshlrev_b32_e32", vOff16, 4, V(0))
     k.ds_write(64, vOff8, tq, LDS_COEF)
     pool.give(tq)
-    k.s_mov64_lit(s7p5, dbits(2.0 ** 47))
+    k.s_mov64_lit(s7p5, dbits(2.0 ** (47 if "OLDIDX" in ABLATE else 52)))
     k.magic = s7p5
     # the gap-X sums of the slots at the traceback point are the forward wave's (a parked slot holds -inf)
     k.add64(sAp(8), sAp(8), 8 * 1024)
@@ -1374,26 +1431,24 @@ def backward_loop(k, v):
         k.rol64(rhB, M[k2][0])
         k.rol64(rhP, PMB[k2][0])
         k.rol64(rBx, BX[0])
-        bmin, bxin, byin, y1, y2 = [], [], [], [], []
-        w = pool.take(2)
+        # gather form of cell_calculateBackward (:378-389): (t + 2) middle block first; stage by stage over the layers
+        sB_ = [M[k2][j + 1] if j < L - 1 else rhB for j in range(L)]
+        sP_ = [PMB[k2][j + 1] if j < L - 1 else rhP for j in range(L)]
+        sBx_ = [BX[j + 1] if j < L - 1 else rBx for j in range(L)]
+        pe = [PXe(j + 1) if j < L - 1 else RP.sub(2, 2) for j in range(L)]
+        po = [PXo(j + 1) if j < L - 1 else RP.sub(0, 2) for j in range(L)]
+        bmin, bxin, byin, y1, y2 = [[pool.take(2) for _ in range(L)] for _ in range(5)]
+        for dst, t in ((bmin, sTMM), (bxin, sTXM), (byin, sTYM)):
+            for j in range(L):
+                k.add(dst[j], sP_[j], t)
         for j in range(L):
-            sB_ = M[k2][j + 1] if j < L - 1 else rhB
-            sP_ = PMB[k2][j + 1] if j < L - 1 else rhP
-            sBx_ = BX[j + 1] if j < L - 1 else rBx
-            pe = PXe(j + 1) if j < L - 1 else RP.sub(2, 2)
-            po = PXo(j + 1) if j < L - 1 else RP.sub(0, 2)
-            a, b, c, d, e = [pool.take(2) for _ in range(5)]
-            # gather form of cell_calculateBackward (:378-389): (t + 2) middle block first
-            k.add(w, sP_, sTMM)
-            k.add(a, sB_, w)
-            k.add(w, sP_, sTXM)
-            k.add(b, sB_, w)
-            k.add(w, sP_, sTYM)
-            k.add(c, sB_, w)
-            k.add(d, sBx_, pe)
-            k.add(e, sBx_, po)
-            bmin.append(a); bxin.append(b); byin.append(c); y1.append(d); y2.append(e)
-        pool.give(w, rhB, rhP, rBx)
+            k.add(y1[j], sBx_[j], pe[j])
+        for j in range(L):
+            k.add(y2[j], sBx_[j], po[j])
+        for dst in (bmin, bxin, byin):
+            for j in range(L):
+                k.add(dst[j], sB_[j], dst[j])
+        pool.give(rhB, rhP, rBx)
         # the k-mers that left / entered the band coming down to t: their slots change hands now, for the diagonals below
         k.salu("s_cmp_lg_u64", SM[k1].sub(6, 2), SM[kk].sub(6, 2))
         if "NOEVENTS" not in ABLATE:
@@ -1409,10 +1464,10 @@ def backward_loop(k, v):
         # (t + 1, same slot) upper block, then (t + 1, slot + 1) lower block -- the reference's scatter order per state;
         # the loads of ring row t - 2 (into the registers of row t + 1) go out one layer at a time between stretches of
         # arithmetic
-        ra, rb = [], []
+        ra = k.ladd_front_group([(bmin[j], UM[j]) for j in range(L)], free=bmin)
+        rb = k.ladd_front_group([(byin[j], UY[j]) for j in range(L)], free=byin)
+        k.ladd_rows(ra + rb)
         for j in range(L):
-            ra.append(k.ladd_front(bmin[j], UM[j], free=(bmin[j],)))
-            rb.append(k.ladd_front(byin[j], UY[j], free=(byin[j],)))
             k.salu("s_mov_b64", "exec", sLm[j])
             off = j * LAYER_BYTES
             if "NOLOAD" not in ABLATE:
@@ -1431,19 +1486,17 @@ def backward_loop(k, v):
         if "NOMASKB" not in ABLATE:
             load_row_masks(sA[1])
         k.need_recs(ra)
-        for j in range(L):
-            k.ladd_back(ra[j], M[kk][j], s7p5)
-        rc = [k.ladd_front(bxin[j], y1[j], free=(bxin[j], y1[j])) for j in range(L)]
+        k.ladd_back_group(ra, [M[kk][j] for j in range(L)])
+        rc = k.ladd_front_group([(bxin[j], y1[j]) for j in range(L)], free=bxin + y1)
+        k.ladd_rows(rc)
         k.need_recs(rb)
-        for j in range(L):
-            k.ladd_back(rb[j], BY[j], s7p5)
-        rd = [k.ladd_front(M[kk][j], y2[j], free=(y2[j],)) for j in range(L)]
+        k.ladd_back_group(rb, BY)
+        rd = k.ladd_front_group([(M[kk][j], y2[j]) for j in range(L)], free=y2)
+        k.ladd_rows(rd)
         k.need_recs(rc)
-        for j in range(L):
-            k.ladd_back(rc[j], BX[j], s7p5)
+        k.ladd_back_group(rc, BX)
         k.need_recs(rd)
-        for j in range(L):
-            k.ladd_back(rd[j], M[kk][j], s7p5)
+        k.ladd_back_group(rd, [M[kk][j] for j in range(L)])
         # ------------------------------------------------------------ tail: what diagonal t hands down, its candidates
         k.label(lbl("tail%d" % kk))
         k.raw_wait_vm(2 * L if "NOPY" in ABLATE else 2 * (L + 2))   # this diagonal's ring row (the L + 2 loads of each of the next two may still be under way)
@@ -1469,13 +1522,14 @@ def backward_loop(k, v):
                 k.mul(PYB[kk][j], Tpm(kk, j), "4.0")                   # (benign: 16 x the match emissions instead)
                 k.mul(PYB[kk][j], PYB[kk][j], "4.0")
                 pool.give(*cs, ev, g0, g1, g2)
-        w = pool.take(2)
         for j in range(L):
-            k.add(w, PYB[kk][j], sTMY)
-            k.add(UM[j], BY[j], w)
-            k.add(w, PYB[kk][j], sTYY)
-            k.add(UY[j], BY[j], w)
-        pool.give(w)
+            k.add(UM[j], PYB[kk][j], sTMY)
+        for j in range(L):
+            k.add(UY[j], PYB[kk][j], sTYY)
+        for j in range(L):
+            k.add(UM[j], BY[j], UM[j])
+        for j in range(L):
+            k.add(UY[j], BY[j], UY[j])
         fb = [pool.take(2) for _ in range(L)]
         for j in range(L):
             k.add(fb[j], Tf(kk, j), M[kk][j])
@@ -1591,14 +1645,14 @@ def backward_loop(k, v):
             k.add(a1[j], xyT[j].sub(0, 2), BX[j])
             k.add(a2[j], xyT[j].sub(2, 2), BY[j])
         pool.give(*xyT)
-        r = [k.ladd_front(fb[j], a1[j]) for j in range(L)]
+        r = k.ladd_front_group([(fb[j], a1[j]) for j in range(L)])
+        k.ladd_rows(r)
         k.need_recs(r)
-        for j in range(L):
-            k.ladd_back(r[j], a1[j], s7p5)
-        r = [k.ladd_front(a1[j], a2[j]) for j in range(L)]
+        k.ladd_back_group(r, a1)
+        r = k.ladd_front_group([(a1[j], a2[j]) for j in range(L)])
+        k.ladd_rows(r)
         k.need_recs(r)
-        for j in range(L):
-            k.ladd_back(r[j], out[0].sub(2 * j, 2), s7p5)
+        k.ladd_back_group(r, [out[0].sub(2 * j, 2) for j in range(L)])
         pool.give(*a1)
         pool.give(*a2)
         k.salu("s_mul_i32", sA[0], sNTot, 2 * P * 8)
@@ -1782,7 +1836,7 @@ def main():
     name = "cpecan_k_asm_backward_l%d" % L
     k, v = backward_kernel(name)
     backward_loop(k, v)
-    nv = (v["pool0"] + 2 * k.pool.high + 7) // 8 * 8
+    nv = (k.pool.first + 2 * k.pool.high + 7) // 8 * 8
     kernels.append(dict(name=name, body=k.text(), lds=LDS_B_BYTES, kernarg=ARGS_BYTES, vgprs=nv, sgprs=102, accum=nv,
                         stats=dict(k.stats, vgprs=nv)))
     text = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6"]

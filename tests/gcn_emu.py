@@ -9,6 +9,7 @@ Besides computing what the kernel computes it checks what the hardware leaves to
 Addresses of instructions are 4 * index, which is all s_getpc / s_swappc / label differences need.
 """
 import ctypes
+import platform
 import re
 import struct
 
@@ -17,6 +18,8 @@ import numpy as np
 _libm = ctypes.CDLL("libm.so.6")
 _libm.fma.restype = ctypes.c_double
 _libm.fma.argtypes = [ctypes.c_double] * 3
+_FE_TONEAREST, _FE_UPWARD = 0, 0x800       # <fenv.h> of x86-64 glibc
+assert platform.machine() == "x86_64"
 
 LANES = np.arange(64)
 U64 = np.uint64
@@ -118,6 +121,11 @@ def parse(text):
         ins.text, ins.line = s, ln + 1
         rest = parts[1] if len(parts) > 1 else ""
         mods = {}
+        m = re.match(r"^hwreg\(HW_REG_MODE,\s*(\d+),\s*(\d+)\),\s*(\S+)$", rest) if ins.op == "s_setreg_imm32_b32" else None
+        if m:                                        # (the only hardware register the sweeps write: bit offset, width, value)
+            ins.ops, ins.mods = [m.group(1), m.group(2), m.group(3)], mods
+            instrs.append(ins)
+            continue
         # trailing modifiers: offset:N, wave_ror:1, row_mask:0xf, bank_mask:0xf, vmcnt(N), lgkmcnt(N)
         toks = []
         for piece in rest.split(","):
@@ -166,6 +174,7 @@ class Wave:
         self.pc = labels[entry]
         self.lgkm, self.vmq = [], []       # pending operations: (regs: list of ('v'|'s', idx), commit closure)
         self.m0 = 0
+        self.round64 = 0                   # MODE[3:2]: fp64 rounding, 0 to nearest even, 1 towards +inf (fma only)
         # values read from LDS bytes a load to LDS was still writing: any use of one but overwriting or deselecting it is an
         # error (the logAdd table is indexed without a clamp; what lies beyond it is read and thrown away)
         self.taint = np.zeros((256, 64), bool)
@@ -479,6 +488,12 @@ class Wave:
     def i_s_bitcmp0_b64(self, ins, o): self.scc = 1 - ((self.s_rd(o[0], 64) >> (self.s_rd(o[1]) & 63)) & 1)
     def i_s_nop(self, ins, o): self.count += o[0].val
     def i_s_setprio(self, ins, o): pass
+
+    def i_s_setreg_imm32_b32(self, ins, o):
+        off, width, val = o[0].val, o[1].val, o[2].val
+        if (off, width) != (2, 2) or val not in (0, 1):
+            raise NotImplementedError("s_setreg of MODE bits %d..%d to %d" % (off, off + width - 1, val))
+        self.round64 = val
     def i_s_sleep(self, ins, o): pass
 
     def i_s_waitcnt(self, ins, o):
@@ -540,6 +555,8 @@ class Wave:
 
     # ----- vector ALU
     def _v64(self, ins, o, f, n_src):
+        if self.round64 != 0:
+            raise RuntimeError("%s under a rounding mode other than to nearest (line %d)" % (ins.op, ins.line))
         srcs = [self.rdf64(x) for x in o[1: 1 + n_src]]
         with np.errstate(all="ignore"):
             r = f(*srcs)
@@ -554,7 +571,13 @@ class Wave:
 
     def i_v_fma_f64(self, ins, o):
         a, b, c = (self.rdf64(x) for x in o[1:4])
-        r = np.array([_libm.fma(float(a[i]), float(b[i]), float(c[i])) for i in range(64)])
+        if self.round64 == 1:
+            _libm.fesetround(_FE_UPWARD)
+        try:
+            r = np.array([_libm.fma(float(a[i]), float(b[i]), float(c[i])) for i in range(64)])
+        finally:
+            if self.round64 == 1:
+                _libm.fesetround(_FE_TONEAREST)
         self._valu_writes(self._dst_regs(o[0], 2))
         self.wr64(o[0], _u64(r))
 

@@ -107,3 +107,22 @@ def test_assembly_sweeps_share_a_simd_and_a_cu():
     assert 4 * (f["group_segment_fixed_size"] + b["group_segment_fixed_size"]) <= 160 * 1024
     for r in (f, b):
         assert r["private_segment_fixed_size"] == 0 and r["vgpr_spill_count"] == 0
+
+
+def test_assembly_sweeps_stay_inside_their_register_allocation():
+    """No instruction of a hand-scheduled kernel names a VGPR or an SGPR beyond what its descriptor asks for: registers
+    past the allocation are another wave's (the CPU emulator of tests/gcn_emu.py has all 256 and would not notice)."""
+    text = open(os.path.join(ROOT, "cpecan-signal_amd", "csrc", "asm", "cpecan_sweeps_gfx950.s")).read()
+    for name in ("cpecan_k_asm_forward_l3", "cpecan_k_asm_backward_l3"):
+        body = text[text.index("\n%s:\n" % name):]
+        desc = body[body.index(".amdhsa_kernel %s" % name):]
+        body = body[:body.index(".amdhsa_kernel %s" % name)]
+        nv = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", desc).group(1))
+        ns = int(re.search(r"\.amdhsa_next_free_sgpr (\d+)", desc).group(1))
+        top = {"v": -1, "s": -1}
+        for kind, a, b in re.findall(r"\b([vs])\[(\d+):(\d+)\]", body):
+            top[kind] = max(top[kind], int(b))
+        for kind, a in re.findall(r"\b([vs])(\d+)\b", body):
+            top[kind] = max(top[kind], int(a))
+        assert 0 <= top["v"] < nv, (name, top, nv)
+        assert 0 <= top["s"] < ns, (name, top, ns)
