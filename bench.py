@@ -434,8 +434,10 @@ def main(argv=None):
                 "fp64_valu_busy": valu,
                 "note": ("fp64 log-space recurrence with the reference's approximate logAdd reproduced bit for bit.  The "
                          "assembly sweeps run at the rate HBM moves their traffic: forward writes and backward reads of "
-                         "the ring overlap at about the rate of a copy (4.6-4.9 TB/s measured on these boxes), same-box "
-                         "A/B runs move with the bytes and not with the instruction count -- DESIGN.md section 5")
+                         "the ring overlap at about the rate of a copy (4.6-4.9 TB/s measured on these boxes); underneath, "
+                         "each wave waits for its own previous vector instruction (8.8 cycles for a dependent one), which "
+                         "is why the sweeps' arithmetic is emitted stage by stage over the three layers -- DESIGN.md "
+                         "section 5")
                         if asm else
                         ("fp64 log-space recurrence with the reference's approximate logAdd reproduced bit for bit: "
                          "the compiled kernels are bound by VALU issue (one fp64 instruction per SIMD per ~4 cycles) -- "
