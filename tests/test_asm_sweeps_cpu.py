@@ -110,3 +110,26 @@ def test_sweeps_on_the_emulator_equal_the_oracle(lX, lY, ragged, seed, every):
     assert st["finished"] == 1 and st["d"] == lX + lY
     xmin, xmax, _, _ = img.bands[0]
     assert st["cells"] == int((xmax - xmin + 1).sum())
+
+
+def test_table_row_by_round_up_fma_is_ceil_of_twice_the_difference():
+    """ladd_rows() of gen_sweeps.py: the low word of fma(d, 2, 2^52) rounded towards +inf is ceil(2 d) -- at, just above and
+    just below every limit of the reference's cubic pieces (impl/pairwiseAligner.c:238-249), for tiny and for random d."""
+    import ctypes
+    import math
+    import struct
+    import gcn_emu
+    lib = gcn_emu._libm
+    rng = np.random.default_rng(7)
+    ds = [0.0, 5e-324, 1e-300, 2.0 ** -53, 7.5, 1e6, 2.0 ** 30]
+    for lim in [0.5 * i for i in range(1, 16)]:
+        ds += [lim, math.nextafter(lim, 0.0), math.nextafter(lim, 10.0)]
+    ds += list(rng.uniform(0.0, 8.0, 2000)) + list(np.exp(rng.uniform(-40.0, 3.0, 2000)))
+    lib.fesetround(gcn_emu._FE_UPWARD)
+    try:
+        got = [struct.unpack("<Q", struct.pack("<d", lib.fma(ctypes.c_double(d), ctypes.c_double(2.0), ctypes.c_double(2.0 ** 52))))[0]
+               & 0xFFFFFFFF for d in ds]
+    finally:
+        lib.fesetround(gcn_emu._FE_TONEAREST)
+    for d, n in zip(ds, got):
+        assert n == math.ceil(2.0 * d), (d, n)
